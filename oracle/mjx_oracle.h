@@ -1,0 +1,81 @@
+/*
+ * mjx_oracle.h -- CPU restatement of martinhath/jpeg-rust's decode path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it, and only as the checker / the timed CPU baseline.  The product
+ * library (jpeg-rust_amd/libmjx.so) never links or calls into this file.
+ *
+ * Parity pin: the reference ships no tests or golden vectors,
+ * and cannot be compiled here (no rustc/cargo).  The oracle is pinned against
+ * the four sample JPEGs the reference holds and the known answers recorded in
+ * SURVEY.md s4 (coefficient-stream SHA-256s, bit counts, huff_simple0 pixels);
+ * see tests/test_oracle_golden.py.
+ *
+ * Every function cites the reference file:line it restates
+ * (paths relative to /root/reference/src).
+ */
+#ifndef MJX_ORACLE_H
+#define MJX_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    ORC_OK = 0,
+    ORC_ERR_REF_PANIC = 1,      /* input on which the reference would panic (bounds, unwrap, assert) */
+    ORC_ERR_UNSUPPORTED = 2,    /* marker / feature outside the reference's parser (strict_ref=0 only reports
+                                   what cannot be skipped, e.g. DRI, SOF2) */
+    ORC_ERR_NO_SCAN = 3,        /* parse reached EOF without SOS: reference returns image_data() == None */
+    ORC_ERR_NOMEM = 4
+};
+
+enum { ORC_LAYOUT_REF = 0, ORC_LAYOUT_STD = 1 };
+
+typedef struct {
+    int strict_ref;   /* 1: APP12/APP14/unknown markers are errors as in jpeg/mod.rs:166-179,445-462;
+                         0: skip unknown length-prefixed segments */
+    int layout;       /* ORC_LAYOUT_REF: decoder.rs:239-312 bug-for-bug (Q2-Q5);
+                         ORC_LAYOUT_STD: standard MCU count / placement / box upsample / edge clip */
+    int faithful_cos; /* 1: evaluate cosf() 8192x per block exactly like transform.rs:77-79 (CPU baseline);
+                         0: same arithmetic with the 64 distinct cosf() values tabulated (bit-identical, faster) */
+    int faithful_huff;/* 1: linear-search per length like huffman.rs:211-227 / 60-76 (CPU baseline);
+                         0: same result via per-length first-code table */
+} orc_opts;
+
+typedef struct {
+    int width, height, ncomp;
+    int hs[3], vs[3];            /* sampling factors in scan order */
+    uint8_t *rgb;                /* width*height*3, R,G,B, row-major, unpadded (decoder.rs:317-331) */
+    int16_t *coef[3];            /* T0 stream per component (scan order): blocks in decode order,
+                                    64 x i16 zig-zag order, after DC prediction, before dequant */
+    size_t nblocks[3];
+    size_t mcus_read;            /* Q2 count (REF) or standard count (STD) */
+    size_t bits_used;            /* total bits consumed by the entropy decoder */
+    char msg[160];               /* panic / error text */
+} orc_image;
+
+int  orc_decode(const uint8_t *jpeg, size_t len, const orc_opts *opts, orc_image *out);
+void orc_free_image(orc_image *img);
+
+/* transform.rs:55-87 on one 8x8 block (natural order in, natural order out). */
+void orc_idct_ref(const float in[64], float out[64], int faithful_cos);
+/* decoder.rs:392-402 + 382-390 */
+void orc_ycbcr_to_rgb(float y, float cb, float cr, uint8_t rgb[3]);
+/* decoder.rs:382-390 */
+uint8_t orc_f32_to_u8(float n);
+
+/* Decode n independent JPEGs with nthreads worker threads (one image per thread at a time).
+ * Used by bench.py's cpu_baseline leg.  status[i] receives the per-image result code.
+ * Returns total pixels decoded successfully. */
+uint64_t orc_decode_many(const uint8_t *const *jpegs, const size_t *lens, size_t n,
+                         const orc_opts *opts, int nthreads, int *status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
