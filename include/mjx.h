@@ -1,0 +1,160 @@
+/*
+ * mjx.h -- C ABI of the MI355X-native baseline-JPEG decode path.
+ *
+ * Drop-in boundary for martinhath/jpeg-rust's decode(&[u8]) -> RGB surface
+ * (SURVEY.md s8(b)).  Every entry point cites the reference interface it replaces
+ * (paths relative to /root/reference/src).  Plain pointers and sizes only: this is what a
+ * Rust `extern "C"` block binds (see INTEGRATION.md for the binding a maintainer would add).
+ *
+ * Nothing here ever panics/aborts across the ABI: the reference's panics (jpeg/mod.rs Q12)
+ * become status codes.  The GPU entry points fail with MJX_ERR_DEVICE when no HIP device or
+ * kernel image is available -- there is no CPU fallback.
+ */
+#ifndef MJX_H
+#define MJX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------------ */
+enum {
+    MJX_OK = 0,
+    MJX_ERR_TRUNCATED = 1,          /* ran off the end of the file while parsing (ref: slice-index panic) */
+    MJX_ERR_UNSUPPORTED_MARKER = 2, /* strict_ref: marker outside jpeg/mod.rs:166-179 (incl. APP12/APP14, :445-450) */
+    MJX_ERR_DRI_UNSUPPORTED = 3,    /* jpeg/mod.rs:424-428 panics on DRI */
+    MJX_ERR_BAD_HUFFMAN = 4,        /* invalid DHT, or no code matched during decode (huffman.rs:156,162) */
+    MJX_ERR_REF_PANIC = 5,          /* other input on which the reference panics (asserts, bad DQT precision ...) */
+    MJX_ERR_DEVICE = 6,             /* HIP error / no device / kernels missing */
+    MJX_ERR_UNSUPPORTED_FORMAT = 7, /* non-baseline SOF, ncomp not in {1,3} (decoder.rs:328-330), sampling > 2 */
+    MJX_ERR_NO_SCAN = 8,            /* EOF without SOS: the reference returns image_data() == None */
+    MJX_ERR_INVALID_ARG = 9,
+    MJX_ERR_NOMEM = 10,
+    MJX_ERR_MISSING_TABLE = 11      /* scan references a DQT/DHT slot that was never defined (decoder.rs:154-160,222) */
+};
+
+enum {
+    MJX_LAYOUT_STANDARD = 0,  /* standard MCU count, block placement, box chroma replication, edge clipping */
+    MJX_LAYOUT_REF_COMPAT = 1 /* bug-for-bug placement of decoder.rs:239-312 */
+};
+
+typedef struct mjx_opts {
+    uint8_t strict_ref;   /* 1: unknown / APP12 / APP14 markers are errors like the reference; 0: skip them */
+    uint8_t layout;       /* MJX_LAYOUT_* */
+    uint8_t keep_coefs;   /* 1: keep the whole batch's coefficient stream resident (T0 checks, stage-B-only sweeps) */
+    uint8_t reserved0;
+    uint32_t chunk_images;/* images per kernel chunk; 0 = library default */
+} mjx_opts;
+
+/* ---- inner seam: what jpeg/mod.rs:388-415 hands to JPEGDecoder -------------------------- */
+typedef struct mjx_comp {          /* decoder.rs:39-52 JPEGDecoderComponentFields */
+    uint8_t id, h, v, tq, td, ta;
+} mjx_comp;
+
+typedef struct mjx_hufftab {       /* the two slices given to HuffmanTable::from_size_data_tables, huffman.rs:37 */
+    uint8_t bits[16];
+    uint8_t vals[256];
+} mjx_hufftab;
+
+typedef struct mjx_scan_desc {
+    const uint8_t *scan;           /* de-stuffed bytes after the SOS header to end of file (jpeg/mod.rs:371-385) */
+    size_t scan_len;
+    uint16_t width, height;        /* .dimensions() decoder.rs:66 */
+    uint8_t ncomp;                 /* 1 or 3 */
+    mjx_comp comp[3];              /* scan order (decoder.rs:141-150) */
+    uint16_t qt[4][64];            /* zig-zag (file) order as in DQT, jpeg/mod.rs:236-256; .quantization_table() */
+    uint8_t qt_present;            /* bit i = slot i defined */
+    mjx_hufftab dc[4], ac[4];      /* .huffman_dc_tables() / .huffman_ac_tables() decoder.rs:71-77 */
+    uint8_t dc_present, ac_present;
+    void *owner_;                  /* internal: storage behind `scan` when filled by mjx_parse */
+} mjx_scan_desc;
+
+/* ---- outer surface ------------------------------------------------------------------------ */
+typedef struct mjx_image {         /* JPEGImage: width() mod.rs:467, height() :471, image_data() :475 */
+    uint32_t width, height;
+    uint8_t *rgb;                  /* width*height*3 bytes, R,G,B, row-major, unpadded; NULL on error */
+} mjx_image;
+
+/* JPEGImage::parse, jpeg/mod.rs:202 -- host-side marker walk only (no GPU): fills the POD the decoder needs
+ * exactly as mod.rs:228-362 does, de-stuffs the scan (mod.rs:371-385).  Release with mjx_free_scan. */
+int mjx_parse(const uint8_t *jpeg, size_t len, const mjx_opts *opts, mjx_scan_desc *out);
+void mjx_free_scan(mjx_scan_desc *desc);
+
+/* JPEGImage::parse + image_data() in one call on device `0` (main.rs:31-36 usage): parse, upload, decode on the
+ * GPU, copy the RGB back.  Release with mjx_free_image. */
+int mjx_decode(const uint8_t *jpeg, size_t len, const mjx_opts *opts, mjx_image *out);
+void mjx_free_image(mjx_image *img);
+
+/* ---- batch / device-resident API (one context per process per GPU) ------------------------ */
+typedef struct mjx_ctx mjx_ctx;
+typedef struct mjx_batch mjx_batch;
+
+int mjx_ctx_create(int device, mjx_ctx **out);
+void mjx_ctx_destroy(mjx_ctx *ctx);
+/* 1: record HIP events around every kernel class of mjx_batch_decode (read with mjx_batch_kernel_ms) */
+int mjx_ctx_set_profiling(mjx_ctx *ctx, int enable);
+
+/* JPEGDecoder::new(..).frame_header(..).scan_header(..).dimensions(..) + table setters for n images
+ * (decoder.rs:55-152): validates, builds decode tables, packs and uploads the scans; device buffers for the
+ * outputs are allocated here.  status[i] (optional) receives the per-image code; images with an error are
+ * skipped by decode and produce no output.  Inputs are only borrowed for the duration of the call. */
+int mjx_batch_create(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t n, const mjx_opts *opts,
+                     mjx_batch **out, int *status);
+void mjx_batch_free(mjx_batch *b);
+
+/* Replicate the uploaded images `times`x on the device (image i*n+k is a byte copy of image k): builds the
+ * large synthetic batches of BASELINE.json configs 4/5 from n unique images without re-uploading. */
+int mjx_batch_tile(mjx_ctx *ctx, const mjx_batch *src, size_t times, mjx_batch **out);
+
+/* JPEGDecoder::decode, decoder.rs:162 -- the hot path.  Enqueues every kernel for the whole batch on the
+ * context's stream and returns; inputs and outputs stay in HBM.  stages: MJX_STAGE_* mask (0 = all). */
+enum { MJX_STAGE_ENTROPY = 1, MJX_STAGE_PIXELS = 2, MJX_STAGE_ALL = 3 };
+int mjx_batch_decode(mjx_batch *b, unsigned stages);
+/* Block until the stream is idle; fold device-side error flags into the per-image status. */
+int mjx_batch_wait(mjx_batch *b);
+
+size_t mjx_batch_size(const mjx_batch *b);
+int mjx_batch_status(const mjx_batch *b, size_t i);
+/* geometry of image i: width, height, number of blocks per MCU, MCUs decoded */
+int mjx_batch_image_info(const mjx_batch *b, size_t i, uint32_t *width, uint32_t *height, uint32_t *blocks_per_mcu,
+                         uint32_t *mcus);
+/* device pointer + byte size of image i's packed RGB (valid until mjx_batch_free) */
+int mjx_batch_rgb_device(const mjx_batch *b, size_t i, void **dev_ptr, size_t *bytes);
+/* copy image i's RGB to host memory (width*height*3 bytes) */
+int mjx_batch_copy_rgb(mjx_batch *b, size_t i, uint8_t *host_rgb);
+/* T0 stream of image i (needs keep_coefs, or i inside the last decoded chunk): blocks in decode (MCU-interleaved)
+ * order, 64 x i16 zig-zag, DC prediction applied, before dequantisation.  `cap_blocks` = capacity of host buffer. */
+int mjx_batch_copy_coefs(mjx_batch *b, size_t i, int16_t *host_coefs, size_t cap_blocks, size_t *nblocks);
+
+/* bytes used to compute roofline figures: sum of de-stuffed entropy bytes and of RGB bytes over valid images */
+int mjx_batch_bytes(const mjx_batch *b, uint64_t *scan_bytes, uint64_t *rgb_bytes, uint64_t *coef_bytes,
+                    uint64_t *pixels);
+
+/* accumulated kernel time (ms) and launch count per kernel class since the last reset (profiling enabled) */
+enum {
+    MJX_K_CLEAR = 0,      /* zero-fill of the coefficient chunk */
+    MJX_K_HUFF_SYNC = 1,  /* speculative decode + intra-workgroup synchronisation */
+    MJX_K_HUFF_FIX = 2,   /* inter-workgroup synchronisation passes */
+    MJX_K_HUFF_SCAN = 3,  /* block-count prefix sums */
+    MJX_K_HUFF_WRITE = 4, /* final decode writing coefficients */
+    MJX_K_DC_SCAN = 5,    /* DC prediction prefix sums */
+    MJX_K_IDCT_COLOR = 6, /* dequant + IDCT + upsample + colour + RGB store */
+    MJX_K_COUNT = 7
+};
+int mjx_batch_kernel_ms(mjx_batch *b, double ms[MJX_K_COUNT], uint64_t launches[MJX_K_COUNT], int reset);
+
+/* SURVEY s8(b) convenience form: create + decode + wait; rgb_dev[i] receives device pointers owned by *out. */
+int mjx_decode_scans(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t n, const mjx_opts *opts,
+                     uint8_t **rgb_dev, int *status, mjx_batch **out);
+
+const char *mjx_strerror(int code);
+/* library build info: "mjx <version> gfx950 subseq=<bits> ..." */
+const char *mjx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,138 @@
+// mjx_huff.h -- per-lane baseline-JPEG entropy decode, shared by the HIP kernels (device) and
+// the CPU emulation harness in tests/emul (host).  No wave/workgroup cooperation lives here:
+// one call decodes one fixed-size *subsequence* of the bitstream from a given entry state.
+//
+// What it replaces in the reference (src/jpeg/huffman.rs): next_code (211-227) becomes a
+// two-level table lookup, read_n_bits + value_correction (198-208, 256-268) become a shift and a
+// branch-free EXTEND, next_block's EOB / ZRL / run clamps (164-189) are folded into the table so
+// the symbol step is uniform:  pos = min(z + run, 63); coef[pos] = value; z = pos + 1.
+//   * EOB (0x00)  -> run = 63, size 0 : jumps to the end of the block (huffman.rs:164-169)
+//   * ZRL (0xf0)  -> run = 15, size 0 : min(z+15,63)+1 == min(z+16,64)   (huffman.rs:170-175)
+//   * r/s         -> run = r,  size s : min(r, 64-len-1) zeros then the value (huffman.rs:183-189)
+//   * DC symbol s -> run = 0,  size s at z == 0 (huffman.rs:151-159)
+#ifndef MJX_HUFF_H
+#define MJX_HUFF_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MJX_HD __host__ __device__ __forceinline__
+#else
+#define MJX_HD inline
+#endif
+
+namespace mjx {
+
+constexpr int kSubseqBytes = 128;              // bytes of scan per lane
+constexpr int kSubseqBits = kSubseqBytes * 8;
+constexpr int kLutPrimaryBits = 9;
+constexpr int kLutPrimarySize = 1 << kLutPrimaryBits;
+constexpr int kMaxBlocksPerMcu = 12;           // 3 components x (2x2)
+
+// ---- decode table entry (uint16) ---------------------------------------------------------------
+//  direct : bit15 = 0 | size[14:11] | run[10:5] | len[4:0]      (len = total code length, 1..16)
+//  link   : bit15 = 1 | sub-table offset[14:4] (entries, relative to the table base) | nbits[3:0]
+//  invalid: 0
+constexpr uint16_t kLutLinkBit = 0x8000;
+MJX_HD constexpr uint16_t lut_direct(unsigned len, unsigned run, unsigned size)
+{
+    return uint16_t((size << 11) | (run << 5) | len);
+}
+MJX_HD constexpr uint16_t lut_link(unsigned offset, unsigned nbits) { return uint16_t(0x8000u | (offset << 4) | nbits); }
+
+// ---- per-subsequence synchronisation state (8 bytes, one naturally aligned store) ----------------
+struct SubseqState {
+    uint32_t p;    // bit position (relative to the image's scan) of the first symbol at/after the boundary
+    uint16_t n;    // blocks completed inside the subsequence
+    uint8_t z;     // zig-zag index of the next coefficient (0 = next symbol is a DC code)
+    uint8_t c;     // block index inside the MCU (selects the DC/AC table pair)
+};
+MJX_HD bool same_entry(const SubseqState &a, const SubseqState &b) { return a.p == b.p && a.z == b.z && a.c == b.c; }
+
+// Per-image constants the lane needs (lives in LDS on the device).
+struct HuffImage {
+    uint32_t blktab[kMaxBlocksPerMcu];   // per block-in-MCU: dc table base | ac table base << 16 (entry offsets)
+    uint32_t bpm;                        // blocks per MCU
+    uint32_t total_bits;                 // scan_len * 8
+    uint32_t total_blocks;               // MCUs to decode * bpm
+    uint32_t nsub;                       // ceil(total_bits / kSubseqBits)
+};
+
+// A sink that discards everything (synchronisation passes).
+struct NullSink {
+    MJX_HD void dc(uint32_t, int) const {}
+    MJX_HD void ac(uint32_t, unsigned, int) const {}
+    MJX_HD void bad_code(uint32_t) const {}
+};
+
+// Decode from `entry` until the bit position reaches `end_bit`.
+//   BitSrc::be32(i)  -> big-endian dword i of the image's scan (0xAAAAAAAA past the end, huffman.rs:236-246)
+//   lut              -> the image's decode tables
+//   WRITE            -> emit coefficients for blocks < img.total_blocks through `sink`, starting at block `blk`
+template <bool WRITE, class BitSrc, class Sink>
+MJX_HD SubseqState decode_subseq(const BitSrc &bits, const uint16_t *lut, const HuffImage &img, SubseqState entry,
+                                 uint32_t end_bit, uint32_t blk, Sink &sink)
+{
+    uint32_t p = entry.p, z = entry.z, c = entry.c, n = 0;
+    uint32_t tab = img.blktab[c];
+    uint32_t wi = p >> 5, o = p & 31;
+    uint32_t w0 = bits.be32(wi), w1 = bits.be32(wi + 1);
+    while (p < end_bit) {
+        if (WRITE && blk >= img.total_blocks) break;
+        const uint32_t w = o ? ((w0 << o) | (w1 >> (32 - o))) : w0;               // next 32 bits of the stream
+        const uint32_t base = z ? (tab >> 16) : (tab & 0xffff);
+        uint32_t e = lut[base + (w >> (32 - kLutPrimaryBits))];
+        if (e & kLutLinkBit) {
+            const uint32_t nb = e & 15, off = (e >> 4) & 0x7ff;
+            e = lut[base + off + ((w << kLutPrimaryBits) >> (32 - nb))];
+        }
+        uint32_t len = e & 31;
+        const uint32_t run = (e >> 5) & 63, size = (e >> 11) & 15;
+        if (len == 0) {                                                           // no code matches (huffman.rs:156/162)
+            if (WRITE) sink.bad_code(blk);
+            len = 1;
+        }
+        const uint32_t v = w << len;                                              // value bits, left aligned
+        const uint32_t vb = (v >> 1) >> (31 - size);                              // size == 0 -> 0
+        const int32_t val = int32_t(vb) - int32_t(((1u << size) - 1u) & ((v >> 31) - 1u));   // EXTEND, T.81 F.2
+        uint32_t pos = z + run;
+        pos = pos > 63 ? 63 : pos;
+        if (WRITE) {
+            if (z == 0) sink.dc(blk, val);
+            else if (size) sink.ac(blk, pos, val);
+        }
+        z = pos + 1;
+        if (z == 64) {
+            z = 0;
+            c = (c + 1 == img.bpm) ? 0 : c + 1;
+            tab = img.blktab[c];
+            n++;
+            blk++;
+        }
+        const uint32_t adv = len + size;
+        p += adv;
+        o += adv;
+        if (o >= 32) {
+            o -= 32;
+            wi++;
+            w0 = w1;
+            w1 = bits.be32(wi + 1);
+        }
+    }
+    SubseqState s;
+    s.p = p;
+    s.n = uint16_t(n);
+    s.z = uint8_t(z);
+    s.c = uint8_t(c);
+    return s;
+}
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+// ---- host-side table construction (mjx_lut.cpp) ---------------------------------------------------
+// Appends the two-level decode table for one DHT table to `out` (uint16 entries) and returns its size in
+// entries, or a negative MJX_ERR_* code.  `is_dc`: symbols are DC size categories (run = 0).
+int build_decode_table(const uint8_t bits[16], const uint8_t *vals, bool is_dc, uint16_t *out, int cap);
+#endif
+
+}   // namespace mjx
+#endif

@@ -1,0 +1,83 @@
+// mjx_lut.cpp -- host-side construction of the two-level Huffman decode tables.
+//
+// Replaces HuffmanTable::from_size_data_tables / make_code_table (reference src/jpeg/huffman.rs:37-98):
+// canonical codes are assigned exactly as T.81 Figure C.2 does (code <<= 1 per length step, +1 per symbol);
+// instead of a sorted Vec<HuffmanCode> searched linearly per length (huffman.rs:60-76, 211-227) the codes are
+// expanded into a 2^9-entry primary table plus small sub-tables for longer codes, with the symbol's
+// run / size already decoded and the reference's EOB / ZRL behaviour folded in (see mjx_huff.h).
+#include "mjx.h"
+#include "mjx_huff.h"
+
+#include <cstring>
+
+namespace mjx {
+
+static uint16_t entry_for_symbol(unsigned len, uint8_t sym, bool is_dc)
+{
+    if (is_dc) {
+        if (sym > 15) return 0;                      // read_n_bits asserts n <= 16 (huffman.rs:202); 16 is unusable
+        return lut_direct(len, 0, sym);
+    }
+    const unsigned r = sym >> 4, s = sym & 15;
+    if (sym == 0x00) return lut_direct(len, 63, 0);  // EOB
+    return lut_direct(len, r, s);                    // includes ZRL (r = 15, s = 0) and the degenerate r/0 symbols
+}
+
+int build_decode_table(const uint8_t bits[16], const uint8_t *vals, bool is_dc, uint16_t *out, int cap)
+{
+    // canonical code assignment
+    struct Code { uint16_t code; uint8_t len, sym; };
+    Code codes[256];
+    int ncodes = 0;
+    unsigned code = 0;
+    for (int l = 1; l <= 16; l++) {
+        for (int k = 0; k < bits[l - 1]; k++) {
+            if (ncodes >= 256) return -MJX_ERR_BAD_HUFFMAN;
+            if (code >= (1u << l)) return -MJX_ERR_BAD_HUFFMAN;          // over-subscribed
+            codes[ncodes] = Code{uint16_t(code), uint8_t(l), vals[ncodes]};
+            ncodes++;
+            code++;
+        }
+        code <<= 1;
+    }
+    if (ncodes == 0) return -MJX_ERR_BAD_HUFFMAN;
+    if (cap < kLutPrimarySize) return -MJX_ERR_NOMEM;
+    std::memset(out, 0, sizeof(uint16_t) * kLutPrimarySize);
+    int used = kLutPrimarySize;
+
+    // longest code under each primary prefix that needs a sub-table
+    uint8_t maxlen[kLutPrimarySize];
+    std::memset(maxlen, 0, sizeof maxlen);
+    for (int i = 0; i < ncodes; i++) {
+        const Code &c = codes[i];
+        if (c.len > kLutPrimaryBits) {
+            const unsigned prefix = c.code >> (c.len - kLutPrimaryBits);
+            if (c.len > maxlen[prefix]) maxlen[prefix] = c.len;
+        }
+    }
+    for (int i = 0; i < ncodes; i++) {
+        const Code &c = codes[i];
+        const uint16_t e = entry_for_symbol(c.len, c.sym, is_dc);
+        if (c.len <= kLutPrimaryBits) {
+            const unsigned first = unsigned(c.code) << (kLutPrimaryBits - c.len), count = 1u << (kLutPrimaryBits - c.len);
+            for (unsigned k = 0; k < count; k++) out[first + k] = e;
+        } else {
+            const unsigned prefix = c.code >> (c.len - kLutPrimaryBits);
+            const unsigned nb = maxlen[prefix] - kLutPrimaryBits;        // 1..7
+            if (!(out[prefix] & kLutLinkBit)) {
+                if (used + (1 << nb) > cap || used > 0x7ff) return -MJX_ERR_NOMEM;
+                out[prefix] = lut_link(unsigned(used), nb);
+                std::memset(out + used, 0, sizeof(uint16_t) << nb);
+                used += 1 << nb;
+            }
+            const unsigned sub = (out[prefix] >> 4) & 0x7ff;
+            const unsigned rest_len = c.len - kLutPrimaryBits;
+            const unsigned rest = c.code & ((1u << rest_len) - 1);
+            const unsigned first = rest << (nb - rest_len), count = 1u << (nb - rest_len);
+            for (unsigned k = 0; k < count; k++) out[sub + first + k] = e;
+        }
+    }
+    return used;
+}
+
+}   // namespace mjx

@@ -1,0 +1,115 @@
+// mjx_plan.cpp -- see mjx_plan.h.
+#include "mjx_plan.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace mjx {
+
+const uint8_t kZigZag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                             41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p)
+{
+    p = ImagePlan{};
+    auto fail = [&](int code) { p.status = code; return code; };
+    if (!d.scan) return fail(MJX_ERR_INVALID_ARG);
+    if (d.ncomp != 1 && d.ncomp != 3) return fail(MJX_ERR_UNSUPPORTED_FORMAT);     // decoder.rs:328-330
+    if (d.width == 0 || d.height == 0) return fail(MJX_ERR_REF_PANIC);             // x_factor division by zero
+    if (d.scan_len < 4) return fail(MJX_ERR_TRUNCATED);                            // huffman.rs:127-128 data[0..4]
+    if (d.scan_len >= (size_t(1) << 28)) return fail(MJX_ERR_UNSUPPORTED_FORMAT);  // bit positions are 32 bit
+    p.width = d.width;
+    p.height = d.height;
+    p.ncomp = d.ncomp;
+    p.layout = opts.layout;
+    p.scan = d.scan;
+    p.scan_len = d.scan_len;
+    for (uint32_t c = 0; c < p.ncomp; c++) {
+        const mjx_comp &k = d.comp[c];
+        if (k.h < 1 || k.h > 2 || k.v < 1 || k.v > 2) return fail(MJX_ERR_UNSUPPORTED_FORMAT);   // mod.rs:275-277
+        if (k.tq > 3 || !(d.qt_present & (1u << k.tq))) return fail(MJX_ERR_MISSING_TABLE);      // decoder.rs:222-225
+        if (k.td > 3 || !(d.dc_present & (1u << k.td))) return fail(MJX_ERR_MISSING_TABLE);      // decoder.rs:158-160
+        if (k.ta > 3 || !(d.ac_present & (1u << k.ta))) return fail(MJX_ERR_MISSING_TABLE);      // decoder.rs:154-156
+        p.h[c] = k.h;
+        p.v[c] = k.v;
+        p.tq[c] = k.tq;
+    }
+    // A single-component scan is non-interleaved in the standard: one block per MCU whatever SOF0 says.
+    // The reference keeps h*v blocks per "MCU" (decoder.rs:200-201), which REF_COMPAT reproduces.
+    if (p.ncomp == 1 && p.layout == MJX_LAYOUT_STANDARD) p.h[0] = p.v[0] = 1;
+    p.hmax = p.vmax = 1;
+    for (uint32_t c = 0; c < p.ncomp; c++) {
+        if (p.h[c] > p.hmax) p.hmax = p.h[c];
+        if (p.v[c] > p.vmax) p.vmax = p.v[c];
+    }
+    for (uint32_t c = 0; c < p.ncomp; c++)
+        if (p.hmax % p.h[c] || p.vmax % p.v[c]) return fail(MJX_ERR_UNSUPPORTED_FORMAT);
+    p.bpm = 0;
+    for (uint32_t c = 0; c < p.ncomp; c++)
+        for (uint32_t by = 0; by < p.v[c]; by++)
+            for (uint32_t bx = 0; bx < p.h[c]; bx++) {
+                p.blk_comp[p.bpm] = uint8_t(c);
+                p.blk_bx[p.bpm] = uint8_t(bx);
+                p.blk_by[p.bpm] = uint8_t(by);
+                p.bpm++;
+            }
+    p.mcux = (p.width + 8 * p.hmax - 1) / (8 * p.hmax);
+    p.mcuy = (p.height + 8 * p.vmax - 1) / (8 * p.vmax);
+    if (p.layout == MJX_LAYOUT_REF_COMPAT) {
+        const uint64_t nb = uint64_t((p.width + 7) / 8) * ((p.height + 7) / 8);    // decoder.rs:164-166
+        const uint64_t f = uint64_t(p.hmax) * p.vmax;
+        p.nmcu = uint32_t((nb + f - 1) / f);                                       // decoder.rs:191-192 (Q2)
+    } else {
+        p.nmcu = p.mcux * p.mcuy;
+    }
+
+    // decode tables: each distinct (class, slot) used by the scan is built once
+    int dc_base[4] = {-1, -1, -1, -1}, ac_base[4] = {-1, -1, -1, -1};
+    p.lut.clear();
+    uint16_t tmp[kLutPrimarySize + 2048];
+    auto add_table = [&](const mjx_hufftab &t, bool is_dc) -> int {
+        const int n = build_decode_table(t.bits, t.vals, is_dc, tmp, int(sizeof tmp / sizeof tmp[0]));
+        if (n < 0) return n;
+        const int base = int(p.lut.size());
+        p.lut.insert(p.lut.end(), tmp, tmp + n);
+        return base;
+    };
+    for (uint32_t c = 0; c < p.ncomp; c++) {
+        const mjx_comp &k = d.comp[c];
+        if (dc_base[k.td] < 0) {
+            const int b = add_table(d.dc[k.td], true);
+            if (b < 0) return fail(-b);
+            dc_base[k.td] = b;
+        }
+        if (ac_base[k.ta] < 0) {
+            const int b = add_table(d.ac[k.ta], false);
+            if (b < 0) return fail(-b);
+            ac_base[k.ta] = b;
+        }
+    }
+    if (p.lut.size() > 0xffff) return fail(MJX_ERR_BAD_HUFFMAN);
+    while (p.lut.size() % 8) p.lut.push_back(0);                                    // 16-byte granules for staging
+    std::memset(&p.himg, 0, sizeof p.himg);
+    for (uint32_t b = 0; b < p.bpm; b++) {
+        const mjx_comp &k = d.comp[p.blk_comp[b]];
+        p.himg.blktab[b] = uint32_t(dc_base[k.td]) | (uint32_t(ac_base[k.ta]) << 16);
+    }
+    p.himg.bpm = p.bpm;
+    p.himg.total_bits = uint32_t(p.scan_len * 8);
+    p.himg.total_blocks = p.nmcu * p.bpm;
+    p.himg.nsub = (p.himg.total_bits + kSubseqBits - 1) / kSubseqBits;
+
+    // dequantisation x IDCT prescale, zig-zag order (reference: decoder.rs:230-232 multiplies by the raw table;
+    // the AAN row/column factors and the 1/8 are folded in here so the kernel does one multiply per coefficient)
+    double aan[8];
+    for (int k = 0; k < 8; k++) aan[k] = k == 0 ? 1.0 : std::cos(k * 3.14159265358979323846 / 16.0) * std::sqrt(2.0);
+    for (uint32_t c = 0; c < p.ncomp; c++)
+        for (int k = 0; k < 64; k++) {
+            const int nat = kZigZag[k];
+            p.qmult[c][k] = float(double(d.qt[p.tq[c]][k]) * aan[nat >> 3] * aan[nat & 7] / 8.0);
+        }
+    return p.status;
+}
+
+}   // namespace mjx

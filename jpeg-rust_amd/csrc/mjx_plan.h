@@ -1,0 +1,41 @@
+// mjx_plan.h -- host-side per-image decode plan: geometry (reference src/jpeg/decoder.rs:164-192,
+// 239-250), decode tables, dequantisation multipliers.  Shared by the device API (mjx_device.hip) and the
+// CPU emulation harness (tests/emul).
+#ifndef MJX_PLAN_H
+#define MJX_PLAN_H
+
+#include "mjx.h"
+#include "mjx_huff.h"
+
+#include <vector>
+
+namespace mjx {
+
+struct ImagePlan {
+    int status = MJX_OK;
+    uint32_t width = 0, height = 0;
+    uint32_t ncomp = 0;
+    uint32_t h[3] = {1, 1, 1}, v[3] = {1, 1, 1};   // effective sampling factors (scan order)
+    uint32_t tq[3] = {0, 0, 0};
+    uint32_t hmax = 1, vmax = 1;
+    uint32_t bpm = 0;                              // blocks per MCU
+    uint32_t mcux = 0, mcuy = 0;                   // MCU grid of the standard layout
+    uint32_t nmcu = 0;                             // MCUs to decode (Q2 count in REF_COMPAT)
+    uint32_t layout = MJX_LAYOUT_STANDARD;
+    uint8_t blk_comp[kMaxBlocksPerMcu] = {0};      // block position in MCU -> component
+    uint8_t blk_bx[kMaxBlocksPerMcu] = {0};        //                       -> block column inside the MCU
+    uint8_t blk_by[kMaxBlocksPerMcu] = {0};        //                       -> block row inside the MCU
+    HuffImage himg{};
+    std::vector<uint16_t> lut;                     // all decode tables of the image, concatenated
+    float qmult[3][64];                            // per component, zig-zag order: q[k] * idct prescale
+    const uint8_t *scan = nullptr;
+    size_t scan_len = 0;
+};
+
+// Validates `d` and fills `plan`.  Returns plan.status.
+int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &plan);
+
+extern const uint8_t kZigZag[64];                  // decoder.rs:404-407 ZIGZAG_INDICES
+
+}   // namespace mjx
+#endif
