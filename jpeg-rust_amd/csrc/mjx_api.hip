@@ -1,0 +1,693 @@
+// mjx_api.hip -- host side of the C ABI: context, batch planning / upload, chunked launch sequence.
+//
+// Replaces the JPEGDecoder builder and decode() driver (reference src/jpeg/decoder.rs:55-162) and the
+// hand-off in JPEGImage::parse (src/jpeg/mod.rs:388-417).  One context = one HIP device + one stream; a batch owns
+// every device buffer of its images; mjx_batch_decode only enqueues kernels (no allocation, no host sync).
+#include <hip/hip_runtime.h>
+
+#include "mjx.h"
+#include "mjx_kernels.h"
+#include "mjx_plan.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+using namespace mjx;
+
+#define HIPOK(expr)                                   \
+    do {                                              \
+        if ((expr) != hipSuccess) {                   \
+            (void)hipGetLastError();                  \
+            return MJX_ERR_DEVICE;                    \
+        }                                             \
+    } while (0)
+
+struct mjx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool profiling = false;
+    int fix_passes = 2;            // inter-workgroup passes enqueued up front (the last one must count 0 mismatches)
+};
+
+namespace {
+
+struct ImageInfo {
+    int status = MJX_OK;
+    uint32_t width = 0, height = 0, bpm = 0, nmcu = 0;
+    uint64_t nblocks = 0;
+    uint64_t rgb_off = 0, rgb_bytes = 0;
+    uint64_t coef_off = 0;         // blocks, inside the coefficient buffer of its chunk (or of the batch with keep_coefs)
+    uint64_t scan_len = 0;
+    uint32_t chunk = 0;
+};
+
+struct Chunk {
+    size_t first = 0, count = 0;
+    uint32_t nsub = 0;             // subsequences in the chunk
+    uint64_t blocks = 0;           // coefficient blocks in the chunk
+    uint64_t coef_base = 0;        // first block of the chunk inside d_coef (keep_coefs) or 0
+    uint32_t max_wg = 0, max_tiles = 0, lut_cap = 0, max_tile_blocks = 0;
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+    int kind;
+};
+
+}   // namespace
+
+struct mjx_batch {
+    mjx_ctx *ctx = nullptr;
+    mjx_opts opts{};
+    std::vector<ImageInfo> info;
+    std::vector<DevImage> himages;
+    std::vector<Chunk> chunks;
+    DevImage *d_images = nullptr;
+    uint8_t *d_scan = nullptr;
+    size_t scan_pool_bytes = 0;
+    uint16_t *d_lut = nullptr;
+    float *d_qm = nullptr;
+    SubseqState *d_entry = nullptr, *d_exit = nullptr;
+    uint32_t *d_blkbase = nullptr;
+    int16_t *d_coef = nullptr, *d_dc = nullptr;
+    uint8_t *d_rgb = nullptr;
+    size_t rgb_pool_bytes = 0;
+    int *d_status = nullptr;
+    uint32_t *d_mismatch = nullptr;     // [chunks][kMaxFix]
+    uint32_t *h_mismatch = nullptr;     // pinned mirror
+    size_t huff_lds = 0, idct_lds = 0;
+    bool decoded_entropy = false;
+    int last_chunk_resident = -1;
+    uint64_t scan_bytes = 0, rgb_bytes = 0, coef_bytes = 0, pixels = 0;
+    // profiling
+    std::vector<EventPair> events;
+    std::vector<EventPair> event_pool;
+    double ms[MJX_K_COUNT] = {0};
+    uint64_t launches[MJX_K_COUNT] = {0};
+};
+
+namespace {
+
+constexpr int kMaxFix = 16;
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+void release(mjx_batch *b)
+{
+    if (!b) return;
+    if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    for (auto &e : b->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto &e : b->event_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    (void)hipFree(b->d_images); (void)hipFree(b->d_scan); (void)hipFree(b->d_lut); (void)hipFree(b->d_qm);
+    (void)hipFree(b->d_entry); (void)hipFree(b->d_exit); (void)hipFree(b->d_blkbase);
+    (void)hipFree(b->d_coef); (void)hipFree(b->d_dc); (void)hipFree(b->d_rgb); (void)hipFree(b->d_status);
+    (void)hipFree(b->d_mismatch);
+    if (b->h_mismatch) (void)hipHostFree(b->h_mismatch);
+    delete b;
+}
+
+// Fills the DevImage of image i from its plan (offsets are assigned by the caller).
+void fill_dev_image(const ImagePlan &p, DevImage &d)
+{
+    std::memset(&d, 0, sizeof d);
+    d.himg = p.himg;
+    d.width = p.width; d.height = p.height; d.mcux = p.mcux; d.mcuy = p.mcuy; d.nmcu = p.nmcu;
+    d.ncomp = p.ncomp; d.bpm = p.bpm; d.hmax = p.hmax; d.vmax = p.vmax;
+    d.valid = 1;
+    uint32_t t = tile_mcus(p.bpm, p.hmax), l2 = 0;
+    while ((1u << (l2 + 1)) <= t) l2++;
+    d.log2_tile = l2;
+    std::memcpy(d.blk_comp, p.blk_comp, sizeof d.blk_comp);
+    std::memcpy(d.blk_bx, p.blk_bx, sizeof d.blk_bx);
+    std::memcpy(d.blk_by, p.blk_by, sizeof d.blk_by);
+    uint32_t first = 0;
+    for (uint32_t c = 0; c < 3; c++) {
+        d.ch[c] = uint8_t(c < p.ncomp ? p.h[c] : 1);
+        d.cv[c] = uint8_t(c < p.ncomp ? p.v[c] : 1);
+        d.cfirst[c] = uint8_t(first);
+        if (c < p.ncomp) first += p.h[c] * p.v[c];
+    }
+}
+
+// Splits the batch into chunks and assigns chunk-relative offsets (subsequence arrays, coefficient blocks).
+void plan_chunks(mjx_batch *b)
+{
+    const size_t n = b->info.size();
+    const bool keep = b->opts.keep_coefs != 0;
+    size_t per_chunk = b->opts.chunk_images ? b->opts.chunk_images : 128;
+    per_chunk = std::min<size_t>(per_chunk, 65535);
+    const uint64_t kMaxChunkBlocks = (uint64_t(6) << 30) / 128;          // 6 GiB of coefficients per chunk
+    b->chunks.clear();
+    uint64_t coef_running = 0;
+    size_t i = 0;
+    while (i < n) {
+        Chunk c;
+        c.first = i;
+        c.coef_base = keep ? coef_running : 0;
+        while (i < n && c.count < per_chunk) {
+            const ImageInfo &inf = b->info[i];
+            if (c.count > 0 && c.blocks + inf.nblocks > kMaxChunkBlocks) break;
+            DevImage &d = b->himages[i];
+            if (inf.status == MJX_OK) {
+                d.sub_off = c.nsub;
+                d.coef_off = c.coef_base + c.blocks;
+                b->info[i].coef_off = d.coef_off;
+                c.nsub += d.himg.nsub;
+                c.blocks += inf.nblocks;
+                c.max_wg = std::max<uint32_t>(c.max_wg, (d.himg.nsub + kWgLanes - 1) / kWgLanes);
+                const uint32_t T = 1u << d.log2_tile;
+                c.max_tiles = std::max<uint32_t>(c.max_tiles, (d.nmcu + T - 1) / T);
+                c.max_tile_blocks = std::max<uint32_t>(c.max_tile_blocks, T * d.bpm);
+                c.lut_cap = std::max<uint32_t>(c.lut_cap, d.lut_n);
+            }
+            b->info[i].chunk = uint32_t(b->chunks.size());
+            c.count++;
+            i++;
+        }
+        coef_running += c.blocks;
+        b->chunks.push_back(c);
+    }
+}
+
+int allocate_work_buffers(mjx_batch *b)
+{
+    uint32_t max_nsub = 1;
+    uint64_t max_blocks = 1, total_blocks = 0;
+    uint32_t lut_cap = 8, max_tile_blocks = 1;
+    for (const Chunk &c : b->chunks) {
+        max_nsub = std::max(max_nsub, c.nsub);
+        max_blocks = std::max(max_blocks, c.blocks);
+        total_blocks += c.blocks;
+        lut_cap = std::max(lut_cap, c.lut_cap);
+        max_tile_blocks = std::max(max_tile_blocks, c.max_tile_blocks);
+    }
+    const uint64_t coef_blocks = b->opts.keep_coefs ? std::max<uint64_t>(total_blocks, 1) : max_blocks;
+    HIPOK(hipMalloc(&b->d_entry, size_t(max_nsub) * sizeof(SubseqState)));
+    HIPOK(hipMalloc(&b->d_exit, size_t(max_nsub) * sizeof(SubseqState)));
+    HIPOK(hipMalloc(&b->d_blkbase, size_t(max_nsub) * sizeof(uint32_t)));
+    HIPOK(hipMalloc(&b->d_coef, size_t(coef_blocks) * 128));
+    HIPOK(hipMalloc(&b->d_dc, size_t(coef_blocks) * sizeof(int16_t) + 16));
+    HIPOK(hipMalloc(&b->d_rgb, std::max<size_t>(b->rgb_pool_bytes, 16)));
+    HIPOK(hipMalloc(&b->d_status, std::max<size_t>(b->info.size(), 1) * sizeof(int)));
+    HIPOK(hipMemset(b->d_status, 0, std::max<size_t>(b->info.size(), 1) * sizeof(int)));
+    const size_t mm = std::max<size_t>(b->chunks.size(), 1) * kMaxFix * sizeof(uint32_t);
+    HIPOK(hipMalloc(&b->d_mismatch, mm));
+    HIPOK(hipHostMalloc(reinterpret_cast<void **>(&b->h_mismatch), mm, hipHostMallocDefault));
+    std::memset(b->h_mismatch, 0, mm);
+    b->huff_lds = huff_lds_bytes(lut_cap);
+    b->idct_lds = idct_lds_bytes(max_tile_blocks);
+    if (b->huff_lds > 160 * 1024 || b->idct_lds > 160 * 1024) return MJX_ERR_UNSUPPORTED_FORMAT;
+    if (configure_kernels(b->huff_lds, b->idct_lds) != 0) { (void)hipGetLastError(); return MJX_ERR_DEVICE; }
+    return MJX_OK;
+}
+
+void prof_begin(mjx_batch *b, int kind)
+{
+    if (!b->ctx->profiling) return;
+    EventPair e;
+    if (!b->event_pool.empty()) { e = b->event_pool.back(); b->event_pool.pop_back(); }
+    else { (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); }
+    e.kind = kind;
+    (void)hipEventRecord(e.a, b->ctx->stream);
+    b->events.push_back(e);
+}
+void prof_end(mjx_batch *b)
+{
+    if (!b->ctx->profiling) return;
+    (void)hipEventRecord(b->events.back().b, b->ctx->stream);
+}
+
+// Enqueue one chunk.  `fix_passes` inter-workgroup passes are launched; the mismatch count of the last one is copied
+// to the pinned mirror and examined in mjx_batch_wait.  `phases` selects which parts of the entropy stage run
+// (the repair path of mjx_batch_wait continues fix passes without restarting the speculative decode).
+enum { PH_SYNC = 1, PH_FIX = 2, PH_TAIL = 4, PH_ENTROPY_ALL = 7 };
+int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned phases = PH_ENTROPY_ALL)
+{
+    const Chunk &c = b->chunks[ci];
+    if (c.count == 0 || c.nsub == 0) return MJX_OK;
+    hipStream_t st = b->ctx->stream;
+    const DevImage *imgs = b->d_images + c.first;
+    const uint32_t nimg = uint32_t(c.count);
+    int16_t *coef = b->d_coef;           // image coef_off values already include the chunk base
+    int16_t *dcb = b->d_dc;
+    fix_passes = std::min(fix_passes, kMaxFix);
+    if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_SYNC)) {
+        prof_begin(b, MJX_K_HUFF_SYNC);
+        launch_huff_sync(st, c.max_wg, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, c.lut_cap);
+        prof_end(b);
+    }
+    if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_FIX)) {
+        HIPOK(hipMemsetAsync(b->d_mismatch + ci * kMaxFix, 0, kMaxFix * sizeof(uint32_t), st));
+        if (c.max_wg > 1) {
+            for (int k = 0; k < fix_passes; k++) {
+                prof_begin(b, MJX_K_HUFF_FIX);
+                launch_huff_fix(st, c.max_wg, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, c.lut_cap,
+                                b->d_mismatch + ci * kMaxFix + k);
+                prof_end(b);
+            }
+            HIPOK(hipMemcpyAsync(b->h_mismatch + ci * kMaxFix, b->d_mismatch + ci * kMaxFix, kMaxFix * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, st));
+        }
+    }
+    if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_TAIL)) {
+        prof_begin(b, MJX_K_CLEAR);
+        HIPOK(hipMemsetAsync(coef + c.coef_base * 64, 0, size_t(c.blocks) * 128, st));
+        prof_end(b);
+        prof_begin(b, MJX_K_HUFF_SCAN);
+        launch_huff_scan(st, nimg, imgs, b->d_exit, b->d_blkbase);
+        prof_end(b);
+        prof_begin(b, MJX_K_HUFF_WRITE);
+        launch_huff_write(st, c.max_wg, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_blkbase, c.lut_cap, coef,
+                          dcb, b->d_status);
+        prof_end(b);
+        prof_begin(b, MJX_K_DC_SCAN);
+        launch_dc_scan(st, nimg, imgs, dcb);
+        prof_end(b);
+    }
+    if (stages & MJX_STAGE_PIXELS) {
+        prof_begin(b, MJX_K_IDCT_COLOR);
+        launch_idct_color(st, c.max_tiles, nimg, b->idct_lds, imgs, coef, dcb, b->d_qm, b->d_rgb);
+        prof_end(b);
+    }
+    HIPOK(hipGetLastError());
+    return MJX_OK;
+}
+
+void collect_events(mjx_batch *b)
+{
+    for (auto &e : b->events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            b->ms[e.kind] += ms;
+            b->launches[e.kind]++;
+        }
+        b->event_pool.push_back(e);
+    }
+    b->events.clear();
+}
+
+// Builds a batch from plans.  Scan bytes come from the plans' host pointers, or (src != nullptr) are copied on the
+// device from `src`'s pool, `times` repetitions of its images.
+int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opts &opts, const mjx_batch *src,
+                size_t times, mjx_batch **out, int *status)
+{
+    mjx_batch *b = new (std::nothrow) mjx_batch;
+    if (!b) return MJX_ERR_NOMEM;
+    b->ctx = ctx;
+    b->opts = opts;
+    const size_t nu = plans.size(), n = nu * times;
+    b->info.resize(n);
+    b->himages.resize(n);
+    // pools for the unique images
+    std::vector<uint64_t> scan_off(nu, 0);
+    std::vector<uint32_t> scan_padded(nu, 0), lut_off(nu, 0), lut_n(nu, 0);
+    size_t scan_pool = 0, lut_pool = 0;
+    for (size_t k = 0; k < nu; k++) {
+        if (plans[k].status != MJX_OK) continue;
+        scan_off[k] = scan_pool;
+        scan_padded[k] = uint32_t(align_up(plans[k].scan_len, 16) + 16);
+        scan_pool += scan_padded[k];
+        lut_off[k] = uint32_t(lut_pool);
+        lut_n[k] = uint32_t(plans[k].lut.size());
+        lut_pool += plans[k].lut.size();
+    }
+    scan_pool = align_up(std::max<size_t>(scan_pool, 16), 256);
+    b->scan_pool_bytes = scan_pool * times;
+    uint64_t rgb_pool = 0;
+    for (size_t i = 0; i < n; i++) {
+        const size_t k = i % nu, rep = i / nu;
+        const ImagePlan &p = plans[k];
+        ImageInfo &inf = b->info[i];
+        inf.status = p.status;
+        DevImage &d = b->himages[i];
+        std::memset(&d, 0, sizeof d);
+        d.status_idx = uint32_t(i);
+        if (p.status != MJX_OK) continue;
+        fill_dev_image(p, d);
+        d.status_idx = uint32_t(i);
+        d.scan_off = rep * scan_pool + scan_off[k];
+        d.scan_padded = scan_padded[k];
+        d.lut_off = lut_off[k];
+        d.lut_n = lut_n[k];
+        d.qm_off = uint32_t(k * 192);
+        inf.width = p.width; inf.height = p.height; inf.bpm = p.bpm; inf.nmcu = p.nmcu;
+        inf.nblocks = uint64_t(p.nmcu) * p.bpm;
+        inf.scan_len = p.scan_len;
+        inf.rgb_off = rgb_pool;
+        inf.rgb_bytes = uint64_t(p.width) * p.height * 3;
+        d.rgb_off = rgb_pool;
+        rgb_pool += align_up(inf.rgb_bytes, 256);
+        b->scan_bytes += p.scan_len;
+        b->rgb_bytes += inf.rgb_bytes;
+        b->coef_bytes += inf.nblocks * 128;
+        b->pixels += uint64_t(p.width) * p.height;
+    }
+    b->rgb_pool_bytes = rgb_pool;
+    plan_chunks(b);
+
+    int rc = MJX_OK;
+    auto dev = [&]() -> int {
+        HIPOK(hipSetDevice(ctx->device));
+        HIPOK(hipMalloc(&b->d_images, std::max<size_t>(n, 1) * sizeof(DevImage)));
+        HIPOK(hipMemcpy(b->d_images, b->himages.data(), n * sizeof(DevImage), hipMemcpyHostToDevice));
+        HIPOK(hipMalloc(&b->d_scan, b->scan_pool_bytes));
+        HIPOK(hipMalloc(&b->d_lut, std::max<size_t>(lut_pool, 8) * sizeof(uint16_t)));
+        HIPOK(hipMalloc(&b->d_qm, std::max<size_t>(nu, 1) * 192 * sizeof(float)));
+        if (src) {
+            if (src->scan_pool_bytes != scan_pool) return MJX_ERR_INVALID_ARG;
+            for (size_t rep = 0; rep < times; rep++)
+                HIPOK(hipMemcpy(b->d_scan + rep * scan_pool, src->d_scan, scan_pool, hipMemcpyDeviceToDevice));
+            HIPOK(hipMemcpy(b->d_lut, src->d_lut, std::max<size_t>(lut_pool, 8) * sizeof(uint16_t), hipMemcpyDeviceToDevice));
+            HIPOK(hipMemcpy(b->d_qm, src->d_qm, std::max<size_t>(nu, 1) * 192 * sizeof(float), hipMemcpyDeviceToDevice));
+        } else {
+            std::vector<uint8_t> hs(scan_pool, 0xaa);
+            std::vector<uint16_t> hl(std::max<size_t>(lut_pool, 8), 0);
+            std::vector<float> hq(std::max<size_t>(nu, 1) * 192, 0.f);
+            for (size_t k = 0; k < nu; k++) {
+                const ImagePlan &p = plans[k];
+                if (p.status != MJX_OK) continue;
+                std::memcpy(hs.data() + scan_off[k], p.scan, p.scan_len);
+                std::memcpy(hl.data() + lut_off[k], p.lut.data(), p.lut.size() * sizeof(uint16_t));
+                std::memcpy(hq.data() + k * 192, p.qmult, sizeof p.qmult);
+            }
+            HIPOK(hipMemcpy(b->d_scan, hs.data(), scan_pool, hipMemcpyHostToDevice));
+            HIPOK(hipMemcpy(b->d_lut, hl.data(), hl.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            HIPOK(hipMemcpy(b->d_qm, hq.data(), hq.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        return allocate_work_buffers(b);
+    };
+    rc = dev();
+    if (rc != MJX_OK) { release(b); return rc; }
+    if (status) for (size_t i = 0; i < n; i++) status[i] = b->info[i].status;
+    *out = b;
+    return MJX_OK;
+}
+
+std::mutex g_default_mu;
+mjx_ctx *g_default_ctx = nullptr;
+
+}   // namespace
+
+// ---- context -------------------------------------------------------------------------------------
+extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
+{
+    if (!out) return MJX_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return MJX_ERR_DEVICE; }
+    if (device < 0 || device >= ndev) return MJX_ERR_INVALID_ARG;
+    HIPOK(hipSetDevice(device));
+    mjx_ctx *c = new (std::nothrow) mjx_ctx;
+    if (!c) return MJX_ERR_NOMEM;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MJX_ERR_DEVICE; }
+    if (const char *e = std::getenv("MJX_FIX_PASSES")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= kMaxFix) c->fix_passes = v;
+    }
+    *out = c;
+    return MJX_OK;
+}
+
+extern "C" void mjx_ctx_destroy(mjx_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int mjx_ctx_set_profiling(mjx_ctx *ctx, int enable)
+{
+    if (!ctx) return MJX_ERR_INVALID_ARG;
+    ctx->profiling = enable != 0;
+    return MJX_OK;
+}
+
+// ---- batch ---------------------------------------------------------------------------------------
+extern "C" int mjx_batch_create(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t n, const mjx_opts *opts,
+                                mjx_batch **out, int *status)
+{
+    if (!ctx || !out || (!descs && n)) return MJX_ERR_INVALID_ARG;
+    *out = nullptr;
+    mjx_opts o{};
+    if (opts) o = *opts;
+    std::vector<ImagePlan> plans(n);
+    for (size_t i = 0; i < n; i++) plan_image(descs[i], o, plans[i]);
+    return build_batch(ctx, plans, o, nullptr, 1, out, status);
+}
+
+extern "C" int mjx_batch_tile(mjx_ctx *ctx, const mjx_batch *src, size_t times, mjx_batch **out)
+{
+    if (!ctx || !src || !out || times == 0) return MJX_ERR_INVALID_ARG;
+    *out = nullptr;
+    // rebuild light-weight plans from the source batch's device images (geometry only; tables stay on the device)
+    const size_t nu = src->info.size();
+    std::vector<ImagePlan> plans(nu);
+    for (size_t k = 0; k < nu; k++) {
+        ImagePlan &p = plans[k];
+        const DevImage &d = src->himages[k];
+        p.status = src->info[k].status;
+        if (p.status != MJX_OK) continue;
+        p.width = d.width; p.height = d.height; p.ncomp = d.ncomp; p.bpm = d.bpm; p.hmax = d.hmax; p.vmax = d.vmax;
+        p.mcux = d.mcux; p.mcuy = d.mcuy; p.nmcu = d.nmcu;
+        for (uint32_t c = 0; c < 3; c++) { p.h[c] = d.ch[c]; p.v[c] = d.cv[c]; }
+        std::memcpy(p.blk_comp, d.blk_comp, sizeof p.blk_comp);
+        std::memcpy(p.blk_bx, d.blk_bx, sizeof p.blk_bx);
+        std::memcpy(p.blk_by, d.blk_by, sizeof p.blk_by);
+        p.himg = d.himg;
+        p.lut.assign(d.lut_n, 0);                         // sizes only: the pool is copied device-to-device
+        p.scan = nullptr;
+        p.scan_len = src->info[k].scan_len;
+    }
+    return build_batch(ctx, plans, src->opts, src, times, out, nullptr);
+}
+
+extern "C" void mjx_batch_free(mjx_batch *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    release(b);
+}
+
+extern "C" int mjx_batch_decode(mjx_batch *b, unsigned stages)
+{
+    if (!b) return MJX_ERR_INVALID_ARG;
+    if (stages == 0) stages = MJX_STAGE_ALL;
+    HIPOK(hipSetDevice(b->ctx->device));
+    if ((stages & MJX_STAGE_PIXELS) && !(stages & MJX_STAGE_ENTROPY)) {
+        // stage-B-only sweep: the coefficients of every chunk must still be resident
+        if (!b->decoded_entropy || (!b->opts.keep_coefs && b->chunks.size() > 1)) return MJX_ERR_INVALID_ARG;
+    }
+    for (size_t ci = 0; ci < b->chunks.size(); ci++) {
+        const int rc = run_chunk(b, ci, stages, b->ctx->fix_passes);
+        if (rc != MJX_OK) return rc;
+    }
+    if (stages & MJX_STAGE_ENTROPY) {
+        b->decoded_entropy = true;
+        b->last_chunk_resident = int(b->chunks.size()) - 1;
+    }
+    return MJX_OK;
+}
+
+extern "C" int mjx_batch_wait(mjx_batch *b)
+{
+    if (!b) return MJX_ERR_INVALID_ARG;
+    HIPOK(hipSetDevice(b->ctx->device));
+    HIPOK(hipStreamSynchronize(b->ctx->stream));
+    collect_events(b);
+    // Fixed-point check: the last inter-workgroup pass of every chunk must have found nothing to repair.  If it did
+    // (pathological stream that stays unsynchronised across a whole 32 KiB workgroup span), redo that chunk with
+    // more passes until a pass counts zero.
+    if (b->decoded_entropy) {
+        for (size_t ci = 0; ci < b->chunks.size(); ci++) {
+            const Chunk &c = b->chunks[ci];
+            if (c.max_wg < 2) continue;
+            const int passes = std::min(b->ctx->fix_passes, kMaxFix);
+            if (b->h_mismatch[ci * kMaxFix + passes - 1] == 0) continue;
+            // repair: restart this chunk's synchronisation (its state arrays may have been reused by a later chunk),
+            // then keep running fix passes -- each one extends the verified prefix -- until one finds nothing.
+            HIPOK(hipMemsetAsync(b->d_status + c.first, 0, c.count * sizeof(int), b->ctx->stream));
+            int rc = run_chunk(b, ci, MJX_STAGE_ENTROPY, 0, PH_SYNC);
+            if (rc != MJX_OK) return rc;
+            for (;;) {
+                rc = run_chunk(b, ci, MJX_STAGE_ENTROPY, kMaxFix, PH_FIX);
+                if (rc != MJX_OK) return rc;
+                HIPOK(hipStreamSynchronize(b->ctx->stream));
+                if (b->h_mismatch[ci * kMaxFix + kMaxFix - 1] == 0) break;
+            }
+            rc = run_chunk(b, ci, MJX_STAGE_ALL, 0, PH_TAIL);
+            if (rc != MJX_OK) return rc;
+            HIPOK(hipStreamSynchronize(b->ctx->stream));
+            collect_events(b);
+            b->last_chunk_resident = int(ci);
+        }
+    }
+    std::vector<int> dev(b->info.size());
+    if (!dev.empty()) HIPOK(hipMemcpy(dev.data(), b->d_status, dev.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < dev.size(); i++)
+        if (b->info[i].status == MJX_OK && dev[i]) b->info[i].status = MJX_ERR_BAD_HUFFMAN;
+    return MJX_OK;
+}
+
+extern "C" size_t mjx_batch_size(const mjx_batch *b) { return b ? b->info.size() : 0; }
+
+extern "C" int mjx_batch_status(const mjx_batch *b, size_t i)
+{
+    if (!b || i >= b->info.size()) return MJX_ERR_INVALID_ARG;
+    return b->info[i].status;
+}
+
+extern "C" int mjx_batch_image_info(const mjx_batch *b, size_t i, uint32_t *width, uint32_t *height,
+                                    uint32_t *blocks_per_mcu, uint32_t *mcus)
+{
+    if (!b || i >= b->info.size()) return MJX_ERR_INVALID_ARG;
+    const ImageInfo &inf = b->info[i];
+    if (width) *width = inf.width;
+    if (height) *height = inf.height;
+    if (blocks_per_mcu) *blocks_per_mcu = inf.bpm;
+    if (mcus) *mcus = inf.nmcu;
+    return inf.status;
+}
+
+extern "C" int mjx_batch_rgb_device(const mjx_batch *b, size_t i, void **dev_ptr, size_t *bytes)
+{
+    if (!b || i >= b->info.size() || !dev_ptr) return MJX_ERR_INVALID_ARG;
+    const ImageInfo &inf = b->info[i];
+    if (inf.status != MJX_OK) { *dev_ptr = nullptr; if (bytes) *bytes = 0; return inf.status; }
+    *dev_ptr = b->d_rgb + inf.rgb_off;
+    if (bytes) *bytes = size_t(inf.rgb_bytes);
+    return MJX_OK;
+}
+
+extern "C" int mjx_batch_copy_rgb(mjx_batch *b, size_t i, uint8_t *host_rgb)
+{
+    if (!b || i >= b->info.size() || !host_rgb) return MJX_ERR_INVALID_ARG;
+    const ImageInfo &inf = b->info[i];
+    if (inf.status != MJX_OK) return inf.status;
+    HIPOK(hipSetDevice(b->ctx->device));
+    HIPOK(hipStreamSynchronize(b->ctx->stream));
+    HIPOK(hipMemcpy(host_rgb, b->d_rgb + inf.rgb_off, size_t(inf.rgb_bytes), hipMemcpyDeviceToHost));
+    return MJX_OK;
+}
+
+extern "C" int mjx_batch_copy_coefs(mjx_batch *b, size_t i, int16_t *host_coefs, size_t cap_blocks, size_t *nblocks)
+{
+    if (!b || i >= b->info.size() || !host_coefs) return MJX_ERR_INVALID_ARG;
+    const ImageInfo &inf = b->info[i];
+    if (inf.status != MJX_OK) return inf.status;
+    if (nblocks) *nblocks = size_t(inf.nblocks);
+    if (cap_blocks < inf.nblocks) return MJX_ERR_INVALID_ARG;
+    if (!b->decoded_entropy) return MJX_ERR_INVALID_ARG;
+    if (!b->opts.keep_coefs && int(inf.chunk) != b->last_chunk_resident) return MJX_ERR_INVALID_ARG;
+    HIPOK(hipSetDevice(b->ctx->device));
+    HIPOK(hipStreamSynchronize(b->ctx->stream));
+    HIPOK(hipMemcpy(host_coefs, b->d_coef + inf.coef_off * 64, size_t(inf.nblocks) * 128, hipMemcpyDeviceToHost));
+    std::vector<int16_t> dc(size_t(inf.nblocks));
+    HIPOK(hipMemcpy(dc.data(), b->d_dc + inf.coef_off, dc.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < dc.size(); k++) host_coefs[k * 64] = dc[k];
+    return MJX_OK;
+}
+
+extern "C" int mjx_batch_bytes(const mjx_batch *b, uint64_t *scan_bytes, uint64_t *rgb_bytes, uint64_t *coef_bytes,
+                               uint64_t *pixels)
+{
+    if (!b) return MJX_ERR_INVALID_ARG;
+    if (scan_bytes) *scan_bytes = b->scan_bytes;
+    if (rgb_bytes) *rgb_bytes = b->rgb_bytes;
+    if (coef_bytes) *coef_bytes = b->coef_bytes;
+    if (pixels) *pixels = b->pixels;
+    return MJX_OK;
+}
+
+extern "C" int mjx_batch_kernel_ms(mjx_batch *b, double ms[MJX_K_COUNT], uint64_t launches[MJX_K_COUNT], int reset)
+{
+    if (!b) return MJX_ERR_INVALID_ARG;
+    HIPOK(hipSetDevice(b->ctx->device));
+    HIPOK(hipStreamSynchronize(b->ctx->stream));
+    collect_events(b);
+    for (int k = 0; k < MJX_K_COUNT; k++) {
+        if (ms) ms[k] = b->ms[k];
+        if (launches) launches[k] = b->launches[k];
+        if (reset) { b->ms[k] = 0; b->launches[k] = 0; }
+    }
+    return MJX_OK;
+}
+
+extern "C" int mjx_decode_scans(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t n, const mjx_opts *opts,
+                                uint8_t **rgb_dev, int *status, mjx_batch **out)
+{
+    if (!out) return MJX_ERR_INVALID_ARG;
+    int rc = mjx_batch_create(ctx, descs, n, opts, out, nullptr);
+    if (rc != MJX_OK) return rc;
+    rc = mjx_batch_decode(*out, MJX_STAGE_ALL);
+    if (rc == MJX_OK) rc = mjx_batch_wait(*out);
+    if (rc != MJX_OK) { mjx_batch_free(*out); *out = nullptr; return rc; }
+    for (size_t i = 0; i < n; i++) {
+        if (status) status[i] = (*out)->info[i].status;
+        if (rgb_dev) {
+            void *p = nullptr;
+            (void)mjx_batch_rgb_device(*out, i, &p, nullptr);
+            rgb_dev[i] = static_cast<uint8_t *>(p);
+        }
+    }
+    return MJX_OK;
+}
+
+// ---- one-shot surface ------------------------------------------------------------------------------
+extern "C" int mjx_decode(const uint8_t *jpeg, size_t len, const mjx_opts *opts, mjx_image *out)
+{
+    if (!out) return MJX_ERR_INVALID_ARG;
+    out->width = out->height = 0;
+    out->rgb = nullptr;
+    mjx_scan_desc d;
+    int rc = mjx_parse(jpeg, len, opts, &d);
+    if (rc != MJX_OK) return rc;
+    mjx_ctx *ctx = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_default_mu);
+        if (!g_default_ctx) {
+            rc = mjx_ctx_create(0, &g_default_ctx);
+            if (rc != MJX_OK) { mjx_free_scan(&d); return rc; }
+        }
+        ctx = g_default_ctx;
+    }
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    mjx_batch *b = nullptr;
+    int st = MJX_OK;
+    rc = mjx_batch_create(ctx, &d, 1, opts, &b, &st);
+    mjx_free_scan(&d);
+    if (rc != MJX_OK) return rc;
+    if (st != MJX_OK) { mjx_batch_free(b); return st; }
+    rc = mjx_batch_decode(b, MJX_STAGE_ALL);
+    if (rc == MJX_OK) rc = mjx_batch_wait(b);
+    if (rc == MJX_OK) rc = mjx_batch_status(b, 0);
+    if (rc == MJX_OK) {
+        out->width = b->info[0].width;
+        out->height = b->info[0].height;
+        out->rgb = static_cast<uint8_t *>(std::malloc(size_t(b->info[0].rgb_bytes) + 1));
+        if (!out->rgb) rc = MJX_ERR_NOMEM;
+        else rc = mjx_batch_copy_rgb(b, 0, out->rgb);
+        if (rc != MJX_OK) { std::free(out->rgb); out->rgb = nullptr; }
+    }
+    mjx_batch_free(b);
+    return rc;
+}
+
+extern "C" void mjx_free_image(mjx_image *img)
+{
+    if (!img) return;
+    std::free(img->rgb);
+    img->rgb = nullptr;
+}
+
+extern "C" const char *mjx_version(void)
+{
+    return "mjx 0.1 gfx950 subseq_bits=1024 lut_primary_bits=9 wg_lanes=256";
+}

@@ -41,7 +41,7 @@ MJX_HD constexpr uint16_t lut_direct(unsigned len, unsigned run, unsigned size)
 MJX_HD constexpr uint16_t lut_link(unsigned offset, unsigned nbits) { return uint16_t(0x8000u | (offset << 4) | nbits); }
 
 // ---- per-subsequence synchronisation state (8 bytes, one naturally aligned store) ----------------
-struct SubseqState {
+struct alignas(8) SubseqState {
     uint32_t p;    // bit position (relative to the image's scan) of the first symbol at/after the boundary
     uint16_t n;    // blocks completed inside the subsequence
     uint8_t z;     // zig-zag index of the next coefficient (0 = next symbol is a DC code)

@@ -1,0 +1,68 @@
+// mjx_kernels.h -- device-side data layout shared by the kernel file and the host API.
+#ifndef MJX_KERNELS_H
+#define MJX_KERNELS_H
+
+#include "mjx_huff.h"
+
+namespace mjx {
+
+constexpr int kWgLanes = 256;                                   // lanes (= subsequences) per entropy workgroup
+constexpr int kWgScanBytes = kWgLanes * kSubseqBytes;           // 32 KiB of scan per workgroup
+constexpr int kWgScanDwords = kWgScanBytes / 4;
+constexpr int kStageDwords = kWgScanDwords + 4;                 // + 16 bytes of look-ahead for the last lane
+constexpr int kStageLds = kStageDwords + (kStageDwords >> 5) + 1;   // one pad dword per 32 (bank = lane + k)
+
+// One image of a chunk, as the kernels see it (HBM, read-only during decode).
+struct DevImage {
+    HuffImage himg;
+    uint64_t scan_off;      // bytes into the scan pool, 16-byte aligned
+    uint64_t coef_off;      // blocks into the coefficient buffer
+    uint64_t rgb_off;       // bytes into the RGB pool
+    uint32_t scan_padded;   // bytes that may be read at scan_off (multiple of 16; tail filled with 0xAA)
+    uint32_t lut_off;       // entries into the decode-table pool (multiple of 8)
+    uint32_t lut_n;         // entries (multiple of 8)
+    uint32_t sub_off;       // index of subsequence 0 in the per-subsequence arrays
+    uint32_t qm_off;        // floats into the dequant-multiplier pool (3 x 64 per image)
+    uint32_t width, height, mcux, mcuy, nmcu;
+    uint32_t ncomp, bpm, hmax, vmax;
+    uint32_t valid;         // 0: skip (error at plan time)
+    uint32_t status_idx;    // index into the batch-wide device status array
+    uint32_t log2_tile;     // stage-B tile = 1 << log2_tile MCUs
+    uint32_t pad0_;
+    uint8_t blk_comp[kMaxBlocksPerMcu], blk_bx[kMaxBlocksPerMcu], blk_by[kMaxBlocksPerMcu];
+    uint8_t ch[4], cv[4];   // sampling factors per component
+    uint8_t cfirst[4];      // first block position of each component inside the MCU
+};
+
+// MCUs per stage-B tile: a power of two so that lane -> (MCU, strip) is a shift, and at most 256 strips per row.
+inline uint32_t tile_mcus(uint32_t bpm, uint32_t hmax)
+{
+    uint32_t t = 1;
+    while (t * 2 * bpm <= 256) t *= 2;
+    const uint32_t cap = 256 / (2 * hmax);
+    return t < cap ? t : cap;
+}
+
+
+// ---- launchers (mjx_kernels.hip); all asynchronous on `st` ---------------------------------------------
+#if defined(__HIPCC__) || defined(MJX_WITH_HIP_RUNTIME)
+size_t huff_lds_bytes(uint32_t lut_cap_entries);
+size_t idct_lds_bytes(uint32_t max_tile_blocks);
+int configure_kernels(size_t huff_lds, size_t idct_lds);
+void launch_huff_sync(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
+                      const uint8_t *scan_pool, const uint16_t *lut_pool, SubseqState *entry, SubseqState *exit_,
+                      uint32_t lut_cap);
+void launch_huff_fix(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
+                     const uint8_t *scan_pool, const uint16_t *lut_pool, SubseqState *entry, SubseqState *exit_,
+                     uint32_t lut_cap, uint32_t *mismatches);
+void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase);
+void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
+                       const uint8_t *scan_pool, const uint16_t *lut_pool, const SubseqState *entry,
+                       const uint32_t *blkbase, uint32_t lut_cap, int16_t *coef, int16_t *dcbuf, int *status);
+void launch_dc_scan(hipStream_t st, uint32_t nimg, const DevImage *images, int16_t *dcbuf);
+void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
+                       const int16_t *coef, const int16_t *dcbuf, const float *qmult, uint8_t *rgb);
+#endif
+
+}   // namespace mjx
+#endif

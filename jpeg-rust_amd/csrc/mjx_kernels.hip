@@ -1,0 +1,569 @@
+// mjx_kernels.hip -- gfx950 kernels of the baseline-JPEG decode path.
+//
+//   stage A (entropy, replaces HuffmanDecoder::next_block + the MCU loop, reference
+//            src/jpeg/huffman.rs:146-254 and src/jpeg/decoder.rs:195-215):
+//     k_huff_sync   speculative decode of every 128-byte subsequence + intra-workgroup synchronisation
+//     k_huff_fix    inter-workgroup synchronisation pass
+//     k_huff_scan   per-image exclusive scan of completed-block counts
+//     k_huff_write  final decode from the synchronised entry states, scattering coefficients
+//     k_dc_scan     DC prediction (decoder.rs:208-210) as a per-component prefix sum
+//   stage B (pixels, replaces decoder.rs:227-235, 239-331 and src/transform.rs:55-87):
+//     k_idct_color  dequant + un-zigzag + 8x8 float IDCT + chroma replication + YCbCr->RGB + packed store
+//
+// The bitstream has no restart markers (the reference panics on DRI, jpeg/mod.rs:424-428), so intra-image
+// parallelism comes from the self-synchronisation of Huffman codes: a lane that starts decoding at an arbitrary bit
+// with a guessed state converges to the true symbol boundaries; entry states are iterated to a fixed point.
+#include <hip/hip_runtime.h>
+
+#include "mjx_kernels.h"
+
+namespace mjx {
+
+// ------------------------------------------------------------------------------------------------
+// LDS view of the staged scan chunk: big-endian dwords, one pad dword per 32 so that lane l reading its
+// k-th dword hits bank (l + k) % 32.
+// ------------------------------------------------------------------------------------------------
+struct LdsBits {
+    const uint32_t *lds;
+    uint32_t dword0;        // index (in the image's scan) of the first staged dword
+    __device__ __forceinline__ uint32_t be32(uint32_t i) const
+    {
+        const uint32_t d = i - dword0;
+        return lds[d + (d >> 5)];
+    }
+};
+
+struct GlobalSink {
+    int16_t *coef;          // chunk coefficient buffer, already offset to the image's first block
+    int16_t *dcbuf;
+    int *status;
+    __device__ __forceinline__ void dc(uint32_t b, int v) const { dcbuf[b] = int16_t(v); }
+    __device__ __forceinline__ void ac(uint32_t b, unsigned pos, int v) const { coef[size_t(b) * 64 + pos] = int16_t(v); }
+    __device__ __forceinline__ void bad_code(uint32_t) const { atomicOr(status, 1); }
+};
+
+// Cooperative staging of a workgroup's 32 KiB (+16 B) scan chunk and the image's decode tables into LDS.
+__device__ __forceinline__ void stage_chunk(const DevImage &im, const uint8_t *scan_pool, const uint16_t *lut_pool,
+                                            uint32_t wg, uint32_t *s_bits, uint16_t *s_lut)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint8_t *src = scan_pool + im.scan_off;
+    const uint32_t byte0 = wg * kWgScanBytes;
+    constexpr uint32_t kGranules = kStageDwords / 4;               // 2049 x 16 B
+    for (uint32_t g = tid; g < kGranules; g += kWgLanes) {
+        const uint32_t off = byte0 + g * 16;
+        uint4 q = make_uint4(0xaaaaaaaau, 0xaaaaaaaau, 0xaaaaaaaau, 0xaaaaaaaau);
+        if (off + 16 <= im.scan_padded) q = *reinterpret_cast<const uint4 *>(src + off);
+        const uint32_t d = g * 4;
+        uint32_t *dst = s_bits + d + (d >> 5);
+        dst[0] = __builtin_bswap32(q.x);
+        dst[1] = __builtin_bswap32(q.y);
+        dst[2] = __builtin_bswap32(q.z);
+        dst[3] = __builtin_bswap32(q.w);
+    }
+    const uint4 *lsrc = reinterpret_cast<const uint4 *>(lut_pool + im.lut_off);
+    uint4 *ldst = reinterpret_cast<uint4 *>(s_lut);
+    for (uint32_t g = tid; g < im.lut_n / 8; g += kWgLanes) ldst[g] = lsrc[g];
+}
+
+__device__ __forceinline__ uint32_t subseq_end(const HuffImage &h, uint32_t s)
+{
+    const uint32_t e = (s + 1) * uint32_t(kSubseqBits);
+    return e < h.total_bits ? e : h.total_bits;
+}
+
+// Work-list driven synchronisation inside one workgroup.  On entry s_entry / s_exit hold the current states of the
+// workgroup's `ns` subsequences and s_work[0..nwork) lists the ones whose entry changed.  Iterates
+//   decode(work) -> compare exit[l-1] with entry[l] -> compact the mismatches into the next work list
+// until nothing changes.  Compaction keeps the active lanes dense, so the tail iterations cost waves, not workgroups.
+__device__ __forceinline__ void wg_synchronise(const HuffImage &h, const LdsBits &bits, const uint16_t *s_lut,
+                                               SubseqState *s_entry, SubseqState *s_exit, uint16_t *s_work,
+                                               uint32_t *s_wcount, uint32_t s0, uint32_t ns, uint32_t nwork)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    NullSink ns_sink;
+    for (;;) {
+        if (tid < nwork) {
+            const uint32_t l = s_work[tid];
+            SubseqState e = s_entry[l];
+            s_exit[l] = decode_subseq<false>(bits, s_lut, h, e, subseq_end(h, s0 + l), 0, ns_sink);
+        }
+        __syncthreads();
+        bool changed = false;
+        if (tid > 0 && tid < ns) {
+            const SubseqState prev = s_exit[tid - 1];
+            SubseqState mine = s_entry[tid];
+            if (!same_entry(prev, mine)) {
+                mine.p = prev.p; mine.z = prev.z; mine.c = prev.c; mine.n = 0;
+                s_entry[tid] = mine;
+                changed = true;
+            }
+        }
+        const unsigned long long m = __ballot(changed);
+        if (lane == 0) s_wcount[wave] = __popcll(m);
+        __syncthreads();
+        uint32_t off = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kWgLanes / 64; w++) {
+            const uint32_t cnt = s_wcount[w];
+            off += (w < wave) ? cnt : 0;
+            total += cnt;
+        }
+        if (changed) s_work[off + __popcll(m & ((1ull << lane) - 1ull))] = uint16_t(tid);
+        __syncthreads();
+        nwork = total;
+        if (nwork == 0) break;
+    }
+}
+
+// Dynamic LDS carve shared by the three staging kernels.
+struct HuffLds {
+    uint32_t *bits;
+    uint16_t *lut;
+    SubseqState *entry, *exit_;
+    uint16_t *work;
+    uint32_t *wcount;
+    HuffImage *himg;
+};
+__device__ __forceinline__ HuffLds carve(unsigned char *base, uint32_t lut_cap_entries)
+{
+    HuffLds L;
+    L.bits = reinterpret_cast<uint32_t *>(base);
+    base += ((kStageLds * 4 + 15) / 16) * 16;
+    L.entry = reinterpret_cast<SubseqState *>(base);
+    base += kWgLanes * sizeof(SubseqState);
+    L.exit_ = reinterpret_cast<SubseqState *>(base);
+    base += kWgLanes * sizeof(SubseqState);
+    L.himg = reinterpret_cast<HuffImage *>(base);
+    base += sizeof(HuffImage);
+    L.wcount = reinterpret_cast<uint32_t *>(base);
+    base += 16;
+    L.work = reinterpret_cast<uint16_t *>(base);
+    base += kWgLanes * 2;
+    L.lut = reinterpret_cast<uint16_t *>(base);
+    (void)lut_cap_entries;
+    return L;
+}
+
+extern "C" __global__ __launch_bounds__(256) void k_huff_sync(const DevImage *images, const uint8_t *scan_pool,
+                                                               const uint16_t *lut_pool, SubseqState *g_entry,
+                                                               SubseqState *g_exit, uint32_t lut_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const DevImage &im = images[blockIdx.y];
+    const uint32_t s0 = blockIdx.x * kWgLanes;
+    if (!im.valid || s0 >= im.himg.nsub) return;
+    HuffLds L = carve(smem, lut_cap);
+    const uint32_t tid = threadIdx.x;
+    if (tid < sizeof(HuffImage) / 4) reinterpret_cast<uint32_t *>(L.himg)[tid] = reinterpret_cast<const uint32_t *>(&im.himg)[tid];
+    stage_chunk(im, scan_pool, lut_pool, blockIdx.x, L.bits, L.lut);
+    const uint32_t ns = min(uint32_t(kWgLanes), im.himg.nsub - s0);
+    if (tid < ns) {
+        SubseqState e;
+        e.p = (s0 + tid) * kSubseqBits; e.n = 0; e.z = 0; e.c = 0;      // guess: a block starts exactly here
+        L.entry[tid] = e;
+        L.work[tid] = uint16_t(tid);
+    }
+    __syncthreads();
+    const LdsBits bits{L.bits, s0 * (kSubseqBytes / 4)};
+    wg_synchronise(*L.himg, bits, L.lut, L.entry, L.exit_, L.work, L.wcount, s0, ns, ns);
+    if (tid < ns) {
+        g_entry[im.sub_off + s0 + tid] = L.entry[tid];
+        g_exit[im.sub_off + s0 + tid] = L.exit_[tid];
+    }
+}
+
+// Inter-workgroup pass: a workgroup whose first entry differs from the previous workgroup's last exit re-decodes
+// from the corrected entry and re-synchronises.  `mismatches` counts such workgroups; a pass that counts zero proves
+// the entry states are the true ones (fixed point), because then nothing was written during the pass.
+extern "C" __global__ __launch_bounds__(256) void k_huff_fix(const DevImage *images, const uint8_t *scan_pool,
+                                                              const uint16_t *lut_pool, SubseqState *g_entry,
+                                                              SubseqState *g_exit, uint32_t lut_cap,
+                                                              uint32_t *mismatches)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const DevImage &im = images[blockIdx.y];
+    const uint32_t s0 = (blockIdx.x + 1) * kWgLanes;                      // workgroup 0 starts at the true state
+    if (!im.valid || s0 >= im.himg.nsub) return;
+    const SubseqState prev = g_exit[im.sub_off + s0 - 1];
+    SubseqState first = g_entry[im.sub_off + s0];
+    if (same_entry(prev, first)) return;                                  // workgroup-uniform
+    HuffLds L = carve(smem, lut_cap);
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) atomicAdd(mismatches, 1u);
+    if (tid < sizeof(HuffImage) / 4) reinterpret_cast<uint32_t *>(L.himg)[tid] = reinterpret_cast<const uint32_t *>(&im.himg)[tid];
+    stage_chunk(im, scan_pool, lut_pool, blockIdx.x + 1, L.bits, L.lut);
+    const uint32_t ns = min(uint32_t(kWgLanes), im.himg.nsub - s0);
+    if (tid < ns) {
+        L.entry[tid] = g_entry[im.sub_off + s0 + tid];
+        L.exit_[tid] = g_exit[im.sub_off + s0 + tid];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        first.p = prev.p; first.z = prev.z; first.c = prev.c; first.n = 0;
+        L.entry[0] = first;
+        L.work[0] = 0;
+    }
+    __syncthreads();
+    const LdsBits bits{L.bits, s0 * (kSubseqBytes / 4)};
+    wg_synchronise(*L.himg, bits, L.lut, L.entry, L.exit_, L.work, L.wcount, s0, ns, 1);
+    if (tid < ns) {
+        g_entry[im.sub_off + s0 + tid] = L.entry[tid];
+        g_exit[im.sub_off + s0 + tid] = L.exit_[tid];
+    }
+}
+
+// Workgroup-wide exclusive scan helper (256 lanes): returns the exclusive prefix of v, total in *total.
+__device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t *s_tmp, uint32_t *total)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= uint32_t(d)) incl += o;
+    }
+    if (lane == 63) s_tmp[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kWgLanes / 64; w++) {
+        const uint32_t c = s_tmp[w];
+        base += (w < wave) ? c : 0;
+        tot += c;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+// blkbase[s] = number of blocks completed before subsequence s (one workgroup per image).
+extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *images, const SubseqState *g_exit,
+                                                               uint32_t *g_blkbase)
+{
+    __shared__ uint32_t s_tmp[4];
+    const DevImage &im = images[blockIdx.x];
+    if (!im.valid) return;
+    const uint32_t nsub = im.himg.nsub, tid = threadIdx.x;
+    const uint32_t per = (nsub + kWgLanes - 1) / kWgLanes;
+    const uint32_t a = min(nsub, tid * per), b = min(nsub, a + per);
+    uint32_t sum = 0;
+    for (uint32_t s = a; s < b; s++) sum += g_exit[im.sub_off + s].n;
+    uint32_t total;
+    uint32_t run = wg_exclusive_scan(sum, s_tmp, &total);
+    for (uint32_t s = a; s < b; s++) {
+        g_blkbase[im.sub_off + s] = run;
+        run += g_exit[im.sub_off + s].n;
+    }
+}
+
+extern "C" __global__ __launch_bounds__(256) void k_huff_write(const DevImage *images, const uint8_t *scan_pool,
+                                                                const uint16_t *lut_pool, const SubseqState *g_entry,
+                                                                const uint32_t *g_blkbase, uint32_t lut_cap,
+                                                                int16_t *coef, int16_t *dcbuf, int *status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const DevImage &im = images[blockIdx.y];
+    const uint32_t s0 = blockIdx.x * kWgLanes;
+    if (!im.valid || s0 >= im.himg.nsub) return;
+    HuffLds L = carve(smem, lut_cap);
+    const uint32_t tid = threadIdx.x;
+    if (tid < sizeof(HuffImage) / 4) reinterpret_cast<uint32_t *>(L.himg)[tid] = reinterpret_cast<const uint32_t *>(&im.himg)[tid];
+    stage_chunk(im, scan_pool, lut_pool, blockIdx.x, L.bits, L.lut);
+    __syncthreads();
+    const uint32_t ns = min(uint32_t(kWgLanes), im.himg.nsub - s0);
+    if (tid < ns) {
+        const uint32_t s = s0 + tid;
+        const SubseqState e = g_entry[im.sub_off + s];
+        const uint32_t blk = g_blkbase[im.sub_off + s];
+        const LdsBits bits{L.bits, s0 * (kSubseqBytes / 4)};
+        GlobalSink sink{coef + im.coef_off * 64, dcbuf + im.coef_off, status + im.status_idx};
+        decode_subseq<true>(bits, L.lut, *L.himg, e, subseq_end(*L.himg, s), blk, sink);
+    }
+}
+
+// DC prediction: dcbuf holds per-block differences in decode order; turn them into absolute values per component
+// (running sum never reset, decoder.rs:173, 208-210).  One workgroup per image, contiguous MCU range per lane.
+extern "C" __global__ __launch_bounds__(256) void k_dc_scan(const DevImage *images, int16_t *dcbuf)
+{
+    __shared__ uint32_t s_tmp[4];
+    const DevImage &im = images[blockIdx.x];
+    if (!im.valid) return;
+    const uint32_t tid = threadIdx.x, bpm = im.bpm;
+    const uint32_t per = (im.nmcu + kWgLanes - 1) / kWgLanes;
+    const uint32_t a = min(im.nmcu, tid * per), b = min(im.nmcu, a + per);
+    int16_t *dc = dcbuf + im.coef_off;
+    int32_t sum[3] = {0, 0, 0};
+    for (uint32_t m = a; m < b; m++)
+        for (uint32_t j = 0; j < bpm; j++) {
+            const int32_t v = dc[m * bpm + j];
+            const uint32_t c = im.blk_comp[j];
+            sum[0] += c == 0 ? v : 0;
+            sum[1] += c == 1 ? v : 0;
+            sum[2] += c == 2 ? v : 0;
+        }
+    int32_t run[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        uint32_t total;
+        run[c] = int32_t(wg_exclusive_scan(uint32_t(sum[c]), s_tmp, &total));
+    }
+    for (uint32_t m = a; m < b; m++)
+        for (uint32_t j = 0; j < bpm; j++) {
+            const uint32_t c = im.blk_comp[j];
+            int32_t r = c == 0 ? run[0] : (c == 1 ? run[1] : run[2]);
+            r += dc[m * bpm + j];
+            dc[m * bpm + j] = int16_t(r);
+            run[0] = c == 0 ? r : run[0];
+            run[1] = c == 1 ? r : run[1];
+            run[2] = c == 2 ? r : run[2];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage B
+// ------------------------------------------------------------------------------------------------
+constexpr int kCoefStride = 144;     // bytes per staged coefficient block (128 + 16: conflict-free ds_read_b128)
+constexpr int kPixStride = 68;       // floats per IDCT output block (64 + 4)
+
+// 8-point inverse DCT, Arai-Agui-Nakajima factorisation on inputs pre-scaled by the AAN factors (folded into the
+// dequantisation multipliers on the host, mjx_plan.cpp).  5 multiplies, 29 additions.  Same transform as the
+// reference's direct-form DCT-III (transform.rs:55-87) up to float rounding.
+__device__ __forceinline__ void idct8(float &i0, float &i1, float &i2, float &i3, float &i4, float &i5, float &i6,
+                                      float &i7)
+{
+    const float t10 = i0 + i4, t11 = i0 - i4;
+    const float t13 = i2 + i6, t12 = (i2 - i6) * 1.414213562f - t13;
+    const float e0 = t10 + t13, e3 = t10 - t13, e1 = t11 + t12, e2 = t11 - t12;
+    const float z13 = i5 + i3, z10 = i5 - i3, z11 = i1 + i7, z12 = i1 - i7;
+    const float o7 = z11 + z13;
+    const float u11 = (z11 - z13) * 1.414213562f;
+    const float z5 = (z10 + z12) * 1.847759065f;
+    const float u10 = 1.082392200f * z12 - z5;
+    const float u12 = -2.613125930f * z10 + z5;
+    const float o6 = u12 - o7, o5 = u11 - o6, o4 = u10 + o5;
+    i0 = e0 + o7; i7 = e0 - o7;
+    i1 = e1 + o6; i6 = e1 - o6;
+    i2 = e2 + o5; i5 = e2 - o5;
+    i4 = e3 + o4; i3 = e3 - o4;
+}
+
+// decoder.rs:382-390 f32_to_u8: clamp to [0,255], truncate toward zero.
+__device__ __forceinline__ uint32_t f32_to_u8(float n)
+{
+    n = __builtin_fminf(__builtin_fmaxf(n, 0.0f), 255.0f);
+    return uint32_t(n);
+}
+
+// decoder.rs:392-402 y_cb_cr_to_rgb, same operation order, every operation rounded to f32 (no FMA contraction).
+__device__ __forceinline__ void ycc_to_rgb(float y, float cb, float cr, uint32_t &r8, uint32_t &g8, uint32_t &b8)
+{
+#pragma clang fp contract(off)
+    const float c_red = 0.299f, c_green = 0.587f, c_blue = 0.114f;
+    const float kr = 2.0f - 2.0f * c_red, kb = 2.0f - 2.0f * c_blue;
+    const float r = cr * kr + y;
+    const float b = cb * kb + y;
+    const float g = (y - c_blue * b - c_red * r) / c_green;
+    r8 = f32_to_u8(r + 128.0f);
+    g8 = f32_to_u8(g + 128.0f);
+    b8 = f32_to_u8(b + 128.0f);
+}
+
+struct __attribute__((packed, aligned(4))) Rgb4 { uint32_t a, b, c; };
+struct __attribute__((packed, aligned(1))) Rgb4u { uint32_t a, b, c; };
+
+// Reads 4 horizontally adjacent samples of one component for the pixel strip starting at MCU-local (x, y);
+// replicates when the component is subsampled (box replication: the reference never interpolates).
+__device__ __forceinline__ void load4(const float *tile, const DevImage &im, uint32_t mcu_blk0, uint32_t c,
+                                      uint32_t x, uint32_t y, float out[4])
+{
+    const uint32_t xr = im.hmax / im.ch[c], yr = im.vmax / im.cv[c];
+    const uint32_t xs = x / xr, ys = y / yr;
+    const uint32_t blk = mcu_blk0 + im.cfirst[c] + (ys >> 3) * im.ch[c] + (xs >> 3);
+    const float *p = tile + blk * kPixStride + (ys & 7) * 8 + (xs & 7);
+    if (xr == 1) {
+        const float4 v = *reinterpret_cast<const float4 *>(p);
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else {
+        const float2 v = *reinterpret_cast<const float2 *>(p);
+        out[0] = v.x; out[1] = v.x; out[2] = v.y; out[3] = v.y;
+    }
+}
+
+extern "C" __global__ __launch_bounds__(256) void k_idct_color(const DevImage *images, const int16_t *coef,
+                                                                const int16_t *dcbuf, const float *qmult,
+                                                                uint8_t *rgb)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float s_qm[3 * 64];
+    const DevImage &im = images[blockIdx.y];
+    const uint32_t T = 1u << im.log2_tile;
+    const uint32_t m0 = blockIdx.x * T;
+    if (!im.valid || m0 >= im.nmcu) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t bpm = im.bpm;
+    const uint32_t nm = min(T, im.nmcu - m0), nblk = nm * bpm;
+    const uint64_t blk0 = im.coef_off + uint64_t(m0) * bpm;
+
+    if (tid < 192) s_qm[tid] = qmult[im.qm_off + tid];
+    // phase 1: coalesced 16-byte loads of the tile's coefficient blocks into LDS (stride 144 B)
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(coef + blk0 * 64);
+        const uint32_t ngran = nblk * 8;
+        for (uint32_t g = tid; g < ngran; g += 256) {
+            const uint4 q = src[g];
+            *reinterpret_cast<uint4 *>(smem + (g >> 3) * kCoefStride + (g & 7) * 16) = q;
+        }
+    }
+    __syncthreads();
+    // phase 2: one lane = one 8x8 block: dequant + un-zigzag into registers, 8 column + 8 row transforms
+    float v[64];
+    const bool have_block = tid < nblk;
+    if (have_block) {
+        const uint32_t c = im.blk_comp[tid % bpm];
+        const float *qm = s_qm + c * 64;
+        const uint4 *cb = reinterpret_cast<const uint4 *>(smem + tid * kCoefStride);
+        constexpr int ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const uint4 q = cb[g];
+            const float4 m0q = *reinterpret_cast<const float4 *>(qm + g * 8);
+            const float4 m1q = *reinterpret_cast<const float4 *>(qm + g * 8 + 4);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            const float mm[8] = {m0q.x, m0q.y, m0q.z, m0q.w, m1q.x, m1q.y, m1q.z, m1q.w};
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int32_t ci = (k & 1) ? (int32_t(w[k >> 1]) >> 16) : int32_t(int16_t(w[k >> 1] & 0xffff));
+                v[ZZ[g * 8 + k]] = float(ci) * mm[k];
+            }
+        }
+        v[0] = float(int32_t(dcbuf[blk0 + tid])) * qm[0];
+#pragma unroll
+        for (int c8 = 0; c8 < 8; c8++)
+            idct8(v[c8], v[8 + c8], v[16 + c8], v[24 + c8], v[32 + c8], v[40 + c8], v[48 + c8], v[56 + c8]);
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+            idct8(v[8 * r], v[8 * r + 1], v[8 * r + 2], v[8 * r + 3], v[8 * r + 4], v[8 * r + 5], v[8 * r + 6], v[8 * r + 7]);
+    }
+    __syncthreads();                                         // every lane has consumed the staged coefficients
+    float *tile = reinterpret_cast<float *>(smem);           // the sample tile aliases the coefficient staging
+    if (have_block) {
+        float4 *dst = reinterpret_cast<float4 *>(tile + tid * kPixStride);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            dst[2 * r] = make_float4(v[8 * r], v[8 * r + 1], v[8 * r + 2], v[8 * r + 3]);
+            dst[2 * r + 1] = make_float4(v[8 * r + 4], v[8 * r + 5], v[8 * r + 6], v[8 * r + 7]);
+        }
+    }
+    __syncthreads();
+    // phase 3: 4-pixel strips; lane -> (MCU t, strip sx) is fixed, rows advance by 256/R per step
+    const uint32_t strips = 2 * im.hmax;                     // 4-pixel strips per MCU row
+    const uint32_t R = T * strips;                           // strips per pixel row of the tile (power of two <= 256)
+    const uint32_t q = tid & (R - 1);
+    const uint32_t t = q / strips, sx = q % strips;
+    const uint32_t rows = 8 * im.vmax, rstep = 256 / R;
+    if (t >= nm) return;
+    const uint32_t m = m0 + t;
+    const uint32_t mx = m % im.mcux, my = m / im.mcux;
+    const uint32_t px = mx * 8 * im.hmax + sx * 4;
+    if (px >= im.width) return;
+    const bool full_x = px + 4 <= im.width;
+    const bool aligned = ((im.width * 3u) & 3u) == 0 && (im.rgb_off & 3u) == 0;
+    uint8_t *out_img = rgb + im.rgb_off;
+    for (uint32_t r = tid / R; r < rows; r += rstep) {
+        const uint32_t py = my * rows + r;
+        if (py >= im.height) break;
+        float yv[4], cbv[4], crv[4];
+        load4(tile, im, t * bpm, 0, sx * 4, r, yv);
+        uint32_t r8[4], g8[4], b8[4];
+        if (im.ncomp == 3) {
+            load4(tile, im, t * bpm, 1, sx * 4, r, cbv);
+            load4(tile, im, t * bpm, 2, sx * 4, r, crv);
+#pragma unroll
+            for (int k = 0; k < 4; k++) ycc_to_rgb(yv[k], cbv[k], crv[k], r8[k], g8[k], b8[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) r8[k] = g8[k] = b8[k] = f32_to_u8(yv[k] + 128.0f);   // decoder.rs:318-325
+        }
+        uint8_t *dst = out_img + (size_t(py) * im.width + px) * 3;
+        if (full_x) {
+            const uint32_t d0 = r8[0] | (g8[0] << 8) | (b8[0] << 16) | (r8[1] << 24);
+            const uint32_t d1 = g8[1] | (b8[1] << 8) | (r8[2] << 16) | (g8[2] << 24);
+            const uint32_t d2 = b8[2] | (r8[3] << 8) | (g8[3] << 16) | (b8[3] << 24);
+            if (aligned) *reinterpret_cast<Rgb4 *>(dst) = Rgb4{d0, d1, d2};
+            else *reinterpret_cast<Rgb4u *>(dst) = Rgb4u{d0, d1, d2};
+        } else {
+            for (uint32_t k = 0; k < 4 && px + k < im.width; k++) {
+                dst[3 * k] = uint8_t(r8[k]);
+                dst[3 * k + 1] = uint8_t(g8[k]);
+                dst[3 * k + 2] = uint8_t(b8[k]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers (declared in mjx_kernels.h)
+// ------------------------------------------------------------------------------------------------
+size_t huff_lds_bytes(uint32_t lut_cap_entries)
+{
+    return size_t((kStageLds * 4 + 15) / 16) * 16 + 2 * kWgLanes * sizeof(SubseqState) + sizeof(HuffImage) + 16 +
+           kWgLanes * 2 + size_t(lut_cap_entries) * 2;
+}
+
+size_t idct_lds_bytes(uint32_t max_tile_blocks) { return size_t(max_tile_blocks) * kPixStride * 4; }
+
+int configure_kernels(size_t huff_lds, size_t idct_lds)
+{
+    hipError_t e = hipSuccess;
+    if (huff_lds > 64 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_sync), hipFuncAttributeMaxDynamicSharedMemorySize, int(huff_lds));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_fix), hipFuncAttributeMaxDynamicSharedMemorySize, int(huff_lds));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_write), hipFuncAttributeMaxDynamicSharedMemorySize, int(huff_lds));
+    }
+    if (e == hipSuccess && idct_lds > 64 * 1024)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_idct_color), hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
+    return e == hipSuccess ? 0 : int(e);
+}
+
+void launch_huff_sync(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
+                      const uint8_t *scan_pool, const uint16_t *lut_pool, SubseqState *entry, SubseqState *exit_,
+                      uint32_t lut_cap)
+{
+    hipLaunchKernelGGL(k_huff_sync, dim3(max_wg, nimg), dim3(kWgLanes), lds, st, images, scan_pool, lut_pool, entry, exit_, lut_cap);
+}
+
+void launch_huff_fix(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
+                     const uint8_t *scan_pool, const uint16_t *lut_pool, SubseqState *entry, SubseqState *exit_,
+                     uint32_t lut_cap, uint32_t *mismatches)
+{
+    if (max_wg < 2) return;
+    hipLaunchKernelGGL(k_huff_fix, dim3(max_wg - 1, nimg), dim3(kWgLanes), lds, st, images, scan_pool, lut_pool, entry, exit_, lut_cap, mismatches);
+}
+
+void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase)
+{
+    hipLaunchKernelGGL(k_huff_scan, dim3(nimg), dim3(kWgLanes), 0, st, images, exit_, blkbase);
+}
+
+void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
+                       const uint8_t *scan_pool, const uint16_t *lut_pool, const SubseqState *entry,
+                       const uint32_t *blkbase, uint32_t lut_cap, int16_t *coef, int16_t *dcbuf, int *status)
+{
+    hipLaunchKernelGGL(k_huff_write, dim3(max_wg, nimg), dim3(kWgLanes), lds, st, images, scan_pool, lut_pool, entry, blkbase, lut_cap, coef, dcbuf, status);
+}
+
+void launch_dc_scan(hipStream_t st, uint32_t nimg, const DevImage *images, int16_t *dcbuf)
+{
+    hipLaunchKernelGGL(k_dc_scan, dim3(nimg), dim3(kWgLanes), 0, st, images, dcbuf);
+}
+
+void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
+                       const int16_t *coef, const int16_t *dcbuf, const float *qmult, uint8_t *rgb)
+{
+    hipLaunchKernelGGL(k_idct_color, dim3(max_tiles, nimg), dim3(256), lds, st, images, coef, dcbuf, qmult, rgb);
+}
+
+}   // namespace mjx

@@ -1,0 +1,127 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu).  Every call goes through the C ABI (libmjx.so) and is
+compared with the CPU oracle on the same bytes:
+  T0  coefficient stream bit-exact (integer Huffman / DC-prediction path)
+  T2  full-image RGB within +-1 LSB per channel (float IDCT + truncating colour conversion)
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FIXTURES = ["huff_simple0.jpg", "lena-bw.jpeg", "lena.jpeg", "2x2-chroma.jpeg"]
+TOL = 1   # LSB per channel, BASELINE.json north_star
+
+
+def _decode_both(mjx, orc, ctx, datas, layout_std=True, **kw):
+    scans = [mjx.ParsedScan(d) for d in datas]
+    batch = mjx.Batch(ctx, scans, keep_coefs=True,
+                      layout=mjx.LAYOUT_STANDARD if layout_std else mjx.LAYOUT_REF_COMPAT, **kw)
+    batch.decode()
+    batch.wait()
+    out = []
+    for i, d in enumerate(datas):
+        assert batch.status(i) == mjx.OK, "image %d status %d" % (i, batch.status(i))
+        ref = orc.decode(d, layout=orc.LAYOUT_STD if layout_std else orc.LAYOUT_REF)
+        out.append((ref, batch.coefs(i), batch.rgb(i)))
+    batch.close()
+    return out
+
+
+def _check(ref, coefs, rgb, name):
+    assert coefs.shape == (ref.mcus * sum(ref.hv), 64), name
+    assert np.array_equal(coefs, _interleave(ref)), "T0 differs: " + name
+    assert rgb.shape == ref.rgb.shape, name
+    diff = np.abs(rgb.astype(np.int16) - ref.rgb.astype(np.int16))
+    assert diff.max() <= TOL, "%s: max |diff| %d at %s" % (name, diff.max(), np.argwhere(diff > TOL)[:4].tolist())
+    return float((diff > 0).mean())
+
+
+def _interleave(ref):
+    import oracle_binding
+    return oracle_binding.interleave(ref)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_reference_fixtures_standard_layout(mjx, orc, gpu_ctx, data_dir, name):
+    data = open(os.path.join(data_dir, name), "rb").read()
+    (ref, coefs, rgb), = _decode_both(mjx, orc, gpu_ctx, [data])
+    frac = _check(ref, coefs, rgb, name)
+    assert frac < 0.01, "%s: %.4f of samples differ by 1" % (name, frac)
+
+
+CASES = [
+    (16, 8, "444"), (64, 48, "444"), (64, 48, "422"), (64, 36, "420"), (60, 44, "420"), (61, 45, "420"),
+    (33, 17, "422"), (100, 60, "gray"), (7, 5, "gray"), (48, 64, "440"), (750, 595, "420"), (512, 512, "422"),
+    (1920, 1080, "420"), (1, 1, "444"), (17, 33, "420"),
+]
+
+
+@pytest.mark.parametrize("w,h,sub", CASES)
+@pytest.mark.parametrize("quality", [50, 90])
+def test_synthetic_standard_layout(mjx, orc, gpu_ctx, w, h, sub, quality):
+    data = mjx.synth_jpeg(w, h, sub, quality, seed=w * 31 + h)
+    (ref, coefs, rgb), = _decode_both(mjx, orc, gpu_ctx, [data])
+    _check(ref, coefs, rgb, "%dx%d %s q%d" % (w, h, sub, quality))
+
+
+def test_heterogeneous_batch_and_chunking(mjx, orc, gpu_ctx, data_dir):
+    datas = [open(os.path.join(data_dir, n), "rb").read() for n in FIXTURES]
+    datas += [mjx.synth_jpeg(w, h, s, 75, seed=i) for i, (w, h, s) in enumerate(CASES[:10])]
+    for chunk in (0, 3):
+        res = _decode_both(mjx, orc, gpu_ctx, datas, chunk_images=chunk)
+        for i, (ref, coefs, rgb) in enumerate(res):
+            _check(ref, coefs, rgb, "batch image %d chunk=%d" % (i, chunk))
+
+
+def test_4k_image_many_workgroups(mjx, orc, gpu_ctx):
+    data = mjx.synth_jpeg(3840, 2160, "420", 75, seed=11)
+    (ref, coefs, rgb), = _decode_both(mjx, orc, gpu_ctx, [data])
+    _check(ref, coefs, rgb, "4K")
+
+
+def test_bad_image_does_not_kill_batch(mjx, orc, gpu_ctx, data_dir):
+    good = open(os.path.join(data_dir, "lena.jpeg"), "rb").read()
+    scans = [mjx.ParsedScan(good), mjx.ParsedScan(good)]
+    scans[0].desc.dc_present = 0       # scan references an undefined table (decoder.rs:158-160 unwrap)
+    batch = mjx.Batch(gpu_ctx, scans)
+    assert batch.create_status[0] == mjx.ERR_MISSING_TABLE and batch.create_status[1] == mjx.OK
+    batch.decode()
+    batch.wait()
+    ref = orc.decode(good, layout=orc.LAYOUT_STD)
+    assert np.abs(batch.rgb(1).astype(int) - ref.rgb.astype(int)).max() <= TOL
+    batch.close()
+
+
+def test_one_shot_and_mirror_api(mjx, orc, gpu_ctx, data_dir):
+    data = open(os.path.join(data_dir, "lena.jpeg"), "rb").read()
+    ref = orc.decode(data, layout=orc.LAYOUT_STD)
+    rgb = mjx.decode(data)
+    assert np.abs(rgb.astype(int) - ref.rgb.astype(int)).max() <= TOL
+    img = mjx.JPEGImage.parse(data, ctx=gpu_ctx)
+    assert (img.width(), img.height()) == (512, 512)
+    assert np.array_equal(img.image_data(), rgb)
+    with pytest.raises(mjx.MjxError) as e:     # the reference panics on APP12 (jpeg/mod.rs:445-447)
+        mjx.JPEGImage.parse(open(os.path.join(data_dir, "huff_simple0.jpg"), "rb").read(), strict_ref=True, ctx=gpu_ctx)
+    assert e.value.code == mjx.ERR_UNSUPPORTED_MARKER
+
+
+def test_tiled_batch_round_trip(mjx, orc, gpu_ctx):
+    datas = [mjx.synth_jpeg(320, 240, "420", 75, seed=s) for s in range(3)]
+    scans = [mjx.ParsedScan(d) for d in datas]
+    base = mjx.Batch(gpu_ctx, scans)
+    big = base.tile(5)
+    assert len(big) == 15
+    big.decode()
+    big.wait()
+    for i in range(15):
+        ref = orc.decode(datas[i % 3], layout=orc.LAYOUT_STD)
+        assert np.abs(big.rgb(i).astype(int) - ref.rgb.astype(int)).max() <= TOL
+    # idempotence: decoding again gives the same bytes
+    first = big.rgb(7).copy()
+    big.decode()
+    big.wait()
+    assert np.array_equal(first, big.rgb(7))
+    big.close()
+    base.close()
