@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixels/s of the baseline-JPEG decode hot path on 4K 4:2:0 batches (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A *step* = one pass of the whole hot path (entropy decode -> dequant -> IDCT -> upsample -> RGB) over the rank's batch:
+`--images-per-gpu` synthetic 3840x2160 4:2:0 q75 baseline JPEGs (BASELINE.json configs[4] is 16384 images over 8 GPUs
+= 2048 per GPU; per-GPU work is fixed as N grows -> weak scaling).  Inputs (de-stuffed scans, tables) are resident in
+HBM before the timed region; outputs stay in HBM.  Images are independent, so ranks never exchange data: image i of the
+global batch goes to rank i mod N; the only collective is the reporting barrier / max-reduce of the elapsed time.
+
+The JSON line carries, besides the contract fields:
+  roofline      dominant kernel (by summed HIP-event time over the timed region): algorithmic bytes per launch / average
+                launch duration vs the 8 TB/s HBM3E peak
+  roofline_e2e  whole path: sum over images of (S + 3*W*H) (SURVEY.md s8(d) B_e2e) / sum of all kernel time
+  kernels       per kernel class: launches, total ms
+  cpu_baseline  the oracle (C restatement of the reference's algorithm, kind "port") on the host cores, rank 0, N=1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--images-per-gpu", type=int, default=2048)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--subsampling", default="420")
+    ap.add_argument("--quality", type=int, default=75)
+    ap.add_argument("--unique", type=int, default=64, help="distinct synthetic images in the global batch (SURVEY s8(d))")
+    ap.add_argument("--chunk-images", type=int, default=0)
+    ap.add_argument("--stages", default="all", choices=["all", "pixels"], help="pixels = stage-B-only sweep on resident coefficients")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(kind, by, nsub_total):
+    """Per-step algorithmic bytes of each kernel class (DESIGN.md 'Kernels'); by = mjx.Batch.bytes()."""
+    S, rgb, coef = by["scan"], by["rgb"], by["coef"]
+    nblk = coef // 128
+    return {
+        "clear": coef,                              # zero fill of the coefficient buffer
+        "huff_sync": S + 16 * nsub_total,           # scan in, entry + exit state out
+        "huff_fix": 16 * nsub_total // 256,         # reads one state pair per workgroup when nothing needs repair
+        "huff_scan": 12 * nsub_total,               # exit state in, block base out
+        "huff_write": S + 12 * nsub_total + coef,   # scan + entry state in, coefficient blocks out
+        "dc_scan": 4 * nblk,                        # DC differences in, absolute DC out
+        "idct_color": coef + 2 * nblk + rgb,        # B_idct = 128*n_blocks + 3*W*H + DC
+    }[kind]
+
+
+def cpu_baseline(mjx, datas, width, height, threads):
+    import oracle_binding as orc
+    cores = os.cpu_count() or 1
+    threads = threads or min(cores, 32)
+    sample = [datas[i % len(datas)] for i in range(threads)]
+    t = time.perf_counter()
+    px, st = orc.decode_many(sample, threads, layout=orc.LAYOUT_REF, faithful=True)
+    dt = time.perf_counter() - t
+    ok = sum(1 for s in st if s == 0)
+    return {
+        "value": round(px / dt / 1e6, 4), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+        "sample": "%d images of the same %dx%d batch, one per thread, reference algorithm restated in C "
+                  "(oracle/: O(n^4) float IDCT with cosf per term, linear-search Huffman; gcc -O2 -ffp-contract=off); "
+                  "%d decoded ok in %.1f s; host has %d cores" % (len(sample), width, height, ok, dt, cores),
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    ge.build()
+    mjx = ge.load_package()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- this rank's shard of the global batch: global image i -> rank i % world, content seed i % unique ----
+    per_gpu = args.images_per_gpu
+    seeds, j = [], 0
+    while True:
+        s = (rank + world * j) % args.unique
+        if j > 0 and s == seeds[0]:
+            break
+        seeds.append(s)
+        j += 1
+    period = len(seeds)
+    reps = max(1, per_gpu // period)
+    per_gpu = reps * period
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
+        datas = list(ex.map(lambda s: mjx.synth_jpeg(args.width, args.height, args.subsampling, args.quality, s), seeds))
+
+    ctx = mjx.Context(local_rank, profiling=True)
+    scans = [mjx.ParsedScan(d) for d in datas]
+    keep = args.stages == "pixels"
+    base = mjx.Batch(ctx, scans, keep_coefs=keep, chunk_images=args.chunk_images)
+    assert all(s == mjx.OK for s in base.create_status), base.create_status
+    batch = base.tile(reps) if reps > 1 else base
+    if batch is not base:
+        base.close()
+    by = batch.bytes()
+    nsub_total = sum((len(mjx.ParsedScan(d).scan_bytes()) * 8 + 1023) // 1024 for d in datas) * reps
+    stages = mjx.STAGE_ALL if args.stages == "all" else mjx.STAGE_PIXELS
+    if args.stages == "pixels":
+        batch.decode(mjx.STAGE_ALL)
+        batch.wait()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.decode(stages)
+        batch.wait()
+    batch.kernel_ms(reset=True)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.decode(stages)
+    batch.wait()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    bad = [i for i in range(len(batch)) if batch.status(i) != mjx.OK]
+    assert not bad, "images failed: %s" % bad[:8]
+
+    kms = batch.kernel_ms()
+    total_px = by["pixels"] * world * args.steps
+    value = total_px / elapsed / 1e6
+    kernels = {k: {"launches": v[1], "ms": round(v[0], 4)} for k, v in kms.items() if v[1]}
+    out = {
+        "metric": "Mpixels/sec decode, 4K 4:2:0 baseline batch", "value": round(value, 2), "unit": "Mpixels/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%d x %dx%d 4:%s baseline JPEG q%d per GPU (%d unique, tiled on device), de-stuffed scans "
+                               "resident in HBM, RGB out in HBM, stages=%s"
+                               % (per_gpu, args.width, args.height, args.subsampling[1:] if args.subsampling[0] == "4" else args.subsampling,
+                                  args.quality, period, args.stages),
+                   "images_per_gpu": per_gpu, "width": args.width, "height": args.height, "subsampling": args.subsampling,
+                   "quality": args.quality, "layout": "standard", "sharding": "image i -> gpu i %% %d, no collective" % world},
+        "kernels": kernels,
+    }
+    if kernels:
+        dom = max(kernels, key=lambda k: kernels[k]["ms"])
+        steps_bytes = algorithmic_bytes(dom, by, nsub_total)
+        n_launch = kernels[dom]["launches"]
+        avg_s = kernels[dom]["ms"] / 1e3 / n_launch
+        per_launch = steps_bytes * args.steps / n_launch
+        ach = per_launch / avg_s / 1e9
+        out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                           "bytes_per_launch": int(per_launch), "avg_launch_ms": round(avg_s * 1e3, 5)}
+        tot_ms = sum(v["ms"] for v in kernels.values())
+        e2e_bytes = (by["scan"] + by["rgb"]) if args.stages == "all" else algorithmic_bytes("idct_color", by, nsub_total)
+        e2e = e2e_bytes * args.steps / (tot_ms / 1e3) / 1e9
+        out["roofline_e2e"] = {"bound": "hbm", "achieved": round(e2e, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(e2e / HBM_PEAK_GBS, 5), "bytes_per_step": int(e2e_bytes),
+                               "kernel_ms_per_step": round(tot_ms / args.steps, 4),
+                               "definition": "sum(S + 3*W*H) / sum of kernel time" if args.stages == "all" else "B_idct / kernel time"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(mjx, datas, args.width, args.height, args.cpu_threads)
+    batch.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
