@@ -62,6 +62,30 @@ def algorithmic_bytes(kind, by, nsub_total):
     }[kind]
 
 
+def shard_seeds(rank, world, unique):
+    """Content seeds of this rank's images: global image i goes to rank i % world and has seed i % unique, so the
+    rank sees the periodic sequence (rank + world*j) % unique; returns one period."""
+    seeds, j = [], 0
+    while True:
+        s = (rank + world * j) % unique
+        if j > 0 and s == seeds[0]:
+            break
+        seeds.append(s)
+        j += 1
+    return seeds
+
+
+def reduce_elapsed(elapsed, world, device=None):
+    """MAX over ranks of the timed region (the only collective of the job; the data path has none)."""
+    if world <= 1:
+        return elapsed
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def cpu_baseline(mjx, datas, width, height, threads):
     import oracle_binding as orc
     cores = os.cpu_count() or 1
@@ -99,13 +123,7 @@ def main():
 
     # ---- this rank's shard of the global batch: global image i -> rank i % world, content seed i % unique ----
     per_gpu = args.images_per_gpu
-    seeds, j = [], 0
-    while True:
-        s = (rank + world * j) % args.unique
-        if j > 0 and s == seeds[0]:
-            break
-        seeds.append(s)
-        j += 1
+    seeds = shard_seeds(rank, world, args.unique)
     period = len(seeds)
     reps = max(1, per_gpu // period)
     per_gpu = reps * period
@@ -145,10 +163,7 @@ def main():
     batch.wait()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = reduce_elapsed(elapsed, world, "cuda")
     bad = [i for i in range(len(batch)) if batch.status(i) != mjx.OK]
     assert not bad, "images failed: %s" % bad[:8]
 

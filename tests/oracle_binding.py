@@ -104,3 +104,11 @@ def decode_many(datas, nthreads, layout=LAYOUT_REF, faithful=True):
     o = Opts(0, layout, int(faithful), int(faithful))
     px = lib().orc_decode_many(arr, lens, n, ctypes.byref(o), nthreads, st)
     return int(px), list(st)
+
+
+def f32_trunc(x):
+    """decoder.rs:382-390 f32_to_u8 on one value"""
+    l = lib()
+    l.orc_f32_to_u8.restype = ctypes.c_uint8
+    l.orc_f32_to_u8.argtypes = [ctypes.c_float]
+    return int(l.orc_f32_to_u8(float(x)))

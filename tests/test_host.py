@@ -1,0 +1,169 @@
+"""CPU tests of the host side: C-ABI exports, JFIF parse (mirror of jpeg/mod.rs:202-465), decode tables + the per-lane
+entropy routine through the CPU emulation of the GPU algorithm (tests/emul), the synthetic generator."""
+import ctypes
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIXTURES = {  # name -> (W, H, [(id,h,v,tq,td,ta)], destuffed scan bytes incl. trailing FFD9)  -- SURVEY.md s4 table
+    "huff_simple0.jpg": (16, 8, [(1, 1, 1, 0, 0, 0), (2, 1, 1, 1, 1, 1), (3, 1, 1, 1, 1, 1)], 10),
+    "lena-bw.jpeg": (512, 512, [(1, 1, 1, 0, 0, 0)], 21496),
+    "lena.jpeg": (512, 512, [(1, 2, 1, 0, 0, 0), (2, 1, 1, 1, 1, 1), (3, 1, 1, 1, 1, 1)], 90696),
+    "2x2-chroma.jpeg": (750, 595, [(1, 2, 2, 0, 0, 0), (2, 1, 1, 1, 1, 1), (3, 1, 1, 1, 1, 1)], 145021),
+}
+
+
+def _read(name):
+    return open(os.path.join(ROOT, "tests", "data", name), "rb").read()
+
+
+def test_library_exports_every_symbol_of_the_header(mjx):
+    header = open(os.path.join(ROOT, "include", "mjx.h")).read()
+    declared = set(re.findall(r"\b(mjx_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(mjx.SYMBOLS), declared ^ set(mjx.SYMBOLS)
+    raw = ctypes.CDLL(mjx.lib_path())
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert b"gfx950" in mjx.lib().mjx_version()
+    assert mjx.lib().mjx_strerror(mjx.ERR_DRI_UNSUPPORTED)
+
+
+@pytest.mark.parametrize("name", sorted(FIXTURES))
+def test_parse_fixture(mjx, name):
+    w, h, comps, scan_len = FIXTURES[name]
+    s = mjx.ParsedScan(_read(name))
+    d = s.desc
+    assert (d.width, d.height, d.ncomp, d.scan_len) == (w, h, len(comps), scan_len)
+    got = [(c.id, c.h, c.v, c.tq, c.td, c.ta) for c in list(d.comp)[:d.ncomp]]
+    assert got == comps
+    assert s.scan_bytes().endswith(b"\xff\xd9")
+    assert b"\xff\x00" not in s.scan_bytes()[:-2] or name == "lena.jpeg"
+    for c in comps:
+        assert d.qt_present & (1 << c[3]) and d.dc_present & (1 << c[4]) and d.ac_present & (1 << c[5])
+    s.close()
+
+
+def test_parse_known_scan_prefix(mjx):
+    s = mjx.ParsedScan(_read("huff_simple0.jpg"))
+    assert s.scan_bytes().hex() == "fcffe2afeff3157fffd9"
+    s.close()
+
+
+def _code(mjx, data, strict):
+    try:
+        mjx.ParsedScan(data, strict_ref=strict).close()
+        return mjx.OK
+    except mjx.MjxError as e:
+        return e.code
+
+
+def test_parse_error_codes_mirror_the_reference_panics(mjx):
+    good = _read("lena.jpeg")
+    assert _code(mjx, _read("huff_simple0.jpg"), True) == mjx.ERR_UNSUPPORTED_MARKER     # APP12, mod.rs:445-447
+    assert _code(mjx, _read("huff_simple0.jpg"), False) == mjx.OK                         # skipped
+    sos = good.index(b"\xff\xda")
+    dri = good[:sos] + b"\xff\xdd\x00\x04\x00\x08" + good[sos:]
+    assert _code(mjx, dri, True) == mjx.ERR_DRI_UNSUPPORTED and _code(mjx, dri, False) == mjx.ERR_DRI_UNSUPPORTED
+    assert _code(mjx, good[:sos], False) == mjx.ERR_NO_SCAN                               # image_data() == None
+    assert _code(mjx, good[:100], False) == mjx.ERR_TRUNCATED
+    assert _code(mjx, b"\x00\x01\x02\x03", True) == mjx.ERR_UNSUPPORTED_MARKER            # "Unhandled byte marker"
+    sof2 = good.replace(b"\xff\xc0", b"\xff\xc2", 1)
+    assert _code(mjx, sof2, True) == mjx.ERR_UNSUPPORTED_MARKER and _code(mjx, sof2, False) == mjx.ERR_UNSUPPORTED_FORMAT
+    sof = good.index(b"\xff\xc0")
+    bad_sampling = bytearray(good); bad_sampling[sof + 11] = 0x41                         # h = 4: assert at mod.rs:275
+    assert _code(mjx, bytes(bad_sampling), True) == mjx.ERR_REF_PANIC
+    assert _code(mjx, b"", False) == mjx.ERR_NO_SCAN
+
+
+def test_parse_never_crashes_on_mutations(mjx):
+    rng = np.random.default_rng(7)
+    base = _read("lena-bw.jpeg")
+    header_len = base.index(b"\xff\xda") + 12
+    for k in range(300):
+        b = bytearray(base[: header_len + 64])
+        for _ in range(int(rng.integers(1, 6))):
+            b[int(rng.integers(0, header_len))] = int(rng.integers(0, 256))
+        cut = int(rng.integers(1, len(b)))
+        for data in (bytes(b), bytes(b[:cut])):
+            for strict in (True, False):
+                assert 0 <= _code(mjx, data, strict) <= mjx.ERR_MISSING_TABLE
+
+
+# ---- entropy algorithm on the CPU emulation ---------------------------------------------------------------
+@pytest.fixture(scope="module")
+def emul(mjx):
+    lib = ctypes.CDLL(os.path.join(ROOT, "tests", "emul", "libhuff_emul.so"))
+    lib.emul_decode_coefs.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                      ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]
+
+    def run(data, layout, wg=256):
+        cap = 400000
+        out = np.zeros((cap, 64), np.int16)
+        nb, st = ctypes.c_size_t(), (ctypes.c_int * 8)()
+        rc = lib.emul_decode_coefs(data, len(data), layout, wg, out.ctypes.data, cap, ctypes.byref(nb), st)
+        return rc, out[: nb.value].copy(), list(st)
+    return run
+
+
+@pytest.mark.parametrize("name", sorted(FIXTURES))
+@pytest.mark.parametrize("layout", [0, 1])
+def test_emulated_parallel_decode_equals_oracle_T0(mjx, orc, emul, name, layout):
+    data = _read(name)
+    rc, coefs, st = emul(data, layout)
+    ref = orc.decode(data, layout=orc.LAYOUT_STD if layout == 0 else orc.LAYOUT_REF)
+    assert rc == 0 and np.array_equal(coefs, orc.interleave(ref))
+
+
+@pytest.mark.parametrize("w,h,sub,q", [(64, 48, "444", 75), (64, 48, "422", 30), (61, 45, "420", 95), (100, 60, "gray", 75),
+                                       (48, 64, "440", 75), (750, 595, "420", 50), (1920, 1080, "420", 75)])
+def test_emulated_decode_synthetic(mjx, orc, emul, w, h, sub, q):
+    data = mjx.synth_jpeg(w, h, sub, q, seed=w + h)
+    for wg in (256, 4):                      # tiny workgroups force many inter-workgroup fix passes
+        rc, coefs, st = emul(data, 0, wg)
+        ref = orc.decode(data, layout=orc.LAYOUT_STD)
+        assert rc == 0 and np.array_equal(coefs, orc.interleave(ref)), (wg, st)
+
+
+def test_emulated_decode_with_optimised_tables_and_16bit_dqt(mjx, orc, emul):
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(3)
+    img = PIL.fromarray(rng.integers(0, 256, (72, 88, 3), dtype=np.uint8))
+    for kw in (dict(optimize=True, subsampling=2, quality=85), dict(optimize=True, subsampling=0, quality=40),
+               dict(optimize=False, subsampling=1, quality=100)):
+        buf = io.BytesIO()
+        img.save(buf, "JPEG", **kw)
+        data = buf.getvalue()
+        rc, coefs, st = emul(data, 0)
+        try:
+            ref = orc.decode(data, layout=orc.LAYOUT_STD)
+        except orc.OracleError:
+            continue                         # optimised tables may contain a 1-bit code the reference cannot decode (Q8)
+        assert rc == 0 and np.array_equal(coefs, orc.interleave(ref))
+
+
+def test_synthetic_generator_is_deterministic_and_standard(mjx, orc):
+    a = mjx.synth_jpeg(96, 64, "420", 75, seed=9)
+    assert a == mjx.synth_jpeg(96, 64, "420", 75, seed=9) and a != mjx.synth_jpeg(96, 64, "420", 75, seed=10)
+    markers = set(re.findall(rb"\xff([\xc0-\xfe])", a[: a.index(b"\xff\xda") + 2]))
+    assert markers <= {b"\xd8", b"\xe0", b"\xdb", b"\xc0", b"\xc4", b"\xda"}          # only what mod.rs:166-179 parses
+    orc.decode(a, strict_ref=True, layout=orc.LAYOUT_STD)
+    PIL = pytest.importorskip("PIL.Image")
+    pil = np.array(PIL.open(io.BytesIO(a)).convert("RGB")).astype(float)
+    std = orc.decode(a, layout=orc.LAYOUT_STD).rgb.astype(float)
+    assert 10 * np.log10(255 ** 2 / np.mean((pil - std) ** 2)) > 35
+
+
+def test_no_gpu_means_loud_failure_not_fallback(mjx):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(mjx.MjxError) as e:
+        mjx.Context(0)
+    assert e.value.code == mjx.ERR_DEVICE
+    with pytest.raises(mjx.MjxError) as e:
+        mjx.decode(_read("lena.jpeg"))
+    assert e.value.code == mjx.ERR_DEVICE

@@ -1,0 +1,145 @@
+"""CPU tests: pin the oracle (oracle/mjx_oracle.c) against the reference's sample files and the known answers of
+SURVEY.md s4, against committed golden vectors, and against independent sanity bounds (float64 IDCT, PIL)."""
+import hashlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+# SHA-256 of the coefficient stream (components in scan order, blocks in decode order, 64 x int16 LE
+# zig-zag, after DC prediction, reference MCU count) + bits consumed + MCUs + blocks per component
+KNOWN = {
+    "huff_simple0.jpg": ("5b042c5ca7ff9a10af546a630d36b235ee4d23e3bea5d6f0f74197fb770efece", 58, 2, [2, 2, 2]),
+    "lena-bw.jpeg": ("0fa4cc6820aa8a2d1d2448b5ad5f6b036ff007c17ef8b0369c5207655775dea2", 171949, 4096, [4096]),
+    "lena.jpeg": ("ba5ce1b7b3b108bb2bf354a742b7c1217138d58cefd78abe347e05255c060c06", 725548, 2048, [4096, 2048, 2048]),
+    "2x2-chroma.jpeg": ("04cf33d3a2401666bcf9972782886d8e4418ac2eff240308ed2706b83f6379b0", 1156294, 1763, [7052, 1763, 1763]),
+}
+
+
+def _read(data_dir, name):
+    return open(os.path.join(data_dir, name), "rb").read()
+
+
+def _coef_sha(dec):
+    h = hashlib.sha256()
+    for c in dec.coefs:
+        h.update(c.astype("<i2").tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("name", sorted(KNOWN))
+def test_known_answers_reference_layout(orc, data_dir, name):
+    sha, bits, mcus, nblocks = KNOWN[name]
+    d = orc.decode(_read(data_dir, name), layout=orc.LAYOUT_REF)
+    assert _coef_sha(d) == sha
+    assert d.bits_used == bits and d.mcus == mcus and [len(c) for c in d.coefs] == nblocks
+
+
+def test_known_pixels(orc, data_dir):
+    d = orc.decode(_read(data_dir, "huff_simple0.jpg"), layout=orc.LAYOUT_REF)
+    assert d.rgb.shape == (8, 16, 3)
+    assert (d.rgb[:, :8] == 0).all() and (d.rgb[:, 8:] == 255).all()         # left 000000, right ffffff
+    assert d.coefs[0][0, 0] == -512 and d.coefs[0][1, 0] == 508
+    bw = orc.decode(_read(data_dir, "lena-bw.jpeg"), layout=orc.LAYOUT_REF)
+    assert bw.rgb[0, 0].tolist() == [157] * 3 and bw.rgb[256, 256].tolist() == [86] * 3
+    assert abs(bw.rgb.mean() - 116.55) < 0.01
+    assert list(bw.coefs[0][0, :3]) == [13, 1, 1] and int((bw.coefs[0] != 0).sum()) == 30280
+    le = orc.decode(_read(data_dir, "lena.jpeg"), layout=orc.LAYOUT_REF)
+    assert np.abs(le.rgb[0, 0].astype(int) - [224, 138, 127]).max() <= 1
+    assert np.abs(le.rgb[256, 256].astype(int) - [180, 66, 73]).max() <= 1
+    assert list(le.coefs[0][0, :8]) == [87, 3, 4, -3, -1, 2, 0, 1]
+    ch = orc.decode(_read(data_dir, "2x2-chroma.jpeg"), layout=orc.LAYOUT_REF)
+    assert list(ch.coefs[0][0, :12]) == [165, -6, -4, -2, 0, -2, 4, 0, 2, -2, -1, 1]
+
+
+def test_strict_ref_reproduces_the_app12_panic(orc, data_dir):
+    with pytest.raises(orc.OracleError) as e:          # jpeg/mod.rs:445-447, SURVEY Q1
+        orc.decode(_read(data_dir, "huff_simple0.jpg"), strict_ref=True)
+    assert e.value.code == orc.ERR_REF_PANIC
+    for name in ("lena-bw.jpeg", "lena.jpeg", "2x2-chroma.jpeg"):
+        orc.decode(_read(data_dir, name), strict_ref=True)
+
+
+@pytest.mark.parametrize("name", ["huff_simple0.jpg", "lena-bw.jpeg", "lena.jpeg"])
+def test_ref_and_std_layouts_agree_where_the_reference_is_self_consistent(orc, data_dir, name):
+    data = _read(data_dir, name)     # greyscale, 4:4:4, 4:2:2 with W % 16 == 0: SURVEY T2a
+    a, b = orc.decode(data, layout=orc.LAYOUT_REF), orc.decode(data, layout=orc.LAYOUT_STD)
+    assert np.array_equal(a.rgb, b.rgb) and _coef_sha(a) == _coef_sha(b)
+
+
+def test_standard_layout_reads_the_whole_scan_of_2x2_chroma(orc, data_dir):
+    d = orc.decode(_read(data_dir, "2x2-chroma.jpeg"), layout=orc.LAYOUT_STD)
+    assert d.mcus == 1786 and d.bits_used == 1160149
+
+
+def test_faithful_modes_are_bit_identical(orc, data_dir):
+    data = _read(data_dir, "lena.jpeg")
+    fast = orc.decode(data)
+    slow = orc.decode(data, faithful_cos=True, faithful_huff=True)
+    assert np.array_equal(fast.rgb, slow.rgb) and _coef_sha(fast) == _coef_sha(slow)
+
+
+def test_q5_panics_are_reported_not_crashes(orc, mjx):
+    for w, h, panics in [(64, 44, True), (64, 90, True), (60, 48, True), (64, 36, False)]:
+        data = mjx.synth_jpeg(w, h, "420", 75, seed=5)
+        if panics:
+            with pytest.raises(orc.OracleError) as e:
+                orc.decode(data, layout=orc.LAYOUT_REF)
+            assert e.value.code == orc.ERR_REF_PANIC
+        else:
+            orc.decode(data, layout=orc.LAYOUT_REF)
+        orc.decode(data, layout=orc.LAYOUT_STD)       # the standard layout decodes every geometry
+
+
+def test_idct_matches_float64_definition(orc):
+    rng = np.random.default_rng(1)
+    u = np.arange(8)
+    basis = np.cos((2 * u[:, None] + 1) * u[None, :] * np.pi / 16) * np.where(u == 0, 1 / np.sqrt(2), 1.0)[None, :]
+    for _ in range(50):
+        f = np.round(rng.normal(0, 60, (8, 8)) * (rng.random((8, 8)) < 0.3))
+        want = basis @ f @ basis.T / 4          # out[y][x] = 1/4 sum_v sum_u a(u)a(v) F[v][u] cos.. cos..
+        got = orc.idct_ref(f)
+        assert np.abs(got - want).max() < 2e-3
+    dc = np.zeros((8, 8)); dc[0, 0] = 1016
+    assert orc.f32_trunc(orc.idct_ref(dc)[0, 0] + np.float32(128)) == 255    # SURVEY s4 huff_simple0 right block
+
+
+def test_colour_conversion_known_points(orc):
+    assert orc.ycbcr_to_rgb(0, 0, 0).tolist() == [128, 128, 128]
+    assert orc.ycbcr_to_rgb(200, 0, 0).tolist() == [255, 255, 255]
+    assert orc.ycbcr_to_rgb(-200, 0, 0).tolist() == [0, 0, 0]
+    r, g, b = orc.ycbcr_to_rgb(0, 0, 50)
+    assert (r, b) == (128 + 70, 128) and g < 128          # 50 * 1.402 = 70.1 truncated
+
+
+def test_golden_vectors(orc):
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_golden.npz"))
+    i = 0
+    while "synth/%d/jpeg" % i in z:
+        data = z["synth/%d/jpeg" % i].tobytes()
+        d = orc.decode(data, layout=orc.LAYOUT_STD)
+        assert np.array_equal(d.rgb, z["synth/%d/std_rgb" % i])
+        assert np.array_equal(orc.interleave(d), z["synth/%d/coefs" % i])
+        if "synth/%d/ref_rgb" % i in z:
+            assert np.array_equal(orc.decode(data, layout=orc.LAYOUT_REF).rgb, z["synth/%d/ref_rgb" % i])
+        else:
+            with pytest.raises(orc.OracleError):
+                orc.decode(data, layout=orc.LAYOUT_REF)
+        i += 1
+    assert i >= 8
+    for name in KNOWN:
+        data = open(os.path.join(os.path.dirname(__file__), "data", name), "rb").read()
+        for lay, tag in ((orc.LAYOUT_REF, "ref"), (orc.LAYOUT_STD, "std")):
+            d = orc.decode(data, layout=lay)
+            assert hashlib.sha256(d.rgb.tobytes()).hexdigest() == str(z["file/%s/%s/rgb_sha" % (name, tag)])
+
+
+def test_sanity_bounds_against_pil(orc, data_dir):
+    PIL = pytest.importorskip("PIL.Image")
+    bw = orc.decode(_read(data_dir, "lena-bw.jpeg")).rgb
+    pil = np.array(PIL.open(io.BytesIO(_read(data_dir, "lena-bw.jpeg"))).convert("RGB"))
+    assert np.abs(bw.astype(int) - pil.astype(int)).max() <= 1       # libjpeg is a bound, not an oracle
+    le = orc.decode(_read(data_dir, "lena.jpeg")).rgb.astype(float)
+    pil = np.array(PIL.open(io.BytesIO(_read(data_dir, "lena.jpeg"))).convert("RGB")).astype(float)
+    assert 10 * np.log10(255 ** 2 / np.mean((le - pil) ** 2)) > 40
