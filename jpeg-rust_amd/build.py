@@ -92,9 +92,20 @@ def build_emul(force=False):
     return out
 
 
+def build_cli(force=False):
+    """mjx_cli: the reference's main.rs counterpart, linked against libmjx.so (rpath = package dir)."""
+    src = os.path.join(CSRC, "mjx_cli.cpp")
+    out = os.path.join(PKG, "mjx_cli")
+    if force or _newer(out, [src, os.path.join(CSRC, "jpeg.hpp"), os.path.join(PKG, "libmjx.so")]):
+        _run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", out, src,
+              "-L" + PKG, "-lmjx", "-Wl,-rpath," + PKG, "-Wl,-rpath,$ORIGIN"])
+    return out
+
+
 def build_all(force=False, verbose=False):
     return {
         "libmjx": build_product(force, verbose),
+        "cli": build_cli(force),
         "synth": build_synth(force),
         "oracle": build_oracle(force),
         "emul": build_emul(force),
