@@ -50,7 +50,7 @@ struct Chunk {
     uint32_t nsub = 0;             // subsequences in the chunk
     uint64_t blocks = 0;           // coefficient blocks in the chunk
     uint64_t coef_base = 0;        // first block of the chunk inside d_coef (keep_coefs) or 0
-    uint32_t max_wg = 0, max_tiles = 0, lut_cap = 0, max_tile_blocks = 0;
+    uint32_t max_wg = 0, max_tiles = 0, lut_cap = 0, max_tile_blocks = 0, mode_mask = 0;
 };
 
 struct EventPair {
@@ -121,6 +121,7 @@ void fill_dev_image(const ImagePlan &p, DevImage &d)
     uint32_t t = tile_mcus(p.bpm, p.hmax), l2 = 0;
     while ((1u << (l2 + 1)) <= t) l2++;
     d.log2_tile = l2;
+    d.mode = (p.ncomp == 3 && p.h[0] == 2 && p.v[0] == 2 && p.h[1] == 1 && p.v[1] == 1 && p.h[2] == 1 && p.v[2] == 1) ? 1 : 0;
     std::memcpy(d.blk_comp, p.blk_comp, sizeof d.blk_comp);
     std::memcpy(d.blk_bx, p.blk_bx, sizeof d.blk_bx);
     std::memcpy(d.blk_by, p.blk_by, sizeof d.blk_by);
@@ -163,6 +164,7 @@ void plan_chunks(mjx_batch *b)
                 c.max_tiles = std::max<uint32_t>(c.max_tiles, (d.nmcu + T - 1) / T);
                 c.max_tile_blocks = std::max<uint32_t>(c.max_tile_blocks, T * d.bpm);
                 c.lut_cap = std::max<uint32_t>(c.lut_cap, d.lut_n);
+                c.mode_mask |= 1u << d.mode;
             }
             b->info[i].chunk = uint32_t(b->chunks.size());
             c.count++;
@@ -270,7 +272,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     }
     if (stages & MJX_STAGE_PIXELS) {
         prof_begin(b, MJX_K_IDCT_COLOR);
-        launch_idct_color(st, c.max_tiles, nimg, b->idct_lds, imgs, coef, dcb, b->d_qm, b->d_rgb);
+        launch_idct_color(st, c.max_tiles, nimg, b->idct_lds, imgs, coef, dcb, b->d_qm, b->d_rgb, c.mode_mask);
         prof_end(b);
     }
     HIPOK(hipGetLastError());

@@ -28,7 +28,7 @@ struct DevImage {
     uint32_t valid;         // 0: skip (error at plan time)
     uint32_t status_idx;    // index into the batch-wide device status array
     uint32_t log2_tile;     // stage-B tile = 1 << log2_tile MCUs
-    uint32_t pad0_;
+    uint32_t mode;          // stage-B specialisation: 0 generic, 1 = 4:2:0 (Y 2x2, Cb 1x1, Cr 1x1)
     uint8_t blk_comp[kMaxBlocksPerMcu], blk_bx[kMaxBlocksPerMcu], blk_by[kMaxBlocksPerMcu];
     uint8_t ch[4], cv[4];   // sampling factors per component
     uint8_t cfirst[4];      // first block position of each component inside the MCU
@@ -61,7 +61,7 @@ void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ld
                        const uint32_t *blkbase, uint32_t lut_cap, int16_t *coef, int16_t *dcbuf, int *status);
 void launch_dc_scan(hipStream_t st, uint32_t nimg, const DevImage *images, int16_t *dcbuf);
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
-                       const int16_t *coef, const int16_t *dcbuf, const float *qmult, uint8_t *rgb);
+                       const int16_t *coef, const int16_t *dcbuf, const float *qmult, uint8_t *rgb, uint32_t mode_mask);
 #endif
 
 }   // namespace mjx

@@ -348,65 +348,83 @@ __device__ __forceinline__ void idct8(float &i0, float &i1, float &i2, float &i3
     i4 = e3 + o4; i3 = e3 - o4;
 }
 
-// decoder.rs:382-390 f32_to_u8: clamp to [0,255], truncate toward zero.
-__device__ __forceinline__ uint32_t f32_to_u8(float n)
+// decoder.rs:382-390 f32_to_u8 (clamp to [0,255], truncate toward zero) fused with the byte packing:
+// floor() then v_cvt_pk_u8_f32, which saturates to [0,255] and inserts the byte (it rounds to nearest, hence the
+// floor; negative inputs saturate to 0 either way).  Checked against clamp+truncate in tools/probes/cvt_probe.hip.
+__device__ __forceinline__ uint32_t pack_u8(float n, uint32_t byte, uint32_t word)
 {
-    n = __builtin_fminf(__builtin_fmaxf(n, 0.0f), 255.0f);
-    return uint32_t(n);
+    return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(n), byte, word);
 }
 
-// decoder.rs:392-402 y_cb_cr_to_rgb, same operation order, every operation rounded to f32 (no FMA contraction).
-__device__ __forceinline__ void ycc_to_rgb(float y, float cb, float cr, uint32_t &r8, uint32_t &g8, uint32_t &b8)
+// x / 0.587f, correctly rounded, in three operations (multiply by the rounded reciprocal, exact residual by FMA, one
+// correction).  Bit-identical to IEEE division for every |x| in [2^-100, 8192) -- exhaustively checked on the host
+// (DESIGN.md s5); outside that range the result is clamped or vanishes in the +128.
+__device__ __forceinline__ float div_c_green(float x)
+{
+    const float d = 0.587f, rcp = 1.0f / 0.587f;
+    const float q = x * rcp;
+    const float r = __builtin_fmaf(-q, d, x);
+    return __builtin_fmaf(r, rcp, q);
+}
+
+// decoder.rs:392-402 y_cb_cr_to_rgb with the two chroma products hoisted (crk = cr * (2 - 2*c_red), cbk likewise: the
+// same rounded products the reference forms per pixel).  Every operation is rounded to f32 separately (no contraction)
+// in the reference's order:  r = crk + y;  b = cbk + y;  g = (y - c_blue*b - c_red*r) / c_green;  then +128, clamp, truncate.
+struct Rgb { float r, g, b; };
+__device__ __forceinline__ Rgb ycc_to_rgb(float y, float cbk, float crk)
 {
 #pragma clang fp contract(off)
-    const float c_red = 0.299f, c_green = 0.587f, c_blue = 0.114f;
-    const float kr = 2.0f - 2.0f * c_red, kb = 2.0f - 2.0f * c_blue;
-    const float r = cr * kr + y;
-    const float b = cb * kb + y;
-    const float g = (y - c_blue * b - c_red * r) / c_green;
-    r8 = f32_to_u8(r + 128.0f);
-    g8 = f32_to_u8(g + 128.0f);
-    b8 = f32_to_u8(b + 128.0f);
+    const float c_red = 0.299f, c_blue = 0.114f;
+    Rgb o;
+    o.r = crk + y;
+    o.b = cbk + y;
+    const float t1 = c_blue * o.b;
+    const float t2 = c_red * o.r;
+    float g = y - t1;
+    g = g - t2;
+    o.g = div_c_green(g) + 128.0f;
+    o.r = o.r + 128.0f;
+    o.b = o.b + 128.0f;
+    return o;
+}
+__device__ __forceinline__ void chroma_products(float cb, float cr, float &cbk, float &crk)
+{
+#pragma clang fp contract(off)
+    const float kr = 2.0f - 2.0f * 0.299f, kb = 2.0f - 2.0f * 0.114f;
+    crk = cr * kr;
+    cbk = cb * kb;
 }
 
 struct __attribute__((packed, aligned(4))) Rgb4 { uint32_t a, b, c; };
 struct __attribute__((packed, aligned(1))) Rgb4u { uint32_t a, b, c; };
 
-// Reads 4 horizontally adjacent samples of one component for the pixel strip starting at MCU-local (x, y);
-// replicates when the component is subsampled (box replication: the reference never interpolates, SURVEY Q4).
-__device__ __forceinline__ void load4(const float *tile, const DevImage &im, uint32_t mcu_blk0, uint32_t c,
-                                      uint32_t x, uint32_t y, float out[4])
+// 4 pixels -> 12 bytes R,G,B,R,G,B,...
+__device__ __forceinline__ Rgb4 pack4(const Rgb p[4])
 {
-    const uint32_t xr = im.hmax / im.ch[c], yr = im.vmax / im.cv[c];
-    const uint32_t xs = x / xr, ys = y / yr;
-    const uint32_t blk = mcu_blk0 + im.cfirst[c] + (ys >> 3) * im.ch[c] + (xs >> 3);
-    const float *p = tile + blk * kPixStride + (ys & 7) * 8 + (xs & 7);
-    if (xr == 1) {
-        const float4 v = *reinterpret_cast<const float4 *>(p);
-        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    Rgb4 o;
+    o.a = pack_u8(p[1].r, 3, pack_u8(p[0].b, 2, pack_u8(p[0].g, 1, pack_u8(p[0].r, 0, 0))));
+    o.b = pack_u8(p[2].g, 3, pack_u8(p[2].r, 2, pack_u8(p[1].b, 1, pack_u8(p[1].g, 0, 0))));
+    o.c = pack_u8(p[3].b, 3, pack_u8(p[3].g, 2, pack_u8(p[3].r, 1, pack_u8(p[2].b, 0, 0))));
+    return o;
+}
+
+__device__ __forceinline__ void store4(uint8_t *dst, const Rgb4 &v, bool aligned, uint32_t npix)
+{
+    if (npix >= 4) {
+        if (aligned) *reinterpret_cast<Rgb4 *>(dst) = v;
+        else *reinterpret_cast<Rgb4u *>(dst) = Rgb4u{v.a, v.b, v.c};
     } else {
-        const float2 v = *reinterpret_cast<const float2 *>(p);
-        out[0] = v.x; out[1] = v.x; out[2] = v.y; out[3] = v.y;
+        const uint32_t w[3] = {v.a, v.b, v.c};
+        for (uint32_t k = 0; k < npix * 3; k++) dst[k] = uint8_t(w[k >> 2] >> ((k & 3) * 8));
     }
 }
 
-extern "C" __global__ __launch_bounds__(256) void k_idct_color(const DevImage *images, const int16_t *coef,
-                                                                const int16_t *dcbuf, const float *qmult,
-                                                                uint8_t *rgb)
+// Phases 1 + 2 of stage B, common to every sampling layout: stage the tile's coefficient blocks in LDS, one lane = one
+// 8x8 block (dequant, un-zigzag, 16 one-dimensional transforms in registers), results to the LDS sample tile.
+__device__ __forceinline__ void idct_tile(const DevImage &im, const int16_t *coef, const int16_t *dcbuf,
+                                          const float *s_qm, unsigned char *smem, uint64_t blk0, uint32_t nblk)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ float s_qm[3 * 64];
-    const DevImage &im = images[blockIdx.y];
-    const uint32_t T = 1u << im.log2_tile;
-    const uint32_t m0 = blockIdx.x * T;
-    if (!im.valid || m0 >= im.nmcu) return;
     const uint32_t tid = threadIdx.x;
-    const uint32_t bpm = im.bpm;
-    const uint32_t nm = min(T, im.nmcu - m0), nblk = nm * bpm;
-    const uint64_t blk0 = im.coef_off + uint64_t(m0) * bpm;
-
-    if (tid < 192) s_qm[tid] = qmult[im.qm_off + tid];
-    // phase 1: coalesced 16-byte loads of the tile's coefficient blocks into LDS (stride 144 B)
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(coef + blk0 * 64);
         const uint32_t ngran = nblk * 8;
@@ -416,11 +434,10 @@ extern "C" __global__ __launch_bounds__(256) void k_idct_color(const DevImage *i
         }
     }
     __syncthreads();
-    // phase 2: one lane = one 8x8 block: dequant + un-zigzag into registers, 8 column + 8 row transforms
     float v[64];
     const bool have_block = tid < nblk;
     if (have_block) {
-        const uint32_t c = im.blk_comp[tid % bpm];
+        const uint32_t c = im.blk_comp[tid % im.bpm];
         const float *qm = s_qm + c * 64;
         const uint4 *cb = reinterpret_cast<const uint4 *>(smem + tid * kCoefStride);
         constexpr int ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
@@ -458,49 +475,120 @@ extern "C" __global__ __launch_bounds__(256) void k_idct_color(const DevImage *i
         }
     }
     __syncthreads();
-    // phase 3: 4-pixel strips; lane -> (MCU t, strip sx) is fixed, rows advance by 256/R per step
-    const uint32_t strips = 2 * im.hmax;                     // 4-pixel strips per MCU row
-    const uint32_t R = T * strips;                           // strips per pixel row of the tile (power of two <= 256)
+}
+
+// Reads 4 horizontally adjacent samples of one component for the pixel strip starting at MCU-local (x, y);
+// replicates when the component is subsampled (box replication: the reference never interpolates, SURVEY Q4).
+// Sampling ratios are 1 or 2 (jpeg/mod.rs:275-277), so the divisions are shifts.
+__device__ __forceinline__ void load4(const float *tile, const DevImage &im, uint32_t mcu_blk0, uint32_t c,
+                                      uint32_t x, uint32_t y, float out[4])
+{
+    const uint32_t xsh = im.hmax > im.ch[c] ? 1 : 0, ysh = im.vmax > im.cv[c] ? 1 : 0;
+    const uint32_t xs = x >> xsh, ys = y >> ysh;
+    const uint32_t blk = mcu_blk0 + im.cfirst[c] + (ys >> 3) * im.ch[c] + (xs >> 3);
+    const float *p = tile + blk * kPixStride + (ys & 7) * 8 + (xs & 7);
+    if (!xsh) {
+        const float4 v = *reinterpret_cast<const float4 *>(p);
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else {
+        const float2 v = *reinterpret_cast<const float2 *>(p);
+        out[0] = v.x; out[1] = v.x; out[2] = v.y; out[3] = v.y;
+    }
+}
+
+// MODE 0: any sampling layout.  MODE 1: Y 2x2 + Cb 1x1 + Cr 1x1 (4:2:0, 6 blocks per MCU, tile = 32 MCUs).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_idct_color(const DevImage *images, const int16_t *coef, const int16_t *dcbuf,
+                                                     const float *qmult, uint8_t *rgb)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float s_qm[3 * 64];
+    const DevImage &im = images[blockIdx.y];
+    if (!im.valid || im.mode != uint32_t(MODE)) return;
+    const uint32_t T = MODE == 1 ? 32u : (1u << im.log2_tile);
+    const uint32_t m0 = blockIdx.x * T;
+    if (m0 >= im.nmcu) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t bpm = MODE == 1 ? 6u : im.bpm;
+    const uint32_t nm = min(T, im.nmcu - m0), nblk = nm * bpm;
+    const uint64_t blk0 = im.coef_off + uint64_t(m0) * bpm;
+    if (tid < 192) s_qm[tid] = qmult[im.qm_off + tid];
+    idct_tile(im, coef, dcbuf, s_qm, smem, blk0, nblk);
+    const float *tile = reinterpret_cast<const float *>(smem);
+    uint8_t *out_img = rgb + im.rgb_off;
+    const bool aligned = ((im.width * 3u) & 3u) == 0 && (im.rgb_off & 3u) == 0;
+
+    if (MODE == 1) {
+        // phase 3, 4:2:0: lane -> (MCU t, 4-pixel strip sx) fixed; each step handles a 4x2 pixel patch that shares
+        // one pair of chroma samples per component (box replication).
+        const uint32_t q = tid & 127, t = q >> 2, sx = q & 3;
+        if (t >= nm) return;
+        const uint32_t m = m0 + t;
+        const uint32_t mx = m % im.mcux, my = m / im.mcux;
+        const uint32_t px = mx * 16 + sx * 4;
+        if (px >= im.width) return;
+        const uint32_t npix = min(4u, im.width - px);
+        const float *ybase = tile + (t * 6 + (sx >> 1)) * kPixStride + (sx & 1) * 4;
+        const float *cbase = tile + (t * 6 + 4) * kPixStride + sx * 2;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t rp = (tid >> 7) + 2 * j;                           // row pair 0..7 inside the MCU
+            const uint32_t py = my * 16 + rp * 2;
+            if (py >= im.height) break;
+            const float *yp = ybase + (rp >> 2) * 2 * kPixStride + ((rp * 2) & 7) * 8;
+            const float4 ya = *reinterpret_cast<const float4 *>(yp);
+            const float4 yb = *reinterpret_cast<const float4 *>(yp + 8);
+            const float2 cb = *reinterpret_cast<const float2 *>(cbase + rp * 8);
+            const float2 cr = *reinterpret_cast<const float2 *>(cbase + kPixStride + rp * 8);
+            float cbk0, crk0, cbk1, crk1;
+            chroma_products(cb.x, cr.x, cbk0, crk0);
+            chroma_products(cb.y, cr.y, cbk1, crk1);
+            Rgb p[4];
+            p[0] = ycc_to_rgb(ya.x, cbk0, crk0); p[1] = ycc_to_rgb(ya.y, cbk0, crk0);
+            p[2] = ycc_to_rgb(ya.z, cbk1, crk1); p[3] = ycc_to_rgb(ya.w, cbk1, crk1);
+            uint8_t *dst = out_img + (size_t(py) * im.width + px) * 3;
+            store4(dst, pack4(p), aligned, npix);
+            if (py + 1 < im.height) {
+                p[0] = ycc_to_rgb(yb.x, cbk0, crk0); p[1] = ycc_to_rgb(yb.y, cbk0, crk0);
+                p[2] = ycc_to_rgb(yb.z, cbk1, crk1); p[3] = ycc_to_rgb(yb.w, cbk1, crk1);
+                store4(dst + size_t(im.width) * 3, pack4(p), aligned, npix);
+            }
+        }
+        return;
+    }
+
+    // phase 3, generic: 4-pixel strips; lane -> (MCU t, strip sx) is fixed, rows advance by 256/R per step
+    const uint32_t lstrips = im.hmax == 2 ? 2u : 1u;         // log2 of the 4-pixel strips per MCU row (2*hmax)
+    const uint32_t R = T << lstrips;                         // strips per pixel row of the tile (power of two <= 256)
     const uint32_t q = tid & (R - 1);
-    const uint32_t t = q / strips, sx = q % strips;
-    const uint32_t rows = 8 * im.vmax, rstep = 256 / R;
+    const uint32_t t = q >> lstrips, sx = q & ((1u << lstrips) - 1);
+    const uint32_t rows = 8 * im.vmax, lR = im.log2_tile + lstrips, rstep = 256u >> lR;
     if (t >= nm) return;
     const uint32_t m = m0 + t;
     const uint32_t mx = m % im.mcux, my = m / im.mcux;
     const uint32_t px = mx * 8 * im.hmax + sx * 4;
     if (px >= im.width) return;
-    const bool full_x = px + 4 <= im.width;
-    const bool aligned = ((im.width * 3u) & 3u) == 0 && (im.rgb_off & 3u) == 0;
-    uint8_t *out_img = rgb + im.rgb_off;
-    for (uint32_t r = tid / R; r < rows; r += rstep) {
+    const uint32_t npix = min(4u, im.width - px);
+    for (uint32_t r = tid >> lR; r < rows; r += rstep) {
         const uint32_t py = my * rows + r;
         if (py >= im.height) break;
         float yv[4], cbv[4], crv[4];
         load4(tile, im, t * bpm, 0, sx * 4, r, yv);
-        uint32_t r8[4], g8[4], b8[4];
+        Rgb p[4];
         if (im.ncomp == 3) {
             load4(tile, im, t * bpm, 1, sx * 4, r, cbv);
             load4(tile, im, t * bpm, 2, sx * 4, r, crv);
 #pragma unroll
-            for (int k = 0; k < 4; k++) ycc_to_rgb(yv[k], cbv[k], crv[k], r8[k], g8[k], b8[k]);
+            for (int k = 0; k < 4; k++) {
+                float cbk, crk;
+                chroma_products(cbv[k], crv[k], cbk, crk);
+                p[k] = ycc_to_rgb(yv[k], cbk, crk);
+            }
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; k++) r8[k] = g8[k] = b8[k] = f32_to_u8(yv[k] + 128.0f);   // decoder.rs:318-325
+            for (int k = 0; k < 4; k++) p[k].r = p[k].g = p[k].b = yv[k] + 128.0f;                 // decoder.rs:318-325
         }
-        uint8_t *dst = out_img + (size_t(py) * im.width + px) * 3;
-        if (full_x) {
-            const uint32_t d0 = r8[0] | (g8[0] << 8) | (b8[0] << 16) | (r8[1] << 24);
-            const uint32_t d1 = g8[1] | (b8[1] << 8) | (r8[2] << 16) | (g8[2] << 24);
-            const uint32_t d2 = b8[2] | (r8[3] << 8) | (g8[3] << 16) | (b8[3] << 24);
-            if (aligned) *reinterpret_cast<Rgb4 *>(dst) = Rgb4{d0, d1, d2};
-            else *reinterpret_cast<Rgb4u *>(dst) = Rgb4u{d0, d1, d2};
-        } else {
-            for (uint32_t k = 0; k < 4 && px + k < im.width; k++) {
-                dst[3 * k] = uint8_t(r8[k]);
-                dst[3 * k + 1] = uint8_t(g8[k]);
-                dst[3 * k + 2] = uint8_t(b8[k]);
-            }
-        }
+        store4(out_img + (size_t(py) * im.width + px) * 3, pack4(p), aligned, npix);
     }
 }
 
@@ -524,7 +612,10 @@ int configure_kernels(size_t huff_lds, size_t idct_lds)
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_write), hipFuncAttributeMaxDynamicSharedMemorySize, int(huff_lds));
     }
     if (e == hipSuccess && idct_lds > 64 * 1024)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_idct_color), hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
+    {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_idct_color<0>), hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_idct_color<1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
+    }
     return e == hipSuccess ? 0 : int(e);
 }
 
@@ -561,9 +652,12 @@ void launch_dc_scan(hipStream_t st, uint32_t nimg, const DevImage *images, int16
 }
 
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
-                       const int16_t *coef, const int16_t *dcbuf, const float *qmult, uint8_t *rgb)
+                       const int16_t *coef, const int16_t *dcbuf, const float *qmult, uint8_t *rgb, uint32_t mode_mask)
 {
-    hipLaunchKernelGGL(k_idct_color, dim3(max_tiles, nimg), dim3(256), lds, st, images, coef, dcbuf, qmult, rgb);
+    if (mode_mask & 1u)
+        hipLaunchKernelGGL(k_idct_color<0>, dim3(max_tiles, nimg), dim3(256), lds, st, images, coef, dcbuf, qmult, rgb);
+    if (mode_mask & 2u)
+        hipLaunchKernelGGL(k_idct_color<1>, dim3(max_tiles, nimg), dim3(256), lds, st, images, coef, dcbuf, qmult, rgb);
 }
 
 }   // namespace mjx
