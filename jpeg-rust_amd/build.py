@@ -53,7 +53,7 @@ def build_product(force=False, verbose=False):
     objs, log = [], ""
     for s in HIP_SOURCES:      # device + host code: hipcc cross-compiles gfx950 without a GPU
         o = os.path.join(objdir, s + ".o")
-        log += _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, s), "-o", o] + inc)
+        log += _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-c", os.path.join(CSRC, s), "-o", o] + inc)
         objs.append(o)
     for s in CXX_SOURCES:      # host-only code: plain C++
         o = os.path.join(objdir, s + ".o")

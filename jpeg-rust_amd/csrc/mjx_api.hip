@@ -50,7 +50,7 @@ struct Chunk {
     uint32_t nsub = 0;             // subsequences in the chunk
     uint64_t blocks = 0;           // coefficient blocks in the chunk
     uint64_t coef_base = 0;        // first block of the chunk inside d_coef (keep_coefs) or 0
-    uint32_t max_wg = 0, max_tiles = 0, lut_cap = 0, max_tile_blocks = 0, mode_mask = 0;
+    uint32_t max_wg = 0, max_wg_sync = 0, max_tiles = 0, lut_cap = 0, max_tile_blocks = 0, mode_mask = 0, max_segs = 0;
 };
 
 struct EventPair {
@@ -73,6 +73,7 @@ struct mjx_batch {
     float *d_qm = nullptr;
     SubseqState *d_entry = nullptr, *d_exit = nullptr;
     uint32_t *d_blkbase = nullptr;
+    int32_t *d_segsum = nullptr;
     int16_t *d_coef = nullptr, *d_dc = nullptr;
     uint8_t *d_rgb = nullptr;
     size_t rgb_pool_bytes = 0;
@@ -105,7 +106,7 @@ void release(mjx_batch *b)
     (void)hipFree(b->d_images); (void)hipFree(b->d_scan); (void)hipFree(b->d_lut); (void)hipFree(b->d_qm);
     (void)hipFree(b->d_entry); (void)hipFree(b->d_exit); (void)hipFree(b->d_blkbase);
     (void)hipFree(b->d_coef); (void)hipFree(b->d_dc); (void)hipFree(b->d_rgb); (void)hipFree(b->d_status);
-    (void)hipFree(b->d_mismatch);
+    (void)hipFree(b->d_mismatch); (void)hipFree(b->d_segsum);
     if (b->h_mismatch) (void)hipHostFree(b->h_mismatch);
     delete b;
 }
@@ -160,11 +161,13 @@ void plan_chunks(mjx_batch *b)
                 c.nsub += d.himg.nsub;
                 c.blocks += inf.nblocks;
                 c.max_wg = std::max<uint32_t>(c.max_wg, (d.himg.nsub + kWgLanes - 1) / kWgLanes);
+                c.max_wg_sync = std::max<uint32_t>(c.max_wg_sync, (d.himg.nsub + kOwn - 1) / kOwn);
                 const uint32_t T = 1u << d.log2_tile;
                 c.max_tiles = std::max<uint32_t>(c.max_tiles, (d.nmcu + T - 1) / T);
                 c.max_tile_blocks = std::max<uint32_t>(c.max_tile_blocks, T * d.bpm);
                 c.lut_cap = std::max<uint32_t>(c.lut_cap, d.lut_n);
                 c.mode_mask |= 1u << d.mode;
+                c.max_segs = std::max<uint32_t>(c.max_segs, (d.nmcu + kDcSegMcus - 1) / kDcSegMcus);
             }
             b->info[i].chunk = uint32_t(b->chunks.size());
             c.count++;
@@ -180,7 +183,9 @@ int allocate_work_buffers(mjx_batch *b)
     uint32_t max_nsub = 1;
     uint64_t max_blocks = 1, total_blocks = 0;
     uint32_t lut_cap = 8, max_tile_blocks = 1;
+    size_t max_segsum = 1;
     for (const Chunk &c : b->chunks) {
+        max_segsum = std::max<size_t>(max_segsum, size_t(c.max_segs) * c.count);
         max_nsub = std::max(max_nsub, c.nsub);
         max_blocks = std::max(max_blocks, c.blocks);
         total_blocks += c.blocks;
@@ -191,6 +196,7 @@ int allocate_work_buffers(mjx_batch *b)
     HIPOK(hipMalloc(&b->d_entry, size_t(max_nsub) * sizeof(SubseqState)));
     HIPOK(hipMalloc(&b->d_exit, size_t(max_nsub) * sizeof(SubseqState)));
     HIPOK(hipMalloc(&b->d_blkbase, size_t(max_nsub) * sizeof(uint32_t)));
+    HIPOK(hipMalloc(&b->d_segsum, max_segsum * 3 * sizeof(int32_t)));
     HIPOK(hipMalloc(&b->d_coef, size_t(coef_blocks) * 128));
     HIPOK(hipMalloc(&b->d_dc, size_t(coef_blocks) * sizeof(int16_t) + 16));
     HIPOK(hipMalloc(&b->d_rgb, std::max<size_t>(b->rgb_pool_bytes, 16)));
@@ -239,15 +245,15 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     fix_passes = std::min(fix_passes, kMaxFix);
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_SYNC)) {
         prof_begin(b, MJX_K_HUFF_SYNC);
-        launch_huff_sync(st, c.max_wg, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, c.lut_cap);
+        launch_huff_sync(st, c.max_wg_sync, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, c.lut_cap);
         prof_end(b);
     }
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_FIX)) {
         HIPOK(hipMemsetAsync(b->d_mismatch + ci * kMaxFix, 0, kMaxFix * sizeof(uint32_t), st));
-        if (c.max_wg > 1) {
+        if (c.max_wg_sync > 1) {
             for (int k = 0; k < fix_passes; k++) {
                 prof_begin(b, MJX_K_HUFF_FIX);
-                launch_huff_fix(st, c.max_wg, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, c.lut_cap,
+                launch_huff_fix(st, c.max_wg_sync, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, c.lut_cap,
                                 b->d_mismatch + ci * kMaxFix + k);
                 prof_end(b);
             }
@@ -267,7 +273,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
                           dcb, b->d_status);
         prof_end(b);
         prof_begin(b, MJX_K_DC_SCAN);
-        launch_dc_scan(st, nimg, imgs, dcb);
+        launch_dc_scan(st, c.max_segs, nimg, imgs, dcb, b->d_segsum);
         prof_end(b);
     }
     if (stages & MJX_STAGE_PIXELS) {
@@ -510,7 +516,7 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
     if (b->decoded_entropy) {
         for (size_t ci = 0; ci < b->chunks.size(); ci++) {
             const Chunk &c = b->chunks[ci];
-            if (c.max_wg < 2) continue;
+            if (c.max_wg_sync < 2) continue;
             const int passes = std::min(b->ctx->fix_passes, kMaxFix);
             if (b->h_mismatch[ci * kMaxFix + passes - 1] == 0) continue;
             // repair: restart this chunk's synchronisation (its state arrays may have been reused by a later chunk),

@@ -23,7 +23,10 @@
 
 namespace mjx {
 
-constexpr int kSubseqBytes = 128;              // bytes of scan per lane
+#ifndef MJX_SUBSEQ_BYTES
+#define MJX_SUBSEQ_BYTES 128
+#endif
+constexpr int kSubseqBytes = MJX_SUBSEQ_BYTES;  // bytes of scan per lane
 constexpr int kSubseqBits = kSubseqBytes * 8;
 constexpr int kLutPrimaryBits = 9;
 constexpr int kLutPrimarySize = 1 << kLutPrimaryBits;
@@ -63,22 +66,56 @@ struct NullSink {
     MJX_HD void dc(uint32_t, int) const {}
     MJX_HD void ac(uint32_t, unsigned, int) const {}
     MJX_HD void bad_code(uint32_t) const {}
+    MJX_HD void tick() const {}          // one call per decoded symbol (statistics in the CPU emulation)
+};
+
+// ---- checkpoints: early merge of a re-decode with the path of the previous decode ----------------------
+// While decoding a subsequence the lane records its state at the first symbol at/after every 128-bit boundary
+// inside the subsequence.  A later re-decode of the same subsequence (its entry changed) compares its own state
+// at each boundary with the recorded one: equal (p, z, c) means the two decodes coincide from there on, so the
+// re-decode stops and inherits the old exit.  This is the self-synchronisation property used at a finer grain:
+// most re-decodes merge after a few dozen symbols instead of running all ~180.
+//   word: bit31 valid | n[30:16] | c[15:12] | z[11:6] | p - boundary [5:0]
+//   n = blocks completed from the checkpoint to the end of the subsequence (after the decode's fix-up); while a
+//   decode is running it temporarily holds the blocks completed from the start to the checkpoint.
+constexpr int kCpBits = 128;
+constexpr int kNumCp = kSubseqBits / kCpBits - 1;
+constexpr uint32_t kCpValid = 0x80000000u, kCpStateMask = 0x8000ffffu;
+struct NoCheckpoints {
+    MJX_HD uint32_t get(uint32_t) const { return 0; }
+    MJX_HD void set(uint32_t, uint32_t) const {}
 };
 
 // Decode from `entry` until the bit position reaches `end_bit`.
 //   BitSrc::be32(i)  -> big-endian dword i of the image's scan (0xAAAAAAAA past the end, huffman.rs:236-246)
 //   lut              -> the image's decode tables
 //   WRITE            -> emit coefficients for blocks < img.total_blocks through `sink`, starting at block `blk`
-template <bool WRITE, class BitSrc, class Sink>
+//   CP               -> record checkpoints in `cps` and merge with the previous decode of this subsequence
+//                       (`sub_start` = first bit of the subsequence, `old_exit` = exit of that previous decode)
+template <bool WRITE, bool CP, class BitSrc, class Sink, class CpStore>
 MJX_HD SubseqState decode_subseq(const BitSrc &bits, const uint16_t *lut, const HuffImage &img, SubseqState entry,
-                                 uint32_t end_bit, uint32_t blk, Sink &sink)
+                                 uint32_t end_bit, uint32_t blk, Sink &sink, CpStore &cps, uint32_t sub_start,
+                                 SubseqState old_exit)
 {
     uint32_t p = entry.p, z = entry.z, c = entry.c, n = 0;
     uint32_t tab = img.blktab[c];
     uint32_t wi = p >> 5, o = p & 31;
     uint32_t w0 = bits.be32(wi), w1 = bits.be32(wi + 1);
+    uint32_t cp_bit = sub_start + kCpBits, k = 0;
     while (p < end_bit) {
         if (WRITE && blk >= img.total_blocks) break;
+        if (CP && p >= cp_bit) {
+            const uint32_t st = (p - cp_bit) | (z << 6) | (c << 12) | kCpValid;
+            const uint32_t old = cps.get(k);
+            if ((old & kCpStateMask) == st) {                                     // same state as the previous decode
+                n += (old >> 16) & 0x7fffu;
+                p = old_exit.p; z = old_exit.z; c = old_exit.c;
+                break;
+            }
+            cps.set(k, st | (n << 16));
+            k++;
+            cp_bit += kCpBits;
+        }
         const uint32_t w = o ? ((w0 << o) | (w1 >> (32 - o))) : w0;               // next 32 bits of the stream
         const uint32_t base = z ? (tab >> 16) : (tab & 0xffff);
         uint32_t e = lut[base + (w >> (32 - kLutPrimaryBits))];
@@ -88,6 +125,7 @@ MJX_HD SubseqState decode_subseq(const BitSrc &bits, const uint16_t *lut, const 
         }
         uint32_t len = e & 31;
         const uint32_t run = (e >> 5) & 63, size = (e >> 11) & 15;
+        sink.tick();
         if (len == 0) {                                                           // no code matches (huffman.rs:156/162)
             if (WRITE) sink.bad_code(blk);
             len = 1;
@@ -117,6 +155,12 @@ MJX_HD SubseqState decode_subseq(const BitSrc &bits, const uint16_t *lut, const 
             wi++;
             w0 = w1;
             w1 = bits.be32(wi + 1);
+        }
+    }
+    if (CP) {                                                                     // blocks-so-far -> blocks-to-the-end
+        for (uint32_t j = 0; j < k; j++) {
+            const uint32_t wv = cps.get(j);
+            cps.set(j, (wv & kCpStateMask) | ((n - ((wv >> 16) & 0x7fffu)) << 16));
         }
     }
     SubseqState s;

@@ -7,8 +7,11 @@
 namespace mjx {
 
 constexpr int kWgLanes = 256;                                   // lanes (= subsequences) per entropy workgroup
+constexpr int kWarm = 4;                                        // warm-up slots of k_huff_sync (previous range's tail)
+constexpr int kOwn = kWgLanes - kWarm;                          // subsequences a k_huff_sync workgroup owns
 constexpr int kWgScanBytes = kWgLanes * kSubseqBytes;           // 32 KiB of scan per workgroup
 constexpr int kWgScanDwords = kWgScanBytes / 4;
+constexpr int kDcSegMcus = 2048;                                // MCUs per DC-prediction segment (k_dc_sums / k_dc_apply)
 constexpr int kStageDwords = kWgScanDwords + 4;                 // + 16 bytes of look-ahead for the last lane
 constexpr int kStageLds = kStageDwords + (kStageDwords >> 5) + 1;   // one pad dword per 32 (bank = lane + k)
 
@@ -59,7 +62,8 @@ void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, con
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint8_t *scan_pool, const uint16_t *lut_pool, const SubseqState *entry,
                        const uint32_t *blkbase, uint32_t lut_cap, int16_t *coef, int16_t *dcbuf, int *status);
-void launch_dc_scan(hipStream_t st, uint32_t nimg, const DevImage *images, int16_t *dcbuf);
+void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int16_t *dcbuf,
+                    int32_t *segsum);
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
                        const int16_t *coef, const int16_t *dcbuf, const float *qmult, uint8_t *rgb, uint32_t mode_mask);
 #endif

@@ -40,15 +40,15 @@ struct GlobalSink {
     __device__ __forceinline__ void dc(uint32_t b, int v) const { dcbuf[b] = int16_t(v); }
     __device__ __forceinline__ void ac(uint32_t b, unsigned pos, int v) const { coef[size_t(b) * 64 + pos] = int16_t(v); }
     __device__ __forceinline__ void bad_code(uint32_t) const { atomicOr(status, 1); }
+    __device__ __forceinline__ void tick() const {}
 };
 
 // Cooperative staging of a workgroup's 32 KiB (+16 B) scan chunk and the image's decode tables into LDS.
 __device__ __forceinline__ void stage_chunk(const DevImage &im, const uint8_t *scan_pool, const uint16_t *lut_pool,
-                                            uint32_t wg, uint32_t *s_bits, uint16_t *s_lut)
+                                            uint32_t byte0, uint32_t *s_bits, uint16_t *s_lut)
 {
     const uint32_t tid = threadIdx.x;
     const uint8_t *src = scan_pool + im.scan_off;
-    const uint32_t byte0 = wg * kWgScanBytes;
     constexpr uint32_t kGranules = kStageDwords / 4;               // 2049 x 16 B
     for (uint32_t g = tid; g < kGranules; g += kWgLanes) {
         const uint32_t off = byte0 + g * 16;
@@ -72,21 +72,38 @@ __device__ __forceinline__ uint32_t subseq_end(const HuffImage &h, uint32_t s)
     return e < h.total_bits ? e : h.total_bits;
 }
 
-// Work-list driven synchronisation inside one workgroup.  On entry s_entry / s_exit hold the current states of the
-// workgroup's `ns` subsequences and s_work[0..nwork) lists the ones whose entry changed.  Iterates
-//   decode(work) -> compare exit[l-1] with entry[l] -> compact the mismatches into the next work list
-// until nothing changes.  Compaction keeps the active lanes dense, so the tail iterations cost waves, not workgroups.
+// Checkpoint words of one slot: k-major in LDS so that lanes touching the same k hit different banks.
+struct LdsCps {
+    uint32_t *w;            // &cps[slot]
+    __device__ __forceinline__ uint32_t get(uint32_t k) const { return w[k * kWgLanes]; }
+    __device__ __forceinline__ void set(uint32_t k, uint32_t v) const { w[k * kWgLanes] = v; }
+};
+
+// Work-list driven synchronisation inside one workgroup.  Slot l of the workgroup is subsequence s0 + l.  On entry
+// s_entry / s_exit hold the current states of the `ns` slots and s_work[0..nwork) lists the slots to (re-)decode.
+// Iterates   decode(work) -> compare exit[l-1] with entry[l] -> compact the mismatches into the next work list
+// until nothing changes.  Compaction keeps the active lanes dense, so late iterations cost one wave, not the
+// workgroup; with USE_CP a re-decode stops as soon as it meets the path of the slot's previous decode.
+template <bool USE_CP>
 __device__ __forceinline__ void wg_synchronise(const HuffImage &h, const LdsBits &bits, const uint16_t *s_lut,
-                                               SubseqState *s_entry, SubseqState *s_exit, uint16_t *s_work,
-                                               uint32_t *s_wcount, uint32_t s0, uint32_t ns, uint32_t nwork)
+                                               SubseqState *s_entry, SubseqState *s_exit, uint32_t *s_cps,
+                                               uint16_t *s_work, uint32_t *s_wcount, uint32_t s0, uint32_t ns,
+                                               uint32_t nwork)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     NullSink ns_sink;
     for (;;) {
         if (tid < nwork) {
             const uint32_t l = s_work[tid];
-            SubseqState e = s_entry[l];
-            s_exit[l] = decode_subseq<false>(bits, s_lut, h, e, subseq_end(h, s0 + l), 0, ns_sink);
+            const SubseqState e = s_entry[l];
+            if (USE_CP) {
+                LdsCps cps{s_cps + l};
+                s_exit[l] = decode_subseq<false, true>(bits, s_lut, h, e, subseq_end(h, s0 + l), 0, ns_sink, cps,
+                                                       (s0 + l) * kSubseqBits, s_exit[l]);
+            } else {
+                NoCheckpoints cps;
+                s_exit[l] = decode_subseq<false, false>(bits, s_lut, h, e, subseq_end(h, s0 + l), 0, ns_sink, cps, 0, e);
+            }
         }
         __syncthreads();
         bool changed = false;
@@ -121,6 +138,7 @@ struct HuffLds {
     uint32_t *bits;
     uint16_t *lut;
     SubseqState *entry, *exit_;
+    uint32_t *cps;
     uint16_t *work;
     uint32_t *wcount;
     HuffImage *himg;
@@ -134,6 +152,8 @@ __device__ __forceinline__ HuffLds carve(unsigned char *base, uint32_t lut_cap_e
     base += kWgLanes * sizeof(SubseqState);
     L.exit_ = reinterpret_cast<SubseqState *>(base);
     base += kWgLanes * sizeof(SubseqState);
+    L.cps = reinterpret_cast<uint32_t *>(base);
+    base += kNumCp * kWgLanes * sizeof(uint32_t);
     L.himg = reinterpret_cast<HuffImage *>(base);
     base += sizeof(HuffImage);
     L.wcount = reinterpret_cast<uint32_t *>(base);
@@ -145,29 +165,36 @@ __device__ __forceinline__ HuffLds carve(unsigned char *base, uint32_t lut_cap_e
     return L;
 }
 
+// Workgroup w owns subsequences [w*kOwn, (w+1)*kOwn); for w > 0 its first kWarm slots re-decode the tail of the
+// previous workgroup's range (results discarded) so that the first owned slot almost always starts synchronised.
 extern "C" __global__ __launch_bounds__(256) void k_huff_sync(const DevImage *images, const uint8_t *scan_pool,
                                                                const uint16_t *lut_pool, SubseqState *g_entry,
                                                                SubseqState *g_exit, uint32_t lut_cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const DevImage &im = images[blockIdx.y];
-    const uint32_t s0 = blockIdx.x * kWgLanes;
-    if (!im.valid || s0 >= im.himg.nsub) return;
+    const uint32_t own0 = blockIdx.x * kOwn;
+    if (!im.valid || own0 >= im.himg.nsub) return;
+    const uint32_t own1 = min(im.himg.nsub, own0 + kOwn);
+    const uint32_t s0 = own0 >= uint32_t(kWarm) ? own0 - kWarm : 0;
+    const uint32_t ns = own1 - s0;
     HuffLds L = carve(smem, lut_cap);
     const uint32_t tid = threadIdx.x;
     if (tid < sizeof(HuffImage) / 4) reinterpret_cast<uint32_t *>(L.himg)[tid] = reinterpret_cast<const uint32_t *>(&im.himg)[tid];
-    stage_chunk(im, scan_pool, lut_pool, blockIdx.x, L.bits, L.lut);
-    const uint32_t ns = min(uint32_t(kWgLanes), im.himg.nsub - s0);
+    stage_chunk(im, scan_pool, lut_pool, s0 * kSubseqBytes, L.bits, L.lut);
+#pragma unroll
+    for (uint32_t k = 0; k < kNumCp; k++) L.cps[k * kWgLanes + tid] = 0;
     if (tid < ns) {
         SubseqState e;
         e.p = (s0 + tid) * kSubseqBits; e.n = 0; e.z = 0; e.c = 0;      // guess: a block starts exactly here
         L.entry[tid] = e;
+        L.exit_[tid] = e;
         L.work[tid] = uint16_t(tid);
     }
     __syncthreads();
     const LdsBits bits{L.bits, s0 * (kSubseqBytes / 4)};
-    wg_synchronise(*L.himg, bits, L.lut, L.entry, L.exit_, L.work, L.wcount, s0, ns, ns);
-    if (tid < ns) {
+    wg_synchronise<true>(*L.himg, bits, L.lut, L.entry, L.exit_, L.cps, L.work, L.wcount, s0, ns, ns);
+    if (tid < ns && s0 + tid >= own0) {
         g_entry[im.sub_off + s0 + tid] = L.entry[tid];
         g_exit[im.sub_off + s0 + tid] = L.exit_[tid];
     }
@@ -183,7 +210,7 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_fix(const DevImage *ima
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const DevImage &im = images[blockIdx.y];
-    const uint32_t s0 = (blockIdx.x + 1) * kWgLanes;                      // workgroup 0 starts at the true state
+    const uint32_t s0 = (blockIdx.x + 1) * kOwn;                          // workgroup 0 starts at the true state
     if (!im.valid || s0 >= im.himg.nsub) return;
     const SubseqState prev = g_exit[im.sub_off + s0 - 1];
     SubseqState first = g_entry[im.sub_off + s0];
@@ -192,8 +219,8 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_fix(const DevImage *ima
     const uint32_t tid = threadIdx.x;
     if (tid == 0) atomicAdd(mismatches, 1u);
     if (tid < sizeof(HuffImage) / 4) reinterpret_cast<uint32_t *>(L.himg)[tid] = reinterpret_cast<const uint32_t *>(&im.himg)[tid];
-    stage_chunk(im, scan_pool, lut_pool, blockIdx.x + 1, L.bits, L.lut);
-    const uint32_t ns = min(uint32_t(kWgLanes), im.himg.nsub - s0);
+    stage_chunk(im, scan_pool, lut_pool, s0 * kSubseqBytes, L.bits, L.lut);
+    const uint32_t ns = min(uint32_t(kOwn), im.himg.nsub - s0);
     if (tid < ns) {
         L.entry[tid] = g_entry[im.sub_off + s0 + tid];
         L.exit_[tid] = g_exit[im.sub_off + s0 + tid];
@@ -206,7 +233,7 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_fix(const DevImage *ima
     }
     __syncthreads();
     const LdsBits bits{L.bits, s0 * (kSubseqBytes / 4)};
-    wg_synchronise(*L.himg, bits, L.lut, L.entry, L.exit_, L.work, L.wcount, s0, ns, 1);
+    wg_synchronise<false>(*L.himg, bits, L.lut, L.entry, L.exit_, L.cps, L.work, L.wcount, s0, ns, 1);
     if (tid < ns) {
         g_entry[im.sub_off + s0 + tid] = L.entry[tid];
         g_exit[im.sub_off + s0 + tid] = L.exit_[tid];
@@ -269,7 +296,7 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_write(const DevImage *i
     HuffLds L = carve(smem, lut_cap);
     const uint32_t tid = threadIdx.x;
     if (tid < sizeof(HuffImage) / 4) reinterpret_cast<uint32_t *>(L.himg)[tid] = reinterpret_cast<const uint32_t *>(&im.himg)[tid];
-    stage_chunk(im, scan_pool, lut_pool, blockIdx.x, L.bits, L.lut);
+    stage_chunk(im, scan_pool, lut_pool, s0 * kSubseqBytes, L.bits, L.lut);
     __syncthreads();
     const uint32_t ns = min(uint32_t(kWgLanes), im.himg.nsub - s0);
     if (tid < ns) {
@@ -278,46 +305,130 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_write(const DevImage *i
         const uint32_t blk = g_blkbase[im.sub_off + s];
         const LdsBits bits{L.bits, s0 * (kSubseqBytes / 4)};
         GlobalSink sink{coef + im.coef_off * 64, dcbuf + im.coef_off, status + im.status_idx};
-        decode_subseq<true>(bits, L.lut, *L.himg, e, subseq_end(*L.himg, s), blk, sink);
+        NoCheckpoints nocp;
+        decode_subseq<true, false>(bits, L.lut, *L.himg, e, subseq_end(*L.himg, s), blk, sink, nocp, 0, e);
     }
 }
 
-// DC prediction: dcbuf holds per-block differences in decode order; turn them into absolute values per component
-// (running sum never reset, decoder.rs:173, 208-210).  One workgroup per image, contiguous MCU range per lane.
-extern "C" __global__ __launch_bounds__(256) void k_dc_scan(const DevImage *images, int16_t *dcbuf)
+// DC prediction (decoder.rs:173, 208-210: running sum per component, never reset) as a two-level prefix sum over
+// dcbuf, which holds per-block differences in decode order.  An image is cut into segments of kDcSegMcus MCUs:
+//   k_dc_sums   one workgroup per segment: per-component sum of the segment's differences -> segsum
+//   k_dc_apply  one workgroup per segment: carry-in = sums of the preceding segments; then MCU chunks of 256 with
+//               coalesced loads into LDS, one lane per MCU, a workgroup scan, coalesced write-back of absolute DCs.
+__device__ __forceinline__ void wg_reduce3(int32_t v[3], int32_t (*s_w)[3], int32_t out[3])
 {
-    __shared__ uint32_t s_tmp[4];
-    const DevImage &im = images[blockIdx.x];
-    if (!im.valid) return;
-    const uint32_t tid = threadIdx.x, bpm = im.bpm;
-    const uint32_t per = (im.nmcu + kWgLanes - 1) / kWgLanes;
-    const uint32_t a = min(im.nmcu, tid * per), b = min(im.nmcu, a + per);
-    int16_t *dc = dcbuf + im.coef_off;
-    int32_t sum[3] = {0, 0, 0};
-    for (uint32_t m = a; m < b; m++)
-        for (uint32_t j = 0; j < bpm; j++) {
-            const int32_t v = dc[m * bpm + j];
-            const uint32_t c = im.blk_comp[j];
-            sum[0] += c == 0 ? v : 0;
-            sum[1] += c == 1 ? v : 0;
-            sum[2] += c == 2 ? v : 0;
-        }
-    int32_t run[3];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        uint32_t total;
-        run[c] = int32_t(wg_exclusive_scan(uint32_t(sum[c]), s_tmp, &total));
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v[c] += __shfl_xor(v[c], d);
+    if (lane == 0) { s_w[wave][0] = v[0]; s_w[wave][1] = v[1]; s_w[wave][2] = v[2]; }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; c++) out[c] = s_w[0][c] + s_w[1][c] + s_w[2][c] + s_w[3][c];
+    __syncthreads();
+}
+
+extern "C" __global__ __launch_bounds__(256) void k_dc_sums(const DevImage *images, const int16_t *dcbuf,
+                                                             int32_t *segsum, uint32_t max_segs)
+{
+    __shared__ int32_t s_w[4][3];
+    const DevImage &im = images[blockIdx.y];
+    const uint32_t m0 = blockIdx.x * kDcSegMcus;
+    if (!im.valid || m0 >= im.nmcu) return;
+    const uint32_t bpm = im.bpm, tid = threadIdx.x;
+    const uint32_t nv = (min(uint32_t(kDcSegMcus), im.nmcu - m0)) * bpm;
+    const int16_t *dc = dcbuf + im.coef_off + size_t(m0) * bpm;
+    int32_t sum[3] = {0, 0, 0};
+    for (uint32_t i = tid; i < nv; i += 256) {
+        const int32_t v = dc[i];
+        const uint32_t c = im.blk_comp[i % bpm];
+        sum[0] += c == 0 ? v : 0;
+        sum[1] += c == 1 ? v : 0;
+        sum[2] += c == 2 ? v : 0;
     }
-    for (uint32_t m = a; m < b; m++)
-        for (uint32_t j = 0; j < bpm; j++) {
-            const uint32_t c = im.blk_comp[j];
-            int32_t r = c == 0 ? run[0] : (c == 1 ? run[1] : run[2]);
-            r += dc[m * bpm + j];
-            dc[m * bpm + j] = int16_t(r);
-            run[0] = c == 0 ? r : run[0];
-            run[1] = c == 1 ? r : run[1];
-            run[2] = c == 2 ? r : run[2];
+    int32_t tot[3];
+    wg_reduce3(sum, s_w, tot);
+    if (tid < 3) segsum[(size_t(blockIdx.y) * max_segs + blockIdx.x) * 3 + tid] = tot[tid];
+}
+
+extern "C" __global__ __launch_bounds__(256) void k_dc_apply(const DevImage *images, int16_t *dcbuf,
+                                                              const int32_t *segsum, uint32_t max_segs)
+{
+    __shared__ int32_t s_dc[256 * kMaxBlocksPerMcu];
+    __shared__ int32_t s_wsum[4][3];
+    const DevImage &im = images[blockIdx.y];
+    const uint32_t seg0 = blockIdx.x * kDcSegMcus;
+    if (!im.valid || seg0 >= im.nmcu) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, bpm = im.bpm;
+    const uint32_t seg1 = min(im.nmcu, seg0 + kDcSegMcus);
+    int16_t *dc = dcbuf + im.coef_off;
+    int32_t carry[3] = {0, 0, 0};
+    for (uint32_t sgi = 0; sgi < blockIdx.x; sgi++) {
+        const int32_t *p = segsum + (size_t(blockIdx.y) * max_segs + sgi) * 3;
+        carry[0] += p[0]; carry[1] += p[1]; carry[2] += p[2];
+    }
+    uint32_t comp[kMaxBlocksPerMcu];
+#pragma unroll
+    for (uint32_t j = 0; j < kMaxBlocksPerMcu; j++) comp[j] = im.blk_comp[j];
+    for (uint32_t m0 = seg0; m0 < seg1; m0 += 256) {
+        const uint32_t nm = min(256u, seg1 - m0), nv = nm * bpm;
+        for (uint32_t i = tid; i < nv; i += 256) s_dc[i] = dc[size_t(m0) * bpm + i];
+        __syncthreads();
+        int32_t sum[3] = {0, 0, 0};
+        if (tid < nm) {
+#pragma unroll
+            for (uint32_t j = 0; j < kMaxBlocksPerMcu; j++) {
+                if (j < bpm) {
+                    const int32_t v = s_dc[tid * bpm + j];
+                    sum[0] += comp[j] == 0 ? v : 0;
+                    sum[1] += comp[j] == 1 ? v : 0;
+                    sum[2] += comp[j] == 2 ? v : 0;
+                }
+            }
         }
+        int32_t incl[3] = {sum[0], sum[1], sum[2]};
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int32_t o = __shfl_up(incl[c], d);
+                if (lane >= uint32_t(d)) incl[c] += o;
+            }
+        }
+        if (lane == 63) { s_wsum[wave][0] = incl[0]; s_wsum[wave][1] = incl[1]; s_wsum[wave][2] = incl[2]; }
+        __syncthreads();
+        int32_t base[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            base[c] = carry[c];
+            int32_t total = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 4; w++) {
+                const int32_t v = s_wsum[w][c];
+                base[c] += w < wave ? v : 0;
+                total += v;
+            }
+            base[c] += incl[c] - sum[c];
+            carry[c] += total;
+        }
+        if (tid < nm) {
+#pragma unroll
+            for (uint32_t j = 0; j < kMaxBlocksPerMcu; j++) {
+                if (j < bpm) {
+                    const uint32_t c = comp[j];
+                    const int32_t r = (c == 0 ? base[0] : (c == 1 ? base[1] : base[2])) + s_dc[tid * bpm + j];
+                    s_dc[tid * bpm + j] = r;
+                    base[0] = c == 0 ? r : base[0];
+                    base[1] = c == 1 ? r : base[1];
+                    base[2] = c == 2 ? r : base[2];
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < nv; i += 256) dc[size_t(m0) * bpm + i] = int16_t(s_dc[i]);
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -597,7 +708,8 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *images, cons
 // ------------------------------------------------------------------------------------------------
 size_t huff_lds_bytes(uint32_t lut_cap_entries)
 {
-    return size_t((kStageLds * 4 + 15) / 16) * 16 + 2 * kWgLanes * sizeof(SubseqState) + sizeof(HuffImage) + 16 +
+    return size_t((kStageLds * 4 + 15) / 16) * 16 + 2 * kWgLanes * sizeof(SubseqState) +
+           kNumCp * kWgLanes * sizeof(uint32_t) + sizeof(HuffImage) + 16 +
            kWgLanes * 2 + size_t(lut_cap_entries) * 2;
 }
 
@@ -630,7 +742,7 @@ void launch_huff_fix(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds,
                      const uint8_t *scan_pool, const uint16_t *lut_pool, SubseqState *entry, SubseqState *exit_,
                      uint32_t lut_cap, uint32_t *mismatches)
 {
-    if (max_wg < 2) return;
+    if (max_wg < 2) return;      // max_wg counts kOwn-sized ranges
     hipLaunchKernelGGL(k_huff_fix, dim3(max_wg - 1, nimg), dim3(kWgLanes), lds, st, images, scan_pool, lut_pool, entry, exit_, lut_cap, mismatches);
 }
 
@@ -646,9 +758,11 @@ void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ld
     hipLaunchKernelGGL(k_huff_write, dim3(max_wg, nimg), dim3(kWgLanes), lds, st, images, scan_pool, lut_pool, entry, blkbase, lut_cap, coef, dcbuf, status);
 }
 
-void launch_dc_scan(hipStream_t st, uint32_t nimg, const DevImage *images, int16_t *dcbuf)
+void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int16_t *dcbuf,
+                    int32_t *segsum)
 {
-    hipLaunchKernelGGL(k_dc_scan, dim3(nimg), dim3(kWgLanes), 0, st, images, dcbuf);
+    hipLaunchKernelGGL(k_dc_sums, dim3(max_segs, nimg), dim3(256), 0, st, images, dcbuf, segsum, max_segs);
+    hipLaunchKernelGGL(k_dc_apply, dim3(max_segs, nimg), dim3(256), 0, st, images, dcbuf, segsum, max_segs);
 }
 
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
