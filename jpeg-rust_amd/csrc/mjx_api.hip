@@ -30,7 +30,7 @@ struct mjx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool profiling = false;
-    int fix_passes = 2;            // inter-workgroup passes enqueued up front (the last one must count 0 mismatches)
+    int fix_passes = 4;            // synchronisation rounds enqueued up front (the last one must re-decode nothing)
 };
 
 namespace {
@@ -50,7 +50,7 @@ struct Chunk {
     uint32_t nsub = 0;             // subsequences in the chunk
     uint64_t blocks = 0;           // coefficient blocks in the chunk
     uint64_t coef_base = 0;        // first block of the chunk inside d_coef (keep_coefs) or 0
-    uint32_t max_wg = 0, max_wg_sync = 0, max_tiles = 0, lut_cap = 0, max_tile_blocks = 0, mode_mask = 0, max_segs = 0;
+    uint32_t max_wg = 0, merge_wgs = 0, max_tiles = 0, lut_cap = 0, max_tile_blocks = 0, mode_mask = 0, max_segs = 0;
 };
 
 struct EventPair {
@@ -73,6 +73,9 @@ struct mjx_batch {
     float *d_qm = nullptr;
     SubseqState *d_entry = nullptr, *d_exit = nullptr;
     uint32_t *d_blkbase = nullptr;
+    uint32_t *d_cps = nullptr;          // [kNumCp][chunk subsequences]
+    uint32_t *d_pull = nullptr;         // [kMaxFix][chunk images] item counters of k_huff_merge
+    uint32_t max_nsub = 1, max_chunk_images = 1;
     int32_t *d_segsum = nullptr;
     int16_t *d_coef = nullptr, *d_dc = nullptr;
     uint8_t *d_rgb = nullptr;
@@ -106,7 +109,7 @@ void release(mjx_batch *b)
     (void)hipFree(b->d_images); (void)hipFree(b->d_scan); (void)hipFree(b->d_lut); (void)hipFree(b->d_qm);
     (void)hipFree(b->d_entry); (void)hipFree(b->d_exit); (void)hipFree(b->d_blkbase);
     (void)hipFree(b->d_coef); (void)hipFree(b->d_dc); (void)hipFree(b->d_rgb); (void)hipFree(b->d_status);
-    (void)hipFree(b->d_mismatch); (void)hipFree(b->d_segsum);
+    (void)hipFree(b->d_mismatch); (void)hipFree(b->d_segsum); (void)hipFree(b->d_cps); (void)hipFree(b->d_pull);
     if (b->h_mismatch) (void)hipHostFree(b->h_mismatch);
     delete b;
 }
@@ -161,7 +164,7 @@ void plan_chunks(mjx_batch *b)
                 c.nsub += d.himg.nsub;
                 c.blocks += inf.nblocks;
                 c.max_wg = std::max<uint32_t>(c.max_wg, (d.himg.nsub + kWgLanes - 1) / kWgLanes);
-                c.max_wg_sync = std::max<uint32_t>(c.max_wg_sync, (d.himg.nsub + kOwn - 1) / kOwn);
+                if (d.himg.nsub > 1) c.merge_wgs = std::max<uint32_t>(c.merge_wgs, (d.himg.nsub - 1 + kWgLanes - 1) / kWgLanes);
                 const uint32_t T = 1u << d.log2_tile;
                 c.max_tiles = std::max<uint32_t>(c.max_tiles, (d.nmcu + T - 1) / T);
                 c.max_tile_blocks = std::max<uint32_t>(c.max_tile_blocks, T * d.bpm);
@@ -196,6 +199,12 @@ int allocate_work_buffers(mjx_batch *b)
     HIPOK(hipMalloc(&b->d_entry, size_t(max_nsub) * sizeof(SubseqState)));
     HIPOK(hipMalloc(&b->d_exit, size_t(max_nsub) * sizeof(SubseqState)));
     HIPOK(hipMalloc(&b->d_blkbase, size_t(max_nsub) * sizeof(uint32_t)));
+    HIPOK(hipMalloc(&b->d_cps, size_t(max_nsub) * kNumCp * sizeof(uint32_t)));
+    size_t max_imgs = 1;
+    for (const Chunk &c : b->chunks) max_imgs = std::max(max_imgs, c.count);
+    b->max_nsub = max_nsub;
+    b->max_chunk_images = uint32_t(max_imgs);
+    HIPOK(hipMalloc(&b->d_pull, max_imgs * kMaxFix * sizeof(uint32_t)));
     HIPOK(hipMalloc(&b->d_segsum, max_segsum * 3 * sizeof(int32_t)));
     HIPOK(hipMalloc(&b->d_coef, size_t(coef_blocks) * 128));
     HIPOK(hipMalloc(&b->d_dc, size_t(coef_blocks) * sizeof(int16_t) + 16));
@@ -245,16 +254,16 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     fix_passes = std::min(fix_passes, kMaxFix);
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_SYNC)) {
         prof_begin(b, MJX_K_HUFF_SYNC);
-        launch_huff_sync(st, c.max_wg_sync, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, c.lut_cap);
+        launch_huff_spec(st, c.max_wg, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, b->d_cps, c.nsub);
         prof_end(b);
     }
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_FIX)) {
         HIPOK(hipMemsetAsync(b->d_mismatch + ci * kMaxFix, 0, kMaxFix * sizeof(uint32_t), st));
-        if (c.max_wg_sync > 1) {
+        if (c.merge_wgs > 0) {
             for (int k = 0; k < fix_passes; k++) {
                 prof_begin(b, MJX_K_HUFF_FIX);
-                launch_huff_fix(st, c.max_wg_sync, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, c.lut_cap,
-                                b->d_mismatch + ci * kMaxFix + k);
+                launch_huff_merge(st, c.merge_wgs, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, b->d_cps,
+                                  c.nsub, b->d_mismatch + ci * kMaxFix + k);
                 prof_end(b);
             }
             HIPOK(hipMemcpyAsync(b->h_mismatch + ci * kMaxFix, b->d_mismatch + ci * kMaxFix, kMaxFix * sizeof(uint32_t),
@@ -269,8 +278,8 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         launch_huff_scan(st, nimg, imgs, b->d_exit, b->d_blkbase);
         prof_end(b);
         prof_begin(b, MJX_K_HUFF_WRITE);
-        launch_huff_write(st, c.max_wg, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_blkbase, c.lut_cap, coef,
-                          dcb, b->d_status);
+        launch_huff_write(st, c.max_wg, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_blkbase, coef, dcb,
+                          b->d_status);
         prof_end(b);
         prof_begin(b, MJX_K_DC_SCAN);
         launch_dc_scan(st, c.max_segs, nimg, imgs, dcb, b->d_segsum);
@@ -516,7 +525,7 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
     if (b->decoded_entropy) {
         for (size_t ci = 0; ci < b->chunks.size(); ci++) {
             const Chunk &c = b->chunks[ci];
-            if (c.max_wg_sync < 2) continue;
+            if (c.merge_wgs == 0) continue;
             const int passes = std::min(b->ctx->fix_passes, kMaxFix);
             if (b->h_mismatch[ci * kMaxFix + passes - 1] == 0) continue;
             // repair: restart this chunk's synchronisation (its state arrays may have been reused by a later chunk),

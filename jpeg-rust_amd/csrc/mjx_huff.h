@@ -24,7 +24,7 @@
 namespace mjx {
 
 #ifndef MJX_SUBSEQ_BYTES
-#define MJX_SUBSEQ_BYTES 128
+#define MJX_SUBSEQ_BYTES 512
 #endif
 constexpr int kSubseqBytes = MJX_SUBSEQ_BYTES;  // bytes of scan per lane
 constexpr int kSubseqBits = kSubseqBytes * 8;
@@ -70,7 +70,7 @@ struct NullSink {
 };
 
 // ---- checkpoints: early merge of a re-decode with the path of the previous decode ----------------------
-// While decoding a subsequence the lane records its state at the first symbol at/after every 128-bit boundary
+// While decoding a subsequence the lane records its state at the first symbol at/after every 256-bit boundary
 // inside the subsequence.  A later re-decode of the same subsequence (its entry changed) compares its own state
 // at each boundary with the recorded one: equal (p, z, c) means the two decodes coincide from there on, so the
 // re-decode stops and inherits the old exit.  This is the self-synchronisation property used at a finer grain:
@@ -78,96 +78,143 @@ struct NullSink {
 //   word: bit31 valid | n[30:16] | c[15:12] | z[11:6] | p - boundary [5:0]
 //   n = blocks completed from the checkpoint to the end of the subsequence (after the decode's fix-up); while a
 //   decode is running it temporarily holds the blocks completed from the start to the checkpoint.
-constexpr int kCpBits = 128;
+constexpr int kCpBits = 256;
 constexpr int kNumCp = kSubseqBits / kCpBits - 1;
 constexpr uint32_t kCpValid = 0x80000000u, kCpStateMask = 0x8000ffffu;
 struct NoCheckpoints {
     MJX_HD uint32_t get(uint32_t) const { return 0; }
+    MJX_HD uint32_t get_plain(uint32_t) const { return 0; }
     MJX_HD void set(uint32_t, uint32_t) const {}
 };
+
+// Registers of one lane's decoder: position + a three-dword look-ahead window of the big-endian bitstream.
+// w2 is fetched one refill early so that a global-memory load has a whole dword of symbols to complete.
+struct LaneState {
+    uint32_t p, z, c, n;      // bit position, zig-zag index, block-in-MCU, blocks completed
+    uint32_t tab;             // img.blktab[c]
+    uint32_t wi, o;           // dword index of w0, bit offset inside it
+    uint32_t w0, w1, w2;
+};
+
+template <class BitSrc>
+MJX_HD void lane_begin(LaneState &st, const BitSrc &bits, const HuffImage &img, SubseqState entry)
+{
+    st.p = entry.p; st.z = entry.z; st.c = entry.c; st.n = 0;
+    st.tab = img.blktab[st.c];
+    st.wi = st.p >> 5; st.o = st.p & 31;
+    st.w0 = bits.be32(st.wi); st.w1 = bits.be32(st.wi + 1); st.w2 = bits.be32(st.wi + 2);
+}
+
+// One Huffman symbol: table lookup, EXTEND, coefficient placement, state update, window refill.
+template <bool WRITE, class BitSrc, class Sink>
+MJX_HD void symbol_step(LaneState &st, const BitSrc &bits, const uint16_t *lut, const HuffImage &img, uint32_t &blk,
+                        Sink &sink)
+{
+    const uint32_t w = st.o ? ((st.w0 << st.o) | (st.w1 >> (32 - st.o))) : st.w0;   // next 32 bits of the stream
+    const uint32_t base = st.z ? (st.tab >> 16) : (st.tab & 0xffff);
+    uint32_t e = lut[base + (w >> (32 - kLutPrimaryBits))];
+    if (e & kLutLinkBit) {
+        const uint32_t nb = e & 15, off = (e >> 4) & 0x7ff;
+        e = lut[base + off + ((w << kLutPrimaryBits) >> (32 - nb))];
+    }
+    uint32_t len = e & 31;
+    const uint32_t run = (e >> 5) & 63, size = (e >> 11) & 15;
+    sink.tick();
+    if (len == 0) {                                                               // no code matches (huffman.rs:156/162)
+        if (WRITE) sink.bad_code(blk);
+        len = 1;
+    }
+    uint32_t pos = st.z + run;
+    pos = pos > 63 ? 63 : pos;
+    if (WRITE) {
+        const uint32_t v = w << len;                                              // value bits, left aligned
+        const uint32_t vb = (v >> 1) >> (31 - size);                              // size == 0 -> 0
+        const int32_t val = int32_t(vb) - int32_t(((1u << size) - 1u) & ((v >> 31) - 1u));   // EXTEND, T.81 F.2
+        if (st.z == 0) sink.dc(blk, val);
+        else if (size) sink.ac(blk, pos, val);
+    }
+    st.z = pos + 1;
+    if (st.z == 64) {
+        st.z = 0;
+        st.c = (st.c + 1 == img.bpm) ? 0 : st.c + 1;
+        st.tab = img.blktab[st.c];
+        st.n++;
+        blk++;
+    }
+    const uint32_t adv = len + size;
+    st.p += adv;
+    st.o += adv;
+    if (st.o >= 32) {
+        st.o -= 32;
+        st.wi++;
+        st.w0 = st.w1;
+        st.w1 = st.w2;
+        st.w2 = bits.be32(st.wi + 2);
+    }
+}
+
+// Checkpoint test at a symbol start.  Returns true when the lane's state equals the one recorded by the previous
+// decode of this subsequence at the same 256-bit boundary (the decodes coincide from here on); otherwise records the
+// state (with the blocks completed so far) and advances to the next boundary.
+template <bool COMPARE, class CpStore>
+MJX_HD bool checkpoint_merge(const LaneState &st, CpStore &cps, uint32_t &k, uint32_t &cp_bit, uint32_t &n_rest)
+{
+    const uint32_t state = (st.p - cp_bit) | (st.z << 6) | (st.c << 12) | kCpValid;
+    if (COMPARE) {
+        const uint32_t old = cps.get(k);
+        if ((old & kCpStateMask) == state) {
+            n_rest = (old >> 16) & 0x7fffu;
+            return true;
+        }
+    }
+    cps.set(k, state | (st.n << 16));
+    k++;
+    cp_bit += kCpBits;
+    return false;
+}
+
+// blocks-so-far -> blocks-to-the-end for the checkpoints this decode recorded
+template <class CpStore>
+MJX_HD void checkpoint_fixup(CpStore &cps, uint32_t k, uint32_t n_total)
+{
+    for (uint32_t j = 0; j < k; j++) {
+        const uint32_t wv = cps.get_plain(j);
+        cps.set(j, (wv & kCpStateMask) | ((n_total - ((wv >> 16) & 0x7fffu)) << 16));
+    }
+}
 
 // Decode from `entry` until the bit position reaches `end_bit`.
 //   BitSrc::be32(i)  -> big-endian dword i of the image's scan (0xAAAAAAAA past the end, huffman.rs:236-246)
 //   lut              -> the image's decode tables
 //   WRITE            -> emit coefficients for blocks < img.total_blocks through `sink`, starting at block `blk`
-//   CP               -> record checkpoints in `cps` and merge with the previous decode of this subsequence
-//                       (`sub_start` = first bit of the subsequence, `old_exit` = exit of that previous decode)
-template <bool WRITE, bool CP, class BitSrc, class Sink, class CpStore>
+//   CP               -> 0: no checkpoints; 1: record checkpoints in `cps`; 2: record and merge with the previous
+//                       decode of this subsequence (`sub_start` = its first bit, `old_exit` = that decode's exit)
+template <bool WRITE, int CP, class BitSrc, class Sink, class CpStore>
 MJX_HD SubseqState decode_subseq(const BitSrc &bits, const uint16_t *lut, const HuffImage &img, SubseqState entry,
                                  uint32_t end_bit, uint32_t blk, Sink &sink, CpStore &cps, uint32_t sub_start,
                                  SubseqState old_exit)
 {
-    uint32_t p = entry.p, z = entry.z, c = entry.c, n = 0;
-    uint32_t tab = img.blktab[c];
-    uint32_t wi = p >> 5, o = p & 31;
-    uint32_t w0 = bits.be32(wi), w1 = bits.be32(wi + 1);
+    LaneState st;
+    lane_begin(st, bits, img, entry);
     uint32_t cp_bit = sub_start + kCpBits, k = 0;
-    while (p < end_bit) {
+    while (st.p < end_bit) {
         if (WRITE && blk >= img.total_blocks) break;
-        if (CP && p >= cp_bit) {
-            const uint32_t st = (p - cp_bit) | (z << 6) | (c << 12) | kCpValid;
-            const uint32_t old = cps.get(k);
-            if ((old & kCpStateMask) == st) {                                     // same state as the previous decode
-                n += (old >> 16) & 0x7fffu;
-                p = old_exit.p; z = old_exit.z; c = old_exit.c;
+        if (CP && st.p >= cp_bit) {
+            uint32_t n_rest;
+            if (checkpoint_merge<CP == 2>(st, cps, k, cp_bit, n_rest)) {
+                st.n += n_rest;
+                st.p = old_exit.p; st.z = old_exit.z; st.c = old_exit.c;
                 break;
             }
-            cps.set(k, st | (n << 16));
-            k++;
-            cp_bit += kCpBits;
         }
-        const uint32_t w = o ? ((w0 << o) | (w1 >> (32 - o))) : w0;               // next 32 bits of the stream
-        const uint32_t base = z ? (tab >> 16) : (tab & 0xffff);
-        uint32_t e = lut[base + (w >> (32 - kLutPrimaryBits))];
-        if (e & kLutLinkBit) {
-            const uint32_t nb = e & 15, off = (e >> 4) & 0x7ff;
-            e = lut[base + off + ((w << kLutPrimaryBits) >> (32 - nb))];
-        }
-        uint32_t len = e & 31;
-        const uint32_t run = (e >> 5) & 63, size = (e >> 11) & 15;
-        sink.tick();
-        if (len == 0) {                                                           // no code matches (huffman.rs:156/162)
-            if (WRITE) sink.bad_code(blk);
-            len = 1;
-        }
-        const uint32_t v = w << len;                                              // value bits, left aligned
-        const uint32_t vb = (v >> 1) >> (31 - size);                              // size == 0 -> 0
-        const int32_t val = int32_t(vb) - int32_t(((1u << size) - 1u) & ((v >> 31) - 1u));   // EXTEND, T.81 F.2
-        uint32_t pos = z + run;
-        pos = pos > 63 ? 63 : pos;
-        if (WRITE) {
-            if (z == 0) sink.dc(blk, val);
-            else if (size) sink.ac(blk, pos, val);
-        }
-        z = pos + 1;
-        if (z == 64) {
-            z = 0;
-            c = (c + 1 == img.bpm) ? 0 : c + 1;
-            tab = img.blktab[c];
-            n++;
-            blk++;
-        }
-        const uint32_t adv = len + size;
-        p += adv;
-        o += adv;
-        if (o >= 32) {
-            o -= 32;
-            wi++;
-            w0 = w1;
-            w1 = bits.be32(wi + 1);
-        }
+        symbol_step<WRITE>(st, bits, lut, img, blk, sink);
     }
-    if (CP) {                                                                     // blocks-so-far -> blocks-to-the-end
-        for (uint32_t j = 0; j < k; j++) {
-            const uint32_t wv = cps.get(j);
-            cps.set(j, (wv & kCpStateMask) | ((n - ((wv >> 16) & 0x7fffu)) << 16));
-        }
-    }
+    if (CP) checkpoint_fixup(cps, k, st.n);
     SubseqState s;
-    s.p = p;
-    s.n = uint16_t(n);
-    s.z = uint8_t(z);
-    s.c = uint8_t(c);
+    s.p = st.p;
+    s.n = uint16_t(st.n);
+    s.z = uint8_t(st.z);
+    s.c = uint8_t(st.c);
     return s;
 }
 

@@ -6,14 +6,8 @@
 
 namespace mjx {
 
-constexpr int kWgLanes = 256;                                   // lanes (= subsequences) per entropy workgroup
-constexpr int kWarm = 4;                                        // warm-up slots of k_huff_sync (previous range's tail)
-constexpr int kOwn = kWgLanes - kWarm;                          // subsequences a k_huff_sync workgroup owns
-constexpr int kWgScanBytes = kWgLanes * kSubseqBytes;           // 32 KiB of scan per workgroup
-constexpr int kWgScanDwords = kWgScanBytes / 4;
+constexpr int kWgLanes = 256;                                   // lanes (= subsequences) per k_huff_spec / k_huff_write workgroup
 constexpr int kDcSegMcus = 2048;                                // MCUs per DC-prediction segment (k_dc_sums / k_dc_apply)
-constexpr int kStageDwords = kWgScanDwords + 4;                 // + 16 bytes of look-ahead for the last lane
-constexpr int kStageLds = kStageDwords + (kStageDwords >> 5) + 1;   // one pad dword per 32 (bank = lane + k)
 
 // One image of a chunk, as the kernels see it (HBM, read-only during decode).
 struct DevImage {
@@ -52,16 +46,16 @@ inline uint32_t tile_mcus(uint32_t bpm, uint32_t hmax)
 size_t huff_lds_bytes(uint32_t lut_cap_entries);
 size_t idct_lds_bytes(uint32_t max_tile_blocks);
 int configure_kernels(size_t huff_lds, size_t idct_lds);
-void launch_huff_sync(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
+void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
                       const uint8_t *scan_pool, const uint16_t *lut_pool, SubseqState *entry, SubseqState *exit_,
-                      uint32_t lut_cap);
-void launch_huff_fix(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
-                     const uint8_t *scan_pool, const uint16_t *lut_pool, SubseqState *entry, SubseqState *exit_,
-                     uint32_t lut_cap, uint32_t *mismatches);
+                      uint32_t *cps, uint32_t cp_stride);
+void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
+                       const uint8_t *scan_pool, const uint16_t *lut_pool, SubseqState *entry, SubseqState *exit_,
+                       uint32_t *cps, uint32_t cp_stride, uint32_t *mismatches);
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase);
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint8_t *scan_pool, const uint16_t *lut_pool, const SubseqState *entry,
-                       const uint32_t *blkbase, uint32_t lut_cap, int16_t *coef, int16_t *dcbuf, int *status);
+                       const uint32_t *blkbase, int16_t *coef, int16_t *dcbuf, int *status);
 void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int16_t *dcbuf,
                     int32_t *segsum);
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,

@@ -20,17 +20,28 @@
 namespace mjx {
 
 // ------------------------------------------------------------------------------------------------
-// LDS view of the staged scan chunk: big-endian dwords, one pad dword per 32 so that lane l reading its
-// k-th dword hits bank (l + k) % 32.
+// stage A building blocks
 // ------------------------------------------------------------------------------------------------
-struct LdsBits {
-    const uint32_t *lds;
-    uint32_t dword0;        // index (in the image's scan) of the first staged dword
+// The image's de-stuffed scan in HBM as big-endian dwords; bytes past the padded end read 0xAA (huffman.rs:236-246).
+// Every lane walks its own 512-byte subsequence, so a lane's loads hit one 128-byte line 32 times in a row (L2 / MALL
+// resident: a chunk's scans are ~1 MB per 4K image).
+struct GlobalBits {
+    const uint32_t *words;
+    uint32_t nwords;
     __device__ __forceinline__ uint32_t be32(uint32_t i) const
     {
-        const uint32_t d = i - dword0;
-        return lds[d + (d >> 5)];
+        return i < nwords ? __builtin_bswap32(words[i]) : 0xaaaaaaaau;
     }
+};
+
+// Checkpoint words of one subsequence, k-major in HBM (lanes of a wave cross the same boundary at about the same
+// time, so their stores to checkpoint k are adjacent).
+struct GlobalCps {
+    uint32_t *w;            // &cps[subsequence]
+    uint32_t stride;        // subsequences in the chunk
+    __device__ __forceinline__ uint32_t get(uint32_t k) const { return w[size_t(k) * stride]; }
+    __device__ __forceinline__ uint32_t get_plain(uint32_t k) const { return w[size_t(k) * stride]; }
+    __device__ __forceinline__ void set(uint32_t k, uint32_t v) const { w[size_t(k) * stride] = v; }
 };
 
 struct GlobalSink {
@@ -43,27 +54,21 @@ struct GlobalSink {
     __device__ __forceinline__ void tick() const {}
 };
 
-// Cooperative staging of a workgroup's 32 KiB (+16 B) scan chunk and the image's decode tables into LDS.
-__device__ __forceinline__ void stage_chunk(const DevImage &im, const uint8_t *scan_pool, const uint16_t *lut_pool,
-                                            uint32_t byte0, uint32_t *s_bits, uint16_t *s_lut)
+// Decode tables + per-image constants into LDS (dynamic LDS: HuffImage, then the tables).
+__device__ __forceinline__ void stage_tables(const DevImage &im, const uint16_t *lut_pool, unsigned char *smem,
+                                             const HuffImage *&himg, const uint16_t *&lut)
 {
-    const uint32_t tid = threadIdx.x;
-    const uint8_t *src = scan_pool + im.scan_off;
-    constexpr uint32_t kGranules = kStageDwords / 4;               // 2049 x 16 B
-    for (uint32_t g = tid; g < kGranules; g += kWgLanes) {
-        const uint32_t off = byte0 + g * 16;
-        uint4 q = make_uint4(0xaaaaaaaau, 0xaaaaaaaau, 0xaaaaaaaau, 0xaaaaaaaau);
-        if (off + 16 <= im.scan_padded) q = *reinterpret_cast<const uint4 *>(src + off);
-        const uint32_t d = g * 4;
-        uint32_t *dst = s_bits + d + (d >> 5);
-        dst[0] = __builtin_bswap32(q.x);
-        dst[1] = __builtin_bswap32(q.y);
-        dst[2] = __builtin_bswap32(q.z);
-        dst[3] = __builtin_bswap32(q.w);
-    }
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    HuffImage *h = reinterpret_cast<HuffImage *>(smem);
+    uint16_t *l = reinterpret_cast<uint16_t *>(smem + sizeof(HuffImage));
+    for (uint32_t i = tid; i < sizeof(HuffImage) / 4; i += nthr)
+        reinterpret_cast<uint32_t *>(h)[i] = reinterpret_cast<const uint32_t *>(&im.himg)[i];
     const uint4 *lsrc = reinterpret_cast<const uint4 *>(lut_pool + im.lut_off);
-    uint4 *ldst = reinterpret_cast<uint4 *>(s_lut);
-    for (uint32_t g = tid; g < im.lut_n / 8; g += kWgLanes) ldst[g] = lsrc[g];
+    uint4 *ldst = reinterpret_cast<uint4 *>(l);
+    for (uint32_t g = tid; g < im.lut_n / 8; g += nthr) ldst[g] = lsrc[g];
+    __syncthreads();
+    himg = h;
+    lut = l;
 }
 
 __device__ __forceinline__ uint32_t subseq_end(const HuffImage &h, uint32_t s)
@@ -72,172 +77,84 @@ __device__ __forceinline__ uint32_t subseq_end(const HuffImage &h, uint32_t s)
     return e < h.total_bits ? e : h.total_bits;
 }
 
-// Checkpoint words of one slot: k-major in LDS so that lanes touching the same k hit different banks.
-struct LdsCps {
-    uint32_t *w;            // &cps[slot]
-    __device__ __forceinline__ uint32_t get(uint32_t k) const { return w[k * kWgLanes]; }
-    __device__ __forceinline__ void set(uint32_t k, uint32_t v) const { w[k * kWgLanes] = v; }
-};
-
-// Work-list driven synchronisation inside one workgroup.  Slot l of the workgroup is subsequence s0 + l.  On entry
-// s_entry / s_exit hold the current states of the `ns` slots and s_work[0..nwork) lists the slots to (re-)decode.
-// Iterates   decode(work) -> compare exit[l-1] with entry[l] -> compact the mismatches into the next work list
-// until nothing changes.  Compaction keeps the active lanes dense, so late iterations cost one wave, not the
-// workgroup; with USE_CP a re-decode stops as soon as it meets the path of the slot's previous decode.
-template <bool USE_CP>
-__device__ __forceinline__ void wg_synchronise(const HuffImage &h, const LdsBits &bits, const uint16_t *s_lut,
-                                               SubseqState *s_entry, SubseqState *s_exit, uint32_t *s_cps,
-                                               uint16_t *s_work, uint32_t *s_wcount, uint32_t s0, uint32_t ns,
-                                               uint32_t nwork)
-{
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    NullSink ns_sink;
-    for (;;) {
-        if (tid < nwork) {
-            const uint32_t l = s_work[tid];
-            const SubseqState e = s_entry[l];
-            if (USE_CP) {
-                LdsCps cps{s_cps + l};
-                s_exit[l] = decode_subseq<false, true>(bits, s_lut, h, e, subseq_end(h, s0 + l), 0, ns_sink, cps,
-                                                       (s0 + l) * kSubseqBits, s_exit[l]);
-            } else {
-                NoCheckpoints cps;
-                s_exit[l] = decode_subseq<false, false>(bits, s_lut, h, e, subseq_end(h, s0 + l), 0, ns_sink, cps, 0, e);
-            }
-        }
-        __syncthreads();
-        bool changed = false;
-        if (tid > 0 && tid < ns) {
-            const SubseqState prev = s_exit[tid - 1];
-            SubseqState mine = s_entry[tid];
-            if (!same_entry(prev, mine)) {
-                mine.p = prev.p; mine.z = prev.z; mine.c = prev.c; mine.n = 0;
-                s_entry[tid] = mine;
-                changed = true;
-            }
-        }
-        const unsigned long long m = __ballot(changed);
-        if (lane == 0) s_wcount[wave] = __popcll(m);
-        __syncthreads();
-        uint32_t off = 0, total = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < kWgLanes / 64; w++) {
-            const uint32_t cnt = s_wcount[w];
-            off += (w < wave) ? cnt : 0;
-            total += cnt;
-        }
-        if (changed) s_work[off + __popcll(m & ((1ull << lane) - 1ull))] = uint16_t(tid);
-        __syncthreads();
-        nwork = total;
-        if (nwork == 0) break;
-    }
-}
-
-// Dynamic LDS carve shared by the three staging kernels.
-struct HuffLds {
-    uint32_t *bits;
-    uint16_t *lut;
-    SubseqState *entry, *exit_;
-    uint32_t *cps;
-    uint16_t *work;
-    uint32_t *wcount;
-    HuffImage *himg;
-};
-__device__ __forceinline__ HuffLds carve(unsigned char *base, uint32_t lut_cap_entries)
-{
-    HuffLds L;
-    L.bits = reinterpret_cast<uint32_t *>(base);
-    base += ((kStageLds * 4 + 15) / 16) * 16;
-    L.entry = reinterpret_cast<SubseqState *>(base);
-    base += kWgLanes * sizeof(SubseqState);
-    L.exit_ = reinterpret_cast<SubseqState *>(base);
-    base += kWgLanes * sizeof(SubseqState);
-    L.cps = reinterpret_cast<uint32_t *>(base);
-    base += kNumCp * kWgLanes * sizeof(uint32_t);
-    L.himg = reinterpret_cast<HuffImage *>(base);
-    base += sizeof(HuffImage);
-    L.wcount = reinterpret_cast<uint32_t *>(base);
-    base += 16;
-    L.work = reinterpret_cast<uint16_t *>(base);
-    base += kWgLanes * 2;
-    L.lut = reinterpret_cast<uint16_t *>(base);
-    (void)lut_cap_entries;
-    return L;
-}
-
-// Workgroup w owns subsequences [w*kOwn, (w+1)*kOwn); for w > 0 its first kWarm slots re-decode the tail of the
-// previous workgroup's range (results discarded) so that the first owned slot almost always starts synchronised.
-extern "C" __global__ __launch_bounds__(256) void k_huff_sync(const DevImage *images, const uint8_t *scan_pool,
+// k_huff_spec: every lane decodes its subsequence from the guess "a block starts exactly here", recording its exit
+// state and a checkpoint every 256 bits.  Lanes do the same amount of work (+-3 %), so plain lock-step is efficient.
+extern "C" __global__ __launch_bounds__(256) void k_huff_spec(const DevImage *images, const uint8_t *scan_pool,
                                                                const uint16_t *lut_pool, SubseqState *g_entry,
-                                                               SubseqState *g_exit, uint32_t lut_cap)
+                                                               SubseqState *g_exit, uint32_t *g_cps, uint32_t cp_stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const DevImage &im = images[blockIdx.y];
-    const uint32_t own0 = blockIdx.x * kOwn;
-    if (!im.valid || own0 >= im.himg.nsub) return;
-    const uint32_t own1 = min(im.himg.nsub, own0 + kOwn);
-    const uint32_t s0 = own0 >= uint32_t(kWarm) ? own0 - kWarm : 0;
-    const uint32_t ns = own1 - s0;
-    HuffLds L = carve(smem, lut_cap);
-    const uint32_t tid = threadIdx.x;
-    if (tid < sizeof(HuffImage) / 4) reinterpret_cast<uint32_t *>(L.himg)[tid] = reinterpret_cast<const uint32_t *>(&im.himg)[tid];
-    stage_chunk(im, scan_pool, lut_pool, s0 * kSubseqBytes, L.bits, L.lut);
-#pragma unroll
-    for (uint32_t k = 0; k < kNumCp; k++) L.cps[k * kWgLanes + tid] = 0;
-    if (tid < ns) {
-        SubseqState e;
-        e.p = (s0 + tid) * kSubseqBits; e.n = 0; e.z = 0; e.c = 0;      // guess: a block starts exactly here
-        L.entry[tid] = e;
-        L.exit_[tid] = e;
-        L.work[tid] = uint16_t(tid);
-    }
-    __syncthreads();
-    const LdsBits bits{L.bits, s0 * (kSubseqBytes / 4)};
-    wg_synchronise<true>(*L.himg, bits, L.lut, L.entry, L.exit_, L.cps, L.work, L.wcount, s0, ns, ns);
-    if (tid < ns && s0 + tid >= own0) {
-        g_entry[im.sub_off + s0 + tid] = L.entry[tid];
-        g_exit[im.sub_off + s0 + tid] = L.exit_[tid];
-    }
+    if (!im.valid || blockIdx.x * kWgLanes >= im.himg.nsub) return;
+    const HuffImage *h;
+    const uint16_t *lut;
+    stage_tables(im, lut_pool, smem, h, lut);
+    const uint32_t s = blockIdx.x * kWgLanes + threadIdx.x;
+    if (s >= h->nsub) return;
+    const GlobalBits bits{reinterpret_cast<const uint32_t *>(scan_pool + im.scan_off), im.scan_padded / 4};
+    SubseqState e;
+    e.p = s * kSubseqBits; e.n = 0; e.z = 0; e.c = 0;
+    NullSink sink;
+    GlobalCps cps{g_cps + im.sub_off + s, cp_stride};
+    const SubseqState x = decode_subseq<false, 1>(bits, lut, *h, e, subseq_end(*h, s), 0, sink, cps, s * kSubseqBits, e);
+    g_entry[im.sub_off + s] = e;
+    g_exit[im.sub_off + s] = x;
 }
 
-// Inter-workgroup pass: a workgroup whose first entry differs from the previous workgroup's last exit re-decodes
-// from the corrected entry and re-synchronises.  `mismatches` counts such workgroups; a pass that counts zero proves
-// the entry states are the true ones (fixed point), because then nothing was written during the pass.
-extern "C" __global__ __launch_bounds__(256) void k_huff_fix(const DevImage *images, const uint8_t *scan_pool,
-                                                              const uint16_t *lut_pool, SubseqState *g_entry,
-                                                              SubseqState *g_exit, uint32_t lut_cap,
-                                                              uint32_t *mismatches)
+// Checkpoint words with a one-ahead prefetch: the word for boundary k+1 is requested while the lane decodes towards
+// it (~45 symbols), so the comparison at the boundary does not expose an HBM/L2 round trip.
+struct GlobalCpsPrefetch {
+    uint32_t *w;
+    uint32_t stride;
+    uint32_t next;          // cps[k_next]
+    __device__ __forceinline__ void prime() { next = w[0]; }
+    __device__ __forceinline__ uint32_t get(uint32_t k)
+    {
+        const uint32_t v = next;
+        if (k + 1 < uint32_t(kNumCp)) next = w[size_t(k + 1) * stride];
+        return v;
+    }
+    __device__ __forceinline__ uint32_t get_plain(uint32_t k) const { return w[size_t(k) * stride]; }
+    __device__ __forceinline__ void set(uint32_t k, uint32_t v) const { w[size_t(k) * stride] = v; }
+};
+
+// k_huff_merge: one synchronisation round.  Subsequence s must start where s-1 ended: if entry[s] differs from
+// exit[s-1] the lane re-decodes s from the corrected entry until it meets the path recorded by the previous decode of
+// s (checkpoint match: median ~100 of ~800 symbols) or reaches the end.  A round that re-decodes nothing proves the
+// fixed point entry[s] == exit[s-1] for all s, which (entry[0] being the true start) is the true decode; `mismatches`
+// counts the re-decoded items of this round.  Exits are read while other lanes may be rewriting them (8-byte aligned
+// accesses): a stale read only defers the repair to the next round, and the zero-count round is race-free by definition.
+extern "C" __global__ __launch_bounds__(256) void k_huff_merge(const DevImage *images, const uint8_t *scan_pool,
+                                                                const uint16_t *lut_pool, SubseqState *g_entry,
+                                                                SubseqState *g_exit, uint32_t *g_cps, uint32_t cp_stride,
+                                                                uint32_t *mismatches)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const DevImage &im = images[blockIdx.y];
-    const uint32_t s0 = (blockIdx.x + 1) * kOwn;                          // workgroup 0 starts at the true state
-    if (!im.valid || s0 >= im.himg.nsub) return;
-    const SubseqState prev = g_exit[im.sub_off + s0 - 1];
-    SubseqState first = g_entry[im.sub_off + s0];
-    if (same_entry(prev, first)) return;                                  // workgroup-uniform
-    HuffLds L = carve(smem, lut_cap);
-    const uint32_t tid = threadIdx.x;
-    if (tid == 0) atomicAdd(mismatches, 1u);
-    if (tid < sizeof(HuffImage) / 4) reinterpret_cast<uint32_t *>(L.himg)[tid] = reinterpret_cast<const uint32_t *>(&im.himg)[tid];
-    stage_chunk(im, scan_pool, lut_pool, s0 * kSubseqBytes, L.bits, L.lut);
-    const uint32_t ns = min(uint32_t(kOwn), im.himg.nsub - s0);
-    if (tid < ns) {
-        L.entry[tid] = g_entry[im.sub_off + s0 + tid];
-        L.exit_[tid] = g_exit[im.sub_off + s0 + tid];
+    if (!im.valid || blockIdx.x * kWgLanes + 1 >= im.himg.nsub) return;
+    const uint32_t s = blockIdx.x * kWgLanes + threadIdx.x + 1;
+    bool need = false;
+    SubseqState prev = {0, 0, 0, 0};
+    if (s < im.himg.nsub) {
+        prev = g_exit[im.sub_off + s - 1];
+        need = !same_entry(prev, g_entry[im.sub_off + s]);
     }
-    __syncthreads();
-    if (tid == 0) {
-        first.p = prev.p; first.z = prev.z; first.c = prev.c; first.n = 0;
-        L.entry[0] = first;
-        L.work[0] = 0;
-    }
-    __syncthreads();
-    const LdsBits bits{L.bits, s0 * (kSubseqBytes / 4)};
-    wg_synchronise<false>(*L.himg, bits, L.lut, L.entry, L.exit_, L.cps, L.work, L.wcount, s0, ns, 1);
-    if (tid < ns) {
-        g_entry[im.sub_off + s0 + tid] = L.entry[tid];
-        g_exit[im.sub_off + s0 + tid] = L.exit_[tid];
-    }
+    if (!__syncthreads_or(need)) return;                                   // nothing to repair in this workgroup
+    const HuffImage *h;
+    const uint16_t *lut;
+    stage_tables(im, lut_pool, smem, h, lut);
+    unsigned long long m = __ballot(need);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(mismatches, uint32_t(__popcll(m)));
+    if (!need) return;
+    const GlobalBits bits{reinterpret_cast<const uint32_t *>(scan_pool + im.scan_off), im.scan_padded / 4};
+    SubseqState e = prev;
+    e.n = 0;
+    const SubseqState old_exit = g_exit[im.sub_off + s];
+    g_entry[im.sub_off + s] = e;
+    NullSink sink;
+    GlobalCpsPrefetch cps{g_cps + im.sub_off + s, cp_stride, 0};
+    cps.prime();
+    g_exit[im.sub_off + s] = decode_subseq<false, 2>(bits, lut, *h, e, subseq_end(*h, s), 0, sink, cps, s * kSubseqBits, old_exit);
 }
 
 // Workgroup-wide exclusive scan helper (256 lanes): returns the exclusive prefix of v, total in *total.
@@ -284,29 +201,69 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *im
     }
 }
 
+// Per-lane window of the bitstream in LDS for the write pass.  The write pass scatters stores to HBM; a bitstream
+// load from HBM would queue behind them (loads and stores retire in issue order on vmcnt), so the lane reads its bits
+// from a private LDS window of kWinDwords big-endian dwords instead.  The wave restages all its windows together
+// (wave-uniform branch) whenever one lane is about to run out, about every 120 symbols.
+constexpr int kWinDwords = 24;
+constexpr int kWinStride = kWinDwords + 1;      // odd stride: lane l, dword k -> bank (25 l + k) % 32, conflict-free per k
+struct LdsWindow {
+    const uint32_t *lds;    // lane's window
+    uint32_t wbase;         // stream dword index of lds[0]
+    __device__ __forceinline__ uint32_t be32(uint32_t i) const { return lds[i - wbase]; }
+};
+__device__ __forceinline__ void window_fill(uint32_t *lds, const GlobalBits &g, uint32_t wbase)
+{
+#pragma unroll
+    for (int q = 0; q < kWinDwords / 4; q++) {
+        const uint32_t i = wbase + 4 * q;
+        uint4 v = make_uint4(0xaaaaaaaau, 0xaaaaaaaau, 0xaaaaaaaau, 0xaaaaaaaau);
+        if (i + 4 <= g.nwords) {
+            v = *reinterpret_cast<const uint4 *>(g.words + i);             // 4-byte aligned 16-byte load
+            v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y); v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w);
+        } else {
+            v.x = g.be32(i); v.y = g.be32(i + 1); v.z = g.be32(i + 2); v.w = g.be32(i + 3);
+        }
+        lds[4 * q] = v.x; lds[4 * q + 1] = v.y; lds[4 * q + 2] = v.z; lds[4 * q + 3] = v.w;
+    }
+}
+
 extern "C" __global__ __launch_bounds__(256) void k_huff_write(const DevImage *images, const uint8_t *scan_pool,
                                                                 const uint16_t *lut_pool, const SubseqState *g_entry,
-                                                                const uint32_t *g_blkbase, uint32_t lut_cap,
-                                                                int16_t *coef, int16_t *dcbuf, int *status)
+                                                                const uint32_t *g_blkbase, int16_t *coef,
+                                                                int16_t *dcbuf, int *status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t s_win[kWgLanes * kWinStride];
     const DevImage &im = images[blockIdx.y];
-    const uint32_t s0 = blockIdx.x * kWgLanes;
-    if (!im.valid || s0 >= im.himg.nsub) return;
-    HuffLds L = carve(smem, lut_cap);
-    const uint32_t tid = threadIdx.x;
-    if (tid < sizeof(HuffImage) / 4) reinterpret_cast<uint32_t *>(L.himg)[tid] = reinterpret_cast<const uint32_t *>(&im.himg)[tid];
-    stage_chunk(im, scan_pool, lut_pool, s0 * kSubseqBytes, L.bits, L.lut);
-    __syncthreads();
-    const uint32_t ns = min(uint32_t(kWgLanes), im.himg.nsub - s0);
-    if (tid < ns) {
-        const uint32_t s = s0 + tid;
-        const SubseqState e = g_entry[im.sub_off + s];
-        const uint32_t blk = g_blkbase[im.sub_off + s];
-        const LdsBits bits{L.bits, s0 * (kSubseqBytes / 4)};
-        GlobalSink sink{coef + im.coef_off * 64, dcbuf + im.coef_off, status + im.status_idx};
-        NoCheckpoints nocp;
-        decode_subseq<true, false>(bits, L.lut, *L.himg, e, subseq_end(*L.himg, s), blk, sink, nocp, 0, e);
+    if (!im.valid || blockIdx.x * kWgLanes >= im.himg.nsub) return;
+    const HuffImage *h;
+    const uint16_t *lut;
+    stage_tables(im, lut_pool, smem, h, lut);
+    const uint32_t s = blockIdx.x * kWgLanes + threadIdx.x;
+    const GlobalBits gbits{reinterpret_cast<const uint32_t *>(scan_pool + im.scan_off), im.scan_padded / 4};
+    GlobalSink sink{coef + im.coef_off * 64, dcbuf + im.coef_off, status + im.status_idx};
+    uint32_t *my = s_win + threadIdx.x * kWinStride;
+    bool live = s < h->nsub;
+    SubseqState e = {0, 0, 0, 0};
+    uint32_t blk = 0, end_bit = 0;
+    if (live) {
+        e = g_entry[im.sub_off + s];
+        blk = g_blkbase[im.sub_off + s];
+        end_bit = subseq_end(*h, s);
+    }
+    LdsWindow win{my, e.p >> 5};
+    window_fill(my, gbits, win.wbase);
+    LaneState st;
+    lane_begin(st, win, *h, e);
+    for (;;) {
+        const bool active = live && st.p < end_bit && blk < h->total_blocks;
+        if (!__any(active)) break;
+        if (__any(active && st.wi + 3 >= win.wbase + kWinDwords)) {        // wave-uniform: restage every window
+            win.wbase = st.wi;
+            window_fill(my, gbits, win.wbase);
+        }
+        if (active) symbol_step<true>(st, win, lut, *h, blk, sink);
     }
 }
 
@@ -706,12 +663,7 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *images, cons
 // ------------------------------------------------------------------------------------------------
 // host launchers (declared in mjx_kernels.h)
 // ------------------------------------------------------------------------------------------------
-size_t huff_lds_bytes(uint32_t lut_cap_entries)
-{
-    return size_t((kStageLds * 4 + 15) / 16) * 16 + 2 * kWgLanes * sizeof(SubseqState) +
-           kNumCp * kWgLanes * sizeof(uint32_t) + sizeof(HuffImage) + 16 +
-           kWgLanes * 2 + size_t(lut_cap_entries) * 2;
-}
+size_t huff_lds_bytes(uint32_t lut_cap_entries) { return sizeof(HuffImage) + size_t(lut_cap_entries) * 2 + 16; }
 
 size_t idct_lds_bytes(uint32_t max_tile_blocks) { return size_t(max_tile_blocks) * kPixStride * 4; }
 
@@ -719,31 +671,29 @@ int configure_kernels(size_t huff_lds, size_t idct_lds)
 {
     hipError_t e = hipSuccess;
     if (huff_lds > 64 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_sync), hipFuncAttributeMaxDynamicSharedMemorySize, int(huff_lds));
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_fix), hipFuncAttributeMaxDynamicSharedMemorySize, int(huff_lds));
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_spec), hipFuncAttributeMaxDynamicSharedMemorySize, int(huff_lds));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_merge), hipFuncAttributeMaxDynamicSharedMemorySize, int(huff_lds));
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_write), hipFuncAttributeMaxDynamicSharedMemorySize, int(huff_lds));
     }
-    if (e == hipSuccess && idct_lds > 64 * 1024)
-    {
+    if (e == hipSuccess && idct_lds > 64 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_idct_color<0>), hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_idct_color<1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
     }
     return e == hipSuccess ? 0 : int(e);
 }
 
-void launch_huff_sync(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
+void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
                       const uint8_t *scan_pool, const uint16_t *lut_pool, SubseqState *entry, SubseqState *exit_,
-                      uint32_t lut_cap)
+                      uint32_t *cps, uint32_t cp_stride)
 {
-    hipLaunchKernelGGL(k_huff_sync, dim3(max_wg, nimg), dim3(kWgLanes), lds, st, images, scan_pool, lut_pool, entry, exit_, lut_cap);
+    hipLaunchKernelGGL(k_huff_spec, dim3(max_wg, nimg), dim3(kWgLanes), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, cp_stride);
 }
 
-void launch_huff_fix(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
-                     const uint8_t *scan_pool, const uint16_t *lut_pool, SubseqState *entry, SubseqState *exit_,
-                     uint32_t lut_cap, uint32_t *mismatches)
+void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
+                       const uint8_t *scan_pool, const uint16_t *lut_pool, SubseqState *entry, SubseqState *exit_,
+                       uint32_t *cps, uint32_t cp_stride, uint32_t *mismatches)
 {
-    if (max_wg < 2) return;      // max_wg counts kOwn-sized ranges
-    hipLaunchKernelGGL(k_huff_fix, dim3(max_wg - 1, nimg), dim3(kWgLanes), lds, st, images, scan_pool, lut_pool, entry, exit_, lut_cap, mismatches);
+    hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kWgLanes), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, cp_stride, mismatches);
 }
 
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase)
@@ -753,9 +703,9 @@ void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, con
 
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint8_t *scan_pool, const uint16_t *lut_pool, const SubseqState *entry,
-                       const uint32_t *blkbase, uint32_t lut_cap, int16_t *coef, int16_t *dcbuf, int *status)
+                       const uint32_t *blkbase, int16_t *coef, int16_t *dcbuf, int *status)
 {
-    hipLaunchKernelGGL(k_huff_write, dim3(max_wg, nimg), dim3(kWgLanes), lds, st, images, scan_pool, lut_pool, entry, blkbase, lut_cap, coef, dcbuf, status);
+    hipLaunchKernelGGL(k_huff_write, dim3(max_wg, nimg), dim3(kWgLanes), lds, st, images, scan_pool, lut_pool, entry, blkbase, coef, dcbuf, status);
 }
 
 void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int16_t *dcbuf,

@@ -53,18 +53,17 @@ struct TickSink {
 struct HostCps {
     uint32_t *w;
     uint32_t get(uint32_t k) const { return w[k]; }
+    uint32_t get_plain(uint32_t k) const { return w[k]; }
     void set(uint32_t k, uint32_t v) const { w[k] = v; }
 };
 }   // namespace
 
-// wg_lanes = subsequence slots per workgroup, warm = slots at the front that re-decode the tail of the previous
-// workgroup's range (results discarded) so that the first owned slot usually starts from a synchronised state.
-extern "C" int emul_decode_coefs(const uint8_t *jpeg, size_t len, int layout, int wg_lanes, int16_t *out,
+// Emulates the kernel sequence  k_huff_spec -> k_huff_merge rounds -> k_huff_scan -> k_huff_write -> DC prediction.
+// `mode`: 0 = rounds see a snapshot of the previous round's exits (what fully concurrent lanes see in the worst case),
+//         1 = rounds update in place in subsequence order (what a single lane walking the items would see).
+extern "C" int emul_decode_coefs(const uint8_t *jpeg, size_t len, int layout, int mode, int16_t *out,
                                  size_t cap_blocks, size_t *nblocks, int *stats /* [8] */)
 {
-    int warm = wg_lanes >= 64 ? 4 : 1;
-    if (wg_lanes < 0) { wg_lanes = -wg_lanes; warm = 0; }
-    const uint32_t own = uint32_t(wg_lanes - warm);
     mjx_opts opts{};
     opts.layout = uint8_t(layout);
     mjx_scan_desc d;
@@ -77,86 +76,54 @@ extern "C" int emul_decode_coefs(const uint8_t *jpeg, size_t len, int layout, in
     const HostBits bits{plan.scan, plan.scan_len};
     const uint32_t nsub = img.nsub;
     std::vector<SubseqState> g_entry(nsub), g_exit(nsub);
+    std::vector<uint32_t> g_cps(size_t(nsub) * kNumCp, 0xdeadbeefu);      // uninitialised on the device
     TickSink ns;
     NoCheckpoints nocp;
-    std::vector<std::vector<long>> iter_ticks;   // per iteration index: symbols of every decode
+    std::vector<std::vector<long>> iter_ticks;
     const char *dump = std::getenv("MJX_EMUL_DUMP");
     auto end_of = [&](uint32_t s) { uint64_t e = uint64_t(s + 1) * kSubseqBits; return uint32_t(e < img.total_bits ? e : img.total_bits); };
-    long redecodes = 0, merged = 0, max_local_iters = 0, fix_passes = 0, fix_mismatch_first = 0;
+    long redecodes = 0, rounds = 0;
 
-    // Work-list synchronisation of the slots [0, nslot) of one workgroup whose slot l is subsequence base + l.
-    auto wg_sync = [&](uint32_t base, uint32_t nslot, std::vector<SubseqState> &entry, std::vector<SubseqState> &exit_,
-                       std::vector<uint32_t> &cps, bool use_cp, std::vector<uint32_t> work) {
-        long iters = 0;
-        while (!work.empty()) {
-            if (iter_ticks.size() <= size_t(iters)) iter_ticks.resize(iters + 1);
-            for (uint32_t l : work) {
-                const long t0 = ns.ticks;
-                const uint32_t s = base + l;
-                SubseqState old = exit_[l];
-                if (use_cp) {
-                    HostCps hc{cps.data() + size_t(l) * kNumCp};
-                    exit_[l] = decode_subseq<false, true>(bits, plan.lut.data(), img, entry[l], end_of(s), 0, ns, hc, s * kSubseqBits, old);
-                } else {
-                    exit_[l] = decode_subseq<false, false>(bits, plan.lut.data(), img, entry[l], end_of(s), 0, ns, nocp, 0, old);
-                }
-                redecodes++;
-                iter_ticks[iters].push_back(ns.ticks - t0);
-            }
-            work.clear();
-            for (uint32_t l = 1; l < nslot; l++)
-                if (!same_entry(exit_[l - 1], entry[l])) {
-                    entry[l].p = exit_[l - 1].p; entry[l].z = exit_[l - 1].z; entry[l].c = exit_[l - 1].c; entry[l].n = 0;
-                    work.push_back(l);
-                }
-            iters++;
-        }
-        if (iters > max_local_iters) max_local_iters = iters;
-    };
-
-    // k_huff_sync
-    const uint32_t nwg = (nsub + own - 1) / own;
-    for (uint32_t w = 0; w < nwg; w++) {
-        const uint32_t own0 = w * own, own1 = std::min(nsub, own0 + own);
-        const uint32_t base = own0 >= uint32_t(warm) ? own0 - warm : 0;
-        const uint32_t nslot = own1 - base;
-        std::vector<SubseqState> entry(nslot), exit_(nslot);
-        std::vector<uint32_t> cps(size_t(nslot) * kNumCp, 0), work(nslot);
-        for (uint32_t l = 0; l < nslot; l++) { entry[l] = SubseqState{(base + l) * uint32_t(kSubseqBits), 0, 0, 0}; exit_[l] = SubseqState{0, 0, 0, 0}; work[l] = l; }
-        wg_sync(base, nslot, entry, exit_, cps, true, work);
-        for (uint32_t l = own0 - base; l < nslot; l++) { g_entry[base + l] = entry[l]; g_exit[base + l] = exit_[l]; }
+    iter_ticks.emplace_back();
+    for (uint32_t s = 0; s < nsub; s++) {                                  // k_huff_spec
+        const SubseqState e{s * uint32_t(kSubseqBits), 0, 0, 0};
+        HostCps hc{g_cps.data() + size_t(s) * kNumCp};
+        const long t0 = ns.ticks;
+        g_exit[s] = decode_subseq<false, 1>(bits, plan.lut.data(), img, e, end_of(s), 0, ns, hc, s * kSubseqBits, e);
+        g_entry[s] = e;
+        iter_ticks[0].push_back(ns.ticks - t0);
     }
-    redecodes -= nsub;   // first decodes are not re-decodes
-    // k_huff_fix passes until one finds nothing
-    for (;;) {
-        long mism = 0;
-        std::vector<SubseqState> snap(g_exit);
-        for (uint32_t w = 1; w < nwg; w++) {
-            const uint32_t own0 = w * own, own1 = std::min(nsub, own0 + own);
-            if (same_entry(snap[own0 - 1], g_entry[own0])) continue;
-            mism++;
-            const uint32_t nslot = own1 - own0;
-            std::vector<SubseqState> entry(g_entry.begin() + own0, g_entry.begin() + own1), exit_(g_exit.begin() + own0, g_exit.begin() + own1);
-            std::vector<uint32_t> cps;
-            entry[0].p = snap[own0 - 1].p; entry[0].z = snap[own0 - 1].z; entry[0].c = snap[own0 - 1].c; entry[0].n = 0;
-            wg_sync(own0, nslot, entry, exit_, cps, false, std::vector<uint32_t>{0});
-            for (uint32_t l = 0; l < nslot; l++) { g_entry[own0 + l] = entry[l]; g_exit[own0 + l] = exit_[l]; }
+    for (;;) {                                                             // k_huff_merge rounds
+        long redone = 0;
+        iter_ticks.emplace_back();
+        std::vector<SubseqState> snap;
+        if (mode == 0) snap = g_exit;
+        for (uint32_t s = 1; s < nsub; s++) {
+            const SubseqState prev = mode == 0 ? snap[s - 1] : g_exit[s - 1];
+            if (same_entry(prev, g_entry[s])) continue;
+            SubseqState e = prev;
+            e.n = 0;
+            g_entry[s] = e;
+            HostCps hc{g_cps.data() + size_t(s) * kNumCp};
+            const long t0 = ns.ticks;
+            g_exit[s] = decode_subseq<false, 2>(bits, plan.lut.data(), img, e, end_of(s), 0, ns, hc, s * kSubseqBits, g_exit[s]);
+            iter_ticks.back().push_back(ns.ticks - t0);
+            redone++;
         }
-        if (fix_passes == 0) fix_mismatch_first = mism;
-        fix_passes++;
-        if (mism == 0) break;
+        rounds++;
+        redecodes += redone;
+        if (redone == 0) break;
     }
-    (void)merged;
     if (dump) {
         for (size_t it = 0; it < iter_ticks.size(); it++) {
             auto &v = iter_ticks[it];
             if (v.empty()) continue;
             std::sort(v.begin(), v.end());
             long sum = 0; for (long x : v) sum += x;
-            std::fprintf(stderr, "iter %zu: items %zu mean %.1f p50 %ld p90 %ld p99 %ld max %ld\n", it, v.size(), double(sum) / v.size(), v[v.size() / 2], v[v.size() * 9 / 10], v[v.size() * 99 / 100], v.back());
+            std::fprintf(stderr, "pass %zu: items %zu mean %.1f p50 %ld p90 %ld p99 %ld max %ld\n", it, v.size(), double(sum) / v.size(), v[v.size() / 2], v[v.size() * 9 / 10], v[v.size() * 99 / 100], v.back());
         }
     }
-    // block-count scan + write pass
+    // k_huff_scan + k_huff_write + DC prediction
     std::vector<uint32_t> blkbase(nsub);
     uint32_t acc = 0;
     for (uint32_t s = 0; s < nsub; s++) { blkbase[s] = acc; acc += g_exit[s].n; }
@@ -168,7 +135,7 @@ extern "C" int emul_decode_coefs(const uint8_t *jpeg, size_t len, int layout, in
         std::vector<int16_t> dcb(nb, 0);
         CoefSink sink{out, dcb.data(), &bad};
         for (uint32_t s = 0; s < nsub; s++)
-            decode_subseq<true, false>(bits, plan.lut.data(), img, g_entry[s], end_of(s), blkbase[s], sink, nocp, 0, g_exit[s]);
+            decode_subseq<true, 0>(bits, plan.lut.data(), img, g_entry[s], end_of(s), blkbase[s], sink, nocp, 0, g_exit[s]);
         int32_t pred[3] = {0, 0, 0};
         for (size_t b = 0; b < nb; b++) {
             const int c = plan.blk_comp[b % plan.bpm];
@@ -177,8 +144,8 @@ extern "C" int emul_decode_coefs(const uint8_t *jpeg, size_t len, int layout, in
         }
     }
     if (stats) {
-        stats[0] = int(nsub); stats[1] = int(max_local_iters); stats[2] = int(redecodes); stats[3] = int(fix_passes);
-        stats[4] = int(plan.bpm); stats[5] = int(plan.lut.size()); stats[6] = bad; stats[7] = int(fix_mismatch_first);
+        stats[0] = int(nsub); stats[1] = int(rounds); stats[2] = int(redecodes); stats[3] = int(rounds);
+        stats[4] = int(plan.bpm); stats[5] = int(plan.lut.size()); stats[6] = bad; stats[7] = 0;
     }
     mjx_free_scan(&d);
     return nb <= cap_blocks ? (bad ? MJX_ERR_BAD_HUFFMAN : MJX_OK) : MJX_ERR_NOMEM;

@@ -100,11 +100,11 @@ def emul(mjx):
     lib.emul_decode_coefs.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]
 
-    def run(data, layout, wg=256):
+    def run(data, layout, mode=0):
         cap = 400000
         out = np.zeros((cap, 64), np.int16)
         nb, st = ctypes.c_size_t(), (ctypes.c_int * 8)()
-        rc = lib.emul_decode_coefs(data, len(data), layout, wg, out.ctypes.data, cap, ctypes.byref(nb), st)
+        rc = lib.emul_decode_coefs(data, len(data), layout, mode, out.ctypes.data, cap, ctypes.byref(nb), st)
         return rc, out[: nb.value].copy(), list(st)
     return run
 
@@ -122,7 +122,7 @@ def test_emulated_parallel_decode_equals_oracle_T0(mjx, orc, emul, name, layout)
                                        (48, 64, "440", 75), (750, 595, "420", 50), (1920, 1080, "420", 75)])
 def test_emulated_decode_synthetic(mjx, orc, emul, w, h, sub, q):
     data = mjx.synth_jpeg(w, h, sub, q, seed=w + h)
-    for wg in (256, 4):                      # tiny workgroups force many inter-workgroup fix passes
+    for wg in (0, 1):                        # merge rounds on a snapshot (concurrent lanes) / in place (one lane)
         rc, coefs, st = emul(data, 0, wg)
         ref = orc.decode(data, layout=orc.LAYOUT_STD)
         assert rc == 0 and np.array_equal(coefs, orc.interleave(ref)), (wg, st)
