@@ -47,18 +47,20 @@ def parse_args():
     return ap.parse_args()
 
 
-def algorithmic_bytes(kind, by, nsub_total):
-    """Per-step algorithmic bytes of each kernel class (DESIGN.md 'Kernels'); by = mjx.Batch.bytes()."""
+def algorithmic_bytes(kind, by, nsub_total, nblk):
+    """Per-step algorithmic bytes of each kernel class; by = mjx.Batch.bytes().
+    by["coef"] = bytes of the intermediate coefficient representation (4 per stream entry + 2 per block of DC)."""
     S, rgb, coef = by["scan"], by["rgb"], by["coef"]
-    nblk = coef // 128
+    state = 32 * nsub_total                       # entry + exit state per subsequence
+    cps = 8 * 15 * nsub_total                     # two checkpoint words every 256 bits
     return {
-        "clear": coef,                              # zero fill of the coefficient buffer
-        "huff_sync": S + 16 * nsub_total,           # scan in, entry + exit state out
-        "huff_fix": 16 * nsub_total // 256,         # reads one state pair per workgroup when nothing needs repair
-        "huff_scan": 12 * nsub_total,               # exit state in, block base out
-        "huff_write": S + 12 * nsub_total + coef,   # scan + entry state in, coefficient blocks out
-        "dc_scan": 4 * nblk,                        # DC differences in, absolute DC out
-        "idct_color": coef + 2 * nblk + rgb,        # B_idct = 128*n_blocks + 3*W*H (SURVEY s8(d)) + DC
+        "clear": 0,
+        "huff_sync": S + state + cps,             # k_huff_spec: scan in, states + checkpoints out
+        "huff_fix": S // 5 + state + cps // 5,    # k_huff_merge rounds: ~1/5 of the scan is re-read (median merge distance)
+        "huff_scan": 24 * nsub_total,             # exit state in, block base + entry base out
+        "huff_write": S + 24 * nsub_total + coef, # scan + entry state + bases in, compact stream + DC out
+        "dc_scan": 4 * nblk,                      # DC differences in, absolute DC out
+        "idct_color": coef + rgb,                 # compact stream + DC in, packed RGB out
     }[kind]
 
 
@@ -139,8 +141,8 @@ def main():
     batch = base.tile(reps) if reps > 1 else base
     if batch is not base:
         base.close()
-    by = batch.bytes()
-    nsub_total = sum((len(mjx.ParsedScan(d).scan_bytes()) * 8 + 1023) // 1024 for d in datas) * reps
+    nsub_total = sum((len(mjx.ParsedScan(d).scan_bytes()) + 511) // 512 for d in datas) * reps
+    nblk = sum(batch.info(i)["bpm"] * batch.info(i)["mcus"] for i in range(period)) * reps
     stages = mjx.STAGE_ALL if args.stages == "all" else mjx.STAGE_PIXELS
     if args.stages == "pixels":
         batch.decode(mjx.STAGE_ALL)
@@ -168,6 +170,7 @@ def main():
     assert not bad, "images failed: %s" % bad[:8]
 
     kms = batch.kernel_ms()
+    by = batch.bytes()
     total_px = by["pixels"] * world * args.steps
     value = total_px / elapsed / 1e6
     kernels = {k: {"launches": v[1], "ms": round(v[0], 4)} for k, v in kms.items() if v[1]}
@@ -186,7 +189,7 @@ def main():
     }
     if kernels:
         dom = max(kernels, key=lambda k: kernels[k]["ms"])
-        steps_bytes = algorithmic_bytes(dom, by, nsub_total)
+        steps_bytes = algorithmic_bytes(dom, by, nsub_total, nblk)
         n_launch = kernels[dom]["launches"]
         avg_s = kernels[dom]["ms"] / 1e3 / n_launch
         per_launch = steps_bytes * args.steps / n_launch
@@ -195,12 +198,12 @@ def main():
                            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
                            "bytes_per_launch": int(per_launch), "avg_launch_ms": round(avg_s * 1e3, 5)}
         tot_ms = sum(v["ms"] for v in kernels.values())
-        e2e_bytes = (by["scan"] + by["rgb"]) if args.stages == "all" else algorithmic_bytes("idct_color", by, nsub_total)
+        e2e_bytes = (by["scan"] + by["rgb"]) if args.stages == "all" else algorithmic_bytes("idct_color", by, nsub_total, nblk)
         e2e = e2e_bytes * args.steps / (tot_ms / 1e3) / 1e9
         out["roofline_e2e"] = {"bound": "hbm", "achieved": round(e2e, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(e2e / HBM_PEAK_GBS, 5), "bytes_per_step": int(e2e_bytes),
                                "kernel_ms_per_step": round(tot_ms / args.steps, 4),
-                               "definition": "sum(S + 3*W*H) / sum of kernel time" if args.stages == "all" else "B_idct / kernel time"}
+                               "definition": "sum(S + 3*W*H) / sum of kernel time" if args.stages == "all" else "(compact stream + DC + 3*W*H) / kernel time"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(mjx, datas, args.width, args.height, args.cpu_threads)
     batch.close()

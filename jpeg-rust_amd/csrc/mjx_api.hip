@@ -40,7 +40,9 @@ struct ImageInfo {
     uint32_t width = 0, height = 0, bpm = 0, nmcu = 0;
     uint64_t nblocks = 0;
     uint64_t rgb_off = 0, rgb_bytes = 0;
-    uint64_t coef_off = 0;         // blocks, inside the coefficient buffer of its chunk (or of the batch with keep_coefs)
+    uint64_t coef_off = 0;         // blocks, inside the per-block arrays of its chunk (or of the batch with keep_coefs)
+    uint64_t ent_off = 0, ent_cap = 0;   // region of the compact coefficient stream (entries)
+    uint32_t tile_off = 0, ntiles = 0, tile_blocks = 0;
     uint64_t scan_len = 0;
     uint32_t chunk = 0;
 };
@@ -49,7 +51,9 @@ struct Chunk {
     size_t first = 0, count = 0;
     uint32_t nsub = 0;             // subsequences in the chunk
     uint64_t blocks = 0;           // coefficient blocks in the chunk
-    uint64_t coef_base = 0;        // first block of the chunk inside d_coef (keep_coefs) or 0
+    uint64_t coef_base = 0;        // first block of the chunk inside the per-block arrays (keep_coefs) or 0
+    uint64_t entries = 0, ent_base = 0;   // capacity of the chunk's stream regions; first entry (keep_coefs) or 0
+    uint32_t tiles = 0, tile_base = 0;    // tile offsets (+1 sentinel per image)
     uint32_t max_wg = 0, merge_wgs = 0, max_tiles = 0, lut_cap = 0, max_tile_blocks = 0, mode_mask = 0, max_segs = 0;
 };
 
@@ -77,7 +81,11 @@ struct mjx_batch {
     uint32_t *d_pull = nullptr;         // [kMaxFix][chunk images] item counters of k_huff_merge
     uint32_t max_nsub = 1, max_chunk_images = 1;
     int32_t *d_segsum = nullptr;
-    int16_t *d_coef = nullptr, *d_dc = nullptr;
+    uint32_t *d_entries = nullptr;      // compact coefficient stream
+    uint32_t *d_tile_eoff = nullptr;    // stream offset of every stage-B tile (+ sentinel per image)
+    uint32_t *d_ebase = nullptr;        // per subsequence: stream entries before it
+    uint32_t *d_img_entries = nullptr;  // per image: entries counted by the synchronisation passes
+    int16_t *d_dc = nullptr;
     uint8_t *d_rgb = nullptr;
     size_t rgb_pool_bytes = 0;
     int *d_status = nullptr;
@@ -108,7 +116,8 @@ void release(mjx_batch *b)
     for (auto &e : b->event_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     (void)hipFree(b->d_images); (void)hipFree(b->d_scan); (void)hipFree(b->d_lut); (void)hipFree(b->d_qm);
     (void)hipFree(b->d_entry); (void)hipFree(b->d_exit); (void)hipFree(b->d_blkbase);
-    (void)hipFree(b->d_coef); (void)hipFree(b->d_dc); (void)hipFree(b->d_rgb); (void)hipFree(b->d_status);
+    (void)hipFree(b->d_entries); (void)hipFree(b->d_tile_eoff); (void)hipFree(b->d_ebase); (void)hipFree(b->d_img_entries);
+    (void)hipFree(b->d_dc); (void)hipFree(b->d_rgb); (void)hipFree(b->d_status);
     (void)hipFree(b->d_mismatch); (void)hipFree(b->d_segsum); (void)hipFree(b->d_cps); (void)hipFree(b->d_pull);
     if (b->h_mismatch) (void)hipHostFree(b->h_mismatch);
     delete b;
@@ -125,6 +134,7 @@ void fill_dev_image(const ImagePlan &p, DevImage &d)
     uint32_t t = tile_mcus(p.bpm, p.hmax), l2 = 0;
     while ((1u << (l2 + 1)) <= t) l2++;
     d.log2_tile = l2;
+    d.tile_blocks = (1u << l2) * p.bpm;
     d.mode = (p.ncomp == 3 && p.h[0] == 2 && p.v[0] == 2 && p.h[1] == 1 && p.v[1] == 1 && p.h[2] == 1 && p.v[2] == 1) ? 1 : 0;
     std::memcpy(d.blk_comp, p.blk_comp, sizeof d.blk_comp);
     std::memcpy(d.blk_bx, p.blk_bx, sizeof d.blk_bx);
@@ -145,22 +155,31 @@ void plan_chunks(mjx_batch *b)
     const bool keep = b->opts.keep_coefs != 0;
     size_t per_chunk = b->opts.chunk_images ? b->opts.chunk_images : 128;
     per_chunk = std::min<size_t>(per_chunk, 65535);
-    const uint64_t kMaxChunkBlocks = (uint64_t(6) << 30) / 128;          // 6 GiB of coefficients per chunk
+    const uint64_t kMaxChunkEntries = (uint64_t(6) << 30) / 4;           // 6 GiB of stream capacity per chunk
     b->chunks.clear();
-    uint64_t coef_running = 0;
+    uint64_t coef_running = 0, ent_running = 0;
+    uint32_t tile_running = 0;
     size_t i = 0;
     while (i < n) {
         Chunk c;
         c.first = i;
         c.coef_base = keep ? coef_running : 0;
+        c.ent_base = keep ? ent_running : 0;
+        c.tile_base = keep ? tile_running : 0;
         while (i < n && c.count < per_chunk) {
             const ImageInfo &inf = b->info[i];
-            if (c.count > 0 && c.blocks + inf.nblocks > kMaxChunkBlocks) break;
+            if (c.count > 0 && c.entries + inf.ent_cap > kMaxChunkEntries) break;
             DevImage &d = b->himages[i];
             if (inf.status == MJX_OK) {
                 d.sub_off = c.nsub;
                 d.coef_off = c.coef_base + c.blocks;
+                d.ent_off = c.ent_base + c.entries;
+                d.tile_off = c.tile_base + c.tiles;
                 b->info[i].coef_off = d.coef_off;
+                b->info[i].ent_off = d.ent_off;
+                b->info[i].tile_off = d.tile_off;
+                c.entries += inf.ent_cap;
+                c.tiles += inf.ntiles + 1;
                 c.nsub += d.himg.nsub;
                 c.blocks += inf.nblocks;
                 c.max_wg = std::max<uint32_t>(c.max_wg, (d.himg.nsub + kWgLanes - 1) / kWgLanes);
@@ -177,6 +196,8 @@ void plan_chunks(mjx_batch *b)
             i++;
         }
         coef_running += c.blocks;
+        ent_running += c.entries;
+        tile_running += c.tiles;
         b->chunks.push_back(c);
     }
 }
@@ -184,7 +205,8 @@ void plan_chunks(mjx_batch *b)
 int allocate_work_buffers(mjx_batch *b)
 {
     uint32_t max_nsub = 1;
-    uint64_t max_blocks = 1, total_blocks = 0;
+    uint64_t max_blocks = 1, total_blocks = 0, max_entries = 4, total_entries = 0;
+    uint32_t max_tiles_arr = 1, total_tiles_arr = 0;
     uint32_t lut_cap = 8, max_tile_blocks = 1;
     size_t max_segsum = 1;
     for (const Chunk &c : b->chunks) {
@@ -192,6 +214,10 @@ int allocate_work_buffers(mjx_batch *b)
         max_nsub = std::max(max_nsub, c.nsub);
         max_blocks = std::max(max_blocks, c.blocks);
         total_blocks += c.blocks;
+        max_entries = std::max(max_entries, c.entries);
+        total_entries += c.entries;
+        max_tiles_arr = std::max(max_tiles_arr, c.tiles);
+        total_tiles_arr += c.tiles;
         lut_cap = std::max(lut_cap, c.lut_cap);
         max_tile_blocks = std::max(max_tile_blocks, c.max_tile_blocks);
     }
@@ -199,14 +225,18 @@ int allocate_work_buffers(mjx_batch *b)
     HIPOK(hipMalloc(&b->d_entry, size_t(max_nsub) * sizeof(SubseqState)));
     HIPOK(hipMalloc(&b->d_exit, size_t(max_nsub) * sizeof(SubseqState)));
     HIPOK(hipMalloc(&b->d_blkbase, size_t(max_nsub) * sizeof(uint32_t)));
-    HIPOK(hipMalloc(&b->d_cps, size_t(max_nsub) * kNumCp * sizeof(uint32_t)));
+    HIPOK(hipMalloc(&b->d_cps, size_t(max_nsub) * kNumCp * 2 * sizeof(uint32_t)));
     size_t max_imgs = 1;
     for (const Chunk &c : b->chunks) max_imgs = std::max(max_imgs, c.count);
     b->max_nsub = max_nsub;
     b->max_chunk_images = uint32_t(max_imgs);
     HIPOK(hipMalloc(&b->d_pull, max_imgs * kMaxFix * sizeof(uint32_t)));
     HIPOK(hipMalloc(&b->d_segsum, max_segsum * 3 * sizeof(int32_t)));
-    HIPOK(hipMalloc(&b->d_coef, size_t(coef_blocks) * 128));
+    HIPOK(hipMalloc(&b->d_entries, size_t(b->opts.keep_coefs ? std::max<uint64_t>(total_entries, 4) : max_entries) * 4 + 64));
+    HIPOK(hipMalloc(&b->d_tile_eoff, size_t(b->opts.keep_coefs ? std::max<uint32_t>(total_tiles_arr, 1) : max_tiles_arr) * 4 + 16));
+    HIPOK(hipMalloc(&b->d_ebase, size_t(max_nsub) * sizeof(uint32_t)));
+    HIPOK(hipMalloc(&b->d_img_entries, std::max<size_t>(b->info.size(), 1) * sizeof(uint32_t)));
+    HIPOK(hipMemset(b->d_img_entries, 0, std::max<size_t>(b->info.size(), 1) * sizeof(uint32_t)));
     HIPOK(hipMalloc(&b->d_dc, size_t(coef_blocks) * sizeof(int16_t) + 16));
     HIPOK(hipMalloc(&b->d_rgb, std::max<size_t>(b->rgb_pool_bytes, 16)));
     HIPOK(hipMalloc(&b->d_status, std::max<size_t>(b->info.size(), 1) * sizeof(int)));
@@ -249,8 +279,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     hipStream_t st = b->ctx->stream;
     const DevImage *imgs = b->d_images + c.first;
     const uint32_t nimg = uint32_t(c.count);
-    int16_t *coef = b->d_coef;           // image coef_off values already include the chunk base
-    int16_t *dcb = b->d_dc;
+    int16_t *dcb = b->d_dc;              // image offsets already include the chunk base
     fix_passes = std::min(fix_passes, kMaxFix);
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_SYNC)) {
         prof_begin(b, MJX_K_HUFF_SYNC);
@@ -271,15 +300,12 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         }
     }
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_TAIL)) {
-        prof_begin(b, MJX_K_CLEAR);
-        HIPOK(hipMemsetAsync(coef + c.coef_base * 64, 0, size_t(c.blocks) * 128, st));
-        prof_end(b);
         prof_begin(b, MJX_K_HUFF_SCAN);
-        launch_huff_scan(st, nimg, imgs, b->d_exit, b->d_blkbase);
+        launch_huff_scan(st, nimg, imgs, b->d_exit, b->d_blkbase, b->d_ebase, b->d_img_entries);
         prof_end(b);
         prof_begin(b, MJX_K_HUFF_WRITE);
-        launch_huff_write(st, c.max_wg, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_blkbase, coef, dcb,
-                          b->d_status);
+        launch_huff_write(st, c.max_wg, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_blkbase, b->d_ebase,
+                          b->d_entries, b->d_tile_eoff, dcb, b->d_status);
         prof_end(b);
         prof_begin(b, MJX_K_DC_SCAN);
         launch_dc_scan(st, c.max_segs, nimg, imgs, dcb, b->d_segsum);
@@ -287,7 +313,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     }
     if (stages & MJX_STAGE_PIXELS) {
         prof_begin(b, MJX_K_IDCT_COLOR);
-        launch_idct_color(st, c.max_tiles, nimg, b->idct_lds, imgs, coef, dcb, b->d_qm, b->d_rgb, c.mode_mask);
+        launch_idct_color(st, c.max_tiles, nimg, b->idct_lds, imgs, b->d_entries, b->d_tile_eoff, dcb, b->d_qm, b->d_rgb, c.mode_mask);
         prof_end(b);
     }
     HIPOK(hipGetLastError());
@@ -353,6 +379,10 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
         d.qm_off = uint32_t(k * 192);
         inf.width = p.width; inf.height = p.height; inf.bpm = p.bpm; inf.nmcu = p.nmcu;
         inf.nblocks = uint64_t(p.nmcu) * p.bpm;
+        inf.tile_blocks = d.tile_blocks;
+        inf.ntiles = uint32_t((inf.nblocks + d.tile_blocks - 1) / d.tile_blocks);
+        // every stream entry consumes at least 2 bits of scan (1-bit code + 1 value bit) and a block holds at most 63
+        inf.ent_cap = (std::min<uint64_t>(uint64_t(p.scan_len) * 4, inf.nblocks * 63) + 7) / 4 * 4;
         inf.scan_len = p.scan_len;
         inf.rgb_off = rgb_pool;
         inf.rgb_bytes = uint64_t(p.width) * p.height * 3;
@@ -605,9 +635,24 @@ extern "C" int mjx_batch_copy_coefs(mjx_batch *b, size_t i, int16_t *host_coefs,
     if (!b->opts.keep_coefs && int(inf.chunk) != b->last_chunk_resident) return MJX_ERR_INVALID_ARG;
     HIPOK(hipSetDevice(b->ctx->device));
     HIPOK(hipStreamSynchronize(b->ctx->stream));
-    HIPOK(hipMemcpy(host_coefs, b->d_coef + inf.coef_off * 64, size_t(inf.nblocks) * 128, hipMemcpyDeviceToHost));
+    // expand the compact stream (entries + tile offsets + predicted DCs) into dense zig-zag blocks on the host
+    std::vector<uint32_t> eoff(size_t(inf.ntiles) + 1);
+    HIPOK(hipMemcpy(eoff.data(), b->d_tile_eoff + inf.tile_off, eoff.size() * 4, hipMemcpyDeviceToHost));
+    const uint32_t nent = eoff.back();
+    if (nent > inf.ent_cap) return MJX_ERR_DEVICE;
+    std::vector<uint32_t> ent(size_t(nent) + 1);
+    if (nent) HIPOK(hipMemcpy(ent.data(), b->d_entries + inf.ent_off, size_t(nent) * 4, hipMemcpyDeviceToHost));
     std::vector<int16_t> dc(size_t(inf.nblocks));
     HIPOK(hipMemcpy(dc.data(), b->d_dc + inf.coef_off, dc.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
+    std::memset(host_coefs, 0, size_t(inf.nblocks) * 128);
+    for (uint32_t t = 0; t < inf.ntiles; t++) {
+        const uint32_t first = t * inf.tile_blocks;
+        for (uint32_t j = eoff[t]; j < eoff[t + 1] && j < nent; j++) {
+            const uint32_t e = ent[j];
+            const uint64_t blk = first + (((e >> 22) - first) & 0xffu);
+            if (blk < inf.nblocks) host_coefs[blk * 64 + ((e >> 16) & 63)] = int16_t(e & 0xffff);
+        }
+    }
     for (size_t k = 0; k < dc.size(); k++) host_coefs[k * 64] = dc[k];
     return MJX_OK;
 }
@@ -618,8 +663,20 @@ extern "C" int mjx_batch_bytes(const mjx_batch *b, uint64_t *scan_bytes, uint64_
     if (!b) return MJX_ERR_INVALID_ARG;
     if (scan_bytes) *scan_bytes = b->scan_bytes;
     if (rgb_bytes) *rgb_bytes = b->rgb_bytes;
-    if (coef_bytes) *coef_bytes = b->coef_bytes;
     if (pixels) *pixels = b->pixels;
+    if (coef_bytes) {
+        // intermediate coefficient representation: 4 bytes per stream entry + 2 bytes of DC per block
+        uint64_t total = 0;
+        if (b->decoded_entropy) {
+            HIPOK(hipSetDevice(b->ctx->device));
+            HIPOK(hipStreamSynchronize(b->ctx->stream));
+            std::vector<uint32_t> cnt(b->info.size());
+            if (!cnt.empty()) HIPOK(hipMemcpy(cnt.data(), b->d_img_entries, cnt.size() * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < cnt.size(); i++)
+                if (b->info[i].status == MJX_OK) total += uint64_t(cnt[i]) * 4 + b->info[i].nblocks * 2;
+        }
+        *coef_bytes = total;
+    }
     return MJX_OK;
 }
 

@@ -43,14 +43,24 @@ MJX_HD constexpr uint16_t lut_direct(unsigned len, unsigned run, unsigned size)
 }
 MJX_HD constexpr uint16_t lut_link(unsigned offset, unsigned nbits) { return uint16_t(0x8000u | (offset << 4) | nbits); }
 
-// ---- per-subsequence synchronisation state (8 bytes, one naturally aligned store) ----------------
+// ---- per-subsequence synchronisation state -------------------------------------------------------------------
+// The first 8 bytes (what the next subsequence must start from) are read while other lanes may rewrite them, so they
+// form one naturally aligned 8-byte word; the counters are only consumed after the rounds have converged.
 struct alignas(8) SubseqState {
     uint32_t p;    // bit position (relative to the image's scan) of the first symbol at/after the boundary
-    uint16_t n;    // blocks completed inside the subsequence
     uint8_t z;     // zig-zag index of the next coefficient (0 = next symbol is a DC code)
     uint8_t c;     // block index inside the MCU (selects the DC/AC table pair)
+    uint16_t pad;
+    uint32_t n;    // blocks completed inside the subsequence
+    uint32_t m;    // non-zero AC coefficients (= entries of the compact coefficient stream) inside the subsequence
 };
 MJX_HD bool same_entry(const SubseqState &a, const SubseqState &b) { return a.p == b.p && a.z == b.z && a.c == b.c; }
+MJX_HD SubseqState make_state(uint32_t p, uint32_t z, uint32_t c, uint32_t n = 0, uint32_t m = 0)
+{
+    SubseqState s;
+    s.p = p; s.z = uint8_t(z); s.c = uint8_t(c); s.pad = 0; s.n = n; s.m = m;
+    return s;
+}
 
 // Per-image constants the lane needs (lives in LDS on the device).
 struct HuffImage {
@@ -61,10 +71,19 @@ struct HuffImage {
     uint32_t nsub;                       // ceil(total_bits / kSubseqBits)
 };
 
+// ---- compact coefficient stream -------------------------------------------------------------------------------
+// One 32-bit entry per non-zero AC coefficient, in decode order:  value[15:0] | zig-zag position[21:16] | block[29:22]
+// (low 8 bits of the block's index inside the image).  DC differences go to a separate array, one per block.
+MJX_HD constexpr uint32_t coef_entry(int val, uint32_t pos, uint32_t blk)
+{
+    return (uint32_t(val) & 0xffffu) | (pos << 16) | ((blk & 0xffu) << 22);
+}
+
 // A sink that discards everything (synchronisation passes).
 struct NullSink {
     MJX_HD void dc(uint32_t, int) const {}
     MJX_HD void ac(uint32_t, unsigned, int) const {}
+    MJX_HD void block_done(uint32_t) const {}
     MJX_HD void bad_code(uint32_t) const {}
     MJX_HD void tick() const {}          // one call per decoded symbol (statistics in the CPU emulation)
 };
@@ -75,22 +94,23 @@ struct NullSink {
 // at each boundary with the recorded one: equal (p, z, c) means the two decodes coincide from there on, so the
 // re-decode stops and inherits the old exit.  This is the self-synchronisation property used at a finer grain:
 // most re-decodes merge after a few dozen symbols instead of running all ~180.
-//   word: bit31 valid | n[30:16] | c[15:12] | z[11:6] | p - boundary [5:0]
-//   n = blocks completed from the checkpoint to the end of the subsequence (after the decode's fix-up); while a
-//   decode is running it temporarily holds the blocks completed from the start to the checkpoint.
+//   word 0: bit31 valid | n[30:16] | c[15:12] | z[11:6] | p - boundary [5:0]      word 1: m
+//   n, m = blocks / stream entries from the checkpoint to the end of the subsequence (after the decode's fix-up);
+//   while a decode is running they temporarily hold the counts from the start to the checkpoint.
 constexpr int kCpBits = 256;
 constexpr int kNumCp = kSubseqBits / kCpBits - 1;
 constexpr uint32_t kCpValid = 0x80000000u, kCpStateMask = 0x8000ffffu;
 struct NoCheckpoints {
-    MJX_HD uint32_t get(uint32_t) const { return 0; }
-    MJX_HD uint32_t get_plain(uint32_t) const { return 0; }
-    MJX_HD void set(uint32_t, uint32_t) const {}
+    MJX_HD uint32_t get(uint32_t) const { return 0; }             // word 0 of checkpoint k (may prefetch k+1)
+    MJX_HD uint32_t get_plain(uint32_t) const { return 0; }       // word 0, no prefetch side effects
+    MJX_HD uint32_t get_m(uint32_t) const { return 0; }           // word 1
+    MJX_HD void set(uint32_t, uint32_t, uint32_t) const {}        // both words
 };
 
 // Registers of one lane's decoder: position + a three-dword look-ahead window of the big-endian bitstream.
 // w2 is fetched one refill early so that a global-memory load has a whole dword of symbols to complete.
 struct LaneState {
-    uint32_t p, z, c, n;      // bit position, zig-zag index, block-in-MCU, blocks completed
+    uint32_t p, z, c, n, m;   // bit position, zig-zag index, block-in-MCU, blocks completed, stream entries produced
     uint32_t tab;             // img.blktab[c]
     uint32_t wi, o;           // dword index of w0, bit offset inside it
     uint32_t w0, w1, w2;
@@ -99,7 +119,7 @@ struct LaneState {
 template <class BitSrc>
 MJX_HD void lane_begin(LaneState &st, const BitSrc &bits, const HuffImage &img, SubseqState entry)
 {
-    st.p = entry.p; st.z = entry.z; st.c = entry.c; st.n = 0;
+    st.p = entry.p; st.z = entry.z; st.c = entry.c; st.n = 0; st.m = 0;
     st.tab = img.blktab[st.c];
     st.wi = st.p >> 5; st.o = st.p & 31;
     st.w0 = bits.be32(st.wi); st.w1 = bits.be32(st.wi + 1); st.w2 = bits.be32(st.wi + 2);
@@ -133,6 +153,7 @@ MJX_HD void symbol_step(LaneState &st, const BitSrc &bits, const uint16_t *lut, 
         if (st.z == 0) sink.dc(blk, val);
         else if (size) sink.ac(blk, pos, val);
     }
+    st.m += (st.z != 0 && size != 0) ? 1u : 0u;
     st.z = pos + 1;
     if (st.z == 64) {
         st.z = 0;
@@ -140,6 +161,7 @@ MJX_HD void symbol_step(LaneState &st, const BitSrc &bits, const uint16_t *lut, 
         st.tab = img.blktab[st.c];
         st.n++;
         blk++;
+        if (WRITE) sink.block_done(blk);
     }
     const uint32_t adv = len + size;
     st.p += adv;
@@ -157,29 +179,31 @@ MJX_HD void symbol_step(LaneState &st, const BitSrc &bits, const uint16_t *lut, 
 // decode of this subsequence at the same 256-bit boundary (the decodes coincide from here on); otherwise records the
 // state (with the blocks completed so far) and advances to the next boundary.
 template <bool COMPARE, class CpStore>
-MJX_HD bool checkpoint_merge(const LaneState &st, CpStore &cps, uint32_t &k, uint32_t &cp_bit, uint32_t &n_rest)
+MJX_HD bool checkpoint_merge(const LaneState &st, CpStore &cps, uint32_t &k, uint32_t &cp_bit, uint32_t &n_rest,
+                             uint32_t &m_rest)
 {
     const uint32_t state = (st.p - cp_bit) | (st.z << 6) | (st.c << 12) | kCpValid;
     if (COMPARE) {
         const uint32_t old = cps.get(k);
         if ((old & kCpStateMask) == state) {
             n_rest = (old >> 16) & 0x7fffu;
+            m_rest = cps.get_m(k);
             return true;
         }
     }
-    cps.set(k, state | (st.n << 16));
+    cps.set(k, state | (st.n << 16), st.m);
     k++;
     cp_bit += kCpBits;
     return false;
 }
 
-// blocks-so-far -> blocks-to-the-end for the checkpoints this decode recorded
+// counts-so-far -> counts-to-the-end for the checkpoints this decode recorded
 template <class CpStore>
-MJX_HD void checkpoint_fixup(CpStore &cps, uint32_t k, uint32_t n_total)
+MJX_HD void checkpoint_fixup(CpStore &cps, uint32_t k, uint32_t n_total, uint32_t m_total)
 {
     for (uint32_t j = 0; j < k; j++) {
         const uint32_t wv = cps.get_plain(j);
-        cps.set(j, (wv & kCpStateMask) | ((n_total - ((wv >> 16) & 0x7fffu)) << 16));
+        cps.set(j, (wv & kCpStateMask) | ((n_total - ((wv >> 16) & 0x7fffu)) << 16), m_total - cps.get_m(j));
     }
 }
 
@@ -200,22 +224,18 @@ MJX_HD SubseqState decode_subseq(const BitSrc &bits, const uint16_t *lut, const 
     while (st.p < end_bit) {
         if (WRITE && blk >= img.total_blocks) break;
         if (CP && st.p >= cp_bit) {
-            uint32_t n_rest;
-            if (checkpoint_merge<CP == 2>(st, cps, k, cp_bit, n_rest)) {
+            uint32_t n_rest, m_rest;
+            if (checkpoint_merge<CP == 2>(st, cps, k, cp_bit, n_rest, m_rest)) {
                 st.n += n_rest;
+                st.m += m_rest;
                 st.p = old_exit.p; st.z = old_exit.z; st.c = old_exit.c;
                 break;
             }
         }
         symbol_step<WRITE>(st, bits, lut, img, blk, sink);
     }
-    if (CP) checkpoint_fixup(cps, k, st.n);
-    SubseqState s;
-    s.p = st.p;
-    s.n = uint16_t(st.n);
-    s.z = uint8_t(st.z);
-    s.c = uint8_t(st.c);
-    return s;
+    if (CP) checkpoint_fixup(cps, k, st.n, st.m);
+    return make_state(st.p, st.z, st.c, st.n, st.m);
 }
 
 #if !defined(__HIP_DEVICE_COMPILE__)

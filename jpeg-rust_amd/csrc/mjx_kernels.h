@@ -13,7 +13,8 @@ constexpr int kDcSegMcus = 2048;                                // MCUs per DC-p
 struct DevImage {
     HuffImage himg;
     uint64_t scan_off;      // bytes into the scan pool, 16-byte aligned
-    uint64_t coef_off;      // blocks into the coefficient buffer
+    uint64_t coef_off;      // blocks into the per-block arrays (dcbuf)
+    uint64_t ent_off;       // entries into the compact coefficient stream pool (start of the image's region)
     uint64_t rgb_off;       // bytes into the RGB pool
     uint32_t scan_padded;   // bytes that may be read at scan_off (multiple of 16; tail filled with 0xAA)
     uint32_t lut_off;       // entries into the decode-table pool (multiple of 8)
@@ -26,6 +27,8 @@ struct DevImage {
     uint32_t status_idx;    // index into the batch-wide device status array
     uint32_t log2_tile;     // stage-B tile = 1 << log2_tile MCUs
     uint32_t mode;          // stage-B specialisation: 0 generic, 1 = 4:2:0 (Y 2x2, Cb 1x1, Cr 1x1)
+    uint32_t tile_off;      // index of the image's first tile offset in the tile_eoff array
+    uint32_t tile_blocks;   // blocks per stage-B tile = (1 << log2_tile) * bpm  (<= 256)
     uint8_t blk_comp[kMaxBlocksPerMcu], blk_bx[kMaxBlocksPerMcu], blk_by[kMaxBlocksPerMcu];
     uint8_t ch[4], cv[4];   // sampling factors per component
     uint8_t cfirst[4];      // first block position of each component inside the MCU
@@ -52,14 +55,17 @@ void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds
 void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint8_t *scan_pool, const uint16_t *lut_pool, SubseqState *entry, SubseqState *exit_,
                        uint32_t *cps, uint32_t cp_stride, uint32_t *mismatches);
-void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase);
+void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,
+                      uint32_t *ebase, uint32_t *img_entries);
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint8_t *scan_pool, const uint16_t *lut_pool, const SubseqState *entry,
-                       const uint32_t *blkbase, int16_t *coef, int16_t *dcbuf, int *status);
+                       const uint32_t *blkbase, const uint32_t *ebase, uint32_t *entries, uint32_t *tile_eoff,
+                       int16_t *dcbuf, int *status);
 void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int16_t *dcbuf,
                     int32_t *segsum);
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
-                       const int16_t *coef, const int16_t *dcbuf, const float *qmult, uint8_t *rgb, uint32_t mode_mask);
+                       const uint32_t *entries, const uint32_t *tile_eoff, const int16_t *dcbuf, const float *qmult,
+                       uint8_t *rgb, uint32_t mode_mask);
 #endif
 
 }   // namespace mjx

@@ -34,22 +34,64 @@ struct GlobalBits {
     }
 };
 
-// Checkpoint words of one subsequence, k-major in HBM (lanes of a wave cross the same boundary at about the same
-// time, so their stores to checkpoint k are adjacent).
+// Checkpoint words of one subsequence, row-major by word in HBM (row 2k = state word of checkpoint k, row 2k+1 = its
+// entry count; lanes of a wave cross the same boundary at about the same time, so their stores to one row are adjacent).
 struct GlobalCps {
     uint32_t *w;            // &cps[subsequence]
     uint32_t stride;        // subsequences in the chunk
-    __device__ __forceinline__ uint32_t get(uint32_t k) const { return w[size_t(k) * stride]; }
-    __device__ __forceinline__ uint32_t get_plain(uint32_t k) const { return w[size_t(k) * stride]; }
-    __device__ __forceinline__ void set(uint32_t k, uint32_t v) const { w[size_t(k) * stride] = v; }
+    __device__ __forceinline__ uint32_t get(uint32_t k) const { return w[size_t(2 * k) * stride]; }
+    __device__ __forceinline__ uint32_t get_plain(uint32_t k) const { return w[size_t(2 * k) * stride]; }
+    __device__ __forceinline__ uint32_t get_m(uint32_t k) const { return w[size_t(2 * k + 1) * stride]; }
+    __device__ __forceinline__ void set(uint32_t k, uint32_t v, uint32_t m) const
+    {
+        w[size_t(2 * k) * stride] = v;
+        w[size_t(2 * k + 1) * stride] = m;
+    }
 };
 
-struct GlobalSink {
-    int16_t *coef;          // chunk coefficient buffer, already offset to the image's first block
-    int16_t *dcbuf;
+struct __attribute__((packed, aligned(4))) Entry4 { uint32_t a, b, c, d; };
+
+// Sink of the write pass: the compact coefficient stream (see coef_entry), DC differences, tile offsets.
+// Entries are buffered four at a time in registers so that the lane issues one 16-byte store per four non-zero
+// coefficients instead of one 2-byte store each; a lane's stream region is contiguous, so its lines fill completely.
+struct StreamSink {
+    uint32_t *entries;      // the image's entry region
+    int16_t *dcbuf;         // the image's DC differences
+    uint32_t *tile_eoff;    // the image's tile offsets (+ sentinel)
     int *status;
-    __device__ __forceinline__ void dc(uint32_t b, int v) const { dcbuf[b] = int16_t(v); }
-    __device__ __forceinline__ void ac(uint32_t b, unsigned pos, int v) const { coef[size_t(b) * 64 + pos] = int16_t(v); }
+    uint32_t off;           // entries produced so far (next entry index)
+    uint32_t nbuf;          // entries waiting in b0..b3 (oldest first ends in b3 after four pushes)
+    uint32_t b0, b1, b2, b3;
+    uint32_t next_tile_blk, tile_idx, tile_blocks, total_blocks, ntiles;
+    __device__ __forceinline__ void dc(uint32_t b, int v)
+    {
+        dcbuf[b] = int16_t(v);
+        if (b == next_tile_blk) {           // first block of a stage-B tile: remember where its entries start
+            tile_eoff[tile_idx] = off;
+            tile_idx++;
+            next_tile_blk += tile_blocks;
+        }
+    }
+    __device__ __forceinline__ void ac(uint32_t b, unsigned pos, int v)
+    {
+        b0 = b1; b1 = b2; b2 = b3; b3 = coef_entry(v, pos, b);
+        off++;
+        if (++nbuf == 4) {
+            *reinterpret_cast<Entry4 *>(entries + (off - 4)) = Entry4{b0, b1, b2, b3};
+            nbuf = 0;
+        }
+    }
+    __device__ __forceinline__ void block_done(uint32_t next_blk)
+    {
+        if (next_blk == total_blocks) tile_eoff[ntiles] = off;
+    }
+    __device__ __forceinline__ void flush()
+    {
+        if (nbuf == 3) entries[off - 3] = b1;
+        if (nbuf >= 2) entries[off - 2] = b2;
+        if (nbuf >= 1) entries[off - 1] = b3;
+        nbuf = 0;
+    }
     __device__ __forceinline__ void bad_code(uint32_t) const { atomicOr(status, 1); }
     __device__ __forceinline__ void tick() const {}
 };
@@ -92,8 +134,7 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_spec(const DevImage *im
     const uint32_t s = blockIdx.x * kWgLanes + threadIdx.x;
     if (s >= h->nsub) return;
     const GlobalBits bits{reinterpret_cast<const uint32_t *>(scan_pool + im.scan_off), im.scan_padded / 4};
-    SubseqState e;
-    e.p = s * kSubseqBits; e.n = 0; e.z = 0; e.c = 0;
+    const SubseqState e = make_state(s * kSubseqBits, 0, 0);
     NullSink sink;
     GlobalCps cps{g_cps + im.sub_off + s, cp_stride};
     const SubseqState x = decode_subseq<false, 1>(bits, lut, *h, e, subseq_end(*h, s), 0, sink, cps, s * kSubseqBits, e);
@@ -106,16 +147,21 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_spec(const DevImage *im
 struct GlobalCpsPrefetch {
     uint32_t *w;
     uint32_t stride;
-    uint32_t next;          // cps[k_next]
+    uint32_t next;          // state word of the next checkpoint
     __device__ __forceinline__ void prime() { next = w[0]; }
     __device__ __forceinline__ uint32_t get(uint32_t k)
     {
         const uint32_t v = next;
-        if (k + 1 < uint32_t(kNumCp)) next = w[size_t(k + 1) * stride];
+        if (k + 1 < uint32_t(kNumCp)) next = w[size_t(2 * (k + 1)) * stride];
         return v;
     }
-    __device__ __forceinline__ uint32_t get_plain(uint32_t k) const { return w[size_t(k) * stride]; }
-    __device__ __forceinline__ void set(uint32_t k, uint32_t v) const { w[size_t(k) * stride] = v; }
+    __device__ __forceinline__ uint32_t get_plain(uint32_t k) const { return w[size_t(2 * k) * stride]; }
+    __device__ __forceinline__ uint32_t get_m(uint32_t k) const { return w[size_t(2 * k + 1) * stride]; }
+    __device__ __forceinline__ void set(uint32_t k, uint32_t v, uint32_t m) const
+    {
+        w[size_t(2 * k) * stride] = v;
+        w[size_t(2 * k + 1) * stride] = m;
+    }
 };
 
 // k_huff_merge: one synchronisation round.  Subsequence s must start where s-1 ended: if entry[s] differs from
@@ -134,7 +180,7 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_merge(const DevImage *i
     if (!im.valid || blockIdx.x * kWgLanes + 1 >= im.himg.nsub) return;
     const uint32_t s = blockIdx.x * kWgLanes + threadIdx.x + 1;
     bool need = false;
-    SubseqState prev = {0, 0, 0, 0};
+    SubseqState prev = make_state(0, 0, 0);
     if (s < im.himg.nsub) {
         prev = g_exit[im.sub_off + s - 1];
         need = !same_entry(prev, g_entry[im.sub_off + s]);
@@ -147,8 +193,7 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_merge(const DevImage *i
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(mismatches, uint32_t(__popcll(m)));
     if (!need) return;
     const GlobalBits bits{reinterpret_cast<const uint32_t *>(scan_pool + im.scan_off), im.scan_padded / 4};
-    SubseqState e = prev;
-    e.n = 0;
+    const SubseqState e = make_state(prev.p, prev.z, prev.c);
     const SubseqState old_exit = g_exit[im.sub_off + s];
     g_entry[im.sub_off + s] = e;
     NullSink sink;
@@ -181,9 +226,10 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t *s_tm
     return base + incl - v;
 }
 
-// blkbase[s] = number of blocks completed before subsequence s (one workgroup per image).
+// blkbase[s] / ebase[s] = blocks completed / stream entries produced before subsequence s (one workgroup per image).
 extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *images, const SubseqState *g_exit,
-                                                               uint32_t *g_blkbase)
+                                                               uint32_t *g_blkbase, uint32_t *g_ebase,
+                                                               uint32_t *img_entries)
 {
     __shared__ uint32_t s_tmp[4];
     const DevImage &im = images[blockIdx.x];
@@ -191,14 +237,18 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *im
     const uint32_t nsub = im.himg.nsub, tid = threadIdx.x;
     const uint32_t per = (nsub + kWgLanes - 1) / kWgLanes;
     const uint32_t a = min(nsub, tid * per), b = min(nsub, a + per);
-    uint32_t sum = 0;
-    for (uint32_t s = a; s < b; s++) sum += g_exit[im.sub_off + s].n;
-    uint32_t total;
-    uint32_t run = wg_exclusive_scan(sum, s_tmp, &total);
+    uint32_t sum_n = 0, sum_m = 0;
+    for (uint32_t s = a; s < b; s++) { sum_n += g_exit[im.sub_off + s].n; sum_m += g_exit[im.sub_off + s].m; }
+    uint32_t total_n, total_m;
+    uint32_t run_n = wg_exclusive_scan(sum_n, s_tmp, &total_n);
+    uint32_t run_m = wg_exclusive_scan(sum_m, s_tmp, &total_m);
     for (uint32_t s = a; s < b; s++) {
-        g_blkbase[im.sub_off + s] = run;
-        run += g_exit[im.sub_off + s].n;
+        g_blkbase[im.sub_off + s] = run_n;
+        g_ebase[im.sub_off + s] = run_m;
+        run_n += g_exit[im.sub_off + s].n;
+        run_m += g_exit[im.sub_off + s].m;
     }
+    if (tid == 0) img_entries[im.status_idx] = total_m;      // upper bound of the entries the write pass produces
 }
 
 // Per-lane window of the bitstream in LDS for the write pass.  The write pass scatters stores to HBM; a bitstream
@@ -230,8 +280,9 @@ __device__ __forceinline__ void window_fill(uint32_t *lds, const GlobalBits &g, 
 
 extern "C" __global__ __launch_bounds__(256) void k_huff_write(const DevImage *images, const uint8_t *scan_pool,
                                                                 const uint16_t *lut_pool, const SubseqState *g_entry,
-                                                                const uint32_t *g_blkbase, int16_t *coef,
-                                                                int16_t *dcbuf, int *status)
+                                                                const uint32_t *g_blkbase, const uint32_t *g_ebase,
+                                                                uint32_t *entries, uint32_t *tile_eoff, int16_t *dcbuf,
+                                                                int *status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t s_win[kWgLanes * kWinStride];
@@ -242,15 +293,31 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_write(const DevImage *i
     stage_tables(im, lut_pool, smem, h, lut);
     const uint32_t s = blockIdx.x * kWgLanes + threadIdx.x;
     const GlobalBits gbits{reinterpret_cast<const uint32_t *>(scan_pool + im.scan_off), im.scan_padded / 4};
-    GlobalSink sink{coef + im.coef_off * 64, dcbuf + im.coef_off, status + im.status_idx};
     uint32_t *my = s_win + threadIdx.x * kWinStride;
-    bool live = s < h->nsub;
-    SubseqState e = {0, 0, 0, 0};
-    uint32_t blk = 0, end_bit = 0;
+    const bool live = s < h->nsub;
+    SubseqState e = make_state(0, 0, 0);
+    uint32_t blk = 0, end_bit = 0, ebase = 0;
     if (live) {
         e = g_entry[im.sub_off + s];
         blk = g_blkbase[im.sub_off + s];
+        ebase = g_ebase[im.sub_off + s];
         end_bit = subseq_end(*h, s);
+    }
+    StreamSink sink;
+    sink.entries = entries + im.ent_off;
+    sink.dcbuf = dcbuf + im.coef_off;
+    sink.tile_eoff = tile_eoff + im.tile_off;
+    sink.status = status + im.status_idx;
+    sink.off = ebase;
+    sink.nbuf = 0;
+    sink.b0 = sink.b1 = sink.b2 = sink.b3 = 0;
+    sink.tile_blocks = im.tile_blocks;
+    sink.total_blocks = h->total_blocks;
+    sink.ntiles = (h->total_blocks + im.tile_blocks - 1) / im.tile_blocks;
+    {
+        const uint32_t first_start = blk + (e.z ? 1u : 0u);                // first block whose DC this lane decodes
+        sink.tile_idx = (first_start + im.tile_blocks - 1) / im.tile_blocks;
+        sink.next_tile_blk = sink.tile_idx * im.tile_blocks;
     }
     LdsWindow win{my, e.p >> 5};
     window_fill(my, gbits, win.wbase);
@@ -265,6 +332,7 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_write(const DevImage *i
         }
         if (active) symbol_step<true>(st, win, lut, *h, blk, sink);
     }
+    sink.flush();
 }
 
 // DC prediction (decoder.rs:173, 208-210: running sum per component, never reset) as a two-level prefix sum over
@@ -391,7 +459,6 @@ extern "C" __global__ __launch_bounds__(256) void k_dc_apply(const DevImage *ima
 // ------------------------------------------------------------------------------------------------
 // stage B
 // ------------------------------------------------------------------------------------------------
-constexpr int kCoefStride = 144;     // bytes per staged coefficient block (128 + 16: conflict-free ds_read_b128)
 constexpr int kPixStride = 68;       // floats per IDCT output block (64 + 4)
 
 // 8-point inverse DCT, Arai-Agui-Nakajima factorisation on inputs pre-scaled by the AAN factors (folded into the
@@ -487,60 +554,57 @@ __device__ __forceinline__ void store4(uint8_t *dst, const Rgb4 &v, bool aligned
     }
 }
 
-// Phases 1 + 2 of stage B, common to every sampling layout: stage the tile's coefficient blocks in LDS, one lane = one
-// 8x8 block (dequant, un-zigzag, 16 one-dimensional transforms in registers), results to the LDS sample tile.
-__device__ __forceinline__ void idct_tile(const DevImage &im, const int16_t *coef, const int16_t *dcbuf,
-                                          const float *s_qm, unsigned char *smem, uint64_t blk0, uint32_t nblk)
+// Phases 1 + 2 of stage B, common to every sampling layout.
+//   phase 1: zero the tile's sample rows in LDS, then scatter the tile's slice of the compact coefficient stream into
+//            them, entry-parallel: lane i takes entries i, i+256, ... (coalesced 4-byte loads), finds the entry's block
+//            from its block byte, multiplies by the dequantisation x IDCT-prescale factor of its zig-zag position and
+//            stores the float at the natural-order position (un-zigzag, decoder.rs:230-232, 425-437).  DC values come
+//            from dcbuf (already prediction-summed).
+//   phase 2: one lane = one 8x8 block: 16 x ds_read_b128 of its row, 8 column + 8 row transforms in registers,
+//            results back to the same row.
+__device__ __forceinline__ void idct_tile(const DevImage &im, const uint32_t *entries, const uint32_t *tile_eoff,
+                                          const int16_t *dcbuf, const float *s_qm, const uint8_t *s_nat,
+                                          uint8_t *s_comp, unsigned char *smem, uint32_t tile, uint64_t blk0,
+                                          uint32_t nblk)
 {
     const uint32_t tid = threadIdx.x;
+    float *tile_f = reinterpret_cast<float *>(smem);
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(coef + blk0 * 64);
-        const uint32_t ngran = nblk * 8;
-        for (uint32_t g = tid; g < ngran; g += 256) {
-            const uint4 q = src[g];
-            *reinterpret_cast<uint4 *>(smem + (g >> 3) * kCoefStride + (g & 7) * 16) = q;
+        float4 *z = reinterpret_cast<float4 *>(smem);
+        const uint32_t nq = nblk * (kPixStride / 4);
+        for (uint32_t i = tid; i < nq; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < nblk) s_comp[tid] = im.blk_comp[tid % im.bpm];
+    }
+    const uint32_t e0 = tile_eoff[im.tile_off + tile], e1 = tile_eoff[im.tile_off + tile + 1];
+    __syncthreads();
+    {
+        const uint32_t *src = entries + im.ent_off;
+        const uint32_t first_lo = uint32_t(blk0 - im.coef_off) & 0xffu;
+        for (uint32_t i = e0 + tid; i < e1; i += 256) {
+            const uint32_t e = src[i];
+            const uint32_t b = ((e >> 22) - first_lo) & 0xffu;
+            const uint32_t pos = (e >> 16) & 63u;
+            if (b < nblk) tile_f[b * kPixStride + s_nat[pos]] = float(int32_t(int16_t(e & 0xffffu))) * s_qm[s_comp[b] * 64 + pos];
         }
+        if (tid < nblk) tile_f[tid * kPixStride] = float(int32_t(dcbuf[blk0 + tid])) * s_qm[s_comp[tid] * 64];
     }
     __syncthreads();
-    float v[64];
-    const bool have_block = tid < nblk;
-    if (have_block) {
-        const uint32_t c = im.blk_comp[tid % im.bpm];
-        const float *qm = s_qm + c * 64;
-        const uint4 *cb = reinterpret_cast<const uint4 *>(smem + tid * kCoefStride);
-        constexpr int ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
-                                41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
-                                30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    if (tid < nblk) {
+        float v[64];
+        float4 *row = reinterpret_cast<float4 *>(tile_f + tid * kPixStride);
 #pragma unroll
-        for (int g = 0; g < 8; g++) {
-            const uint4 q = cb[g];
-            const float4 m0q = *reinterpret_cast<const float4 *>(qm + g * 8);
-            const float4 m1q = *reinterpret_cast<const float4 *>(qm + g * 8 + 4);
-            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-            const float mm[8] = {m0q.x, m0q.y, m0q.z, m0q.w, m1q.x, m1q.y, m1q.z, m1q.w};
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int32_t ci = (k & 1) ? (int32_t(w[k >> 1]) >> 16) : int32_t(int16_t(w[k >> 1] & 0xffff));
-                v[ZZ[g * 8 + k]] = float(ci) * mm[k];
-            }
+        for (int q = 0; q < 16; q++) {
+            const float4 t = row[q];
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
         }
-        v[0] = float(int32_t(dcbuf[blk0 + tid])) * qm[0];
 #pragma unroll
         for (int c8 = 0; c8 < 8; c8++)
             idct8(v[c8], v[8 + c8], v[16 + c8], v[24 + c8], v[32 + c8], v[40 + c8], v[48 + c8], v[56 + c8]);
 #pragma unroll
         for (int r = 0; r < 8; r++)
             idct8(v[8 * r], v[8 * r + 1], v[8 * r + 2], v[8 * r + 3], v[8 * r + 4], v[8 * r + 5], v[8 * r + 6], v[8 * r + 7]);
-    }
-    __syncthreads();                                         // every lane has consumed the staged coefficients
-    float *tile = reinterpret_cast<float *>(smem);           // the sample tile aliases the coefficient staging
-    if (have_block) {
-        float4 *dst = reinterpret_cast<float4 *>(tile + tid * kPixStride);
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            dst[2 * r] = make_float4(v[8 * r], v[8 * r + 1], v[8 * r + 2], v[8 * r + 3]);
-            dst[2 * r + 1] = make_float4(v[8 * r + 4], v[8 * r + 5], v[8 * r + 6], v[8 * r + 7]);
-        }
+        for (int q = 0; q < 16; q++) row[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
     __syncthreads();
 }
@@ -566,11 +630,14 @@ __device__ __forceinline__ void load4(const float *tile, const DevImage &im, uin
 
 // MODE 0: any sampling layout.  MODE 1: Y 2x2 + Cb 1x1 + Cr 1x1 (4:2:0, 6 blocks per MCU, tile = 32 MCUs).
 template <int MODE>
-__global__ __launch_bounds__(256) void k_idct_color(const DevImage *images, const int16_t *coef, const int16_t *dcbuf,
-                                                     const float *qmult, uint8_t *rgb)
+__global__ __launch_bounds__(256) void k_idct_color(const DevImage *images, const uint32_t *entries,
+                                                     const uint32_t *tile_eoff, const int16_t *dcbuf, const float *qmult,
+                                                     uint8_t *rgb)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float s_qm[3 * 64];
+    __shared__ uint8_t s_nat[64];
+    __shared__ uint8_t s_comp[256];
     const DevImage &im = images[blockIdx.y];
     if (!im.valid || im.mode != uint32_t(MODE)) return;
     const uint32_t T = MODE == 1 ? 32u : (1u << im.log2_tile);
@@ -581,7 +648,13 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *images, cons
     const uint32_t nm = min(T, im.nmcu - m0), nblk = nm * bpm;
     const uint64_t blk0 = im.coef_off + uint64_t(m0) * bpm;
     if (tid < 192) s_qm[tid] = qmult[im.qm_off + tid];
-    idct_tile(im, coef, dcbuf, s_qm, smem, blk0, nblk);
+    if (tid < 64) {
+        constexpr uint8_t ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+        s_nat[tid] = ZZ[tid];
+    }
+    idct_tile(im, entries, tile_eoff, dcbuf, s_qm, s_nat, s_comp, smem, blockIdx.x, blk0, nblk);
     const float *tile = reinterpret_cast<const float *>(smem);
     uint8_t *out_img = rgb + im.rgb_off;
     const bool aligned = ((im.width * 3u) & 3u) == 0 && (im.rgb_off & 3u) == 0;
@@ -696,16 +769,18 @@ void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ld
     hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kWgLanes), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, cp_stride, mismatches);
 }
 
-void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase)
+void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,
+                      uint32_t *ebase, uint32_t *img_entries)
 {
-    hipLaunchKernelGGL(k_huff_scan, dim3(nimg), dim3(kWgLanes), 0, st, images, exit_, blkbase);
+    hipLaunchKernelGGL(k_huff_scan, dim3(nimg), dim3(kWgLanes), 0, st, images, exit_, blkbase, ebase, img_entries);
 }
 
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint8_t *scan_pool, const uint16_t *lut_pool, const SubseqState *entry,
-                       const uint32_t *blkbase, int16_t *coef, int16_t *dcbuf, int *status)
+                       const uint32_t *blkbase, const uint32_t *ebase, uint32_t *entries, uint32_t *tile_eoff,
+                       int16_t *dcbuf, int *status)
 {
-    hipLaunchKernelGGL(k_huff_write, dim3(max_wg, nimg), dim3(kWgLanes), lds, st, images, scan_pool, lut_pool, entry, blkbase, coef, dcbuf, status);
+    hipLaunchKernelGGL(k_huff_write, dim3(max_wg, nimg), dim3(kWgLanes), lds, st, images, scan_pool, lut_pool, entry, blkbase, ebase, entries, tile_eoff, dcbuf, status);
 }
 
 void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int16_t *dcbuf,
@@ -716,12 +791,13 @@ void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevI
 }
 
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
-                       const int16_t *coef, const int16_t *dcbuf, const float *qmult, uint8_t *rgb, uint32_t mode_mask)
+                       const uint32_t *entries, const uint32_t *tile_eoff, const int16_t *dcbuf, const float *qmult,
+                       uint8_t *rgb, uint32_t mode_mask)
 {
     if (mode_mask & 1u)
-        hipLaunchKernelGGL(k_idct_color<0>, dim3(max_tiles, nimg), dim3(256), lds, st, images, coef, dcbuf, qmult, rgb);
+        hipLaunchKernelGGL(k_idct_color<0>, dim3(max_tiles, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb);
     if (mode_mask & 2u)
-        hipLaunchKernelGGL(k_idct_color<1>, dim3(max_tiles, nimg), dim3(256), lds, st, images, coef, dcbuf, qmult, rgb);
+        hipLaunchKernelGGL(k_idct_color<1>, dim3(max_tiles, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb);
 }
 
 }   // namespace mjx

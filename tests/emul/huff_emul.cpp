@@ -7,6 +7,7 @@
 // self-synchronising scheme against the oracle without a GPU.  It is never linked into libmjx.so.
 #include "mjx.h"
 #include "mjx_huff.h"
+#include "mjx_kernels.h"
 #include "mjx_plan.h"
 
 #include <algorithm>
@@ -31,30 +32,42 @@ struct HostBits {
         return w;
     }
 };
-struct CoefSink {
-    int16_t *coef;
+// Mirrors the device sink of k_huff_write: AC entries appended to the compact stream, DC differences per block,
+// the stream offset of every tile's first block.
+struct StreamSink {
+    uint32_t *entries;
     int16_t *dcbuf;
+    uint32_t *tile_eoff;
+    uint32_t tile_blocks, total_blocks;
+    uint32_t off;
     int *bad;
-    void dc(uint32_t b, int v) const { dcbuf[b] = int16_t(v); }
-    void ac(uint32_t b, unsigned pos, int v) const { coef[size_t(b) * 64 + pos] = int16_t(v); }
+    void dc(uint32_t b, int v)
+    {
+        dcbuf[b] = int16_t(v);
+        if (b % tile_blocks == 0) tile_eoff[b / tile_blocks] = off;
+    }
+    void ac(uint32_t b, unsigned pos, int v) { entries[off++] = coef_entry(v, pos, b); }
+    void block_done(uint32_t next_blk)
+    {
+        if (next_blk == total_blocks) tile_eoff[(total_blocks + tile_blocks - 1) / tile_blocks] = off;
+    }
     void bad_code(uint32_t) const { *bad = 1; }
     void tick() const {}
 };
-}   // namespace
-
-namespace {
 struct TickSink {
     mutable long ticks = 0;
     void dc(uint32_t, int) const {}
     void ac(uint32_t, unsigned, int) const {}
+    void block_done(uint32_t) const {}
     void bad_code(uint32_t) const {}
     void tick() const { ticks++; }
 };
 struct HostCps {
-    uint32_t *w;
-    uint32_t get(uint32_t k) const { return w[k]; }
-    uint32_t get_plain(uint32_t k) const { return w[k]; }
-    void set(uint32_t k, uint32_t v) const { w[k] = v; }
+    uint32_t *w;     // 2 words per checkpoint
+    uint32_t get(uint32_t k) const { return w[2 * k]; }
+    uint32_t get_plain(uint32_t k) const { return w[2 * k]; }
+    uint32_t get_m(uint32_t k) const { return w[2 * k + 1]; }
+    void set(uint32_t k, uint32_t v, uint32_t m) const { w[2 * k] = v; w[2 * k + 1] = m; }
 };
 }   // namespace
 
@@ -76,7 +89,7 @@ extern "C" int emul_decode_coefs(const uint8_t *jpeg, size_t len, int layout, in
     const HostBits bits{plan.scan, plan.scan_len};
     const uint32_t nsub = img.nsub;
     std::vector<SubseqState> g_entry(nsub), g_exit(nsub);
-    std::vector<uint32_t> g_cps(size_t(nsub) * kNumCp, 0xdeadbeefu);      // uninitialised on the device
+    std::vector<uint32_t> g_cps(size_t(nsub) * kNumCp * 2, 0xdeadbeefu);  // uninitialised on the device
     TickSink ns;
     NoCheckpoints nocp;
     std::vector<std::vector<long>> iter_ticks;
@@ -86,8 +99,8 @@ extern "C" int emul_decode_coefs(const uint8_t *jpeg, size_t len, int layout, in
 
     iter_ticks.emplace_back();
     for (uint32_t s = 0; s < nsub; s++) {                                  // k_huff_spec
-        const SubseqState e{s * uint32_t(kSubseqBits), 0, 0, 0};
-        HostCps hc{g_cps.data() + size_t(s) * kNumCp};
+        const SubseqState e = make_state(s * uint32_t(kSubseqBits), 0, 0);
+        HostCps hc{g_cps.data() + size_t(s) * kNumCp * 2};
         const long t0 = ns.ticks;
         g_exit[s] = decode_subseq<false, 1>(bits, plan.lut.data(), img, e, end_of(s), 0, ns, hc, s * kSubseqBits, e);
         g_entry[s] = e;
@@ -101,10 +114,9 @@ extern "C" int emul_decode_coefs(const uint8_t *jpeg, size_t len, int layout, in
         for (uint32_t s = 1; s < nsub; s++) {
             const SubseqState prev = mode == 0 ? snap[s - 1] : g_exit[s - 1];
             if (same_entry(prev, g_entry[s])) continue;
-            SubseqState e = prev;
-            e.n = 0;
+            const SubseqState e = make_state(prev.p, prev.z, prev.c);
             g_entry[s] = e;
-            HostCps hc{g_cps.data() + size_t(s) * kNumCp};
+            HostCps hc{g_cps.data() + size_t(s) * kNumCp * 2};
             const long t0 = ns.ticks;
             g_exit[s] = decode_subseq<false, 2>(bits, plan.lut.data(), img, e, end_of(s), 0, ns, hc, s * kSubseqBits, g_exit[s]);
             iter_ticks.back().push_back(ns.ticks - t0);
@@ -123,19 +135,34 @@ extern "C" int emul_decode_coefs(const uint8_t *jpeg, size_t len, int layout, in
             std::fprintf(stderr, "pass %zu: items %zu mean %.1f p50 %ld p90 %ld p99 %ld max %ld\n", it, v.size(), double(sum) / v.size(), v[v.size() / 2], v[v.size() * 9 / 10], v[v.size() * 99 / 100], v.back());
         }
     }
-    // k_huff_scan + k_huff_write + DC prediction
-    std::vector<uint32_t> blkbase(nsub);
-    uint32_t acc = 0;
-    for (uint32_t s = 0; s < nsub; s++) { blkbase[s] = acc; acc += g_exit[s].n; }
+    // k_huff_scan + k_huff_write + DC prediction + expansion of the compact stream
+    std::vector<uint32_t> blkbase(nsub), ebase(nsub);
+    uint32_t acc = 0, eacc = 0;
+    for (uint32_t s = 0; s < nsub; s++) { blkbase[s] = acc; ebase[s] = eacc; acc += g_exit[s].n; eacc += g_exit[s].m; }
     const size_t nb = img.total_blocks;
     *nblocks = nb;
     int bad = 0;
     if (nb <= cap_blocks) {
-        std::memset(out, 0, nb * 64 * sizeof(int16_t));
+        const uint32_t tile_blocks = tile_mcus(plan.bpm, plan.hmax) * plan.bpm;
+        const uint32_t ntiles = uint32_t((nb + tile_blocks - 1) / tile_blocks);
+        std::vector<uint32_t> entries(size_t(eacc) + 1, 0xffffffffu), tile_eoff(ntiles + 1, 0xffffffffu);
         std::vector<int16_t> dcb(nb, 0);
-        CoefSink sink{out, dcb.data(), &bad};
-        for (uint32_t s = 0; s < nsub; s++)
+        for (uint32_t s = 0; s < nsub; s++) {
+            StreamSink sink{entries.data(), dcb.data(), tile_eoff.data(), tile_blocks, uint32_t(nb), ebase[s], &bad};
             decode_subseq<true, 0>(bits, plan.lut.data(), img, g_entry[s], end_of(s), blkbase[s], sink, nocp, 0, g_exit[s]);
+            // the entry count of the synchronisation passes must be exact for every subsequence that lies inside the image
+            if (blkbase[s] + g_exit[s].n < nb && sink.off - ebase[s] != g_exit[s].m) { if (dump && !bad) std::fprintf(stderr, "m mismatch s=%u got %u want %u n=%u\n", s, sink.off - ebase[s], g_exit[s].m, g_exit[s].n); bad = 2; }
+        }
+        std::memset(out, 0, nb * 64 * sizeof(int16_t));
+        for (uint32_t t = 0; t < ntiles; t++) {
+            if (tile_eoff[t] == 0xffffffffu || tile_eoff[t + 1] == 0xffffffffu) { bad = 3; break; }
+            for (uint32_t j = tile_eoff[t]; j < tile_eoff[t + 1]; j++) {
+                const uint32_t e = entries[j];
+                const uint32_t blk = t * tile_blocks + (((e >> 22) - t * tile_blocks) & 0xffu);
+                if (blk >= nb) { bad = 4; break; }
+                out[size_t(blk) * 64 + ((e >> 16) & 63)] = int16_t(e & 0xffff);
+            }
+        }
         int32_t pred[3] = {0, 0, 0};
         for (size_t b = 0; b < nb; b++) {
             const int c = plan.blk_comp[b % plan.bpm];
