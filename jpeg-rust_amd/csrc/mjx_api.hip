@@ -105,6 +105,7 @@ struct mjx_batch {
 namespace {
 
 constexpr int kMaxFix = 16;
+constexpr uint32_t kTilesPerWgHost = 8;       // must equal kTilesPerWg in mjx_kernels.hip
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -313,7 +314,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     }
     if (stages & MJX_STAGE_PIXELS) {
         prof_begin(b, MJX_K_IDCT_COLOR);
-        launch_idct_color(st, c.max_tiles, nimg, b->idct_lds, imgs, b->d_entries, b->d_tile_eoff, dcb, b->d_qm, b->d_rgb, c.mode_mask);
+        launch_idct_color(st, (c.max_tiles + kTilesPerWgHost - 1) / kTilesPerWgHost, nimg, b->idct_lds, imgs, b->d_entries, b->d_tile_eoff, dcb, b->d_qm, b->d_rgb, c.mode_mask);
         prof_end(b);
     }
     HIPOK(hipGetLastError());

@@ -554,59 +554,64 @@ __device__ __forceinline__ void store4(uint8_t *dst, const Rgb4 &v, bool aligned
     }
 }
 
-// Phases 1 + 2 of stage B, common to every sampling layout.
-//   phase 1: zero the tile's sample rows in LDS, then scatter the tile's slice of the compact coefficient stream into
-//            them, entry-parallel: lane i takes entries i, i+256, ... (coalesced 4-byte loads), finds the entry's block
-//            from its block byte, multiplies by the dequantisation x IDCT-prescale factor of its zig-zag position and
-//            stores the float at the natural-order position (un-zigzag, decoder.rs:230-232, 425-437).  DC values come
-//            from dcbuf (already prediction-summed).
-//   phase 2: one lane = one 8x8 block: 16 x ds_read_b128 of its row, 8 column + 8 row transforms in registers,
-//            results back to the same row.
-__device__ __forceinline__ void idct_tile(const DevImage &im, const uint32_t *entries, const uint32_t *tile_eoff,
-                                          const int16_t *dcbuf, const float *s_qm, const uint8_t *s_nat,
-                                          uint8_t *s_comp, unsigned char *smem, uint32_t tile, uint64_t blk0,
-                                          uint32_t nblk)
+// ---- stage B pipeline pieces ---------------------------------------------------------------------
+// A workgroup walks kTilesPerWg consecutive tiles of one image.  While it transforms tile t it already holds the loads
+// of tile t+1 in flight (stream offsets, up to kPrefetch entries per lane, the lane's DC), so the HBM round trips of a
+// tile overlap the arithmetic of the previous one instead of sitting on the workgroup's critical path.
+constexpr int kPrefetch = 8;         // stream entries per lane held in registers (2048 per tile; the rest is re-read)
+constexpr int kTilesPerWg = 8;
+
+struct TileFetch {
+    uint32_t e0, e1;                 // the tile's slice of the compact stream
+    uint32_t ent[kPrefetch];
+    int32_t dc;
+};
+
+__device__ __forceinline__ void tile_fetch(const DevImage &im, const uint32_t *entries, const uint32_t *tile_eoff,
+                                           const int16_t *dcbuf, uint32_t tile, uint32_t tile_blocks, TileFetch &f)
 {
     const uint32_t tid = threadIdx.x;
-    float *tile_f = reinterpret_cast<float *>(smem);
-    {
-        float4 *z = reinterpret_cast<float4 *>(smem);
-        const uint32_t nq = nblk * (kPixStride / 4);
-        for (uint32_t i = tid; i < nq; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tid < nblk) s_comp[tid] = im.blk_comp[tid % im.bpm];
+    f.e0 = tile_eoff[im.tile_off + tile];
+    f.e1 = tile_eoff[im.tile_off + tile + 1];
+    const uint32_t *src = entries + im.ent_off;
+#pragma unroll
+    for (int k = 0; k < kPrefetch; k++) {
+        const uint32_t i = f.e0 + tid + 256u * k;
+        f.ent[k] = i < f.e1 ? src[i] : 0u;
     }
-    const uint32_t e0 = tile_eoff[im.tile_off + tile], e1 = tile_eoff[im.tile_off + tile + 1];
-    __syncthreads();
-    {
-        const uint32_t *src = entries + im.ent_off;
-        const uint32_t first_lo = uint32_t(blk0 - im.coef_off) & 0xffu;
-        for (uint32_t i = e0 + tid; i < e1; i += 256) {
-            const uint32_t e = src[i];
-            const uint32_t b = ((e >> 22) - first_lo) & 0xffu;
-            const uint32_t pos = (e >> 16) & 63u;
-            if (b < nblk) tile_f[b * kPixStride + s_nat[pos]] = float(int32_t(int16_t(e & 0xffffu))) * s_qm[s_comp[b] * 64 + pos];
-        }
-        if (tid < nblk) tile_f[tid * kPixStride] = float(int32_t(dcbuf[blk0 + tid])) * s_qm[s_comp[tid] * 64];
+    const uint64_t blk = uint64_t(tile) * tile_blocks + tid;
+    f.dc = (tid < tile_blocks && blk < im.himg.total_blocks) ? int32_t(dcbuf[im.coef_off + blk]) : 0;
+}
+
+// One stream entry -> one float in the tile: find the block from the entry's block byte, multiply by the
+// dequantisation x IDCT-prescale factor of its zig-zag position, store at the natural-order position
+// (un-zigzag, decoder.rs:230-232, 425-437).
+__device__ __forceinline__ void scatter_entry(uint32_t e, uint32_t first_lo, uint32_t nblk, float *tile_f,
+                                              const float *s_qm, const uint8_t *s_nat, const uint8_t *s_comp)
+{
+    const uint32_t b = ((e >> 22) - first_lo) & 0xffu;
+    const uint32_t pos = (e >> 16) & 63u;
+    if (b < nblk) tile_f[b * kPixStride + s_nat[pos]] = float(int32_t(int16_t(e & 0xffffu))) * s_qm[s_comp[b] * 64 + pos];
+}
+
+// One lane = one 8x8 block: 16 x ds_read_b128 of its row, 8 column + 8 row transforms in registers, back to the row.
+__device__ __forceinline__ void idct_row_inplace(float *rowf)
+{
+    float v[64];
+    float4 *row = reinterpret_cast<float4 *>(rowf);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const float4 t = row[q];
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
     }
-    __syncthreads();
-    if (tid < nblk) {
-        float v[64];
-        float4 *row = reinterpret_cast<float4 *>(tile_f + tid * kPixStride);
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const float4 t = row[q];
-            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-        }
+    for (int c8 = 0; c8 < 8; c8++)
+        idct8(v[c8], v[8 + c8], v[16 + c8], v[24 + c8], v[32 + c8], v[40 + c8], v[48 + c8], v[56 + c8]);
 #pragma unroll
-        for (int c8 = 0; c8 < 8; c8++)
-            idct8(v[c8], v[8 + c8], v[16 + c8], v[24 + c8], v[32 + c8], v[40 + c8], v[48 + c8], v[56 + c8]);
+    for (int r = 0; r < 8; r++)
+        idct8(v[8 * r], v[8 * r + 1], v[8 * r + 2], v[8 * r + 3], v[8 * r + 4], v[8 * r + 5], v[8 * r + 6], v[8 * r + 7]);
 #pragma unroll
-        for (int r = 0; r < 8; r++)
-            idct8(v[8 * r], v[8 * r + 1], v[8 * r + 2], v[8 * r + 3], v[8 * r + 4], v[8 * r + 5], v[8 * r + 6], v[8 * r + 7]);
-#pragma unroll
-        for (int q = 0; q < 16; q++) row[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-    }
-    __syncthreads();
+    for (int q = 0; q < 16; q++) row[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
 // Reads 4 horizontally adjacent samples of one component for the pixel strip starting at MCU-local (x, y);
@@ -628,79 +633,54 @@ __device__ __forceinline__ void load4(const float *tile, const DevImage &im, uin
     }
 }
 
-// MODE 0: any sampling layout.  MODE 1: Y 2x2 + Cb 1x1 + Cr 1x1 (4:2:0, 6 blocks per MCU, tile = 32 MCUs).
-template <int MODE>
-__global__ __launch_bounds__(256) void k_idct_color(const DevImage *images, const uint32_t *entries,
-                                                     const uint32_t *tile_eoff, const int16_t *dcbuf, const float *qmult,
-                                                     uint8_t *rgb)
+// Phase 3 for 4:2:0 (Y 2x2, Cb 1x1, Cr 1x1): lane -> (MCU t, 4-pixel strip sx) fixed; each step handles a 4x2 pixel
+// patch that shares one pair of chroma samples per component (box replication).
+__device__ __forceinline__ void pixels_420(const DevImage &im, const float *tile, uint32_t m0, uint32_t nm,
+                                           uint8_t *out_img, bool aligned)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ float s_qm[3 * 64];
-    __shared__ uint8_t s_nat[64];
-    __shared__ uint8_t s_comp[256];
-    const DevImage &im = images[blockIdx.y];
-    if (!im.valid || im.mode != uint32_t(MODE)) return;
-    const uint32_t T = MODE == 1 ? 32u : (1u << im.log2_tile);
-    const uint32_t m0 = blockIdx.x * T;
-    if (m0 >= im.nmcu) return;
     const uint32_t tid = threadIdx.x;
-    const uint32_t bpm = MODE == 1 ? 6u : im.bpm;
-    const uint32_t nm = min(T, im.nmcu - m0), nblk = nm * bpm;
-    const uint64_t blk0 = im.coef_off + uint64_t(m0) * bpm;
-    if (tid < 192) s_qm[tid] = qmult[im.qm_off + tid];
-    if (tid < 64) {
-        constexpr uint8_t ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
-                                    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
-                                    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-        s_nat[tid] = ZZ[tid];
-    }
-    idct_tile(im, entries, tile_eoff, dcbuf, s_qm, s_nat, s_comp, smem, blockIdx.x, blk0, nblk);
-    const float *tile = reinterpret_cast<const float *>(smem);
-    uint8_t *out_img = rgb + im.rgb_off;
-    const bool aligned = ((im.width * 3u) & 3u) == 0 && (im.rgb_off & 3u) == 0;
-
-    if (MODE == 1) {
-        // phase 3, 4:2:0: lane -> (MCU t, 4-pixel strip sx) fixed; each step handles a 4x2 pixel patch that shares
-        // one pair of chroma samples per component (box replication).
-        const uint32_t q = tid & 127, t = q >> 2, sx = q & 3;
-        if (t >= nm) return;
-        const uint32_t m = m0 + t;
-        const uint32_t mx = m % im.mcux, my = m / im.mcux;
-        const uint32_t px = mx * 16 + sx * 4;
-        if (px >= im.width) return;
-        const uint32_t npix = min(4u, im.width - px);
-        const float *ybase = tile + (t * 6 + (sx >> 1)) * kPixStride + (sx & 1) * 4;
-        const float *cbase = tile + (t * 6 + 4) * kPixStride + sx * 2;
+    const uint32_t q = tid & 127, t = q >> 2, sx = q & 3;
+    if (t >= nm) return;
+    const uint32_t m = m0 + t;
+    const uint32_t mx = m % im.mcux, my = m / im.mcux;
+    const uint32_t px = mx * 16 + sx * 4;
+    if (px >= im.width) return;
+    const uint32_t npix = min(4u, im.width - px);
+    const float *ybase = tile + (t * 6 + (sx >> 1)) * kPixStride + (sx & 1) * 4;
+    const float *cbase = tile + (t * 6 + 4) * kPixStride + sx * 2;
 #pragma unroll
-        for (uint32_t j = 0; j < 4; j++) {
-            const uint32_t rp = (tid >> 7) + 2 * j;                           // row pair 0..7 inside the MCU
-            const uint32_t py = my * 16 + rp * 2;
-            if (py >= im.height) break;
-            const float *yp = ybase + (rp >> 2) * 2 * kPixStride + ((rp * 2) & 7) * 8;
-            const float4 ya = *reinterpret_cast<const float4 *>(yp);
-            const float4 yb = *reinterpret_cast<const float4 *>(yp + 8);
-            const float2 cb = *reinterpret_cast<const float2 *>(cbase + rp * 8);
-            const float2 cr = *reinterpret_cast<const float2 *>(cbase + kPixStride + rp * 8);
-            float cbk0, crk0, cbk1, crk1;
-            chroma_products(cb.x, cr.x, cbk0, crk0);
-            chroma_products(cb.y, cr.y, cbk1, crk1);
-            Rgb p[4];
-            p[0] = ycc_to_rgb(ya.x, cbk0, crk0); p[1] = ycc_to_rgb(ya.y, cbk0, crk0);
-            p[2] = ycc_to_rgb(ya.z, cbk1, crk1); p[3] = ycc_to_rgb(ya.w, cbk1, crk1);
-            uint8_t *dst = out_img + (size_t(py) * im.width + px) * 3;
-            store4(dst, pack4(p), aligned, npix);
-            if (py + 1 < im.height) {
-                p[0] = ycc_to_rgb(yb.x, cbk0, crk0); p[1] = ycc_to_rgb(yb.y, cbk0, crk0);
-                p[2] = ycc_to_rgb(yb.z, cbk1, crk1); p[3] = ycc_to_rgb(yb.w, cbk1, crk1);
-                store4(dst + size_t(im.width) * 3, pack4(p), aligned, npix);
-            }
+    for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t rp = (tid >> 7) + 2 * j;                           // row pair 0..7 inside the MCU
+        const uint32_t py = my * 16 + rp * 2;
+        if (py >= im.height) break;
+        const float *yp = ybase + (rp >> 2) * 2 * kPixStride + ((rp * 2) & 7) * 8;
+        const float4 ya = *reinterpret_cast<const float4 *>(yp);
+        const float4 yb = *reinterpret_cast<const float4 *>(yp + 8);
+        const float2 cb = *reinterpret_cast<const float2 *>(cbase + rp * 8);
+        const float2 cr = *reinterpret_cast<const float2 *>(cbase + kPixStride + rp * 8);
+        float cbk0, crk0, cbk1, crk1;
+        chroma_products(cb.x, cr.x, cbk0, crk0);
+        chroma_products(cb.y, cr.y, cbk1, crk1);
+        Rgb p[4];
+        p[0] = ycc_to_rgb(ya.x, cbk0, crk0); p[1] = ycc_to_rgb(ya.y, cbk0, crk0);
+        p[2] = ycc_to_rgb(ya.z, cbk1, crk1); p[3] = ycc_to_rgb(ya.w, cbk1, crk1);
+        uint8_t *dst = out_img + (size_t(py) * im.width + px) * 3;
+        store4(dst, pack4(p), aligned, npix);
+        if (py + 1 < im.height) {
+            p[0] = ycc_to_rgb(yb.x, cbk0, crk0); p[1] = ycc_to_rgb(yb.y, cbk0, crk0);
+            p[2] = ycc_to_rgb(yb.z, cbk1, crk1); p[3] = ycc_to_rgb(yb.w, cbk1, crk1);
+            store4(dst + size_t(im.width) * 3, pack4(p), aligned, npix);
         }
-        return;
     }
+}
 
-    // phase 3, generic: 4-pixel strips; lane -> (MCU t, strip sx) is fixed, rows advance by 256/R per step
+// Phase 3 for any sampling layout: 4-pixel strips; lane -> (MCU t, strip sx) is fixed, rows advance by 256/R per step.
+__device__ __forceinline__ void pixels_generic(const DevImage &im, const float *tile, uint32_t m0, uint32_t nm,
+                                               uint8_t *out_img, bool aligned)
+{
+    const uint32_t tid = threadIdx.x, bpm = im.bpm;
     const uint32_t lstrips = im.hmax == 2 ? 2u : 1u;         // log2 of the 4-pixel strips per MCU row (2*hmax)
-    const uint32_t R = T << lstrips;                         // strips per pixel row of the tile (power of two <= 256)
+    const uint32_t R = (1u << im.log2_tile) << lstrips;      // strips per pixel row of the tile (power of two <= 256)
     const uint32_t q = tid & (R - 1);
     const uint32_t t = q >> lstrips, sx = q & ((1u << lstrips) - 1);
     const uint32_t rows = 8 * im.vmax, lR = im.log2_tile + lstrips, rstep = 256u >> lR;
@@ -730,6 +710,77 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *images, cons
             for (int k = 0; k < 4; k++) p[k].r = p[k].g = p[k].b = yv[k] + 128.0f;                 // decoder.rs:318-325
         }
         store4(out_img + (size_t(py) * im.width + px) * 3, pack4(p), aligned, npix);
+    }
+}
+
+// MODE 0: any sampling layout.  MODE 1: Y 2x2 + Cb 1x1 + Cr 1x1 (4:2:0, 6 blocks per MCU, tile = 32 MCUs).
+//   phase 0  zero the tile's sample rows in LDS
+//   phase 1  scatter the tile's slice of the compact coefficient stream into them, entry-parallel (lane i holds
+//            entries i, i+256, ... prefetched during the previous tile), DC values from dcbuf (prediction-summed);
+//            then issue the loads of the next tile
+//   phase 2  one lane = one 8x8 block: float AAN inverse DCT in registers (transform.rs:55-87 up to rounding)
+//   phase 3  chroma replication + YCbCr->RGB + packed stores
+template <int MODE>
+__global__ __launch_bounds__(256) void k_idct_color(const DevImage *images, const uint32_t *entries,
+                                                     const uint32_t *tile_eoff, const int16_t *dcbuf, const float *qmult,
+                                                     uint8_t *rgb)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float s_qm[3 * 64];
+    __shared__ uint8_t s_nat[64];
+    __shared__ uint8_t s_comp[256];
+    const DevImage &im = images[blockIdx.y];
+    if (!im.valid || im.mode != uint32_t(MODE)) return;
+    const uint32_t T = MODE == 1 ? 32u : (1u << im.log2_tile);
+    const uint32_t bpm = MODE == 1 ? 6u : im.bpm;
+    const uint32_t tile_blocks = T * bpm;
+    const uint32_t ntiles = (im.nmcu + T - 1) / T;
+    const uint32_t tile0 = blockIdx.x * kTilesPerWg;
+    if (tile0 >= ntiles) return;
+    const uint32_t tile1 = min(ntiles, tile0 + kTilesPerWg);
+    const uint32_t tid = threadIdx.x;
+    TileFetch cur;
+    tile_fetch(im, entries, tile_eoff, dcbuf, tile0, tile_blocks, cur);
+    if (tid < 192) s_qm[tid] = qmult[im.qm_off + tid];
+    if (tid < 64) {
+        constexpr uint8_t ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+        s_nat[tid] = ZZ[tid];
+    }
+    if (tid < tile_blocks) s_comp[tid] = im.blk_comp[tid % bpm];
+    float *tile_f = reinterpret_cast<float *>(smem);
+    uint8_t *out_img = rgb + im.rgb_off;
+    const bool aligned = ((im.width * 3u) & 3u) == 0 && (im.rgb_off & 3u) == 0;
+    const uint32_t *src = entries + im.ent_off;
+
+    for (uint32_t tile = tile0; tile < tile1; tile++) {
+        const uint32_t m0 = tile * T;
+        const uint32_t nm = min(T, im.nmcu - m0), nblk = nm * bpm;
+        {   // phase 0
+            float4 *z = reinterpret_cast<float4 *>(smem);
+            const uint32_t nq = nblk * (kPixStride / 4);
+            for (uint32_t i = tid; i < nq; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        {   // phase 1
+            const uint32_t first_lo = (tile * tile_blocks) & 0xffu;
+#pragma unroll
+            for (int k = 0; k < kPrefetch; k++)
+                if (cur.e0 + tid + 256u * k < cur.e1) scatter_entry(cur.ent[k], first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+            for (uint32_t i = cur.e0 + tid + 256u * kPrefetch; i < cur.e1; i += 256)
+                scatter_entry(src[i], first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+            if (tid < nblk) tile_f[tid * kPixStride] = float(cur.dc) * s_qm[s_comp[tid] * 64];
+        }
+        TileFetch nxt = cur;
+        if (tile + 1 < tile1) tile_fetch(im, entries, tile_eoff, dcbuf, tile + 1, tile_blocks, nxt);
+        __syncthreads();
+        if (tid < nblk) idct_row_inplace(tile_f + tid * kPixStride);      // phase 2
+        __syncthreads();
+        if (MODE == 1) pixels_420(im, tile_f, m0, nm, out_img, aligned);  // phase 3
+        else pixels_generic(im, tile_f, m0, nm, out_img, aligned);
+        __syncthreads();
+        cur = nxt;
     }
 }
 
