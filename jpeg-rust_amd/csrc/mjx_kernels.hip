@@ -567,20 +567,20 @@ struct TileFetch {
     int32_t dc;
 };
 
-__device__ __forceinline__ void tile_fetch(const DevImage &im, const uint32_t *entries, const uint32_t *tile_eoff,
-                                           const int16_t *dcbuf, uint32_t tile, uint32_t tile_blocks, TileFetch &f)
+__device__ __forceinline__ void tile_fetch(const uint32_t *__restrict__ src, const uint32_t *__restrict__ eoff,
+                                           const int16_t *__restrict__ dc, uint32_t tile, uint32_t tile_blocks,
+                                           uint32_t total_blocks, TileFetch &f)
 {
     const uint32_t tid = threadIdx.x;
-    f.e0 = tile_eoff[im.tile_off + tile];
-    f.e1 = tile_eoff[im.tile_off + tile + 1];
-    const uint32_t *src = entries + im.ent_off;
+    f.e0 = eoff[tile];
+    f.e1 = eoff[tile + 1];
 #pragma unroll
     for (int k = 0; k < kPrefetch; k++) {
         const uint32_t i = f.e0 + tid + 256u * k;
         f.ent[k] = i < f.e1 ? src[i] : 0u;
     }
-    const uint64_t blk = uint64_t(tile) * tile_blocks + tid;
-    f.dc = (tid < tile_blocks && blk < im.himg.total_blocks) ? int32_t(dcbuf[im.coef_off + blk]) : 0;
+    const uint32_t blk = tile * tile_blocks + tid;
+    f.dc = (tid < tile_blocks && blk < total_blocks) ? int32_t(dc[blk]) : 0;
 }
 
 // One stream entry -> one float in the tile: find the block from the entry's block byte, multiply by the
@@ -634,25 +634,28 @@ __device__ __forceinline__ void load4(const float *tile, const DevImage &im, uin
 }
 
 // Phase 3 for 4:2:0 (Y 2x2, Cb 1x1, Cr 1x1): lane -> (MCU t, 4-pixel strip sx) fixed; each step handles a 4x2 pixel
-// patch that shares one pair of chroma samples per component (box replication).
-__device__ __forceinline__ void pixels_420(const DevImage &im, const float *tile, uint32_t m0, uint32_t nm,
-                                           uint8_t *out_img, bool aligned)
+// patch that shares one pair of chroma samples per component (box replication).  INTERIOR: every pixel of the tile
+// lies inside the image and rows are 4-byte aligned, so all eight stores are unconditional 12-byte stores.
+template <bool INTERIOR>
+__device__ __forceinline__ void pixels_420(uint32_t width, uint32_t height, uint32_t mcux, const float *tile, uint32_t m0,
+                                           uint32_t nm, uint8_t *out_img, bool aligned)
 {
     const uint32_t tid = threadIdx.x;
     const uint32_t q = tid & 127, t = q >> 2, sx = q & 3;
-    if (t >= nm) return;
+    if (!INTERIOR && t >= nm) return;
     const uint32_t m = m0 + t;
-    const uint32_t mx = m % im.mcux, my = m / im.mcux;
+    const uint32_t mx = m % mcux, my = m / mcux;
     const uint32_t px = mx * 16 + sx * 4;
-    if (px >= im.width) return;
-    const uint32_t npix = min(4u, im.width - px);
+    if (!INTERIOR && px >= width) return;
+    const uint32_t npix = INTERIOR ? 4u : min(4u, width - px);
     const float *ybase = tile + (t * 6 + (sx >> 1)) * kPixStride + (sx & 1) * 4;
     const float *cbase = tile + (t * 6 + 4) * kPixStride + sx * 2;
+    uint8_t *col = out_img + (size_t(my) * 16 * width + px) * 3;
 #pragma unroll
     for (uint32_t j = 0; j < 4; j++) {
         const uint32_t rp = (tid >> 7) + 2 * j;                           // row pair 0..7 inside the MCU
         const uint32_t py = my * 16 + rp * 2;
-        if (py >= im.height) break;
+        if (!INTERIOR && py >= height) break;
         const float *yp = ybase + (rp >> 2) * 2 * kPixStride + ((rp * 2) & 7) * 8;
         const float4 ya = *reinterpret_cast<const float4 *>(yp);
         const float4 yb = *reinterpret_cast<const float4 *>(yp + 8);
@@ -664,12 +667,14 @@ __device__ __forceinline__ void pixels_420(const DevImage &im, const float *tile
         Rgb p[4];
         p[0] = ycc_to_rgb(ya.x, cbk0, crk0); p[1] = ycc_to_rgb(ya.y, cbk0, crk0);
         p[2] = ycc_to_rgb(ya.z, cbk1, crk1); p[3] = ycc_to_rgb(ya.w, cbk1, crk1);
-        uint8_t *dst = out_img + (size_t(py) * im.width + px) * 3;
-        store4(dst, pack4(p), aligned, npix);
-        if (py + 1 < im.height) {
+        uint8_t *dst = col + size_t(rp) * 2 * width * 3;
+        if (INTERIOR) *reinterpret_cast<Rgb4 *>(dst) = pack4(p);
+        else store4(dst, pack4(p), aligned, npix);
+        if (INTERIOR || py + 1 < height) {
             p[0] = ycc_to_rgb(yb.x, cbk0, crk0); p[1] = ycc_to_rgb(yb.y, cbk0, crk0);
             p[2] = ycc_to_rgb(yb.z, cbk1, crk1); p[3] = ycc_to_rgb(yb.w, cbk1, crk1);
-            store4(dst + size_t(im.width) * 3, pack4(p), aligned, npix);
+            if (INTERIOR) *reinterpret_cast<Rgb4 *>(dst + size_t(width) * 3) = pack4(p);
+            else store4(dst + size_t(width) * 3, pack4(p), aligned, npix);
         }
     }
 }
@@ -721,9 +726,11 @@ __device__ __forceinline__ void pixels_generic(const DevImage &im, const float *
 //   phase 2  one lane = one 8x8 block: float AAN inverse DCT in registers (transform.rs:55-87 up to rounding)
 //   phase 3  chroma replication + YCbCr->RGB + packed stores
 template <int MODE>
-__global__ __launch_bounds__(256) void k_idct_color(const DevImage *images, const uint32_t *entries,
-                                                     const uint32_t *tile_eoff, const int16_t *dcbuf, const float *qmult,
-                                                     uint8_t *rgb)
+__global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__ images,
+                                                     const uint32_t *__restrict__ entries,
+                                                     const uint32_t *__restrict__ tile_eoff,
+                                                     const int16_t *__restrict__ dcbuf, const float *__restrict__ qmult,
+                                                     uint8_t *__restrict__ rgb)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float s_qm[3 * 64];
@@ -731,16 +738,24 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *images, cons
     __shared__ uint8_t s_comp[256];
     const DevImage &im = images[blockIdx.y];
     if (!im.valid || im.mode != uint32_t(MODE)) return;
+    // everything the tile loop needs from the descriptor, read once (uniform -> scalar registers)
     const uint32_t T = MODE == 1 ? 32u : (1u << im.log2_tile);
     const uint32_t bpm = MODE == 1 ? 6u : im.bpm;
+    const uint32_t nmcu = im.nmcu, width = im.width, height = im.height, mcux = im.mcux;
+    const uint32_t total_blocks = im.himg.total_blocks;
     const uint32_t tile_blocks = T * bpm;
-    const uint32_t ntiles = (im.nmcu + T - 1) / T;
+    const uint32_t ntiles = (nmcu + T - 1) / T;
     const uint32_t tile0 = blockIdx.x * kTilesPerWg;
     if (tile0 >= ntiles) return;
     const uint32_t tile1 = min(ntiles, tile0 + kTilesPerWg);
     const uint32_t tid = threadIdx.x;
+    const uint32_t *__restrict__ src = entries + im.ent_off;
+    const uint32_t *__restrict__ eoff = tile_eoff + im.tile_off;
+    const int16_t *__restrict__ dcs = dcbuf + im.coef_off;
+    uint8_t *__restrict__ out_img = rgb + im.rgb_off;
+    const bool aligned = ((width * 3u) & 3u) == 0 && (im.rgb_off & 3u) == 0;
     TileFetch cur;
-    tile_fetch(im, entries, tile_eoff, dcbuf, tile0, tile_blocks, cur);
+    tile_fetch(src, eoff, dcs, tile0, tile_blocks, total_blocks, cur);
     if (tid < 192) s_qm[tid] = qmult[im.qm_off + tid];
     if (tid < 64) {
         constexpr uint8_t ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
@@ -750,13 +765,10 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *images, cons
     }
     if (tid < tile_blocks) s_comp[tid] = im.blk_comp[tid % bpm];
     float *tile_f = reinterpret_cast<float *>(smem);
-    uint8_t *out_img = rgb + im.rgb_off;
-    const bool aligned = ((im.width * 3u) & 3u) == 0 && (im.rgb_off & 3u) == 0;
-    const uint32_t *src = entries + im.ent_off;
 
     for (uint32_t tile = tile0; tile < tile1; tile++) {
         const uint32_t m0 = tile * T;
-        const uint32_t nm = min(T, im.nmcu - m0), nblk = nm * bpm;
+        const uint32_t nm = min(T, nmcu - m0), nblk = nm * bpm;
         {   // phase 0
             float4 *z = reinterpret_cast<float4 *>(smem);
             const uint32_t nq = nblk * (kPixStride / 4);
@@ -773,12 +785,19 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *images, cons
             if (tid < nblk) tile_f[tid * kPixStride] = float(cur.dc) * s_qm[s_comp[tid] * 64];
         }
         TileFetch nxt = cur;
-        if (tile + 1 < tile1) tile_fetch(im, entries, tile_eoff, dcbuf, tile + 1, tile_blocks, nxt);
+        if (tile + 1 < tile1) tile_fetch(src, eoff, dcs, tile + 1, tile_blocks, total_blocks, nxt);
         __syncthreads();
         if (tid < nblk) idct_row_inplace(tile_f + tid * kPixStride);      // phase 2
         __syncthreads();
-        if (MODE == 1) pixels_420(im, tile_f, m0, nm, out_img, aligned);  // phase 3
-        else pixels_generic(im, tile_f, m0, nm, out_img, aligned);
+        if (MODE == 1) {                                                  // phase 3
+            // interior tile: all 32 MCUs in one MCU row, fully inside the image, rows 4-byte aligned
+            const uint32_t mx0 = m0 % mcux, my0 = m0 / mcux;
+            const bool interior = aligned && nm == T && mx0 + T <= mcux && (mx0 + T) * 16 <= width && (my0 + 1) * 16 <= height;
+            if (interior) pixels_420<true>(width, height, mcux, tile_f, m0, nm, out_img, aligned);
+            else pixels_420<false>(width, height, mcux, tile_f, m0, nm, out_img, aligned);
+        } else {
+            pixels_generic(im, tile_f, m0, nm, out_img, aligned);
+        }
         __syncthreads();
         cur = nxt;
     }
