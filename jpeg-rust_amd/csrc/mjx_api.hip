@@ -85,7 +85,7 @@ struct mjx_batch {
     uint32_t *d_tile_eoff = nullptr;    // stream offset of every stage-B tile (+ sentinel per image)
     uint32_t *d_ebase = nullptr;        // per subsequence: stream entries before it
     uint32_t *d_img_entries = nullptr;  // per image: entries counted by the synchronisation passes
-    int16_t *d_dc = nullptr;
+    int32_t *d_dc = nullptr;            // per block: DC difference, then (after k_dc_apply) the predicted DC
     uint8_t *d_rgb = nullptr;
     size_t rgb_pool_bytes = 0;
     int *d_status = nullptr;
@@ -238,7 +238,7 @@ int allocate_work_buffers(mjx_batch *b)
     HIPOK(hipMalloc(&b->d_ebase, size_t(max_nsub) * sizeof(uint32_t)));
     HIPOK(hipMalloc(&b->d_img_entries, std::max<size_t>(b->info.size(), 1) * sizeof(uint32_t)));
     HIPOK(hipMemset(b->d_img_entries, 0, std::max<size_t>(b->info.size(), 1) * sizeof(uint32_t)));
-    HIPOK(hipMalloc(&b->d_dc, size_t(coef_blocks) * sizeof(int16_t) + 16));
+    HIPOK(hipMalloc(&b->d_dc, size_t(coef_blocks) * sizeof(int32_t) + 64));
     HIPOK(hipMalloc(&b->d_rgb, std::max<size_t>(b->rgb_pool_bytes, 16)));
     HIPOK(hipMalloc(&b->d_status, std::max<size_t>(b->info.size(), 1) * sizeof(int)));
     HIPOK(hipMemset(b->d_status, 0, std::max<size_t>(b->info.size(), 1) * sizeof(int)));
@@ -280,7 +280,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     hipStream_t st = b->ctx->stream;
     const DevImage *imgs = b->d_images + c.first;
     const uint32_t nimg = uint32_t(c.count);
-    int16_t *dcb = b->d_dc;              // image offsets already include the chunk base
+    int32_t *dcb = b->d_dc;              // image offsets already include the chunk base
     fix_passes = std::min(fix_passes, kMaxFix);
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_SYNC)) {
         prof_begin(b, MJX_K_HUFF_SYNC);
@@ -402,7 +402,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
         HIPOK(hipSetDevice(ctx->device));
         HIPOK(hipMalloc(&b->d_images, std::max<size_t>(n, 1) * sizeof(DevImage)));
         HIPOK(hipMemcpy(b->d_images, b->himages.data(), n * sizeof(DevImage), hipMemcpyHostToDevice));
-        HIPOK(hipMalloc(&b->d_scan, b->scan_pool_bytes));
+        HIPOK(hipMalloc(&b->d_scan, b->scan_pool_bytes + 256));    // slack: bit windows read up to 96 bytes past a scan
         HIPOK(hipMalloc(&b->d_lut, std::max<size_t>(lut_pool, 8) * sizeof(uint16_t)));
         HIPOK(hipMalloc(&b->d_qm, std::max<size_t>(nu, 1) * 192 * sizeof(float)));
         if (src) {
@@ -643,8 +643,8 @@ extern "C" int mjx_batch_copy_coefs(mjx_batch *b, size_t i, int16_t *host_coefs,
     if (nent > inf.ent_cap) return MJX_ERR_DEVICE;
     std::vector<uint32_t> ent(size_t(nent) + 1);
     if (nent) HIPOK(hipMemcpy(ent.data(), b->d_entries + inf.ent_off, size_t(nent) * 4, hipMemcpyDeviceToHost));
-    std::vector<int16_t> dc(size_t(inf.nblocks));
-    HIPOK(hipMemcpy(dc.data(), b->d_dc + inf.coef_off, dc.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
+    std::vector<int32_t> dc(size_t(inf.nblocks));
+    HIPOK(hipMemcpy(dc.data(), b->d_dc + inf.coef_off, dc.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     std::memset(host_coefs, 0, size_t(inf.nblocks) * 128);
     for (uint32_t t = 0; t < inf.ntiles; t++) {
         const uint32_t first = t * inf.tile_blocks;
@@ -654,7 +654,7 @@ extern "C" int mjx_batch_copy_coefs(mjx_batch *b, size_t i, int16_t *host_coefs,
             if (blk < inf.nblocks) host_coefs[blk * 64 + ((e >> 16) & 63)] = int16_t(e & 0xffff);
         }
     }
-    for (size_t k = 0; k < dc.size(); k++) host_coefs[k * 64] = dc[k];
+    for (size_t k = 0; k < dc.size(); k++) host_coefs[k * 64] = int16_t(dc[k]);
     return MJX_OK;
 }
 
@@ -674,7 +674,7 @@ extern "C" int mjx_batch_bytes(const mjx_batch *b, uint64_t *scan_bytes, uint64_
             std::vector<uint32_t> cnt(b->info.size());
             if (!cnt.empty()) HIPOK(hipMemcpy(cnt.data(), b->d_img_entries, cnt.size() * 4, hipMemcpyDeviceToHost));
             for (size_t i = 0; i < cnt.size(); i++)
-                if (b->info[i].status == MJX_OK) total += uint64_t(cnt[i]) * 4 + b->info[i].nblocks * 2;
+                if (b->info[i].status == MJX_OK) total += uint64_t(cnt[i]) * 4 + b->info[i].nblocks * 4;
         }
         *coef_bytes = total;
     }

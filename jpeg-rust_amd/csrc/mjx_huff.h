@@ -28,20 +28,21 @@ namespace mjx {
 #endif
 constexpr int kSubseqBytes = MJX_SUBSEQ_BYTES;  // bytes of scan per lane
 constexpr int kSubseqBits = kSubseqBytes * 8;
-constexpr int kLutPrimaryBits = 9;
+constexpr int kLutPrimaryBits = 10;
 constexpr int kLutPrimarySize = 1 << kLutPrimaryBits;
 constexpr int kMaxBlocksPerMcu = 12;           // 3 components x (2x2)
 
 // ---- decode table entry (uint16) ---------------------------------------------------------------
 //  direct : bit15 = 0 | size[14:11] | run[10:5] | len[4:0]      (len = total code length, 1..16)
-//  link   : bit15 = 1 | sub-table offset[14:4] (entries, relative to the table base) | nbits[3:0]
+//  link   : bit15 = 1 | sub-table offset / 2 [14:4] (entries, relative to the table base) | nbits[3:0]
 //  invalid: 0
 constexpr uint16_t kLutLinkBit = 0x8000;
 MJX_HD constexpr uint16_t lut_direct(unsigned len, unsigned run, unsigned size)
 {
     return uint16_t((size << 11) | (run << 5) | len);
 }
-MJX_HD constexpr uint16_t lut_link(unsigned offset, unsigned nbits) { return uint16_t(0x8000u | (offset << 4) | nbits); }
+MJX_HD constexpr uint16_t lut_link(unsigned offset, unsigned nbits) { return uint16_t(0x8000u | ((offset >> 1) << 4) | nbits); }
+MJX_HD constexpr unsigned lut_link_offset(unsigned e) { return ((e >> 4) & 0x7ffu) << 1; }
 
 // ---- per-subsequence synchronisation state -------------------------------------------------------------------
 // The first 8 bytes (what the next subsequence must start from) are read while other lanes may rewrite them, so they
@@ -102,16 +103,20 @@ constexpr int kNumCp = kSubseqBits / kCpBits - 1;
 constexpr uint32_t kCpValid = 0x80000000u, kCpStateMask = 0x8000ffffu;
 struct NoCheckpoints {
     MJX_HD uint32_t get(uint32_t) const { return 0; }             // word 0 of checkpoint k (may prefetch k+1)
-    MJX_HD uint32_t get_plain(uint32_t) const { return 0; }       // word 0, no prefetch side effects
-    MJX_HD uint32_t get_m(uint32_t) const { return 0; }           // word 1
+    MJX_HD uint32_t get_m(uint32_t) const { return 0; }           // word 1 of checkpoint k (previous decode)
+    MJX_HD uint32_t get_plain(uint32_t) const { return 0; }       // word 0 of a checkpoint recorded by *this* decode
+    MJX_HD uint32_t get_m_plain(uint32_t) const { return 0; }     // word 1 of a checkpoint recorded by *this* decode
     MJX_HD void set(uint32_t, uint32_t, uint32_t) const {}        // both words
 };
 
 // Registers of one lane's decoder: position + a three-dword look-ahead window of the big-endian bitstream.
-// w2 is fetched one refill early so that a global-memory load has a whole dword of symbols to complete.
+// w2 is fetched one refill early and kept *raw* (BitSrc::raw32); it is only converted (BitSrc::fix, the byte swap of
+// a little-endian load) when it moves into w1 at the next refill, so nothing consumes a global-memory load for a
+// whole dword of symbols (~6) and its latency stays off the lane's critical path.
 struct LaneState {
     uint32_t p, z, c, n, m;   // bit position, zig-zag index, block-in-MCU, blocks completed, stream entries produced
-    uint32_t tab;             // img.blktab[c]
+    uint32_t tab, tab_next;   // img.blktab[c] and the entry of the following block (fetched a block early)
+    uint32_t bpm;             // blocks per MCU
     uint32_t wi, o;           // dword index of w0, bit offset inside it
     uint32_t w0, w1, w2;
 };
@@ -120,9 +125,11 @@ template <class BitSrc>
 MJX_HD void lane_begin(LaneState &st, const BitSrc &bits, const HuffImage &img, SubseqState entry)
 {
     st.p = entry.p; st.z = entry.z; st.c = entry.c; st.n = 0; st.m = 0;
+    st.bpm = img.bpm;
     st.tab = img.blktab[st.c];
+    st.tab_next = img.blktab[st.c + 1 == st.bpm ? 0 : st.c + 1];
     st.wi = st.p >> 5; st.o = st.p & 31;
-    st.w0 = bits.be32(st.wi); st.w1 = bits.be32(st.wi + 1); st.w2 = bits.be32(st.wi + 2);
+    st.w0 = bits.be32(st.wi); st.w1 = bits.be32(st.wi + 1); st.w2 = bits.raw32(st.wi + 2);
 }
 
 // One Huffman symbol: table lookup, EXTEND, coefficient placement, state update, window refill.
@@ -134,7 +141,7 @@ MJX_HD void symbol_step(LaneState &st, const BitSrc &bits, const uint16_t *lut, 
     const uint32_t base = st.z ? (st.tab >> 16) : (st.tab & 0xffff);
     uint32_t e = lut[base + (w >> (32 - kLutPrimaryBits))];
     if (e & kLutLinkBit) {
-        const uint32_t nb = e & 15, off = (e >> 4) & 0x7ff;
+        const uint32_t nb = e & 15, off = lut_link_offset(e);
         e = lut[base + off + ((w << kLutPrimaryBits) >> (32 - nb))];
     }
     uint32_t len = e & 31;
@@ -157,8 +164,9 @@ MJX_HD void symbol_step(LaneState &st, const BitSrc &bits, const uint16_t *lut, 
     st.z = pos + 1;
     if (st.z == 64) {
         st.z = 0;
-        st.c = (st.c + 1 == img.bpm) ? 0 : st.c + 1;
-        st.tab = img.blktab[st.c];
+        st.c = (st.c + 1 == st.bpm) ? 0 : st.c + 1;
+        st.tab = st.tab_next;
+        st.tab_next = img.blktab[st.c + 1 == st.bpm ? 0 : st.c + 1];
         st.n++;
         blk++;
         if (WRITE) sink.block_done(blk);
@@ -170,8 +178,8 @@ MJX_HD void symbol_step(LaneState &st, const BitSrc &bits, const uint16_t *lut, 
         st.o -= 32;
         st.wi++;
         st.w0 = st.w1;
-        st.w1 = st.w2;
-        st.w2 = bits.be32(st.wi + 2);
+        st.w1 = BitSrc::fix(st.w2);
+        st.w2 = bits.raw32(st.wi + 2);
     }
 }
 
@@ -203,12 +211,13 @@ MJX_HD void checkpoint_fixup(CpStore &cps, uint32_t k, uint32_t n_total, uint32_
 {
     for (uint32_t j = 0; j < k; j++) {
         const uint32_t wv = cps.get_plain(j);
-        cps.set(j, (wv & kCpStateMask) | ((n_total - ((wv >> 16) & 0x7fffu)) << 16), m_total - cps.get_m(j));
+        cps.set(j, (wv & kCpStateMask) | ((n_total - ((wv >> 16) & 0x7fffu)) << 16), m_total - cps.get_m_plain(j));
     }
 }
 
 // Decode from `entry` until the bit position reaches `end_bit`.
-//   BitSrc::be32(i)  -> big-endian dword i of the image's scan (0xAAAAAAAA past the end, huffman.rs:236-246)
+//   BitSrc::be32(i)  -> big-endian dword i of the image's scan (0xAAAAAAAA past the end, huffman.rs:236-246);
+//                       raw32(i) / fix(raw) = the same in two steps (load, then byte order)
 //   lut              -> the image's decode tables
 //   WRITE            -> emit coefficients for blocks < img.total_blocks through `sink`, starting at block `blk`
 //   CP               -> 0: no checkpoints; 1: record checkpoints in `cps`; 2: record and merge with the previous

@@ -60,11 +60,11 @@ void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, con
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint8_t *scan_pool, const uint16_t *lut_pool, const SubseqState *entry,
                        const uint32_t *blkbase, const uint32_t *ebase, uint32_t *entries, uint32_t *tile_eoff,
-                       int16_t *dcbuf, int *status);
-void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int16_t *dcbuf,
+                       int32_t *dcbuf, int *status);
+void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int32_t *dcbuf,
                     int32_t *segsum);
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
-                       const uint32_t *entries, const uint32_t *tile_eoff, const int16_t *dcbuf, const float *qmult,
+                       const uint32_t *entries, const uint32_t *tile_eoff, const int32_t *dcbuf, const float *qmult,
                        uint8_t *rgb, uint32_t mode_mask);
 #endif
 

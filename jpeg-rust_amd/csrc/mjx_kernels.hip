@@ -28,24 +28,34 @@ namespace mjx {
 struct GlobalBits {
     const uint32_t *words;
     uint32_t nwords;
-    __device__ __forceinline__ uint32_t be32(uint32_t i) const
-    {
-        return i < nwords ? __builtin_bswap32(words[i]) : 0xaaaaaaaau;
-    }
+    // No bounds test: a lane reads at most 3 dwords past the last scan byte, and every image's region in the pool ends
+    // with >= 16 bytes of 0xAA (mjx_api.hip build_batch), so the padding *is* the out-of-range value.
+    __device__ __forceinline__ uint32_t be32(uint32_t i) const { return __builtin_bswap32(words[i]); }
+    __device__ __forceinline__ uint32_t raw32(uint32_t i) const { return words[i]; }
+    static __device__ __forceinline__ uint32_t fix(uint32_t raw) { return __builtin_bswap32(raw); }
 };
 
-// Checkpoint words of one subsequence, row-major by word in HBM (row 2k = state word of checkpoint k, row 2k+1 = its
-// entry count; lanes of a wave cross the same boundary at about the same time, so their stores to one row are adjacent).
+// Checkpoint words live row-major by word in HBM (row 2k = state word of checkpoint k, row 2k+1 = its entry count),
+// so lanes with consecutive subsequences touch adjacent words of a row.  In merge rounds the previous decode's state
+// word is requested one boundary ahead (~45 symbols), so the comparison at the boundary does not expose a round trip.
 struct GlobalCps {
-    uint32_t *w;            // &cps[subsequence]
-    uint32_t stride;        // subsequences in the chunk
-    __device__ __forceinline__ uint32_t get(uint32_t k) const { return w[size_t(2 * k) * stride]; }
-    __device__ __forceinline__ uint32_t get_plain(uint32_t k) const { return w[size_t(2 * k) * stride]; }
-    __device__ __forceinline__ uint32_t get_m(uint32_t k) const { return w[size_t(2 * k + 1) * stride]; }
+    uint32_t *g;            // &g_cps[subsequence] (rows `stride` apart; 2 * kNumCp * stride < 2^31 elements)
+    uint32_t stride;
+    uint32_t next;          // prefetched state word of the previous decode
+    __device__ __forceinline__ void prime() { next = g[0]; }
+    __device__ __forceinline__ uint32_t get(uint32_t k)
+    {
+        const uint32_t v = next;
+        if (k + 1 < uint32_t(kNumCp)) next = g[2 * (k + 1) * stride];
+        return v;
+    }
+    __device__ __forceinline__ uint32_t get_m(uint32_t k) const { return g[(2 * k + 1) * stride]; }
+    __device__ __forceinline__ uint32_t get_plain(uint32_t k) const { return g[2 * k * stride]; }
+    __device__ __forceinline__ uint32_t get_m_plain(uint32_t k) const { return g[(2 * k + 1) * stride]; }
     __device__ __forceinline__ void set(uint32_t k, uint32_t v, uint32_t m) const
     {
-        w[size_t(2 * k) * stride] = v;
-        w[size_t(2 * k + 1) * stride] = m;
+        g[2 * k * stride] = v;
+        g[(2 * k + 1) * stride] = m;
     }
 };
 
@@ -56,16 +66,24 @@ struct __attribute__((packed, aligned(4))) Entry4 { uint32_t a, b, c, d; };
 // coefficients instead of one 2-byte store each; a lane's stream region is contiguous, so its lines fill completely.
 struct StreamSink {
     uint32_t *entries;      // the image's entry region
-    int16_t *dcbuf;         // the image's DC differences
+    int32_t *dcbuf;         // the image's DC differences (one int32 per block)
     uint32_t *tile_eoff;    // the image's tile offsets (+ sentinel)
     int *status;
     uint32_t off;           // entries produced so far (next entry index)
     uint32_t nbuf;          // entries waiting in b0..b3 (oldest first ends in b3 after four pushes)
     uint32_t b0, b1, b2, b3;
+    uint32_t ndc;           // DC differences waiting in d0..d3 (a lane's blocks are consecutive)
+    uint32_t d0, d1, d2, d3;
+    uint32_t last_dc_blk;
     uint32_t next_tile_blk, tile_idx, tile_blocks, total_blocks, ntiles;
     __device__ __forceinline__ void dc(uint32_t b, int v)
     {
-        dcbuf[b] = int16_t(v);
+        d0 = d1; d1 = d2; d2 = d3; d3 = uint32_t(v);
+        last_dc_blk = b;
+        if (++ndc == 4) {
+            *reinterpret_cast<Entry4 *>(dcbuf + (b - 3)) = Entry4{d0, d1, d2, d3};
+            ndc = 0;
+        }
         if (b == next_tile_blk) {           // first block of a stage-B tile: remember where its entries start
             tile_eoff[tile_idx] = off;
             tile_idx++;
@@ -91,6 +109,10 @@ struct StreamSink {
         if (nbuf >= 2) entries[off - 2] = b2;
         if (nbuf >= 1) entries[off - 1] = b3;
         nbuf = 0;
+        if (ndc == 3) dcbuf[last_dc_blk - 2] = int32_t(d1);
+        if (ndc >= 2) dcbuf[last_dc_blk - 1] = int32_t(d2);
+        if (ndc >= 1) dcbuf[last_dc_blk] = int32_t(d3);
+        ndc = 0;
     }
     __device__ __forceinline__ void bad_code(uint32_t) const { atomicOr(status, 1); }
     __device__ __forceinline__ void tick() const {}
@@ -119,6 +141,83 @@ __device__ __forceinline__ uint32_t subseq_end(const HuffImage &h, uint32_t s)
     return e < h.total_bits ? e : h.total_bits;
 }
 
+// Per-lane window of the bitstream in LDS.  A lane that read its bits straight from HBM would issue one L2 request
+// per dword and expose an L2 / MALL round trip at almost every symbol (some lane of the wave always needs a refill),
+// and in the write pass such loads would also queue behind the scattered stores (loads and stores retire in issue
+// order on vmcnt).  Instead every lane owns kWinDwords big-endian dwords in LDS; the wave restages all its windows
+// together (wave-uniform branch, 16-byte loads) whenever one lane is about to run out, about every 120 symbols.
+#ifndef MJX_SPEC_WIN
+#define MJX_SPEC_WIN 0
+#endif
+constexpr bool kSpecWin = MJX_SPEC_WIN != 0;   // spec / merge read bits through LDS windows (1) or straight from HBM (0)
+constexpr int kWinDwords = 24;
+constexpr int kWinStride = kWinDwords + 1;      // odd stride: lane l, dword k -> bank (25 l + k) % 32, conflict-free per k
+struct LdsWindow {
+    const uint32_t *lds;    // lane's window
+    uint32_t wbase;         // stream dword index of lds[0]
+    __device__ __forceinline__ uint32_t be32(uint32_t i) const { return lds[i - wbase]; }
+    __device__ __forceinline__ uint32_t raw32(uint32_t i) const { return lds[i - wbase]; }
+    static __device__ __forceinline__ uint32_t fix(uint32_t raw) { return raw; }
+};
+__device__ __forceinline__ void window_fill(uint32_t *lds, const GlobalBits &g, uint32_t wbase)
+{
+#pragma unroll
+    for (int q = 0; q < kWinDwords / 4; q++) {
+        uint4 v = *reinterpret_cast<const uint4 *>(g.words + wbase + 4 * q);    // 4-byte aligned 16-byte load
+        lds[4 * q] = __builtin_bswap32(v.x);
+        lds[4 * q + 1] = __builtin_bswap32(v.y);
+        lds[4 * q + 2] = __builtin_bswap32(v.z);
+        lds[4 * q + 3] = __builtin_bswap32(v.w);
+    }
+}
+
+// The decode loop shared by the three entropy kernels.  All lanes of the wave step together; a lane that is done
+// (reached its end bit, merged with its previous decode, or ran past the last block in the write pass) idles.
+//   WRITE  emit coefficients through `sink`      CP  0: none, 1: record checkpoints, 2: record + merge (see mjx_huff.h)
+template <bool WRITE, int CP, bool USE_WIN, class Sink, class CpStore>
+__device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry, uint32_t end_bit, uint32_t blk,
+                                                   const GlobalBits &g, uint32_t *my_win, const uint16_t *lut,
+                                                   const HuffImage &h, Sink &sink, CpStore &cps, uint32_t sub_start,
+                                                   SubseqState old_exit)
+{
+    LdsWindow win{my_win, entry.p >> 5};
+    if (USE_WIN) window_fill(my_win, g, win.wbase);
+    LaneState st;
+    if (USE_WIN) lane_begin(st, win, h, entry);
+    else lane_begin(st, g, h, entry);
+    const uint32_t total_blocks = h.total_blocks;
+    uint32_t cp_bit = sub_start + kCpBits, k = 0;
+    bool running = live;
+    for (;;) {
+        bool active = running && st.p < end_bit;
+        if (WRITE) active = active && blk < total_blocks;
+        if (!__any(active)) break;
+        if (USE_WIN && __any(active && st.wi + 3 >= win.wbase + kWinDwords)) {   // wave-uniform: restage every window
+            win.wbase = st.wi;
+            window_fill(my_win, g, win.wbase);
+        }
+        if (active) {
+            bool merged = false;
+            if (CP && st.p >= cp_bit) {
+                uint32_t n_rest, m_rest;
+                if (checkpoint_merge<CP == 2>(st, cps, k, cp_bit, n_rest, m_rest)) {
+                    st.n += n_rest;
+                    st.m += m_rest;
+                    st.p = old_exit.p; st.z = old_exit.z; st.c = old_exit.c;
+                    merged = true;
+                    running = false;
+                }
+            }
+            if (!merged) {
+                if (USE_WIN) symbol_step<WRITE>(st, win, lut, h, blk, sink);
+                else symbol_step<WRITE>(st, g, lut, h, blk, sink);
+            }
+        }
+    }
+    if (CP && live) checkpoint_fixup(cps, k, st.n, st.m);
+    return make_state(st.p, st.z, st.c, st.n, st.m);
+}
+
 // k_huff_spec: every lane decodes its subsequence from the guess "a block starts exactly here", recording its exit
 // state and a checkpoint every 256 bits.  Lanes do the same amount of work (+-3 %), so plain lock-step is efficient.
 extern "C" __global__ __launch_bounds__(256) void k_huff_spec(const DevImage *images, const uint8_t *scan_pool,
@@ -126,43 +225,25 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_spec(const DevImage *im
                                                                SubseqState *g_exit, uint32_t *g_cps, uint32_t cp_stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t s_win[kSpecWin ? kWgLanes * kWinStride : 1];
     const DevImage &im = images[blockIdx.y];
     if (!im.valid || blockIdx.x * kWgLanes >= im.himg.nsub) return;
     const HuffImage *h;
     const uint16_t *lut;
     stage_tables(im, lut_pool, smem, h, lut);
     const uint32_t s = blockIdx.x * kWgLanes + threadIdx.x;
-    if (s >= h->nsub) return;
+    const bool live = s < h->nsub;
     const GlobalBits bits{reinterpret_cast<const uint32_t *>(scan_pool + im.scan_off), im.scan_padded / 4};
-    const SubseqState e = make_state(s * kSubseqBits, 0, 0);
+    const SubseqState e = make_state(live ? s * kSubseqBits : 0u, 0, 0);
     NullSink sink;
-    GlobalCps cps{g_cps + im.sub_off + s, cp_stride};
-    const SubseqState x = decode_subseq<false, 1>(bits, lut, *h, e, subseq_end(*h, s), 0, sink, cps, s * kSubseqBits, e);
-    g_entry[im.sub_off + s] = e;
-    g_exit[im.sub_off + s] = x;
+    GlobalCps cps{g_cps + im.sub_off + s, cp_stride, 0};
+    const SubseqState x = wave_decode<false, 1, kSpecWin>(live, e, live ? subseq_end(*h, s) : 0u, 0, bits, s_win + (kSpecWin ? threadIdx.x * kWinStride : 0),
+                                                lut, *h, sink, cps, s * kSubseqBits, e);
+    if (live) {
+        g_entry[im.sub_off + s] = e;
+        g_exit[im.sub_off + s] = x;
+    }
 }
-
-// Checkpoint words with a one-ahead prefetch: the word for boundary k+1 is requested while the lane decodes towards
-// it (~45 symbols), so the comparison at the boundary does not expose an HBM/L2 round trip.
-struct GlobalCpsPrefetch {
-    uint32_t *w;
-    uint32_t stride;
-    uint32_t next;          // state word of the next checkpoint
-    __device__ __forceinline__ void prime() { next = w[0]; }
-    __device__ __forceinline__ uint32_t get(uint32_t k)
-    {
-        const uint32_t v = next;
-        if (k + 1 < uint32_t(kNumCp)) next = w[size_t(2 * (k + 1)) * stride];
-        return v;
-    }
-    __device__ __forceinline__ uint32_t get_plain(uint32_t k) const { return w[size_t(2 * k) * stride]; }
-    __device__ __forceinline__ uint32_t get_m(uint32_t k) const { return w[size_t(2 * k + 1) * stride]; }
-    __device__ __forceinline__ void set(uint32_t k, uint32_t v, uint32_t m) const
-    {
-        w[size_t(2 * k) * stride] = v;
-        w[size_t(2 * k + 1) * stride] = m;
-    }
-};
 
 // k_huff_merge: one synchronisation round.  Subsequence s must start where s-1 ended: if entry[s] differs from
 // exit[s-1] the lane re-decodes s from the corrected entry until it meets the path recorded by the previous decode of
@@ -176,6 +257,7 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_merge(const DevImage *i
                                                                 uint32_t *mismatches)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t s_win[kSpecWin ? kWgLanes * kWinStride : 1];
     const DevImage &im = images[blockIdx.y];
     if (!im.valid || blockIdx.x * kWgLanes + 1 >= im.himg.nsub) return;
     const uint32_t s = blockIdx.x * kWgLanes + threadIdx.x + 1;
@@ -189,17 +271,22 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_merge(const DevImage *i
     const HuffImage *h;
     const uint16_t *lut;
     stage_tables(im, lut_pool, smem, h, lut);
-    unsigned long long m = __ballot(need);
+    const unsigned long long m = __ballot(need);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(mismatches, uint32_t(__popcll(m)));
-    if (!need) return;
+    if (!m) return;                                                        // wave-uniform
     const GlobalBits bits{reinterpret_cast<const uint32_t *>(scan_pool + im.scan_off), im.scan_padded / 4};
     const SubseqState e = make_state(prev.p, prev.z, prev.c);
-    const SubseqState old_exit = g_exit[im.sub_off + s];
-    g_entry[im.sub_off + s] = e;
+    SubseqState old_exit = make_state(0, 0, 0);
+    GlobalCps cps{g_cps + im.sub_off + (need ? s : 0u), cp_stride, 0};
+    if (need) {
+        old_exit = g_exit[im.sub_off + s];
+        g_entry[im.sub_off + s] = e;
+        cps.prime();
+    }
     NullSink sink;
-    GlobalCpsPrefetch cps{g_cps + im.sub_off + s, cp_stride, 0};
-    cps.prime();
-    g_exit[im.sub_off + s] = decode_subseq<false, 2>(bits, lut, *h, e, subseq_end(*h, s), 0, sink, cps, s * kSubseqBits, old_exit);
+    const SubseqState x = wave_decode<false, 2, kSpecWin>(need, e, need ? subseq_end(*h, s) : 0u, 0, bits, s_win + (kSpecWin ? threadIdx.x * kWinStride : 0),
+                                                lut, *h, sink, cps, s * kSubseqBits, old_exit);
+    if (need) g_exit[im.sub_off + s] = x;
 }
 
 // Workgroup-wide exclusive scan helper (256 lanes): returns the exclusive prefix of v, total in *total.
@@ -251,37 +338,10 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *im
     if (tid == 0) img_entries[im.status_idx] = total_m;      // upper bound of the entries the write pass produces
 }
 
-// Per-lane window of the bitstream in LDS for the write pass.  The write pass scatters stores to HBM; a bitstream
-// load from HBM would queue behind them (loads and stores retire in issue order on vmcnt), so the lane reads its bits
-// from a private LDS window of kWinDwords big-endian dwords instead.  The wave restages all its windows together
-// (wave-uniform branch) whenever one lane is about to run out, about every 120 symbols.
-constexpr int kWinDwords = 24;
-constexpr int kWinStride = kWinDwords + 1;      // odd stride: lane l, dword k -> bank (25 l + k) % 32, conflict-free per k
-struct LdsWindow {
-    const uint32_t *lds;    // lane's window
-    uint32_t wbase;         // stream dword index of lds[0]
-    __device__ __forceinline__ uint32_t be32(uint32_t i) const { return lds[i - wbase]; }
-};
-__device__ __forceinline__ void window_fill(uint32_t *lds, const GlobalBits &g, uint32_t wbase)
-{
-#pragma unroll
-    for (int q = 0; q < kWinDwords / 4; q++) {
-        const uint32_t i = wbase + 4 * q;
-        uint4 v = make_uint4(0xaaaaaaaau, 0xaaaaaaaau, 0xaaaaaaaau, 0xaaaaaaaau);
-        if (i + 4 <= g.nwords) {
-            v = *reinterpret_cast<const uint4 *>(g.words + i);             // 4-byte aligned 16-byte load
-            v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y); v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w);
-        } else {
-            v.x = g.be32(i); v.y = g.be32(i + 1); v.z = g.be32(i + 2); v.w = g.be32(i + 3);
-        }
-        lds[4 * q] = v.x; lds[4 * q + 1] = v.y; lds[4 * q + 2] = v.z; lds[4 * q + 3] = v.w;
-    }
-}
-
 extern "C" __global__ __launch_bounds__(256) void k_huff_write(const DevImage *images, const uint8_t *scan_pool,
                                                                 const uint16_t *lut_pool, const SubseqState *g_entry,
                                                                 const uint32_t *g_blkbase, const uint32_t *g_ebase,
-                                                                uint32_t *entries, uint32_t *tile_eoff, int16_t *dcbuf,
+                                                                uint32_t *entries, uint32_t *tile_eoff, int32_t *dcbuf,
                                                                 int *status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -293,7 +353,6 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_write(const DevImage *i
     stage_tables(im, lut_pool, smem, h, lut);
     const uint32_t s = blockIdx.x * kWgLanes + threadIdx.x;
     const GlobalBits gbits{reinterpret_cast<const uint32_t *>(scan_pool + im.scan_off), im.scan_padded / 4};
-    uint32_t *my = s_win + threadIdx.x * kWinStride;
     const bool live = s < h->nsub;
     SubseqState e = make_state(0, 0, 0);
     uint32_t blk = 0, end_bit = 0, ebase = 0;
@@ -311,6 +370,9 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_write(const DevImage *i
     sink.off = ebase;
     sink.nbuf = 0;
     sink.b0 = sink.b1 = sink.b2 = sink.b3 = 0;
+    sink.ndc = 0;
+    sink.d0 = sink.d1 = sink.d2 = sink.d3 = 0;
+    sink.last_dc_blk = 0;
     sink.tile_blocks = im.tile_blocks;
     sink.total_blocks = h->total_blocks;
     sink.ntiles = (h->total_blocks + im.tile_blocks - 1) / im.tile_blocks;
@@ -319,19 +381,8 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_write(const DevImage *i
         sink.tile_idx = (first_start + im.tile_blocks - 1) / im.tile_blocks;
         sink.next_tile_blk = sink.tile_idx * im.tile_blocks;
     }
-    LdsWindow win{my, e.p >> 5};
-    window_fill(my, gbits, win.wbase);
-    LaneState st;
-    lane_begin(st, win, *h, e);
-    for (;;) {
-        const bool active = live && st.p < end_bit && blk < h->total_blocks;
-        if (!__any(active)) break;
-        if (__any(active && st.wi + 3 >= win.wbase + kWinDwords)) {        // wave-uniform: restage every window
-            win.wbase = st.wi;
-            window_fill(my, gbits, win.wbase);
-        }
-        if (active) symbol_step<true>(st, win, lut, *h, blk, sink);
-    }
+    NoCheckpoints nocp;
+    wave_decode<true, 0, true>(live, e, end_bit, blk, gbits, s_win + threadIdx.x * kWinStride, lut, *h, sink, nocp, 0, e);
     sink.flush();
 }
 
@@ -354,7 +405,7 @@ __device__ __forceinline__ void wg_reduce3(int32_t v[3], int32_t (*s_w)[3], int3
     __syncthreads();
 }
 
-extern "C" __global__ __launch_bounds__(256) void k_dc_sums(const DevImage *images, const int16_t *dcbuf,
+extern "C" __global__ __launch_bounds__(256) void k_dc_sums(const DevImage *images, const int32_t *dcbuf,
                                                              int32_t *segsum, uint32_t max_segs)
 {
     __shared__ int32_t s_w[4][3];
@@ -363,7 +414,7 @@ extern "C" __global__ __launch_bounds__(256) void k_dc_sums(const DevImage *imag
     if (!im.valid || m0 >= im.nmcu) return;
     const uint32_t bpm = im.bpm, tid = threadIdx.x;
     const uint32_t nv = (min(uint32_t(kDcSegMcus), im.nmcu - m0)) * bpm;
-    const int16_t *dc = dcbuf + im.coef_off + size_t(m0) * bpm;
+    const int32_t *dc = dcbuf + im.coef_off + size_t(m0) * bpm;
     int32_t sum[3] = {0, 0, 0};
     for (uint32_t i = tid; i < nv; i += 256) {
         const int32_t v = dc[i];
@@ -377,7 +428,7 @@ extern "C" __global__ __launch_bounds__(256) void k_dc_sums(const DevImage *imag
     if (tid < 3) segsum[(size_t(blockIdx.y) * max_segs + blockIdx.x) * 3 + tid] = tot[tid];
 }
 
-extern "C" __global__ __launch_bounds__(256) void k_dc_apply(const DevImage *images, int16_t *dcbuf,
+extern "C" __global__ __launch_bounds__(256) void k_dc_apply(const DevImage *images, int32_t *dcbuf,
                                                               const int32_t *segsum, uint32_t max_segs)
 {
     __shared__ int32_t s_dc[256 * kMaxBlocksPerMcu];
@@ -387,7 +438,7 @@ extern "C" __global__ __launch_bounds__(256) void k_dc_apply(const DevImage *ima
     if (!im.valid || seg0 >= im.nmcu) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, bpm = im.bpm;
     const uint32_t seg1 = min(im.nmcu, seg0 + kDcSegMcus);
-    int16_t *dc = dcbuf + im.coef_off;
+    int32_t *dc = dcbuf + im.coef_off;
     int32_t carry[3] = {0, 0, 0};
     for (uint32_t sgi = 0; sgi < blockIdx.x; sgi++) {
         const int32_t *p = segsum + (size_t(blockIdx.y) * max_segs + sgi) * 3;
@@ -451,7 +502,7 @@ extern "C" __global__ __launch_bounds__(256) void k_dc_apply(const DevImage *ima
             }
         }
         __syncthreads();
-        for (uint32_t i = tid; i < nv; i += 256) dc[size_t(m0) * bpm + i] = int16_t(s_dc[i]);
+        for (uint32_t i = tid; i < nv; i += 256) dc[size_t(m0) * bpm + i] = s_dc[i];
         __syncthreads();
     }
 }
@@ -568,7 +619,7 @@ struct TileFetch {
 };
 
 __device__ __forceinline__ void tile_fetch(const uint32_t *__restrict__ src, const uint32_t *__restrict__ eoff,
-                                           const int16_t *__restrict__ dc, uint32_t tile, uint32_t tile_blocks,
+                                           const int32_t *__restrict__ dc, uint32_t tile, uint32_t tile_blocks,
                                            uint32_t total_blocks, TileFetch &f)
 {
     const uint32_t tid = threadIdx.x;
@@ -580,7 +631,7 @@ __device__ __forceinline__ void tile_fetch(const uint32_t *__restrict__ src, con
         f.ent[k] = i < f.e1 ? src[i] : 0u;
     }
     const uint32_t blk = tile * tile_blocks + tid;
-    f.dc = (tid < tile_blocks && blk < total_blocks) ? int32_t(dc[blk]) : 0;
+    f.dc = (tid < tile_blocks && blk < total_blocks) ? dc[blk] : 0;
 }
 
 // One stream entry -> one float in the tile: find the block from the entry's block byte, multiply by the
@@ -729,7 +780,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__ images,
                                                      const uint32_t *__restrict__ entries,
                                                      const uint32_t *__restrict__ tile_eoff,
-                                                     const int16_t *__restrict__ dcbuf, const float *__restrict__ qmult,
+                                                     const int32_t *__restrict__ dcbuf, const float *__restrict__ qmult,
                                                      uint8_t *__restrict__ rgb)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -751,7 +802,7 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
     const uint32_t tid = threadIdx.x;
     const uint32_t *__restrict__ src = entries + im.ent_off;
     const uint32_t *__restrict__ eoff = tile_eoff + im.tile_off;
-    const int16_t *__restrict__ dcs = dcbuf + im.coef_off;
+    const int32_t *__restrict__ dcs = dcbuf + im.coef_off;
     uint8_t *__restrict__ out_img = rgb + im.rgb_off;
     const bool aligned = ((width * 3u) & 3u) == 0 && (im.rgb_off & 3u) == 0;
     TileFetch cur;
@@ -848,12 +899,12 @@ void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, con
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint8_t *scan_pool, const uint16_t *lut_pool, const SubseqState *entry,
                        const uint32_t *blkbase, const uint32_t *ebase, uint32_t *entries, uint32_t *tile_eoff,
-                       int16_t *dcbuf, int *status)
+                       int32_t *dcbuf, int *status)
 {
     hipLaunchKernelGGL(k_huff_write, dim3(max_wg, nimg), dim3(kWgLanes), lds, st, images, scan_pool, lut_pool, entry, blkbase, ebase, entries, tile_eoff, dcbuf, status);
 }
 
-void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int16_t *dcbuf,
+void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int32_t *dcbuf,
                     int32_t *segsum)
 {
     hipLaunchKernelGGL(k_dc_sums, dim3(max_segs, nimg), dim3(256), 0, st, images, dcbuf, segsum, max_segs);
@@ -861,7 +912,7 @@ void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevI
 }
 
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
-                       const uint32_t *entries, const uint32_t *tile_eoff, const int16_t *dcbuf, const float *qmult,
+                       const uint32_t *entries, const uint32_t *tile_eoff, const int32_t *dcbuf, const float *qmult,
                        uint8_t *rgb, uint32_t mode_mask)
 {
     if (mode_mask & 1u)

@@ -67,7 +67,7 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p)
     // decode tables: each distinct (class, slot) used by the scan is built once
     int dc_base[4] = {-1, -1, -1, -1}, ac_base[4] = {-1, -1, -1, -1};
     p.lut.clear();
-    uint16_t tmp[kLutPrimarySize + 2048];
+    uint16_t tmp[kLutPrimarySize + 4096];
     auto add_table = [&](const mjx_hufftab &t, bool is_dc) -> int {
         const int n = build_decode_table(t.bits, t.vals, is_dc, tmp, int(sizeof tmp / sizeof tmp[0]));
         if (n < 0) return n;

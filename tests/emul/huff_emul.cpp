@@ -31,6 +31,8 @@ struct HostBits {
         }
         return w;
     }
+    uint32_t raw32(uint32_t i) const { return be32(i); }
+    static uint32_t fix(uint32_t raw) { return raw; }
 };
 // Mirrors the device sink of k_huff_write: AC entries appended to the compact stream, DC differences per block,
 // the stream offset of every tile's first block.
@@ -67,6 +69,7 @@ struct HostCps {
     uint32_t get(uint32_t k) const { return w[2 * k]; }
     uint32_t get_plain(uint32_t k) const { return w[2 * k]; }
     uint32_t get_m(uint32_t k) const { return w[2 * k + 1]; }
+    uint32_t get_m_plain(uint32_t k) const { return w[2 * k + 1]; }
     void set(uint32_t k, uint32_t v, uint32_t m) const { w[2 * k] = v; w[2 * k + 1] = m; }
 };
 }   // namespace
