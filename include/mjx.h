@@ -83,6 +83,11 @@ typedef struct mjx_image {         /* JPEGImage: width() mod.rs:467, height() :4
 int mjx_parse(const uint8_t *jpeg, size_t len, const mjx_opts *opts, mjx_scan_desc *out);
 void mjx_free_scan(mjx_scan_desc *desc);
 
+/* Host-only check of a parsed scan: tables present and valid, geometry supported and, for MJX_LAYOUT_REF_COMPAT, not
+ * one of the inputs on which the reference's placement code panics (decoder.rs:300-303, 370-371; SURVEY Q5 ->
+ * MJX_ERR_REF_PANIC).  The same check mjx_batch_create applies per image. */
+int mjx_validate(const mjx_scan_desc *desc, const mjx_opts *opts);
+
 /* JPEGImage::parse + image_data() in one call on device `0` (main.rs:31-36 usage): parse, upload, decode on the
  * GPU, copy the RGB back.  Release with mjx_free_image. */
 int mjx_decode(const uint8_t *jpeg, size_t len, const mjx_opts *opts, mjx_image *out);

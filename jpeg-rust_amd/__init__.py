@@ -71,6 +71,7 @@ _vp, _sz, _int = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
 SYMBOLS = {
     "mjx_parse": (_int, [ctypes.c_char_p, _sz, _P(Opts), _P(ScanDesc)]),
     "mjx_free_scan": (None, [_P(ScanDesc)]),
+    "mjx_validate": (_int, [_P(ScanDesc), _P(Opts)]),
     "mjx_decode": (_int, [ctypes.c_char_p, _sz, _P(Opts), _P(Image)]),
     "mjx_free_image": (None, [_P(Image)]),
     "mjx_ctx_create": (_int, [_int, _P(_vp)]),
@@ -139,6 +140,11 @@ class ParsedScan:
 
     def scan_bytes(self):
         return ctypes.string_at(self.desc.scan, self.desc.scan_len)
+
+    def validate(self, layout=LAYOUT_STANDARD):
+        """Status mjx_batch_create would give this image (host only)."""
+        o = _opts(layout=layout)
+        return int(lib().mjx_validate(ctypes.byref(self.desc), ctypes.byref(o)))
 
     def close(self):
         if self._owned:

@@ -55,6 +55,8 @@ struct Chunk {
     uint64_t entries = 0, ent_base = 0;   // capacity of the chunk's stream regions; first entry (keep_coefs) or 0
     uint32_t tiles = 0, tile_base = 0;    // tile offsets (+1 sentinel per image)
     uint32_t max_wg = 0, merge_wgs = 0, max_tiles = 0, lut_cap = 0, max_tile_blocks = 0, mode_mask = 0, max_segs = 0;
+    uint64_t plane_words = 0;      // REF_COMPAT scratch of the chunk
+    uint32_t max_pixel_wgs = 0;
 };
 
 struct EventPair {
@@ -89,6 +91,7 @@ struct mjx_batch {
     uint8_t *d_rgb = nullptr;
     size_t rgb_pool_bytes = 0;
     int *d_status = nullptr;
+    unsigned long long *d_planes = nullptr;   // REF_COMPAT: f32 planes with write-order keys (chunk scratch)
     uint32_t *d_mismatch = nullptr;     // [chunks][kMaxFix]
     uint32_t *h_mismatch = nullptr;     // pinned mirror
     size_t huff_lds = 0, idct_lds = 0;
@@ -119,6 +122,7 @@ void release(mjx_batch *b)
     (void)hipFree(b->d_entry); (void)hipFree(b->d_exit); (void)hipFree(b->d_blkbase);
     (void)hipFree(b->d_entries); (void)hipFree(b->d_tile_eoff); (void)hipFree(b->d_ebase); (void)hipFree(b->d_img_entries);
     (void)hipFree(b->d_dc); (void)hipFree(b->d_rgb); (void)hipFree(b->d_status);
+    (void)hipFree(b->d_planes);
     (void)hipFree(b->d_mismatch); (void)hipFree(b->d_segsum); (void)hipFree(b->d_cps); (void)hipFree(b->d_pull);
     if (b->h_mismatch) (void)hipHostFree(b->h_mismatch);
     delete b;
@@ -137,6 +141,12 @@ void fill_dev_image(const ImagePlan &p, DevImage &d)
     d.log2_tile = l2;
     d.tile_blocks = (1u << l2) * p.bpm;
     d.mode = (p.ncomp == 3 && p.h[0] == 2 && p.v[0] == 2 && p.h[1] == 1 && p.v[1] == 1 && p.h[2] == 1 && p.v[2] == 1) ? 1 : 0;
+    if (p.layout == MJX_LAYOUT_REF_COMPAT) {
+        d.mode = 2;
+        for (uint32_t c = 0; c < 3; c++) { d.ref_xf[c] = uint8_t(p.ref_xf[c]); d.ref_yf[c] = uint8_t(p.ref_yf[c]); }
+        d.nbx = p.nbx;
+        d.nby = p.nby;
+    }
     std::memcpy(d.blk_comp, p.blk_comp, sizeof d.blk_comp);
     std::memcpy(d.blk_bx, p.blk_bx, sizeof d.blk_bx);
     std::memcpy(d.blk_by, p.blk_by, sizeof d.blk_by);
@@ -190,6 +200,11 @@ void plan_chunks(mjx_batch *b)
                 c.max_tile_blocks = std::max<uint32_t>(c.max_tile_blocks, T * d.bpm);
                 c.lut_cap = std::max<uint32_t>(c.lut_cap, d.lut_n);
                 c.mode_mask |= 1u << d.mode;
+                if (d.mode == 2) {
+                    d.plane_off = c.plane_words;
+                    c.plane_words += uint64_t(d.width) * d.height * d.ncomp;
+                    c.max_pixel_wgs = std::max<uint32_t>(c.max_pixel_wgs, uint32_t((uint64_t(d.width) * d.height + 255) / 256));
+                }
                 c.max_segs = std::max<uint32_t>(c.max_segs, (d.nmcu + kDcSegMcus - 1) / kDcSegMcus);
             }
             b->info[i].chunk = uint32_t(b->chunks.size());
@@ -233,6 +248,11 @@ int allocate_work_buffers(mjx_batch *b)
     b->max_chunk_images = uint32_t(max_imgs);
     HIPOK(hipMalloc(&b->d_pull, max_imgs * kMaxFix * sizeof(uint32_t)));
     HIPOK(hipMalloc(&b->d_segsum, max_segsum * 3 * sizeof(int32_t)));
+    {
+        uint64_t max_planes = 0;
+        for (const Chunk &c : b->chunks) max_planes = std::max(max_planes, c.plane_words);
+        if (max_planes) HIPOK(hipMalloc(&b->d_planes, size_t(max_planes) * 8));
+    }
     HIPOK(hipMalloc(&b->d_entries, size_t(b->opts.keep_coefs ? std::max<uint64_t>(total_entries, 4) : max_entries) * 4 + 64));
     HIPOK(hipMalloc(&b->d_tile_eoff, size_t(b->opts.keep_coefs ? std::max<uint32_t>(total_tiles_arr, 1) : max_tiles_arr) * 4 + 16));
     HIPOK(hipMalloc(&b->d_ebase, size_t(max_nsub) * sizeof(uint32_t)));
@@ -314,7 +334,9 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     }
     if (stages & MJX_STAGE_PIXELS) {
         prof_begin(b, MJX_K_IDCT_COLOR);
-        launch_idct_color(st, (c.max_tiles + kTilesPerWgHost - 1) / kTilesPerWgHost, nimg, b->idct_lds, imgs, b->d_entries, b->d_tile_eoff, dcb, b->d_qm, b->d_rgb, c.mode_mask);
+        if (c.plane_words) HIPOK(hipMemsetAsync(b->d_planes, 0, size_t(c.plane_words) * 8, st));
+        launch_idct_color(st, (c.max_tiles + kTilesPerWgHost - 1) / kTilesPerWgHost, nimg, b->idct_lds, imgs, b->d_entries, b->d_tile_eoff, dcb, b->d_qm, b->d_rgb, c.mode_mask, b->d_planes);
+        if (c.plane_words) launch_ref_color(st, c.max_pixel_wgs, nimg, imgs, b->d_planes, b->d_rgb);
         prof_end(b);
     }
     HIPOK(hipGetLastError());
@@ -490,6 +512,17 @@ extern "C" int mjx_batch_create(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t
     return build_batch(ctx, plans, o, nullptr, 1, out, status);
 }
 
+// Host-only: would this scan decode?  Runs the same planning step as mjx_batch_create (tables, geometry, and for
+// MJX_LAYOUT_REF_COMPAT the inputs on which the reference panics) without touching the GPU.
+extern "C" int mjx_validate(const mjx_scan_desc *desc, const mjx_opts *opts)
+{
+    if (!desc) return MJX_ERR_INVALID_ARG;
+    mjx_opts o{};
+    if (opts) o = *opts;
+    ImagePlan p;
+    return plan_image(*desc, o, p);
+}
+
 extern "C" int mjx_batch_tile(mjx_ctx *ctx, const mjx_batch *src, size_t times, mjx_batch **out)
 {
     if (!ctx || !src || !out || times == 0) return MJX_ERR_INVALID_ARG;
@@ -509,6 +542,10 @@ extern "C" int mjx_batch_tile(mjx_ctx *ctx, const mjx_batch *src, size_t times, 
         std::memcpy(p.blk_bx, d.blk_bx, sizeof p.blk_bx);
         std::memcpy(p.blk_by, d.blk_by, sizeof p.blk_by);
         p.himg = d.himg;
+        p.layout = src->opts.layout;
+        for (uint32_t c = 0; c < 3; c++) { p.ref_xf[c] = d.ref_xf[c]; p.ref_yf[c] = d.ref_yf[c]; }
+        p.nbx = d.nbx;
+        p.nby = d.nby;
         p.lut.assign(d.lut_n, 0);                         // sizes only: the pool is copied device-to-device
         p.scan = nullptr;
         p.scan_len = src->info[k].scan_len;

@@ -26,12 +26,16 @@ struct DevImage {
     uint32_t valid;         // 0: skip (error at plan time)
     uint32_t status_idx;    // index into the batch-wide device status array
     uint32_t log2_tile;     // stage-B tile = 1 << log2_tile MCUs
-    uint32_t mode;          // stage-B specialisation: 0 generic, 1 = 4:2:0 (Y 2x2, Cb 1x1, Cr 1x1)
+    uint32_t mode;          // stage-B specialisation: 0 generic, 1 = 4:2:0 (Y 2x2, Cb 1x1, Cr 1x1), 2 = REF_COMPAT placement
     uint32_t tile_off;      // index of the image's first tile offset in the tile_eoff array
     uint32_t tile_blocks;   // blocks per stage-B tile = (1 << log2_tile) * bpm  (<= 256)
     uint8_t blk_comp[kMaxBlocksPerMcu], blk_bx[kMaxBlocksPerMcu], blk_by[kMaxBlocksPerMcu];
     uint8_t ch[4], cv[4];   // sampling factors per component
     uint8_t cfirst[4];      // first block position of each component inside the MCU
+    // REF_COMPAT layout only (mode 2): decoder.rs:239-250 replication factors, block grid, f32 plane scratch
+    uint8_t ref_xf[4], ref_yf[4];
+    uint32_t nbx, nby;
+    uint64_t plane_off;     // 64-bit words into the plane scratch (ncomp planes of width*height words)
 };
 
 // MCUs per stage-B tile: a power of two so that lane -> (MCU, strip) is a shift, and at most 256 strips per row.
@@ -65,7 +69,9 @@ void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevI
                     int32_t *segsum);
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint32_t *entries, const uint32_t *tile_eoff, const int32_t *dcbuf, const float *qmult,
-                       uint8_t *rgb, uint32_t mode_mask);
+                       uint8_t *rgb, uint32_t mode_mask, unsigned long long *planes);
+void launch_ref_color(hipStream_t st, uint32_t max_pixel_wgs, uint32_t nimg, const DevImage *images,
+                      const unsigned long long *planes, uint8_t *rgb);
 #endif
 
 }   // namespace mjx

@@ -146,6 +146,9 @@ __device__ __forceinline__ uint32_t subseq_end(const HuffImage &h, uint32_t s)
 // and in the write pass such loads would also queue behind the scattered stores (loads and stores retire in issue
 // order on vmcnt).  Instead every lane owns kWinDwords big-endian dwords in LDS; the wave restages all its windows
 // together (wave-uniform branch, 16-byte loads) whenever one lane is about to run out, about every 120 symbols.
+#ifndef MJX_WRITE_WIN
+#define MJX_WRITE_WIN true
+#endif
 #ifndef MJX_SPEC_WIN
 #define MJX_SPEC_WIN 0
 #endif
@@ -382,7 +385,7 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_write(const DevImage *i
         sink.next_tile_blk = sink.tile_idx * im.tile_blocks;
     }
     NoCheckpoints nocp;
-    wave_decode<true, 0, true>(live, e, end_bit, blk, gbits, s_win + threadIdx.x * kWinStride, lut, *h, sink, nocp, 0, e);
+    wave_decode<true, 0, MJX_WRITE_WIN>(live, e, end_bit, blk, gbits, s_win + threadIdx.x * kWinStride, lut, *h, sink, nocp, 0, e);
     sink.flush();
 }
 
@@ -769,7 +772,99 @@ __device__ __forceinline__ void pixels_generic(const DevImage &im, const float *
     }
 }
 
+// ---- REF_COMPAT placement (MODE 2) ---------------------------------------------------------------------------
+// Reproduces decoder.rs:259-312 + fill_block_in_array (:347-379) bug for bug: the component's blocks
+// are taken in decode order as a raster counter, get_indices maps the counter to a block position with formulas
+// fitted to one image, lines are replicated horizontally but *tiled* vertically, nothing is clipped at the right
+// edge, and later writes overwrite earlier ones.  The overwrite order is what makes this hard to parallelise; here
+// every store carries its position in the reference's loop order as the high half of a 64-bit word and lands with
+// atomicMax, so the surviving value is exactly the reference's last write.  Inputs on which the reference would
+// index out of bounds are rejected on the host (mjx_plan.cpp), so every index below is in range.
+__device__ __forceinline__ bool dev_get_indices(uint32_t x, uint32_t y, uint32_t max_x, uint32_t xf, uint32_t yf,
+                                                uint32_t hmax, uint32_t vmax, uint32_t &ox, uint32_t &oy)
+{
+    if (vmax > 1 && yf == 1) {
+        if (hmax > 1 && xf == 1) {
+            if ((y & 1) == 0) {
+                if (((x / 2) & 1) == 1) { ox = x / 2 - 1 + (x & 1); oy = y + 1; }
+                else { ox = x / 2 + (x & 1); oy = y; }
+                return true;
+            }
+            if (((x / 2) & 1) == 0) { ox = max_x / 2 + x / 2 - 1 + (x & 1); oy = y; return true; }
+            ox = max_x / 2 + x / 2 + (x & 1); oy = y - 1;
+            return true;
+        }
+        if ((y & 1) == 0) { ox = x / 2; oy = y + (x & 1); return true; }
+        ox = x / 2 + max_x / 2; oy = y - (x & 1);
+        return true;
+    }
+    ox = x; oy = y;
+    return true;
+}
+
+__device__ __forceinline__ void place_ref(const DevImage &im, const float *tile, uint32_t tile_first_blk, uint32_t nblk,
+                                          unsigned long long *planes)
+{
+    const uint32_t tid = threadIdx.x;
+    if (tid >= nblk) return;
+    const uint32_t b = tile_first_blk + tid, bpm = im.bpm;
+    const uint32_t m = b / bpm, j = b % bpm, c = im.blk_comp[j];
+    const uint32_t hv = uint32_t(im.ch[c]) * im.cv[c];
+    const uint32_t block_i = m * hv + (j - im.cfirst[c]);
+    const uint32_t xs = im.ref_xf[c], ys = im.ref_yf[c];
+    const uint32_t cols = im.nbx / xs, rows = im.nby / ys;
+    if (block_i >= cols * rows) return;                                    // decoder.rs:290-291 never reaches it
+    const uint32_t x = block_i % cols, y = block_i / cols;
+    uint32_t bx, by;
+    dev_get_indices(x, y, im.nbx, xs, ys, im.hmax, im.vmax, bx, by);
+    const size_t W = im.width, len = W * im.height;
+    const size_t start_x = size_t(bx) * 8 * xs;
+    if (W < start_x) return;                                               // :360
+    unsigned long long *plane = planes + im.plane_off + size_t(c) * len;
+    const float *blk = tile + tid * kPixStride;
+    for (uint32_t line = 0; line < 8; line++) {
+        const size_t start_i = size_t(by) * 8 * ys * W + size_t(line) * W + start_x;
+        for (uint32_t ind = 0; ind < 8 * xs; ind++) {
+            const float n = blk[line * 8 + ind / xs];                      // repeat(n).take(x_scale) :356
+            const size_t i = start_i + ind;
+            for (uint32_t jj = 0; jj < ys; jj++) {
+                if (i + size_t(jj) * W < len) {                            // :370 guard; :371 index
+                    const unsigned long long order = ((size_t(block_i) * 8 + line) * (8 * xs) + ind) * ys + jj + 1;
+                    atomicMax(plane + i + size_t(jj) * W * 8, (order << 32) | __float_as_uint(n));
+                }
+            }
+        }
+    }
+}
+
+// decoder.rs:317-331 on the placed planes: one lane per pixel.
+extern "C" __global__ __launch_bounds__(256) void k_ref_color(const DevImage *images, const unsigned long long *planes,
+                                                               uint8_t *rgb)
+{
+    const DevImage &im = images[blockIdx.y];
+    if (!im.valid || im.mode != 2) return;
+    const size_t len = size_t(im.width) * im.height;
+    const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= len) return;
+    const unsigned long long *pl = planes + im.plane_off;
+    const float y = __uint_as_float(uint32_t(pl[i]));
+    uint32_t word = 0;
+    if (im.ncomp == 3) {
+        const float cb = __uint_as_float(uint32_t(pl[len + i])), cr = __uint_as_float(uint32_t(pl[2 * len + i]));
+        float cbk, crk;
+        chroma_products(cb, cr, cbk, crk);
+        const Rgb p = ycc_to_rgb(y, cbk, crk);
+        word = pack_u8(p.b, 2, pack_u8(p.g, 1, pack_u8(p.r, 0, 0)));
+    } else {
+        const float v = y + 128.0f;
+        word = pack_u8(v, 2, pack_u8(v, 1, pack_u8(v, 0, 0)));
+    }
+    uint8_t *dst = rgb + im.rgb_off + i * 3;
+    dst[0] = uint8_t(word); dst[1] = uint8_t(word >> 8); dst[2] = uint8_t(word >> 16);
+}
+
 // MODE 0: any sampling layout.  MODE 1: Y 2x2 + Cb 1x1 + Cr 1x1 (4:2:0, 6 blocks per MCU, tile = 32 MCUs).
+// MODE 2: any sampling layout, REF_COMPAT placement into the f32 plane scratch (k_ref_color finishes the image).
 //   phase 0  zero the tile's sample rows in LDS
 //   phase 1  scatter the tile's slice of the compact coefficient stream into them, entry-parallel (lane i holds
 //            entries i, i+256, ... prefetched during the previous tile), DC values from dcbuf (prediction-summed);
@@ -781,7 +876,7 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
                                                      const uint32_t *__restrict__ entries,
                                                      const uint32_t *__restrict__ tile_eoff,
                                                      const int32_t *__restrict__ dcbuf, const float *__restrict__ qmult,
-                                                     uint8_t *__restrict__ rgb)
+                                                     uint8_t *__restrict__ rgb, unsigned long long *__restrict__ planes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float s_qm[3 * 64];
@@ -846,6 +941,8 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
             const bool interior = aligned && nm == T && mx0 + T <= mcux && (mx0 + T) * 16 <= width && (my0 + 1) * 16 <= height;
             if (interior) pixels_420<true>(width, height, mcux, tile_f, m0, nm, out_img, aligned);
             else pixels_420<false>(width, height, mcux, tile_f, m0, nm, out_img, aligned);
+        } else if (MODE == 2) {
+            place_ref(im, tile_f, tile * tile_blocks, nblk, planes);
         } else {
             pixels_generic(im, tile_f, m0, nm, out_img, aligned);
         }
@@ -872,6 +969,7 @@ int configure_kernels(size_t huff_lds, size_t idct_lds)
     if (e == hipSuccess && idct_lds > 64 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_idct_color<0>), hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_idct_color<1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_idct_color<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
     }
     return e == hipSuccess ? 0 : int(e);
 }
@@ -913,12 +1011,20 @@ void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevI
 
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint32_t *entries, const uint32_t *tile_eoff, const int32_t *dcbuf, const float *qmult,
-                       uint8_t *rgb, uint32_t mode_mask)
+                       uint8_t *rgb, uint32_t mode_mask, unsigned long long *planes)
 {
     if (mode_mask & 1u)
-        hipLaunchKernelGGL(k_idct_color<0>, dim3(max_tiles, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb);
+        hipLaunchKernelGGL(k_idct_color<0>, dim3(max_tiles, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes);
     if (mode_mask & 2u)
-        hipLaunchKernelGGL(k_idct_color<1>, dim3(max_tiles, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb);
+        hipLaunchKernelGGL(k_idct_color<1>, dim3(max_tiles, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes);
+    if (mode_mask & 4u)
+        hipLaunchKernelGGL(k_idct_color<2>, dim3(max_tiles, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes);
+}
+
+void launch_ref_color(hipStream_t st, uint32_t max_pixel_wgs, uint32_t nimg, const DevImage *images,
+                      const unsigned long long *planes, uint8_t *rgb)
+{
+    hipLaunchKernelGGL(k_ref_color, dim3(max_pixel_wgs, nimg), dim3(256), 0, st, images, planes, rgb);
 }
 
 }   // namespace mjx

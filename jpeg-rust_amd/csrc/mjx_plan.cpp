@@ -1,6 +1,7 @@
 // mjx_plan.cpp -- see mjx_plan.h.
 #include "mjx_plan.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -9,6 +10,74 @@ namespace mjx {
 const uint8_t kZigZag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                              41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+bool ref_get_indices(long x, long y, long max_x, long x_factor, long y_factor, long max_x_factor, long max_y_factor,
+                     long *ox, long *oy)
+{
+    if (max_y_factor > 1 && y_factor == 1) {
+        if (max_x_factor > 1 && x_factor == 1) {                 // decoder.rs:262-278, fitted to nbx = 94
+            if ((y & 1) == 0) {
+                if (((x / 2) & 1) == 1) { *ox = x / 2 - 1 + (x & 1); *oy = y + 1; }
+                else { *ox = x / 2 + (x & 1); *oy = y; }
+                return true;
+            }
+            if (y > 0 && ((x / 2) & 1) == 0) {
+                if (max_x / 2 + x / 2 < 1) return false;
+                *ox = max_x / 2 + x / 2 - 1 + (x & 1); *oy = y;
+                return true;
+            }
+            if (y < 1) return false;
+            *ox = max_x / 2 + x / 2 + (x & 1); *oy = y - 1;
+            return true;
+        }
+        if ((y & 1) == 0) { *ox = x / 2; *oy = y + (x & 1); return true; }      // decoder.rs:279-285
+        if (y < (x & 1)) return false;
+        *ox = x / 2 + max_x / 2; *oy = y - (x & 1);
+        return true;
+    }
+    *ox = x; *oy = y;                                            // decoder.rs:287
+    return true;
+}
+
+// REF_COMPAT: geometry of decoder.rs:239-312 and the inputs on which that code panics: a block index
+// past the component's blocks (:303), usize underflow in get_indices, or a store index past the plane where the
+// guard `i + j*stride < len` (:370) disagrees with the index `i + j*stride*8` (:371).
+static int plan_ref_layout(ImagePlan &p)
+{
+    const size_t W = p.width, H = p.height, len = W * H;
+    p.nbx = (p.width + 7) / 8;
+    p.nby = (p.height + 7) / 8;
+    for (uint32_t c = 0; c < p.ncomp; c++) {
+        const float x_i = std::ceil(float(p.width) * (float(p.h[c]) / float(p.hmax)));      // decoder.rs:239-246
+        const float y_i = std::ceil(float(p.height) * (float(p.v[c]) / float(p.vmax)));
+        const float xf = std::ceil(float(p.width) / x_i), yf = std::ceil(float(p.height) / y_i);
+        if (!(xf >= 1.0f) || !(yf >= 1.0f)) return MJX_ERR_REF_PANIC;                       // division by zero at :290
+        const size_t xs = size_t(xf), ys = size_t(yf);
+        p.ref_xf[c] = uint32_t(xs);
+        p.ref_yf[c] = uint32_t(ys);
+        const size_t cols = p.nbx / xs, rows = p.nby / ys;
+        const size_t nblk = size_t(p.nmcu) * p.h[c] * p.v[c];
+        if (cols * rows > nblk) return MJX_ERR_REF_PANIC;                                   // component_blocks[block_i]
+        for (size_t y = 0; y < rows; y++)
+            for (size_t x = 0; x < cols; x++) {
+                long bx, by;
+                if (!ref_get_indices(long(x), long(y), long(p.nbx), long(xs), long(ys), long(p.hmax), long(p.vmax), &bx, &by))
+                    return MJX_ERR_REF_PANIC;
+                const size_t start_x = size_t(bx) * 8 * xs;
+                if (W < start_x) continue;                                                  // :360 skips the line
+                for (size_t line = 0; line < 8; line++) {
+                    const size_t a = size_t(by) * 8 * ys * W + line * W + start_x, b = a + 8 * xs - 1;   // i range
+                    for (size_t j = 1; j < ys; j++) {
+                        // guard passes (i < len - jW) while the index i + 8jW is out of range (i >= len - 8jW)
+                        const size_t lo = len > 8 * j * W ? len - 8 * j * W : 0, hi = len > j * W ? len - j * W : 0;
+                        if (hi == 0) continue;
+                        if (std::max(a, lo) <= std::min(b, hi - 1)) return MJX_ERR_REF_PANIC;
+                    }
+                }
+            }
+    }
+    return MJX_OK;
+}
 
 int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p)
 {
@@ -62,6 +131,10 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p)
         p.nmcu = uint32_t((nb + f - 1) / f);                                       // decoder.rs:191-192 (Q2)
     } else {
         p.nmcu = p.mcux * p.mcuy;
+    }
+    if (p.layout == MJX_LAYOUT_REF_COMPAT) {
+        const int rc = plan_ref_layout(p);
+        if (rc != MJX_OK) return fail(rc);
     }
 
     // decode tables: each distinct (class, slot) used by the scan is built once

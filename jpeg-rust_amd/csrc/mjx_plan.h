@@ -30,7 +30,15 @@ struct ImagePlan {
     float qmult[3][64];                            // per component, zig-zag order: q[k] * idct prescale
     const uint8_t *scan = nullptr;
     size_t scan_len = 0;
+    // REF_COMPAT placement (decoder.rs:239-250): replication factors per component, block grid of the image
+    uint32_t ref_xf[3] = {1, 1, 1}, ref_yf[3] = {1, 1, 1};
+    uint32_t nbx = 0, nby = 0;
 };
+
+// decoder.rs:259-288 get_indices: raster counter (x, y) of a component's blocks -> block position (bug-for-bug, Q3).
+// Returns false where the reference's usize arithmetic underflows (panic).
+bool ref_get_indices(long x, long y, long max_x, long x_factor, long y_factor, long max_x_factor, long max_y_factor,
+                     long *ox, long *oy);
 
 // Validates `d` and fills `plan`.  Returns plan.status.
 int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &plan);

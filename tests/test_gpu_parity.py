@@ -125,3 +125,49 @@ def test_tiled_batch_round_trip(mjx, orc, gpu_ctx):
     assert np.array_equal(first, big.rgb(7))
     big.close()
     base.close()
+
+
+# ---- REF_COMPAT layout: bug-for-bug placement of decoder.rs:239-312 ---------------------------------
+@pytest.mark.parametrize("name", FIXTURES)
+def test_reference_fixtures_ref_compat_layout(mjx, orc, gpu_ctx, data_dir, name):
+    data = open(os.path.join(data_dir, name), "rb").read()
+    (ref, coefs, rgb), = _decode_both(mjx, orc, gpu_ctx, [data], layout_std=False)
+    frac = _check(ref, coefs, rgb, name + " (REF_COMPAT)")
+    assert frac < 0.01
+
+
+REF_CASES = [(64, 36, "420"), (750, 595, "420"), (16, 8, "444"), (64, 48, "422"), (33, 17, "422"), (100, 60, "gray"),
+             (48, 64, "440"), (24, 40, "420"), (1920, 1080, "420"), (512, 512, "420")]
+
+
+@pytest.mark.parametrize("w,h,sub", REF_CASES)
+def test_synthetic_ref_compat_layout(mjx, orc, gpu_ctx, w, h, sub):
+    data = mjx.synth_jpeg(w, h, sub, 75, seed=w + 7 * h)
+    (ref, coefs, rgb), = _decode_both(mjx, orc, gpu_ctx, [data], layout_std=False)
+    _check(ref, coefs, rgb, "%dx%d %s REF_COMPAT" % (w, h, sub))
+
+
+def test_ref_compat_reports_reference_panics(mjx, orc, gpu_ctx):
+    for w, h in [(64, 44), (64, 90), (60, 48)]:
+        data = mjx.synth_jpeg(w, h, "420", 75, seed=3)
+        with pytest.raises(orc.OracleError):
+            orc.decode(data, layout=orc.LAYOUT_REF)
+        batch = mjx.Batch(gpu_ctx, [mjx.ParsedScan(data)], layout=mjx.LAYOUT_REF_COMPAT)
+        assert batch.create_status[0] == mjx.ERR_REF_PANIC
+        batch.decode()
+        batch.wait()
+        batch.close()
+
+
+def test_cli_writes_the_reference_ppm(mjx, orc, gpu_ctx, data_dir, tmp_path):
+    import subprocess
+    cli = os.path.join(os.path.dirname(mjx.lib_path()), "mjx_cli")
+    out = tmp_path / "lena.ppm"
+    subprocess.check_call([cli, os.path.join(data_dir, "lena.jpeg"), str(out)])
+    tok = out.read_text().split()
+    assert tok[:4] == ["P3", "512", "512", "255"]           # main.rs:35
+    px = np.array(tok[4:], dtype=np.int32).reshape(512, 512, 3)
+    ref = orc.decode(open(os.path.join(data_dir, "lena.jpeg"), "rb").read(), layout=orc.LAYOUT_STD)
+    assert np.abs(px - ref.rgb.astype(np.int32)).max() <= TOL
+    rc = subprocess.call([cli, os.path.join(data_dir, "huff_simple0.jpg"), str(out), "--strict"])
+    assert rc == mjx.ERR_UNSUPPORTED_MARKER

@@ -167,3 +167,28 @@ def test_no_gpu_means_loud_failure_not_fallback(mjx):
     with pytest.raises(mjx.MjxError) as e:
         mjx.decode(_read("lena.jpeg"))
     assert e.value.code == mjx.ERR_DEVICE
+
+
+def test_ref_compat_panic_detection_matches_the_oracle(mjx, orc):
+    """geometries on which the reference's placement code indexes out of bounds must be reported as
+    MJX_ERR_REF_PANIC by the host plan (REF_COMPAT layout), everything else must be accepted."""
+    checked = panics = 0
+    for sub in ("420", "422", "440", "444", "gray"):
+        for w in (8, 16, 17, 24, 31, 32, 40, 60, 64):
+            for h in (8, 9, 16, 24, 36, 44, 48, 90):
+                data = mjx.synth_jpeg(w, h, sub, 60, seed=w * 100 + h)
+                try:
+                    orc.decode(data, layout=orc.LAYOUT_REF)
+                    ref_ok = True
+                except orc.OracleError as e:
+                    assert e.code == orc.ERR_REF_PANIC
+                    ref_ok = False
+                s = mjx.ParsedScan(data)
+                rc = s.validate(mjx.LAYOUT_REF_COMPAT)
+                assert s.validate(mjx.LAYOUT_STANDARD) == mjx.OK
+                s.close()
+                assert (rc == mjx.OK) == ref_ok, (sub, w, h, rc)
+                assert rc in (mjx.OK, mjx.ERR_REF_PANIC)
+                checked += 1
+                panics += not ref_ok
+    assert checked == 360 and panics > 10
