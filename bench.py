@@ -49,7 +49,9 @@ def parse_args():
 
 def algorithmic_bytes(kind, by, nsub_total, nblk):
     """Per-step algorithmic bytes of each kernel class; by = mjx.Batch.bytes().
-    by["coef"] = bytes of the intermediate coefficient representation (4 per stream entry + 2 per block of DC)."""
+    by["coef"] = bytes of the intermediate coefficient representation (4 per stream entry + 4 per block of DC).
+    idct_color uses SURVEY.md s8(d)'s stage-B figure B_idct = 128*n_blocks + 3*W*H (6 B/px for 4:2:0); the kernel's
+    real input is the smaller compact stream -- `algorithmic_bytes_physical` gives that variant."""
     S, rgb, coef = by["scan"], by["rgb"], by["coef"]
     state = 32 * nsub_total                       # entry + exit state per subsequence
     cps = 8 * 15 * nsub_total                     # two checkpoint words every 256 bits
@@ -59,9 +61,29 @@ def algorithmic_bytes(kind, by, nsub_total, nblk):
         "huff_fix": S // 5 + state + cps // 5,    # k_huff_merge rounds: ~1/5 of the scan is re-read (median merge distance)
         "huff_scan": 24 * nsub_total,             # exit state in, block base + entry base out
         "huff_write": S + 24 * nsub_total + coef, # scan + entry state + bases in, compact stream + DC out
-        "dc_scan": 4 * nblk,                      # DC differences in, absolute DC out
-        "idct_color": coef + rgb,                 # compact stream + DC in, packed RGB out
+        "dc_scan": 8 * nblk,                      # DC differences in, predicted DC out
+        "idct_color": 128 * nblk + rgb,           # B_idct
     }[kind]
+
+
+def algorithmic_bytes_physical(kind, by, nsub_total, nblk):
+    if kind == "idct_color":
+        return by["coef"] + by["rgb"]             # compact stream + DC in, packed RGB out
+    return algorithmic_bytes(kind, by, nsub_total, nblk)
+
+
+def measured_traffic(kind, images_per_launch):
+    """HBM bytes per launch from the committed rocprofv3 PMC collection (profiles/*_traffic.json, FETCH_SIZE x 2 +
+    WRITE_SIZE, separate passes), scaled to this run's images per launch.  None if no collection is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None
+    t = json.load(open(files[-1]))
+    k = t["kernels"].get(kind)
+    if not k:
+        return None
+    return int(k["hbm_bytes"] * images_per_launch / t["images_per_launch"]), os.path.basename(files[-1])
 
 
 def shard_seeds(rank, world, unique):
@@ -189,14 +211,24 @@ def main():
     }
     if kernels:
         dom = max(kernels, key=lambda k: kernels[k]["ms"])
-        steps_bytes = algorithmic_bytes(dom, by, nsub_total, nblk)
         n_launch = kernels[dom]["launches"]
         avg_s = kernels[dom]["ms"] / 1e3 / n_launch
-        per_launch = steps_bytes * args.steps / n_launch
+        per_launch = algorithmic_bytes(dom, by, nsub_total, nblk) * args.steps / n_launch
+        per_launch_phys = algorithmic_bytes_physical(dom, by, nsub_total, nblk) * args.steps / n_launch
         ach = per_launch / avg_s / 1e9
+        imgs_per_launch = per_gpu * args.steps / n_launch * (4 if dom == "huff_fix" else 1)
+        tr = measured_traffic(dom, imgs_per_launch) if args.width == 3840 and args.height == 2160 and args.quality == 75 else None
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
-                           "bytes_per_launch": int(per_launch), "avg_launch_ms": round(avg_s * 1e3, 5)}
+                           "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": tr[0] if tr else None,
+                           "traffic_source": tr[1] if tr else None,
+                           "bytes_per_launch": int(per_launch), "avg_launch_ms": round(avg_s * 1e3, 5),
+                           "achieved_physical": round(per_launch_phys / avg_s / 1e9, 2),
+                           "bytes_basis": "SURVEY s8(d) B_idct = 128*n_blocks + 3*W*H" if dom == "idct_color" else "DESIGN.md s5"}
+        # every kernel class, same definitions
+        out["kernel_rooflines"] = {
+            k: {"GB/s": round(algorithmic_bytes(k, by, nsub_total, nblk) * args.steps / (v["ms"] / 1e3) / 1e9, 1),
+                "frac": round(algorithmic_bytes(k, by, nsub_total, nblk) * args.steps / (v["ms"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4)}
+            for k, v in kernels.items() if v["ms"] > 0}
         tot_ms = sum(v["ms"] for v in kernels.values())
         e2e_bytes = (by["scan"] + by["rgb"]) if args.stages == "all" else algorithmic_bytes("idct_color", by, nsub_total, nblk)
         e2e = e2e_bytes * args.steps / (tot_ms / 1e3) / 1e9
