@@ -31,6 +31,11 @@ struct mjx_ctx {
     hipStream_t stream = nullptr;
     bool profiling = false;
     int fix_passes = 4;            // synchronisation rounds enqueued up front (the last one must re-decode nothing)
+    // Extra dynamic LDS for k_huff_spec: caps it at 5 workgroups (20 waves) per CU.  Every lane streams its own
+    // 512-byte subsequence, so the lines in flight grow with occupancy; past ~20 waves/CU they no longer fit the XCD's
+    // 4 MB L2 and the kernel slows down (measured: 5.5 ms at 32 waves/CU vs 3.5 ms at 20, 1024 x 4K).
+    size_t spec_lds_pad = 22000;
+    size_t merge_lds_pad = 0;      // the merge rounds are latency-bound on few lanes and prefer full occupancy
 };
 
 namespace {
@@ -164,9 +169,9 @@ void plan_chunks(mjx_batch *b)
 {
     const size_t n = b->info.size();
     const bool keep = b->opts.keep_coefs != 0;
-    size_t per_chunk = b->opts.chunk_images ? b->opts.chunk_images : 128;
+    size_t per_chunk = b->opts.chunk_images ? b->opts.chunk_images : 1024;
     per_chunk = std::min<size_t>(per_chunk, 65535);
-    const uint64_t kMaxChunkEntries = (uint64_t(6) << 30) / 4;           // 6 GiB of stream capacity per chunk
+    const uint64_t kMaxChunkEntries = (uint64_t(24) << 30) / 4;          // 24 GiB of stream capacity per chunk
     b->chunks.clear();
     uint64_t coef_running = 0, ent_running = 0;
     uint32_t tile_running = 0;
@@ -241,7 +246,7 @@ int allocate_work_buffers(mjx_batch *b)
     HIPOK(hipMalloc(&b->d_entry, size_t(max_nsub) * sizeof(SubseqState)));
     HIPOK(hipMalloc(&b->d_exit, size_t(max_nsub) * sizeof(SubseqState)));
     HIPOK(hipMalloc(&b->d_blkbase, size_t(max_nsub) * sizeof(uint32_t)));
-    HIPOK(hipMalloc(&b->d_cps, size_t(max_nsub) * kNumCp * 2 * sizeof(uint32_t)));
+    HIPOK(hipMalloc(&b->d_cps, (size_t(max_nsub) + 256) / 256 * 256 * kNumCp * 2 * sizeof(uint32_t)));
     size_t max_imgs = 1;
     for (const Chunk &c : b->chunks) max_imgs = std::max(max_imgs, c.count);
     b->max_nsub = max_nsub;
@@ -304,7 +309,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     fix_passes = std::min(fix_passes, kMaxFix);
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_SYNC)) {
         prof_begin(b, MJX_K_HUFF_SYNC);
-        launch_huff_spec(st, c.max_wg, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, b->d_cps, c.nsub);
+        launch_huff_spec(st, c.max_wg, nimg, b->huff_lds + b->ctx->spec_lds_pad, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, b->d_cps, c.nsub);
         prof_end(b);
     }
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_FIX)) {
@@ -312,7 +317,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         if (c.merge_wgs > 0) {
             for (int k = 0; k < fix_passes; k++) {
                 prof_begin(b, MJX_K_HUFF_FIX);
-                launch_huff_merge(st, c.merge_wgs, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, b->d_cps,
+                launch_huff_merge(st, c.merge_wgs, nimg, b->huff_lds + b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, b->d_cps,
                                   c.nsub, b->d_mismatch + ci * kMaxFix + k);
                 prof_end(b);
             }
@@ -475,6 +480,8 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     if (!c) return MJX_ERR_NOMEM;
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MJX_ERR_DEVICE; }
+    if (const char *e = std::getenv("MJX_SPEC_LDS_PAD")) c->spec_lds_pad = size_t(std::atoi(e));
+    if (const char *e = std::getenv("MJX_MERGE_LDS_PAD")) c->merge_lds_pad = size_t(std::atoi(e));
     if (const char *e = std::getenv("MJX_FIX_PASSES")) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= kMaxFix) c->fix_passes = v;

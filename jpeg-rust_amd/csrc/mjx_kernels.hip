@@ -35,12 +35,19 @@ struct GlobalBits {
     static __device__ __forceinline__ uint32_t fix(uint32_t raw) { return __builtin_bswap32(raw); }
 };
 
-// Checkpoint words live row-major by word in HBM (row 2k = state word of checkpoint k, row 2k+1 = its entry count),
-// so lanes with consecutive subsequences touch adjacent words of a row.  In merge rounds the previous decode's state
+// Checkpoint words live in HBM in blocks of 256 consecutive subsequences; inside a block they are row-major by word
+// (row 2k = state word of checkpoint k, row 2k+1 = its entry count, rows 256 words apart), so the lanes of a wave
+// touch adjacent words of a row and a workgroup's checkpoints stay within one 30 KB region.  In merge rounds the previous decode's state
 // word is requested one boundary ahead (~45 symbols), so the comparison at the boundary does not expose a round trip.
+constexpr uint32_t kCpRow = 256;
+__device__ __forceinline__ uint32_t *cps_slot(uint32_t *g_cps, uint32_t idx)
+{
+    return g_cps + size_t(idx / kCpRow) * (2 * kNumCp * kCpRow) + idx % kCpRow;
+}
+
 struct GlobalCps {
-    uint32_t *g;            // &g_cps[subsequence] (rows `stride` apart; 2 * kNumCp * stride < 2^31 elements)
-    uint32_t stride;
+    uint32_t *g;            // cps_slot(g_cps, subsequence index in the chunk)
+    uint32_t stride;        // kCpRow
     uint32_t next;          // prefetched state word of the previous decode
     __device__ __forceinline__ void prime() { next = g[0]; }
     __device__ __forceinline__ uint32_t get(uint32_t k)
@@ -239,7 +246,7 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_spec(const DevImage *im
     const GlobalBits bits{reinterpret_cast<const uint32_t *>(scan_pool + im.scan_off), im.scan_padded / 4};
     const SubseqState e = make_state(live ? s * kSubseqBits : 0u, 0, 0);
     NullSink sink;
-    GlobalCps cps{g_cps + im.sub_off + s, cp_stride, 0};
+    GlobalCps cps{cps_slot(g_cps, im.sub_off + s), kCpRow, 0};
     const SubseqState x = wave_decode<false, 1, kSpecWin>(live, e, live ? subseq_end(*h, s) : 0u, 0, bits, s_win + (kSpecWin ? threadIdx.x * kWinStride : 0),
                                                 lut, *h, sink, cps, s * kSubseqBits, e);
     if (live) {
@@ -280,7 +287,7 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_merge(const DevImage *i
     const GlobalBits bits{reinterpret_cast<const uint32_t *>(scan_pool + im.scan_off), im.scan_padded / 4};
     const SubseqState e = make_state(prev.p, prev.z, prev.c);
     SubseqState old_exit = make_state(0, 0, 0);
-    GlobalCps cps{g_cps + im.sub_off + (need ? s : 0u), cp_stride, 0};
+    GlobalCps cps{cps_slot(g_cps, im.sub_off + (need ? s : 0u)), kCpRow, 0};
     if (need) {
         old_exit = g_exit[im.sub_off + s];
         g_entry[im.sub_off + s] = e;
