@@ -36,6 +36,7 @@ struct mjx_ctx {
     // 4 MB L2 and the kernel slows down (measured: 5.5 ms at 32 waves/CU vs 3.5 ms at 20, 1024 x 4K).
     size_t spec_lds_pad = 22000;
     size_t merge_lds_pad = 0;      // the merge rounds are latency-bound on few lanes and prefer full occupancy
+    size_t write_lds_pad = 0;
 };
 
 namespace {
@@ -330,7 +331,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         launch_huff_scan(st, nimg, imgs, b->d_exit, b->d_blkbase, b->d_ebase, b->d_img_entries);
         prof_end(b);
         prof_begin(b, MJX_K_HUFF_WRITE);
-        launch_huff_write(st, c.max_wg, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_blkbase, b->d_ebase,
+        launch_huff_write(st, c.max_wg, nimg, b->huff_lds + b->ctx->write_lds_pad, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_blkbase, b->d_ebase,
                           b->d_entries, b->d_tile_eoff, dcb, b->d_status);
         prof_end(b);
         prof_begin(b, MJX_K_DC_SCAN);
@@ -482,6 +483,7 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MJX_ERR_DEVICE; }
     if (const char *e = std::getenv("MJX_SPEC_LDS_PAD")) c->spec_lds_pad = size_t(std::atoi(e));
     if (const char *e = std::getenv("MJX_MERGE_LDS_PAD")) c->merge_lds_pad = size_t(std::atoi(e));
+    if (const char *e = std::getenv("MJX_WRITE_LDS_PAD")) c->write_lds_pad = size_t(std::atoi(e));
     if (const char *e = std::getenv("MJX_FIX_PASSES")) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= kMaxFix) c->fix_passes = v;

@@ -594,13 +594,33 @@ __device__ __forceinline__ void chroma_products(float cb, float cr, float &cbk, 
 struct __attribute__((packed, aligned(4))) Rgb4 { uint32_t a, b, c; };
 struct __attribute__((packed, aligned(1))) Rgb4u { uint32_t a, b, c; };
 
-// 4 pixels -> 12 bytes R,G,B,R,G,B,...
+// 4 pixels -> 12 bytes R,G,B,R,G,B,...   decoder.rs:382-390 f32_to_u8 = clamp to [0,255] + truncate.  v_cvt_pk_u8_f32
+// saturates and inserts the byte; it rounds in the current f32 rounding mode, so the twelve conversions run with
+// MODE.FP_ROUND = toward-zero (checked against clamp+truncate on the GPU: tools/probes/cvt_rtz_probe.hip) and the mode
+// is back to nearest-even before the block ends.  One opaque asm block: no float arithmetic can move inside it.
 __device__ __forceinline__ Rgb4 pack4(const Rgb p[4])
 {
     Rgb4 o;
-    o.a = pack_u8(p[1].r, 3, pack_u8(p[0].b, 2, pack_u8(p[0].g, 1, pack_u8(p[0].r, 0, 0))));
-    o.b = pack_u8(p[2].g, 3, pack_u8(p[2].r, 2, pack_u8(p[1].b, 1, pack_u8(p[1].g, 0, 0))));
-    o.c = pack_u8(p[3].b, 3, pack_u8(p[3].g, 2, pack_u8(p[3].r, 1, pack_u8(p[2].b, 0, 0))));
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                 "s_nop 1\n\t"
+                 "v_cvt_pk_u8_f32 %0, %3, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %7, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %2, %11, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %4, 1, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %8, 1, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %12, 1, %2\n\t"
+                 "v_cvt_pk_u8_f32 %0, %5, 2, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %9, 2, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %13, 2, %2\n\t"
+                 "v_cvt_pk_u8_f32 %0, %6, 3, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %10, 3, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %14, 3, %2\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\t"
+                 "s_nop 1"
+                 : "=&v"(o.a), "=&v"(o.b), "=&v"(o.c)
+                 : "v"(p[0].r), "v"(p[0].g), "v"(p[0].b), "v"(p[1].r),      // dword a: R0 G0 B0 R1
+                   "v"(p[1].g), "v"(p[1].b), "v"(p[2].r), "v"(p[2].g),      // dword b: G1 B1 R2 G2
+                   "v"(p[2].b), "v"(p[3].r), "v"(p[3].g), "v"(p[3].b));     // dword c: B2 R3 G3 B3
     return o;
 }
 
