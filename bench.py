@@ -141,9 +141,15 @@ def main():
     mjx = ge.load_package()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; MJX_BENCH_BACKEND=gloo + a single visible GPU is only for exercising the N>1 code path in tests
+    backend = os.environ.get("MJX_BENCH_BACKEND", "nccl")
+    device = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
 
     # ---- this rank's shard of the global batch: global image i -> rank i % world, content seed i % unique ----
     per_gpu = args.images_per_gpu
@@ -155,7 +161,7 @@ def main():
     with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
         datas = list(ex.map(lambda s: mjx.synth_jpeg(args.width, args.height, args.subsampling, args.quality, s), seeds))
 
-    ctx = mjx.Context(local_rank, profiling=True)
+    ctx = mjx.Context(device, profiling=True)
     scans = [mjx.ParsedScan(d) for d in datas]
     keep = args.stages == "pixels"
     base = mjx.Batch(ctx, scans, keep_coefs=keep, chunk_images=args.chunk_images)
@@ -187,7 +193,7 @@ def main():
     batch.wait()
     sync_all()
     elapsed = time.perf_counter() - t0
-    elapsed = reduce_elapsed(elapsed, world, "cuda")
+    elapsed = reduce_elapsed(elapsed, world, "cuda" if backend == "nccl" else None)
     bad = [i for i in range(len(batch)) if batch.status(i) != mjx.OK]
     assert not bad, "images failed: %s" % bad[:8]
 
@@ -201,9 +207,10 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%d x %dx%d 4:%s baseline JPEG q%d per GPU (%d unique, tiled on device), de-stuffed scans "
+        "config": {"workload": "%d x %dx%d %s baseline JPEG q%d per GPU (%d unique, tiled on device), de-stuffed scans "
                                "resident in HBM, RGB out in HBM, stages=%s"
-                               % (per_gpu, args.width, args.height, args.subsampling[1:] if args.subsampling[0] == "4" else args.subsampling,
+                               % (per_gpu, args.width, args.height,
+                                  {"420": "4:2:0", "422": "4:2:2", "444": "4:4:4", "440": "4:4:0", "gray": "greyscale"}[args.subsampling],
                                   args.quality, period, args.stages),
                    "images_per_gpu": per_gpu, "width": args.width, "height": args.height, "subsampling": args.subsampling,
                    "quality": args.quality, "layout": "standard", "sharding": "image i -> gpu i %% %d, no collective" % world},
