@@ -93,6 +93,7 @@ struct mjx_batch {
     uint32_t *d_tile_eoff = nullptr;    // stream offset of every stage-B tile (+ sentinel per image)
     uint32_t *d_ebase = nullptr;        // per subsequence: stream entries before it
     uint32_t *d_img_entries = nullptr;  // per image: entries counted by the synchronisation passes
+    uint32_t *d_img_flags = nullptr;    // per image: 1 = scan ends before all MCUs (truncated), set by k_huff_scan
     int32_t *d_dc = nullptr;            // per block: DC difference, then (after k_dc_apply) the predicted DC
     uint8_t *d_rgb = nullptr;
     size_t rgb_pool_bytes = 0;
@@ -126,7 +127,7 @@ void release(mjx_batch *b)
     for (auto &e : b->event_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     (void)hipFree(b->d_images); (void)hipFree(b->d_scan); (void)hipFree(b->d_lut); (void)hipFree(b->d_qm);
     (void)hipFree(b->d_entry); (void)hipFree(b->d_exit); (void)hipFree(b->d_blkbase);
-    (void)hipFree(b->d_entries); (void)hipFree(b->d_tile_eoff); (void)hipFree(b->d_ebase); (void)hipFree(b->d_img_entries);
+    (void)hipFree(b->d_entries); (void)hipFree(b->d_tile_eoff); (void)hipFree(b->d_ebase); (void)hipFree(b->d_img_entries); (void)hipFree(b->d_img_flags);
     (void)hipFree(b->d_dc); (void)hipFree(b->d_rgb); (void)hipFree(b->d_status);
     (void)hipFree(b->d_planes);
     (void)hipFree(b->d_mismatch); (void)hipFree(b->d_segsum); (void)hipFree(b->d_cps); (void)hipFree(b->d_pull);
@@ -264,6 +265,8 @@ int allocate_work_buffers(mjx_batch *b)
     HIPOK(hipMalloc(&b->d_ebase, size_t(max_nsub) * sizeof(uint32_t)));
     HIPOK(hipMalloc(&b->d_img_entries, std::max<size_t>(b->info.size(), 1) * sizeof(uint32_t)));
     HIPOK(hipMemset(b->d_img_entries, 0, std::max<size_t>(b->info.size(), 1) * sizeof(uint32_t)));
+    HIPOK(hipMalloc(&b->d_img_flags, std::max<size_t>(b->info.size(), 1) * sizeof(uint32_t)));
+    HIPOK(hipMemset(b->d_img_flags, 0, std::max<size_t>(b->info.size(), 1) * sizeof(uint32_t)));
     HIPOK(hipMalloc(&b->d_dc, size_t(coef_blocks) * sizeof(int32_t) + 64));
     HIPOK(hipMalloc(&b->d_rgb, std::max<size_t>(b->rgb_pool_bytes, 16)));
     HIPOK(hipMalloc(&b->d_status, std::max<size_t>(b->info.size(), 1) * sizeof(int)));
@@ -328,21 +331,21 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     }
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_TAIL)) {
         prof_begin(b, MJX_K_HUFF_SCAN);
-        launch_huff_scan(st, nimg, imgs, b->d_exit, b->d_blkbase, b->d_ebase, b->d_img_entries);
+        launch_huff_scan(st, nimg, imgs, b->d_exit, b->d_blkbase, b->d_ebase, b->d_img_entries, b->d_img_flags);
         prof_end(b);
         prof_begin(b, MJX_K_HUFF_WRITE);
         launch_huff_write(st, c.max_wg, nimg, b->huff_lds + b->ctx->write_lds_pad, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_blkbase, b->d_ebase,
-                          b->d_entries, b->d_tile_eoff, dcb, b->d_status);
+                          b->d_entries, b->d_tile_eoff, dcb, b->d_status, b->d_img_flags);
         prof_end(b);
         prof_begin(b, MJX_K_DC_SCAN);
-        launch_dc_scan(st, c.max_segs, nimg, imgs, dcb, b->d_segsum);
+        launch_dc_scan(st, c.max_segs, nimg, imgs, dcb, b->d_segsum, b->d_img_flags);
         prof_end(b);
     }
     if (stages & MJX_STAGE_PIXELS) {
         prof_begin(b, MJX_K_IDCT_COLOR);
         if (c.plane_words) HIPOK(hipMemsetAsync(b->d_planes, 0, size_t(c.plane_words) * 8, st));
-        launch_idct_color(st, (c.max_tiles + kTilesPerWgHost - 1) / kTilesPerWgHost, nimg, b->idct_lds, imgs, b->d_entries, b->d_tile_eoff, dcb, b->d_qm, b->d_rgb, c.mode_mask, b->d_planes);
-        if (c.plane_words) launch_ref_color(st, c.max_pixel_wgs, nimg, imgs, b->d_planes, b->d_rgb);
+        launch_idct_color(st, (c.max_tiles + kTilesPerWgHost - 1) / kTilesPerWgHost, nimg, b->idct_lds, imgs, b->d_entries, b->d_tile_eoff, dcb, b->d_qm, b->d_rgb, c.mode_mask, b->d_planes, b->d_img_flags);
+        if (c.plane_words) launch_ref_color(st, c.max_pixel_wgs, nimg, imgs, b->d_planes, b->d_rgb, b->d_img_flags);
         prof_end(b);
     }
     HIPOK(hipGetLastError());
@@ -625,8 +628,13 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
     }
     std::vector<int> dev(b->info.size());
     if (!dev.empty()) HIPOK(hipMemcpy(dev.data(), b->d_status, dev.size() * sizeof(int), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < dev.size(); i++)
-        if (b->info[i].status == MJX_OK && dev[i]) b->info[i].status = MJX_ERR_BAD_HUFFMAN;
+    std::vector<uint32_t> flags(b->info.size());
+    if (!flags.empty()) HIPOK(hipMemcpy(flags.data(), b->d_img_flags, flags.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < dev.size(); i++) {
+        if (b->info[i].status != MJX_OK) continue;
+        if (flags[i]) b->info[i].status = MJX_ERR_TRUNCATED;           // scan ended before the last MCU
+        else if (dev[i]) b->info[i].status = MJX_ERR_BAD_HUFFMAN;       // no code matched (huffman.rs:156/162)
+    }
     return MJX_OK;
 }
 

@@ -60,18 +60,18 @@ void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ld
                        const uint8_t *scan_pool, const uint16_t *lut_pool, SubseqState *entry, SubseqState *exit_,
                        uint32_t *cps, uint32_t cp_stride, uint32_t *mismatches);
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,
-                      uint32_t *ebase, uint32_t *img_entries);
+                      uint32_t *ebase, uint32_t *img_entries, uint32_t *img_flags);
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint8_t *scan_pool, const uint16_t *lut_pool, const SubseqState *entry,
                        const uint32_t *blkbase, const uint32_t *ebase, uint32_t *entries, uint32_t *tile_eoff,
-                       int32_t *dcbuf, int *status);
+                       int32_t *dcbuf, int *status, const uint32_t *img_flags);
 void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int32_t *dcbuf,
-                    int32_t *segsum);
+                    int32_t *segsum, const uint32_t *img_flags);
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint32_t *entries, const uint32_t *tile_eoff, const int32_t *dcbuf, const float *qmult,
-                       uint8_t *rgb, uint32_t mode_mask, unsigned long long *planes);
+                       uint8_t *rgb, uint32_t mode_mask, unsigned long long *planes, const uint32_t *img_flags);
 void launch_ref_color(hipStream_t st, uint32_t max_pixel_wgs, uint32_t nimg, const DevImage *images,
-                      const unsigned long long *planes, uint8_t *rgb);
+                      const unsigned long long *planes, uint8_t *rgb, const uint32_t *img_flags);
 #endif
 
 }   // namespace mjx

@@ -326,7 +326,7 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t *s_tm
 // blkbase[s] / ebase[s] = blocks completed / stream entries produced before subsequence s (one workgroup per image).
 extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *images, const SubseqState *g_exit,
                                                                uint32_t *g_blkbase, uint32_t *g_ebase,
-                                                               uint32_t *img_entries)
+                                                               uint32_t *img_entries, uint32_t *img_flags)
 {
     __shared__ uint32_t s_tmp[4];
     const DevImage &im = images[blockIdx.x];
@@ -345,19 +345,24 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *im
         run_n += g_exit[im.sub_off + s].n;
         run_m += g_exit[im.sub_off + s].m;
     }
-    if (tid == 0) img_entries[im.status_idx] = total_m;      // upper bound of the entries the write pass produces
+    if (tid == 0) {
+        img_entries[im.status_idx] = total_m;      // upper bound of the entries the write pass produces
+        // The scan ends before every MCU is decoded (truncated file): the reference would go on decoding its 0xAA
+        // padding (huffman.rs:236-246); here the image is reported as truncated and skipped by the later kernels.
+        img_flags[im.status_idx] = total_n < im.himg.total_blocks ? 1u : 0u;
+    }
 }
 
 extern "C" __global__ __launch_bounds__(256) void k_huff_write(const DevImage *images, const uint8_t *scan_pool,
                                                                 const uint16_t *lut_pool, const SubseqState *g_entry,
                                                                 const uint32_t *g_blkbase, const uint32_t *g_ebase,
                                                                 uint32_t *entries, uint32_t *tile_eoff, int32_t *dcbuf,
-                                                                int *status)
+                                                                int *status, const uint32_t *img_flags)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t s_win[kWgLanes * kWinStride];
     const DevImage &im = images[blockIdx.y];
-    if (!im.valid || blockIdx.x * kWgLanes >= im.himg.nsub) return;
+    if (!im.valid || blockIdx.x * kWgLanes >= im.himg.nsub || img_flags[im.status_idx]) return;
     const HuffImage *h;
     const uint16_t *lut;
     stage_tables(im, lut_pool, smem, h, lut);
@@ -416,12 +421,12 @@ __device__ __forceinline__ void wg_reduce3(int32_t v[3], int32_t (*s_w)[3], int3
 }
 
 extern "C" __global__ __launch_bounds__(256) void k_dc_sums(const DevImage *images, const int32_t *dcbuf,
-                                                             int32_t *segsum, uint32_t max_segs)
+                                                             int32_t *segsum, uint32_t max_segs, const uint32_t *img_flags)
 {
     __shared__ int32_t s_w[4][3];
     const DevImage &im = images[blockIdx.y];
     const uint32_t m0 = blockIdx.x * kDcSegMcus;
-    if (!im.valid || m0 >= im.nmcu) return;
+    if (!im.valid || m0 >= im.nmcu || img_flags[im.status_idx]) return;
     const uint32_t bpm = im.bpm, tid = threadIdx.x;
     const uint32_t nv = (min(uint32_t(kDcSegMcus), im.nmcu - m0)) * bpm;
     const int32_t *dc = dcbuf + im.coef_off + size_t(m0) * bpm;
@@ -439,13 +444,14 @@ extern "C" __global__ __launch_bounds__(256) void k_dc_sums(const DevImage *imag
 }
 
 extern "C" __global__ __launch_bounds__(256) void k_dc_apply(const DevImage *images, int32_t *dcbuf,
-                                                              const int32_t *segsum, uint32_t max_segs)
+                                                              const int32_t *segsum, uint32_t max_segs,
+                                                              const uint32_t *img_flags)
 {
     __shared__ int32_t s_dc[256 * kMaxBlocksPerMcu];
     __shared__ int32_t s_wsum[4][3];
     const DevImage &im = images[blockIdx.y];
     const uint32_t seg0 = blockIdx.x * kDcSegMcus;
-    if (!im.valid || seg0 >= im.nmcu) return;
+    if (!im.valid || seg0 >= im.nmcu || img_flags[im.status_idx]) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, bpm = im.bpm;
     const uint32_t seg1 = min(im.nmcu, seg0 + kDcSegMcus);
     int32_t *dc = dcbuf + im.coef_off;
@@ -866,10 +872,10 @@ __device__ __forceinline__ void place_ref(const DevImage &im, const float *tile,
 
 // decoder.rs:317-331 on the placed planes: one lane per pixel.
 extern "C" __global__ __launch_bounds__(256) void k_ref_color(const DevImage *images, const unsigned long long *planes,
-                                                               uint8_t *rgb)
+                                                               uint8_t *rgb, const uint32_t *img_flags)
 {
     const DevImage &im = images[blockIdx.y];
-    if (!im.valid || im.mode != 2) return;
+    if (!im.valid || im.mode != 2 || img_flags[im.status_idx]) return;
     const size_t len = size_t(im.width) * im.height;
     const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
     if (i >= len) return;
@@ -903,14 +909,15 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
                                                      const uint32_t *__restrict__ entries,
                                                      const uint32_t *__restrict__ tile_eoff,
                                                      const int32_t *__restrict__ dcbuf, const float *__restrict__ qmult,
-                                                     uint8_t *__restrict__ rgb, unsigned long long *__restrict__ planes)
+                                                     uint8_t *__restrict__ rgb, unsigned long long *__restrict__ planes,
+                                                     const uint32_t *__restrict__ img_flags)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float s_qm[3 * 64];
     __shared__ uint8_t s_nat[64];
     __shared__ uint8_t s_comp[256];
     const DevImage &im = images[blockIdx.y];
-    if (!im.valid || im.mode != uint32_t(MODE)) return;
+    if (!im.valid || im.mode != uint32_t(MODE) || img_flags[im.status_idx]) return;
     // everything the tile loop needs from the descriptor, read once (uniform -> scalar registers)
     const uint32_t T = MODE == 1 ? 32u : (1u << im.log2_tile);
     const uint32_t bpm = MODE == 1 ? 6u : im.bpm;
@@ -1016,42 +1023,42 @@ void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ld
 }
 
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,
-                      uint32_t *ebase, uint32_t *img_entries)
+                      uint32_t *ebase, uint32_t *img_entries, uint32_t *img_flags)
 {
-    hipLaunchKernelGGL(k_huff_scan, dim3(nimg), dim3(kWgLanes), 0, st, images, exit_, blkbase, ebase, img_entries);
+    hipLaunchKernelGGL(k_huff_scan, dim3(nimg), dim3(kWgLanes), 0, st, images, exit_, blkbase, ebase, img_entries, img_flags);
 }
 
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint8_t *scan_pool, const uint16_t *lut_pool, const SubseqState *entry,
                        const uint32_t *blkbase, const uint32_t *ebase, uint32_t *entries, uint32_t *tile_eoff,
-                       int32_t *dcbuf, int *status)
+                       int32_t *dcbuf, int *status, const uint32_t *img_flags)
 {
-    hipLaunchKernelGGL(k_huff_write, dim3(max_wg, nimg), dim3(kWgLanes), lds, st, images, scan_pool, lut_pool, entry, blkbase, ebase, entries, tile_eoff, dcbuf, status);
+    hipLaunchKernelGGL(k_huff_write, dim3(max_wg, nimg), dim3(kWgLanes), lds, st, images, scan_pool, lut_pool, entry, blkbase, ebase, entries, tile_eoff, dcbuf, status, img_flags);
 }
 
 void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int32_t *dcbuf,
-                    int32_t *segsum)
+                    int32_t *segsum, const uint32_t *img_flags)
 {
-    hipLaunchKernelGGL(k_dc_sums, dim3(max_segs, nimg), dim3(256), 0, st, images, dcbuf, segsum, max_segs);
-    hipLaunchKernelGGL(k_dc_apply, dim3(max_segs, nimg), dim3(256), 0, st, images, dcbuf, segsum, max_segs);
+    hipLaunchKernelGGL(k_dc_sums, dim3(max_segs, nimg), dim3(256), 0, st, images, dcbuf, segsum, max_segs, img_flags);
+    hipLaunchKernelGGL(k_dc_apply, dim3(max_segs, nimg), dim3(256), 0, st, images, dcbuf, segsum, max_segs, img_flags);
 }
 
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint32_t *entries, const uint32_t *tile_eoff, const int32_t *dcbuf, const float *qmult,
-                       uint8_t *rgb, uint32_t mode_mask, unsigned long long *planes)
+                       uint8_t *rgb, uint32_t mode_mask, unsigned long long *planes, const uint32_t *img_flags)
 {
     if (mode_mask & 1u)
-        hipLaunchKernelGGL(k_idct_color<0>, dim3(max_tiles, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes);
+        hipLaunchKernelGGL(k_idct_color<0>, dim3(max_tiles, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags);
     if (mode_mask & 2u)
-        hipLaunchKernelGGL(k_idct_color<1>, dim3(max_tiles, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes);
+        hipLaunchKernelGGL(k_idct_color<1>, dim3(max_tiles, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags);
     if (mode_mask & 4u)
-        hipLaunchKernelGGL(k_idct_color<2>, dim3(max_tiles, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes);
+        hipLaunchKernelGGL(k_idct_color<2>, dim3(max_tiles, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags);
 }
 
 void launch_ref_color(hipStream_t st, uint32_t max_pixel_wgs, uint32_t nimg, const DevImage *images,
-                      const unsigned long long *planes, uint8_t *rgb)
+                      const unsigned long long *planes, uint8_t *rgb, const uint32_t *img_flags)
 {
-    hipLaunchKernelGGL(k_ref_color, dim3(max_pixel_wgs, nimg), dim3(256), 0, st, images, planes, rgb);
+    hipLaunchKernelGGL(k_ref_color, dim3(max_pixel_wgs, nimg), dim3(256), 0, st, images, planes, rgb, img_flags);
 }
 
 }   // namespace mjx

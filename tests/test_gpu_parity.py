@@ -171,3 +171,60 @@ def test_cli_writes_the_reference_ppm(mjx, orc, gpu_ctx, data_dir, tmp_path):
     assert np.abs(px - ref.rgb.astype(np.int32)).max() <= TOL
     rc = subprocess.call([cli, os.path.join(data_dir, "huff_simple0.jpg"), str(out), "--strict"])
     assert rc == mjx.ERR_UNSUPPORTED_MARKER
+
+
+# ---- hostile inputs: one bad image must not kill the batch, and nothing may fault on the device --------------------
+def test_truncated_and_garbage_scans(mjx, orc, gpu_ctx, data_dir):
+    import ctypes
+    good = open(os.path.join(data_dir, "lena.jpeg"), "rb").read()
+    big = mjx.synth_jpeg(1024, 768, "420", 75, seed=5)
+    rng = np.random.default_rng(11)
+    scans, expect = [], []
+    for cut in (0.3, 0.7, 0.97):                       # file cut inside the entropy-coded segment
+        scans.append(mjx.ParsedScan(big[: int(len(big) * cut)]))
+        expect.append({mjx.ERR_TRUNCATED})
+    for fill in ("random", "ff", "zero"):              # same headers, meaningless scan bytes
+        s = mjx.ParsedScan(big)
+        n = s.desc.scan_len
+        raw = {"random": rng.integers(0, 256, n, dtype=np.uint8).tobytes(), "ff": b"\xff" * n, "zero": b"\x00" * n}[fill]
+        ctypes.memmove(s.desc.scan, raw, n)
+        scans.append(s)
+        expect.append({mjx.OK, mjx.ERR_TRUNCATED, mjx.ERR_BAD_HUFFMAN})
+    scans.append(mjx.ParsedScan(good))
+    expect.append({mjx.OK})
+    for layout in (mjx.LAYOUT_STANDARD, mjx.LAYOUT_REF_COMPAT):
+        batch = mjx.Batch(gpu_ctx, scans, layout=layout)
+        for _ in range(2):
+            batch.decode()
+            batch.wait()
+        got = [batch.status(i) for i in range(len(scans))]
+        for g, e in zip(got, expect):
+            assert g in e, (got, layout)
+        ref = orc.decode(good, layout=orc.LAYOUT_STD if layout == mjx.LAYOUT_STANDARD else orc.LAYOUT_REF)
+        assert np.abs(batch.rgb(len(scans) - 1).astype(int) - ref.rgb.astype(int)).max() <= TOL
+        batch.close()
+
+
+def test_repair_path_when_the_enqueued_rounds_do_not_converge(mjx, orc, data_dir, tmp_path):
+    """MJX_FIX_PASSES=1 leaves the synchronisation unverified after the enqueued rounds, so mjx_batch_wait must take
+    its repair path (more rounds, then re-run the tail of the pipeline) and still produce the exact result."""
+    import subprocess, sys
+    script = tmp_path / "repair.py"
+    script.write_text(
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "import __graft_entry__ as ge, oracle_binding as orc\n"
+        "mjx = ge.load_package()\n"
+        "ctx = mjx.Context(0)\n"
+        "datas = [mjx.synth_jpeg(3840, 2160, '420', 75, seed=s) for s in (1, 2)] + [mjx.synth_jpeg(640, 480, '422', 60, seed=3)]\n"
+        "b = mjx.Batch(ctx, [mjx.ParsedScan(d) for d in datas], keep_coefs=True, chunk_images=2)\n"
+        "b.decode(); b.wait()\n"
+        "for i, d in enumerate(datas):\n"
+        "    ref = orc.decode(d, layout=orc.LAYOUT_STD)\n"
+        "    assert b.status(i) == 0\n"
+        "    assert np.array_equal(b.coefs(i), orc.interleave(ref))\n"
+        "    assert np.abs(b.rgb(i).astype(int) - ref.rgb.astype(int)).max() <= 1\n"
+        "print('repair ok')\n" % (os.path.dirname(data_dir.rstrip('/')).rsplit('/tests', 1)[0], os.path.dirname(data_dir.rstrip('/')).rsplit('/tests', 1)[0]))
+    env = dict(os.environ, MJX_FIX_PASSES="1")
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "repair ok" in out.stdout, out.stdout + out.stderr
