@@ -99,7 +99,8 @@ _lib = None
 
 
 def lib_path():
-    return os.path.join(_PKG, "libmjx.so")
+    """In-tree library; MJX_LIB overrides it (A/B comparisons of two builds on the same GPU box)."""
+    return os.environ.get("MJX_LIB") or os.path.join(_PKG, "libmjx.so")
 
 
 def lib():

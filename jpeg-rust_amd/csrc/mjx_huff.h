@@ -65,7 +65,11 @@ MJX_HD SubseqState make_state(uint32_t p, uint32_t z, uint32_t c, uint32_t n = 0
 
 // Per-image constants the lane needs (lives in LDS on the device).
 struct HuffImage {
-    uint32_t blktab[kMaxBlocksPerMcu];   // per block-in-MCU: dc table base | ac table base << 16 (entry offsets)
+    // The blocks of an MCU are ordered by component, so the table pair of block c follows from two thresholds:
+    // c < cfirst1 -> component 0, c < cfirst2 -> component 1, else component 2.  All five words are uniform per image
+    // (scalar registers on the device): no memory access when a block ends.
+    uint32_t ctab[3];                    // per component: dc table base | ac table base << 16 (entry offsets)
+    uint32_t cfirst1, cfirst2;           // first block-in-MCU of components 1 and 2 (= bpm when absent)
     uint32_t bpm;                        // blocks per MCU
     uint32_t total_bits;                 // scan_len * 8
     uint32_t total_blocks;               // MCUs to decode * bpm
@@ -115,19 +119,21 @@ struct NoCheckpoints {
 // whole dword of symbols (~6) and its latency stays off the lane's critical path.
 struct LaneState {
     uint32_t p, z, c, n, m;   // bit position, zig-zag index, block-in-MCU, blocks completed, stream entries produced
-    uint32_t tab, tab_next;   // img.blktab[c] and the entry of the following block (fetched a block early)
-    uint32_t bpm;             // blocks per MCU
+    uint32_t tab;             // table pair of block c (see HuffImage::ctab)
     uint32_t wi, o;           // dword index of w0, bit offset inside it
     uint32_t w0, w1, w2;
 };
+
+MJX_HD uint32_t block_tab(const HuffImage &img, uint32_t c)
+{
+    return c < img.cfirst1 ? img.ctab[0] : (c < img.cfirst2 ? img.ctab[1] : img.ctab[2]);
+}
 
 template <class BitSrc>
 MJX_HD void lane_begin(LaneState &st, const BitSrc &bits, const HuffImage &img, SubseqState entry)
 {
     st.p = entry.p; st.z = entry.z; st.c = entry.c; st.n = 0; st.m = 0;
-    st.bpm = img.bpm;
-    st.tab = img.blktab[st.c];
-    st.tab_next = img.blktab[st.c + 1 == st.bpm ? 0 : st.c + 1];
+    st.tab = block_tab(img, st.c);
     st.wi = st.p >> 5; st.o = st.p & 31;
     st.w0 = bits.be32(st.wi); st.w1 = bits.be32(st.wi + 1); st.w2 = bits.raw32(st.wi + 2);
 }
@@ -164,9 +170,8 @@ MJX_HD void symbol_step(LaneState &st, const BitSrc &bits, const uint16_t *lut, 
     st.z = pos + 1;
     if (st.z == 64) {
         st.z = 0;
-        st.c = (st.c + 1 == st.bpm) ? 0 : st.c + 1;
-        st.tab = st.tab_next;
-        st.tab_next = img.blktab[st.c + 1 == st.bpm ? 0 : st.c + 1];
+        st.c = (st.c + 1 == img.bpm) ? 0 : st.c + 1;
+        st.tab = block_tab(img, st.c);
         st.n++;
         blk++;
         if (WRITE) sink.block_done(blk);

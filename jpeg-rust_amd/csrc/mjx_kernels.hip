@@ -247,8 +247,11 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_spec(const DevImage *im
     const SubseqState e = make_state(live ? s * kSubseqBits : 0u, 0, 0);
     NullSink sink;
     GlobalCps cps{cps_slot(g_cps, im.sub_off + s), kCpRow, 0};
-    const SubseqState x = wave_decode<false, 1, kSpecWin>(live, e, live ? subseq_end(*h, s) : 0u, 0, bits, s_win + (kSpecWin ? threadIdx.x * kWinStride : 0),
-                                                lut, *h, sink, cps, s * kSubseqBits, e);
+    // lanes do equal work, so the plain per-lane loop (exec-masked by the compiler) is the cheapest form
+    SubseqState x = e;
+    if (kSpecWin) x = wave_decode<false, 1, true>(live, e, live ? subseq_end(*h, s) : 0u, 0, bits, s_win + threadIdx.x * kWinStride,
+                                                  lut, *h, sink, cps, s * kSubseqBits, e);
+    else if (live) x = decode_subseq<false, 1>(bits, lut, *h, e, subseq_end(*h, s), 0, sink, cps, s * kSubseqBits, e);
     if (live) {
         g_entry[im.sub_off + s] = e;
         g_exit[im.sub_off + s] = x;
@@ -294,8 +297,10 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_merge(const DevImage *i
         cps.prime();
     }
     NullSink sink;
-    const SubseqState x = wave_decode<false, 2, kSpecWin>(need, e, need ? subseq_end(*h, s) : 0u, 0, bits, s_win + (kSpecWin ? threadIdx.x * kWinStride : 0),
-                                                lut, *h, sink, cps, s * kSubseqBits, old_exit);
+    SubseqState x = e;
+    if (kSpecWin) x = wave_decode<false, 2, true>(need, e, need ? subseq_end(*h, s) : 0u, 0, bits, s_win + threadIdx.x * kWinStride,
+                                                  lut, *h, sink, cps, s * kSubseqBits, old_exit);
+    else if (need) x = decode_subseq<false, 2>(bits, lut, *h, e, subseq_end(*h, s), 0, sink, cps, s * kSubseqBits, old_exit);
     if (need) g_exit[im.sub_off + s] = x;
 }
 

@@ -164,10 +164,12 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p)
     if (p.lut.size() > 0xffff) return fail(MJX_ERR_BAD_HUFFMAN);
     while (p.lut.size() % 8) p.lut.push_back(0);                                    // 16-byte granules for staging
     std::memset(&p.himg, 0, sizeof p.himg);
-    for (uint32_t b = 0; b < p.bpm; b++) {
-        const mjx_comp &k = d.comp[p.blk_comp[b]];
-        p.himg.blktab[b] = uint32_t(dc_base[k.td]) | (uint32_t(ac_base[k.ta]) << 16);
+    for (uint32_t c = 0; c < 3; c++) {
+        const mjx_comp &k = d.comp[c < p.ncomp ? c : 0];
+        p.himg.ctab[c] = uint32_t(dc_base[k.td]) | (uint32_t(ac_base[k.ta]) << 16);
     }
+    p.himg.cfirst1 = p.ncomp > 1 ? p.h[0] * p.v[0] : p.bpm;
+    p.himg.cfirst2 = p.ncomp > 2 ? p.himg.cfirst1 + p.h[1] * p.v[1] : p.bpm;
     p.himg.bpm = p.bpm;
     p.himg.total_bits = uint32_t(p.scan_len * 8);
     p.himg.total_blocks = p.nmcu * p.bpm;
