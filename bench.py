@@ -242,7 +242,7 @@ def main():
         out["roofline_e2e"] = {"bound": "hbm", "achieved": round(e2e, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(e2e / HBM_PEAK_GBS, 5), "bytes_per_step": int(e2e_bytes),
                                "kernel_ms_per_step": round(tot_ms / args.steps, 4),
-                               "definition": "sum(S + 3*W*H) / sum of kernel time" if args.stages == "all" else "(compact stream + DC + 3*W*H) / kernel time"}
+                               "definition": "sum(S + 3*W*H) / sum of kernel time" if args.stages == "all" else "B_idct = 128*n_blocks + 3*W*H (SURVEY s8(d)) / kernel time"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(mjx, datas, args.width, args.height, args.cpu_threads)
     batch.close()

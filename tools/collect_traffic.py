@@ -2,7 +2,7 @@
 passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) of `bench.py --images-per-gpu 128` (one chunk = one launch
 per kernel).  FETCH_SIZE is doubled: on gfx950 it reports half the bytes of wide coalesced reads (guide, section HBM);
 for the narrow reads of the entropy kernels that correction is an upper bound.  Usage:
-    python tools/collect_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01b_traffic.json"""
+    python tools/collect_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01b_traffic.json [images per launch]"""
 import collections, csv, glob, json, sys
 
 def per_launch(d, counter):
@@ -19,7 +19,7 @@ def per_launch(d, counter):
 fetch, write = per_launch(sys.argv[1], "FETCH_SIZE"), per_launch(sys.argv[2], "WRITE_SIZE")
 alias = {"k_huff_spec": "huff_sync", "k_huff_merge": "huff_fix", "k_huff_scan": "huff_scan", "k_huff_write": "huff_write",
          "k_idct_color": "idct_color"}
-out = {"images_per_launch": 128, "note": "bytes per launch; fetch = 2 x FETCH_SIZE (gfx950 correction), write = WRITE_SIZE",
+out = {"images_per_launch": int(sys.argv[4]) if len(sys.argv) > 4 else 128, "note": "bytes per launch; fetch = 2 x FETCH_SIZE (gfx950 correction), write = WRITE_SIZE",
        "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     out["kernels"][alias.get(k, k)] = {"fetch_bytes": int(2 * fetch.get(k, 0)), "write_bytes": int(write.get(k, 0)),
