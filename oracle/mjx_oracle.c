@@ -102,7 +102,7 @@ static void orc_htable_build(orc_env *env, orc_htable *t, const uint8_t size_dat
     }
     for (int l = 0; l <= 16; l++) { t->first[l] = 0; t->count[l] = 0; }
     /* codes_of_length :60-76: the first contiguous run of codes with that length */
-    for (int l = 2; l <= 16; l++) {
+    for (int l = 1; l <= 16; l++) {
         int a = 0;
         while (a < n && t->codes[a].length != l) a++;
         int b = a;
@@ -163,12 +163,12 @@ static uint16_t orc_read_n_bits(orc_env *env, orc_hdec *d, size_t n)
 /* huffman.rs:211-227 next_code: lengths 2..=16 ascending; returns -1 for None */
 static int orc_next_code(orc_hdec *d, const orc_htable *t, int faithful)
 {
-    for (int len = 2; len < 17; len++) {
+    for (int len = (faithful & 2) ? 1 : 2; len < 17; len++) {       /* bit 1 of `faithful`: ext_1bit (not reference) */
         uint16_t mask = (uint16_t)(0xffff0000u >> len);
         uint16_t current_16 = (uint16_t)(d->current >> 16);
         uint16_t bits = (uint16_t)((current_16 & mask) >> (16 - len));
         int a, b;
-        if (faithful) {
+        if (faithful & 1) {
             /* codes_of_length :60-76 re-scans the whole vector every call */
             a = 0;
             while (a < t->ncodes && t->codes[a].length != len) a++;
@@ -452,7 +452,7 @@ static void orc_jpeg_decode(orc_env *env, const orc_opts *opts, const orc_parse 
             const orc_htable *dc = &ps->dc[cf[c].dc_table_id];
             for (size_t k = 0; k < per_mcu[c]; k++) {
                 int16_t blk[64];
-                orc_next_block(env, &hd, ac, dc, opts->faithful_huff, blk);   /* :202 */
+                orc_next_block(env, &hd, ac, dc, (opts->faithful_huff ? 1 : 0) | (opts->ext_1bit ? 2 : 0), blk);   /* :202 */
                 float dcv = (float)blk[0] + prev_dc[c];                        /* :208-210 (f32, exact ints) */
                 prev_dc[c] = dcv;
                 int16_t *dst = out->coef[c] + (fill[c]++) * 64;
@@ -727,7 +727,7 @@ static void orc_parse_and_decode(orc_env *env, const uint8_t *vec, size_t len, c
 
 int orc_decode(const uint8_t *jpeg, size_t len, const orc_opts *opts, orc_image *out)
 {
-    static const orc_opts defaults = {0, ORC_LAYOUT_REF, 0, 0};
+    static const orc_opts defaults = {0, ORC_LAYOUT_REF, 0, 0, 0};
     const orc_opts *volatile o = opts ? opts : &defaults;
     memset(out, 0, sizeof *out);
     orc_env *env = (orc_env *)calloc(1, sizeof(orc_env));

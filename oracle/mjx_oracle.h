@@ -45,6 +45,8 @@ typedef struct {
                          0: same arithmetic with the 64 distinct cosf() values tabulated (bit-identical, faster) */
     int faithful_huff;/* 1: linear-search per length like huffman.rs:211-227 / 60-76 (CPU baseline);
                          0: same result via per-length first-code table */
+    int ext_1bit;     /* NOT reference behaviour: also try 1-bit codes (the reference starts at length 2, huffman.rs:211,
+                         SURVEY Q8, and panics on such tables).  Only used to check the GPU path's superset behaviour. */
 } orc_opts;
 
 typedef struct {

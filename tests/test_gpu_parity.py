@@ -228,3 +228,22 @@ def test_repair_path_when_the_enqueued_rounds_do_not_converge(mjx, orc, data_dir
     env = dict(os.environ, MJX_FIX_PASSES="1")
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "repair ok" in out.stdout, out.stdout + out.stderr
+
+
+PIL_FIXTURES = {"opt_420_q85.jpg": True, "opt_444_q40.jpg": True, "opt_422_q95.jpg": False, "std_420_q100.jpg": False,
+                "opt_gray_q70.jpg": False, "opt_420_q10.jpg": True, "std_420_big.jpg": False}
+
+
+@pytest.mark.parametrize("name", sorted(PIL_FIXTURES))
+def test_libjpeg_written_files(mjx, orc, gpu_ctx, name):
+    """Optimised (non Annex-K) Huffman tables, quality 10..100, all samplings; files with a 1-bit code are beyond
+    the reference and are checked against the oracle's 1-bit extension."""
+    data = open(os.path.join(os.path.dirname(__file__), "golden", "pil", name), "rb").read()
+    scan = mjx.ParsedScan(data)
+    batch = mjx.Batch(gpu_ctx, [scan], keep_coefs=True)
+    batch.decode()
+    batch.wait()
+    assert batch.status(0) == mjx.OK
+    ref = orc.decode(data, layout=orc.LAYOUT_STD, ext_1bit=PIL_FIXTURES[name])
+    _check(ref, batch.coefs(0), batch.rgb(0), name)
+    batch.close()

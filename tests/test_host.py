@@ -192,3 +192,28 @@ def test_ref_compat_panic_detection_matches_the_oracle(mjx, orc):
                 checked += 1
                 panics += not ref_ok
     assert checked == 360 and panics > 10
+
+
+PIL_DIR = os.path.join(ROOT, "tests", "golden", "pil")
+# files written by libjpeg (tests/golden/pil): name -> (needs the 1-bit-code extension of the oracle)
+PIL_FIXTURES = {"opt_420_q85.jpg": True, "opt_444_q40.jpg": True, "opt_422_q95.jpg": False, "std_420_q100.jpg": False,
+                "opt_gray_q70.jpg": False, "opt_420_q10.jpg": True, "std_420_big.jpg": False}
+
+
+@pytest.mark.parametrize("name", sorted(PIL_FIXTURES))
+def test_libjpeg_written_files_on_the_emulation(mjx, orc, emul, name):
+    data = open(os.path.join(PIL_DIR, name), "rb").read()
+    needs_ext = PIL_FIXTURES[name]
+    if needs_ext:                       # optimised tables with a 1-bit code: the reference itself cannot decode them
+        with pytest.raises(orc.OracleError):
+            orc.decode(data, layout=orc.LAYOUT_STD)
+    ref = orc.decode(data, layout=orc.LAYOUT_STD, ext_1bit=needs_ext)
+    rc, coefs, st = emul(data, 0)
+    assert rc == 0 and np.array_equal(coefs, orc.interleave(ref))
+
+
+def test_progressive_and_restart_files_are_rejected(mjx):
+    prog = open(os.path.join(PIL_DIR, "progressive.jpg"), "rb").read()
+    rst = open(os.path.join(PIL_DIR, "restart.jpg"), "rb").read()
+    assert _code(mjx, prog, False) == mjx.ERR_UNSUPPORTED_FORMAT and _code(mjx, prog, True) == mjx.ERR_UNSUPPORTED_MARKER
+    assert _code(mjx, rst, False) == mjx.ERR_DRI_UNSUPPORTED          # jpeg/mod.rs:424-428
