@@ -42,6 +42,7 @@ def parse_args():
     ap.add_argument("--unique", type=int, default=64, help="distinct synthetic images in the global batch (SURVEY s8(d))")
     ap.add_argument("--chunk-images", type=int, default=0)
     ap.add_argument("--stages", default="all", choices=["all", "pixels"], help="pixels = stage-B-only sweep on resident coefficients")
+    ap.add_argument("--device-destuff", action="store_true", help="upload stuffed scans; FF00 compaction on the GPU at upload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
@@ -162,7 +163,7 @@ def main():
         datas = list(ex.map(lambda s: mjx.synth_jpeg(args.width, args.height, args.subsampling, args.quality, s), seeds))
 
     ctx = mjx.Context(device, profiling=True)
-    scans = [mjx.ParsedScan(d) for d in datas]
+    scans = [mjx.ParsedScan(d, device_destuff=args.device_destuff) for d in datas]
     keep = args.stages == "pixels"
     base = mjx.Batch(ctx, scans, keep_coefs=keep, chunk_images=args.chunk_images)
     assert all(s == mjx.OK for s in base.create_status), base.create_status

@@ -45,7 +45,8 @@ typedef struct mjx_opts {
     uint8_t strict_ref;   /* 1: unknown / APP12 / APP14 markers are errors like the reference; 0: skip them */
     uint8_t layout;       /* MJX_LAYOUT_* */
     uint8_t keep_coefs;   /* 1: keep the whole batch's coefficient stream resident (T0 checks, stage-B-only sweeps) */
-    uint8_t reserved0;
+    uint8_t device_destuff;/* mjx_parse: 1 = leave the entropy-coded segment byte-stuffed (desc.scan_is_stuffed = 1); the FF00 -> FF
+                             compaction of jpeg/mod.rs:371-385 then runs on the GPU inside mjx_batch_create */
     uint32_t chunk_images;/* images per kernel chunk; 0 = library default */
 } mjx_opts;
 
@@ -60,7 +61,8 @@ typedef struct mjx_hufftab {       /* the two slices given to HuffmanTable::from
 } mjx_hufftab;
 
 typedef struct mjx_scan_desc {
-    const uint8_t *scan;           /* de-stuffed bytes after the SOS header to end of file (jpeg/mod.rs:371-385) */
+    const uint8_t *scan;           /* bytes after the SOS header to end of file, de-stuffed (jpeg/mod.rs:371-385) unless
+                                      scan_is_stuffed */
     size_t scan_len;
     uint16_t width, height;        /* .dimensions() decoder.rs:66 */
     uint8_t ncomp;                 /* 1 or 3 */
@@ -69,6 +71,7 @@ typedef struct mjx_scan_desc {
     uint8_t qt_present;            /* bit i = slot i defined */
     mjx_hufftab dc[4], ac[4];      /* .huffman_dc_tables() / .huffman_ac_tables() decoder.rs:71-77 */
     uint8_t dc_present, ac_present;
+    uint8_t scan_is_stuffed;       /* 1: `scan` still holds FF00 pairs; mjx_batch_create de-stuffs on the device */
     void *owner_;                  /* internal: storage behind `scan` when filled by mjx_parse */
 } mjx_scan_desc;
 

@@ -42,7 +42,7 @@ class MjxError(RuntimeError):
 
 class Opts(ctypes.Structure):
     _fields_ = [("strict_ref", ctypes.c_uint8), ("layout", ctypes.c_uint8), ("keep_coefs", ctypes.c_uint8),
-                ("reserved0", ctypes.c_uint8), ("chunk_images", ctypes.c_uint32)]
+                ("device_destuff", ctypes.c_uint8), ("chunk_images", ctypes.c_uint32)]
 
 
 class Comp(ctypes.Structure):
@@ -58,7 +58,7 @@ class ScanDesc(ctypes.Structure):
                 ("width", ctypes.c_uint16), ("height", ctypes.c_uint16), ("ncomp", ctypes.c_uint8),
                 ("comp", Comp * 3), ("qt", (ctypes.c_uint16 * 64) * 4), ("qt_present", ctypes.c_uint8),
                 ("dc", HuffTab * 4), ("ac", HuffTab * 4), ("dc_present", ctypes.c_uint8),
-                ("ac_present", ctypes.c_uint8), ("owner_", ctypes.c_void_p)]
+                ("ac_present", ctypes.c_uint8), ("scan_is_stuffed", ctypes.c_uint8), ("owner_", ctypes.c_void_p)]
 
 
 class Image(ctypes.Structure):
@@ -124,18 +124,18 @@ def _check(rc, what=""):
         raise MjxError(rc, what)
 
 
-def _opts(strict_ref=False, layout=LAYOUT_STANDARD, keep_coefs=False, chunk_images=0):
-    return Opts(int(bool(strict_ref)), int(layout), int(bool(keep_coefs)), 0, int(chunk_images))
+def _opts(strict_ref=False, layout=LAYOUT_STANDARD, keep_coefs=False, chunk_images=0, device_destuff=False):
+    return Opts(int(bool(strict_ref)), int(layout), int(bool(keep_coefs)), int(bool(device_destuff)), int(chunk_images))
 
 
 # ---- host parse ------------------------------------------------------------------------------------
 class ParsedScan:
     """Owns one mjx_scan_desc filled by mjx_parse (reference: the state JPEGImage::parse hands to JPEGDecoder)."""
 
-    def __init__(self, data, strict_ref=False):
+    def __init__(self, data, strict_ref=False, device_destuff=False):
         self.desc = ScanDesc()
         self._owned = False
-        o = _opts(strict_ref=strict_ref)
+        o = _opts(strict_ref=strict_ref, device_destuff=device_destuff)
         _check(lib().mjx_parse(bytes(data), len(data), ctypes.byref(o), ctypes.byref(self.desc)), "mjx_parse")
         self._owned = True
 

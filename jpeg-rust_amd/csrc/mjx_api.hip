@@ -365,10 +365,21 @@ void collect_events(mjx_batch *b)
     b->events.clear();
 }
 
-// Builds a batch from plans.  Scan bytes come from the plans' host pointers, or (src != nullptr) are copied on the
-// device from `src`'s pool, `times` repetitions of its images.
+// Images whose scan arrives byte-stuffed: the FF00 -> FF compaction runs on the device (k_destuff_*).
+struct DestuffPlan {
+    uint8_t *d_raw = nullptr;
+    uint32_t *d_segbase = nullptr;
+    std::vector<DestuffImg> imgs;      // one per stuffed image; out_off is filled in by build_batch
+    std::vector<size_t> plan_index;    // which plan each entry belongs to
+    uint32_t max_seg = 0;
+    ~DestuffPlan() { (void)hipFree(d_raw); (void)hipFree(d_segbase); }
+};
+
+// Builds a batch from plans.  Scan bytes come from the plans' host pointers (or, for the images listed in `ds`, from
+// the device-side de-stuffing of their raw bytes), or (src != nullptr) are copied on the device from `src`'s pool,
+// `times` repetitions of its images.
 int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opts &opts, const mjx_batch *src,
-                size_t times, mjx_batch **out, int *status)
+                size_t times, mjx_batch **out, int *status, DestuffPlan *ds = nullptr)
 {
     mjx_batch *b = new (std::nothrow) mjx_batch;
     if (!b) return MJX_ERR_NOMEM;
@@ -446,14 +457,37 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
             std::vector<uint8_t> hs(scan_pool, 0xaa);
             std::vector<uint16_t> hl(std::max<size_t>(lut_pool, 8), 0);
             std::vector<float> hq(std::max<size_t>(nu, 1) * 192, 0.f);
+            std::vector<char> on_device(nu, 0);
+            if (ds) for (size_t idx : ds->plan_index) on_device[idx] = 1;
             for (size_t k = 0; k < nu; k++) {
                 const ImagePlan &p = plans[k];
                 if (p.status != MJX_OK) continue;
-                std::memcpy(hs.data() + scan_off[k], p.scan, p.scan_len);
+                if (!on_device[k]) std::memcpy(hs.data() + scan_off[k], p.scan, p.scan_len);
                 std::memcpy(hl.data() + lut_off[k], p.lut.data(), p.lut.size() * sizeof(uint16_t));
                 std::memcpy(hq.data() + k * 192, p.qmult, sizeof p.qmult);
             }
             HIPOK(hipMemcpy(b->d_scan, hs.data(), scan_pool, hipMemcpyHostToDevice));
+            if (ds && !ds->imgs.empty()) {                 // compact the stuffed scans straight into the pool
+                std::vector<DestuffImg> di;
+                for (size_t j = 0; j < ds->imgs.size(); j++) {
+                    if (plans[ds->plan_index[j]].status != MJX_OK) continue;
+                    DestuffImg x = ds->imgs[j];
+                    x.out_off = scan_off[ds->plan_index[j]];
+                    di.push_back(x);
+                }
+                if (!di.empty()) {
+                    DestuffImg *d_di = nullptr;
+                    HIPOK(hipMalloc(&d_di, di.size() * sizeof(DestuffImg)));
+                    int rc3 = MJX_OK;
+                    if (hipMemcpy(d_di, di.data(), di.size() * sizeof(DestuffImg), hipMemcpyHostToDevice) != hipSuccess) rc3 = MJX_ERR_DEVICE;
+                    if (rc3 == MJX_OK) {
+                        launch_destuff_scatter(ctx->stream, ds->max_seg, uint32_t(di.size()), d_di, ds->d_raw, ds->d_segbase, b->d_scan);
+                        if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc3 = MJX_ERR_DEVICE;
+                    }
+                    (void)hipFree(d_di);
+                    if (rc3 != MJX_OK) return rc3;
+                }
+            }
             HIPOK(hipMemcpy(b->d_lut, hl.data(), hl.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             HIPOK(hipMemcpy(b->d_qm, hq.data(), hq.size() * sizeof(float), hipMemcpyHostToDevice));
         }
@@ -519,9 +553,66 @@ extern "C" int mjx_batch_create(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t
     *out = nullptr;
     mjx_opts o{};
     if (opts) o = *opts;
+    std::vector<mjx_scan_desc> dd(descs, descs + n);
+    DestuffPlan ds;
+    bool any_stuffed = false;
+    for (size_t i = 0; i < n; i++) any_stuffed = any_stuffed || (dd[i].scan_is_stuffed && dd[i].scan);
+    if (any_stuffed) {
+        // upload the raw segments, count the bytes that survive de-stuffing: the de-stuffed length fixes the geometry
+        HIPOK(hipSetDevice(ctx->device));
+        size_t raw_bytes = 0;
+        uint32_t nseg_total = 0;
+        for (size_t i = 0; i < n; i++) {
+            if (!dd[i].scan_is_stuffed || !dd[i].scan) continue;
+            DestuffImg x{};
+            x.raw_off = raw_bytes;
+            x.raw_len = dd[i].scan_len;
+            x.seg0 = nseg_total;
+            x.nseg = uint32_t((dd[i].scan_len + kDestuffSeg - 1) / kDestuffSeg);
+            raw_bytes += align_up(dd[i].scan_len, 16) + 16;
+            nseg_total += x.nseg;
+            ds.max_seg = std::max(ds.max_seg, x.nseg);
+            ds.imgs.push_back(x);
+            ds.plan_index.push_back(i);
+        }
+        std::vector<uint8_t> hraw(std::max<size_t>(raw_bytes, 16), 0);
+        for (size_t j = 0; j < ds.imgs.size(); j++)
+            std::memcpy(hraw.data() + ds.imgs[j].raw_off, dd[ds.plan_index[j]].scan, ds.imgs[j].raw_len);
+        DestuffImg *d_di = nullptr;
+        uint32_t *d_cnt = nullptr;
+        std::vector<uint32_t> cnt(std::max<uint32_t>(nseg_total, 1), 0);
+        int rc = MJX_OK;
+        if (hipMalloc(&ds.d_raw, hraw.size()) != hipSuccess || hipMalloc(&d_di, ds.imgs.size() * sizeof(DestuffImg)) != hipSuccess ||
+            hipMalloc(&d_cnt, cnt.size() * 4) != hipSuccess || hipMalloc(&ds.d_segbase, cnt.size() * 4) != hipSuccess)
+            rc = MJX_ERR_DEVICE;
+        if (rc == MJX_OK && (hipMemcpy(ds.d_raw, hraw.data(), hraw.size(), hipMemcpyHostToDevice) != hipSuccess ||
+                             hipMemcpy(d_di, ds.imgs.data(), ds.imgs.size() * sizeof(DestuffImg), hipMemcpyHostToDevice) != hipSuccess))
+            rc = MJX_ERR_DEVICE;
+        if (rc == MJX_OK && nseg_total) {
+            launch_destuff_count(ctx->stream, ds.max_seg, uint32_t(ds.imgs.size()), d_di, ds.d_raw, d_cnt);
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess ||
+                hipMemcpy(cnt.data(), d_cnt, cnt.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+                rc = MJX_ERR_DEVICE;
+        }
+        if (rc == MJX_OK) {
+            std::vector<uint32_t> base(cnt.size(), 0);
+            for (size_t j = 0; j < ds.imgs.size(); j++) {
+                uint64_t run = 0;
+                for (uint32_t sgi = 0; sgi < ds.imgs[j].nseg; sgi++) {
+                    base[ds.imgs[j].seg0 + sgi] = uint32_t(run);
+                    run += cnt[ds.imgs[j].seg0 + sgi];
+                }
+                dd[ds.plan_index[j]].scan_len = size_t(run);          // de-stuffed length
+            }
+            if (hipMemcpy(ds.d_segbase, base.data(), base.size() * 4, hipMemcpyHostToDevice) != hipSuccess) rc = MJX_ERR_DEVICE;
+        }
+        (void)hipFree(d_di);
+        (void)hipFree(d_cnt);
+        if (rc != MJX_OK) { (void)hipGetLastError(); return rc; }
+    }
     std::vector<ImagePlan> plans(n);
-    for (size_t i = 0; i < n; i++) plan_image(descs[i], o, plans[i]);
-    return build_batch(ctx, plans, o, nullptr, 1, out, status);
+    for (size_t i = 0; i < n; i++) plan_image(dd[i], o, plans[i]);
+    return build_batch(ctx, plans, o, nullptr, 1, out, status, any_stuffed ? &ds : nullptr);
 }
 
 // Host-only: would this scan decode?  Runs the same planning step as mjx_batch_create (tables, geometry, and for

@@ -38,6 +38,14 @@ struct DevImage {
     uint64_t plane_off;     // 64-bit words into the plane scratch (ncomp planes of width*height words)
 };
 
+// Device-side de-stuffing (jpeg/mod.rs:371-385 on the GPU): one image of an upload.
+constexpr int kDestuffSeg = 16384;       // raw bytes per workgroup
+struct DestuffImg {
+    uint64_t raw_off, raw_len;           // stuffed bytes in the raw staging buffer
+    uint64_t out_off;                    // where the de-stuffed scan goes in the scan pool
+    uint32_t seg0, nseg;                 // this image's slots in the per-segment count / base arrays
+};
+
 // MCUs per stage-B tile: a power of two so that lane -> (MCU, strip) is a shift, and at most 256 strips per row.
 inline uint32_t tile_mcus(uint32_t bpm, uint32_t hmax)
 {
@@ -53,6 +61,10 @@ inline uint32_t tile_mcus(uint32_t bpm, uint32_t hmax)
 size_t huff_lds_bytes(uint32_t lut_cap_entries);
 size_t idct_lds_bytes(uint32_t max_tile_blocks);
 int configure_kernels(size_t huff_lds, size_t idct_lds);
+void launch_destuff_count(hipStream_t st, uint32_t max_seg, uint32_t nimg, const DestuffImg *imgs, const uint8_t *raw,
+                          uint32_t *segcount);
+void launch_destuff_scatter(hipStream_t st, uint32_t max_seg, uint32_t nimg, const DestuffImg *imgs, const uint8_t *raw,
+                            const uint32_t *segbase, uint8_t *pool);
 void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
                       const uint8_t *scan_pool, const uint16_t *lut_pool, SubseqState *entry, SubseqState *exit_,
                       uint32_t *cps, uint32_t cp_stride);

@@ -328,6 +328,58 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t *s_tm
     return base + incl - v;
 }
 
+// ---- device-side de-stuffing -------------------------------------------------------------------------------
+// jpeg/mod.rs:371-385 copies the bytes after the SOS header and drops the 00 of every FF 00 pair.  Whether byte i is
+// dropped depends only on bytes i-1 and i (a dropped byte is 00, so it never starts a pair itself): keep(i) =
+// !(b[i] == 00 && b[i-1] == FF).  So the copy is a stream compaction: count the kept bytes per 16 KiB segment, prefix
+// the counts per image (host, a few dozen numbers per image), then every lane writes the kept bytes of its 64-byte
+// piece at segment base + workgroup-scan offset.  Runs once per upload, before any decode.
+__device__ __forceinline__ uint32_t destuff_keep_mask(const uint8_t *raw, uint64_t i0, uint64_t raw_len, uint64_t *mask_out)
+{
+    // keep flags of the 64 bytes [i0, i0+64) as a bit mask; returns the number of kept bytes
+    uint64_t mask = 0;
+    uint8_t prev = i0 > 0 && i0 <= raw_len ? raw[i0 - 1] : 0;
+    for (uint32_t k = 0; k < 64; k++) {
+        const uint64_t i = i0 + k;
+        if (i >= raw_len) break;
+        const uint8_t b = raw[i];
+        if (!(b == 0x00 && prev == 0xff)) mask |= 1ull << k;
+        prev = b;
+    }
+    *mask_out = mask;
+    return uint32_t(__popcll(mask));
+}
+
+extern "C" __global__ __launch_bounds__(256) void k_destuff_count(const DestuffImg *imgs, const uint8_t *raw,
+                                                                   uint32_t *segcount)
+{
+    __shared__ uint32_t s_tmp[4];
+    const DestuffImg im = imgs[blockIdx.y];
+    if (blockIdx.x >= im.nseg) return;
+    uint64_t mask;
+    const uint32_t cnt = destuff_keep_mask(raw + im.raw_off, uint64_t(blockIdx.x) * kDestuffSeg + threadIdx.x * 64ull, im.raw_len, &mask);
+    uint32_t total;
+    (void)wg_exclusive_scan(cnt, s_tmp, &total);
+    if (threadIdx.x == 0) segcount[im.seg0 + blockIdx.x] = total;
+}
+
+extern "C" __global__ __launch_bounds__(256) void k_destuff_scatter(const DestuffImg *imgs, const uint8_t *raw,
+                                                                     const uint32_t *segbase, uint8_t *pool)
+{
+    __shared__ uint32_t s_tmp[4];
+    const DestuffImg im = imgs[blockIdx.y];
+    if (blockIdx.x >= im.nseg) return;
+    const uint8_t *src = raw + im.raw_off;
+    const uint64_t i0 = uint64_t(blockIdx.x) * kDestuffSeg + threadIdx.x * 64ull;
+    uint64_t mask;
+    const uint32_t cnt = destuff_keep_mask(src, i0, im.raw_len, &mask);
+    uint32_t total;
+    uint32_t o = segbase[im.seg0 + blockIdx.x] + wg_exclusive_scan(cnt, s_tmp, &total);
+    uint8_t *dst = pool + im.out_off;
+    for (uint32_t k = 0; k < 64; k++)
+        if ((mask >> k) & 1) dst[o++] = src[i0 + k];
+}
+
 // blkbase[s] / ebase[s] = blocks completed / stream entries produced before subsequence s (one workgroup per image).
 extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *images, const SubseqState *g_exit,
                                                                uint32_t *g_blkbase, uint32_t *g_ebase,
@@ -1011,6 +1063,18 @@ int configure_kernels(size_t huff_lds, size_t idct_lds)
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_idct_color<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
     }
     return e == hipSuccess ? 0 : int(e);
+}
+
+void launch_destuff_count(hipStream_t st, uint32_t max_seg, uint32_t nimg, const DestuffImg *imgs, const uint8_t *raw,
+                          uint32_t *segcount)
+{
+    hipLaunchKernelGGL(k_destuff_count, dim3(max_seg, nimg), dim3(256), 0, st, imgs, raw, segcount);
+}
+
+void launch_destuff_scatter(hipStream_t st, uint32_t max_seg, uint32_t nimg, const DestuffImg *imgs, const uint8_t *raw,
+                            const uint32_t *segbase, uint8_t *pool)
+{
+    hipLaunchKernelGGL(k_destuff_scatter, dim3(max_seg, nimg), dim3(256), 0, st, imgs, raw, segbase, pool);
 }
 
 void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,

@@ -125,7 +125,7 @@ void read_dht(const ByteView &f, size_t pos, size_t len, mjx_scan_desc *d)      
 }
 
 // SOS header (mod.rs:337-362) + component re-ordering (decoder.rs:83-152) + de-stuffing (mod.rs:371-385).
-void read_sos(const ByteView &f, size_t pos, ParserState &st, bool strict)
+void read_sos(const ByteView &f, size_t pos, ParserState &st, bool strict, bool keep_stuffed)
 {
     mjx_scan_desc *d = st.d;
     const unsigned n = f.at(pos);
@@ -155,7 +155,12 @@ void read_sos(const ByteView &f, size_t pos, ParserState &st, bool strict)
     if (!buf) throw ParseError{MJX_ERR_NOMEM};
     size_t w = 0;
     const uint8_t *src = remain ? f.span(i, remain) : nullptr;
-    for (size_t k = 0; k < remain; k++) {
+    if (keep_stuffed) {                                  // the GPU compacts FF00 pairs (mjx_batch_create)
+        if (remain) std::memcpy(buf, src, remain);
+        w = remain;
+        d->scan_is_stuffed = 1;
+    }
+    for (size_t k = 0; !keep_stuffed && k < remain; k++) {
         const uint8_t b = src[k];
         buf[w++] = b;
         if (b == 0xff) {
@@ -199,7 +204,7 @@ void walk(const uint8_t *jpeg, size_t len, const mjx_opts &opts, mjx_scan_desc *
         case Seg::DQT: read_dqt(f, i, body, out, strict); break;
         case Seg::SOF0: read_sof0(f, i, st, strict); break;
         case Seg::DHT: read_dht(f, i, body, out); break;
-        case Seg::SOS: read_sos(f, i, st, strict); return;                        // :415-417 returns after the first scan
+        case Seg::SOS: read_sos(f, i, st, strict, opts.device_destuff != 0); return;                        // :415-417 returns after the first scan
         case Seg::DRI: throw ParseError{MJX_ERR_DRI_UNSUPPORTED};                 // :424-428
         case Seg::APP0:                                                            // :429-443 absolute offsets up to vec[15]
             (void)f.span(i, 6);

@@ -247,3 +247,28 @@ def test_libjpeg_written_files(mjx, orc, gpu_ctx, name):
     ref = orc.decode(data, layout=orc.LAYOUT_STD, ext_1bit=PIL_FIXTURES[name])
     _check(ref, batch.coefs(0), batch.rgb(0), name)
     batch.close()
+
+
+# ---- byte de-stuffing on the device ---------------------------------------------------------------
+def test_device_side_destuffing_matches_host_destuffing(mjx, orc, gpu_ctx, data_dir):
+    datas = [open(os.path.join(data_dir, n), "rb").read() for n in FIXTURES]          # lena.jpeg holds 464 FF00 pairs
+    datas += [mjx.synth_jpeg(w, h, s, q, seed=i) for i, (w, h, s, q) in enumerate(
+        [(1920, 1080, "420", 95), (640, 480, "444", 98), (333, 222, "422", 90), (64, 64, "gray", 100), (17, 9, "420", 99)])]
+    stuffed = [mjx.ParsedScan(d, device_destuff=True) for d in datas]
+    plain = [mjx.ParsedScan(d) for d in datas]
+    n_pairs = 0
+    for s, p in zip(stuffed, plain):
+        assert s.desc.scan_is_stuffed == 1 and p.desc.scan_is_stuffed == 0
+        assert s.desc.scan_len >= p.desc.scan_len
+        n_pairs += s.desc.scan_len - p.desc.scan_len
+    assert n_pairs > 1000                                      # the inputs really exercise the compaction
+    mixed = [s if i % 2 == 0 else p for i, (s, p) in enumerate(zip(stuffed, plain))]
+    for scans in (stuffed, mixed):
+        batch = mjx.Batch(gpu_ctx, scans, keep_coefs=True)
+        assert all(st == mjx.OK for st in batch.create_status)
+        batch.decode()
+        batch.wait()
+        for i, d in enumerate(datas):
+            ref = orc.decode(d, layout=orc.LAYOUT_STD)
+            _check(ref, batch.coefs(i), batch.rgb(i), "device destuff image %d" % i)
+        batch.close()
