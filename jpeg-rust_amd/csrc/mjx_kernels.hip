@@ -334,17 +334,28 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t *s_tm
 // !(b[i] == 00 && b[i-1] == FF).  So the copy is a stream compaction: count the kept bytes per 16 KiB segment, prefix
 // the counts per image (host, a few dozen numbers per image), then every lane writes the kept bytes of its 64-byte
 // piece at segment base + workgroup-scan offset.  Runs once per upload, before any decode.
-__device__ __forceinline__ uint32_t destuff_keep_mask(const uint8_t *raw, uint64_t i0, uint64_t raw_len, uint64_t *mask_out)
+// keep flags of the 64 bytes [i0, i0+64) of `raw` as a bit mask (+ the bytes themselves in q[0..3]); returns the
+// number of kept bytes.  The raw staging buffer is 16-byte aligned per image and padded, so 16-byte loads are safe.
+__device__ __forceinline__ uint32_t destuff_keep_mask(const uint8_t *raw, uint64_t i0, uint64_t raw_len, uint4 q[4],
+                                                      uint64_t *mask_out)
 {
-    // keep flags of the 64 bytes [i0, i0+64) as a bit mask; returns the number of kept bytes
     uint64_t mask = 0;
-    uint8_t prev = i0 > 0 && i0 <= raw_len ? raw[i0 - 1] : 0;
-    for (uint32_t k = 0; k < 64; k++) {
-        const uint64_t i = i0 + k;
-        if (i >= raw_len) break;
-        const uint8_t b = raw[i];
-        if (!(b == 0x00 && prev == 0xff)) mask |= 1ull << k;
-        prev = b;
+    if (i0 < raw_len) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(raw + i0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) q[k] = src[k];
+        uint32_t prev = i0 > 0 ? raw[i0 - 1] : 0u;
+        const uint32_t n = uint32_t(min(uint64_t(64), raw_len - i0));
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t w[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const uint32_t b = (w[j >> 2] >> ((j & 3) * 8)) & 0xffu;
+                if (!(b == 0x00u && prev == 0xffu) && uint32_t(k * 16 + j) < n) mask |= 1ull << (k * 16 + j);
+                prev = b;
+            }
+        }
     }
     *mask_out = mask;
     return uint32_t(__popcll(mask));
@@ -357,27 +368,38 @@ extern "C" __global__ __launch_bounds__(256) void k_destuff_count(const DestuffI
     const DestuffImg im = imgs[blockIdx.y];
     if (blockIdx.x >= im.nseg) return;
     uint64_t mask;
-    const uint32_t cnt = destuff_keep_mask(raw + im.raw_off, uint64_t(blockIdx.x) * kDestuffSeg + threadIdx.x * 64ull, im.raw_len, &mask);
+    uint4 q[4];
+    const uint32_t cnt = destuff_keep_mask(raw + im.raw_off, uint64_t(blockIdx.x) * kDestuffSeg + threadIdx.x * 64ull, im.raw_len, q, &mask);
     uint32_t total;
     (void)wg_exclusive_scan(cnt, s_tmp, &total);
     if (threadIdx.x == 0) segcount[im.seg0 + blockIdx.x] = total;
 }
 
+// The workgroup compacts its 16 KiB segment into LDS (each lane drops its kept bytes at its scan offset), then writes
+// the compacted bytes out in lane order, so a wave stores 64 consecutive bytes per instruction.
 extern "C" __global__ __launch_bounds__(256) void k_destuff_scatter(const DestuffImg *imgs, const uint8_t *raw,
                                                                      const uint32_t *segbase, uint8_t *pool)
 {
     __shared__ uint32_t s_tmp[4];
+    __shared__ uint8_t s_out[kDestuffSeg];
     const DestuffImg im = imgs[blockIdx.y];
     if (blockIdx.x >= im.nseg) return;
-    const uint8_t *src = raw + im.raw_off;
     const uint64_t i0 = uint64_t(blockIdx.x) * kDestuffSeg + threadIdx.x * 64ull;
     uint64_t mask;
-    const uint32_t cnt = destuff_keep_mask(src, i0, im.raw_len, &mask);
+    uint4 q[4];
+    const uint32_t cnt = destuff_keep_mask(raw + im.raw_off, i0, im.raw_len, q, &mask);
     uint32_t total;
-    uint32_t o = segbase[im.seg0 + blockIdx.x] + wg_exclusive_scan(cnt, s_tmp, &total);
-    uint8_t *dst = pool + im.out_off;
-    for (uint32_t k = 0; k < 64; k++)
-        if ((mask >> k) & 1) dst[o++] = src[i0 + k];
+    uint32_t o = wg_exclusive_scan(cnt, s_tmp, &total);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t w[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if ((mask >> (k * 16 + j)) & 1) s_out[o++] = uint8_t(w[j >> 2] >> ((j & 3) * 8));
+    }
+    __syncthreads();
+    uint8_t *dst = pool + im.out_off + segbase[im.seg0 + blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < total; i += 256) dst[i] = s_out[i];
 }
 
 // blkbase[s] / ebase[s] = blocks completed / stream entries produced before subsequence s (one workgroup per image).
