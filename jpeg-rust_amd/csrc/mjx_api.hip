@@ -34,7 +34,7 @@ struct mjx_ctx {
     // Extra dynamic LDS for k_huff_spec: caps it at 5 workgroups (20 waves) per CU.  Every lane streams its own
     // 512-byte subsequence, so the lines in flight grow with occupancy; past ~20 waves/CU they no longer fit the XCD's
     // 4 MB L2 and the kernel slows down (measured: 5.5 ms at 32 waves/CU vs 3.5 ms at 20, 1024 x 4K).
-    size_t spec_lds_pad = 22000;
+    size_t spec_lds_pad = 0;       // LDS padding = occupancy caps for experiments (MJX_*_LDS_PAD)
     size_t merge_lds_pad = 0;      // the merge rounds are latency-bound on few lanes and prefer full occupancy
     size_t write_lds_pad = 0;
 };
@@ -81,7 +81,7 @@ struct mjx_batch {
     DevImage *d_images = nullptr;
     uint8_t *d_scan = nullptr;
     size_t scan_pool_bytes = 0;
-    uint16_t *d_lut = nullptr;
+    LutEntry *d_lut = nullptr;
     float *d_qm = nullptr;
     SubseqState *d_entry = nullptr, *d_exit = nullptr;
     uint32_t *d_blkbase = nullptr;
@@ -200,8 +200,8 @@ void plan_chunks(mjx_batch *b)
                 c.tiles += inf.ntiles + 1;
                 c.nsub += d.himg.nsub;
                 c.blocks += inf.nblocks;
-                c.max_wg = std::max<uint32_t>(c.max_wg, (d.himg.nsub + kWgLanes - 1) / kWgLanes);
-                if (d.himg.nsub > 1) c.merge_wgs = std::max<uint32_t>(c.merge_wgs, (d.himg.nsub - 1 + kWgLanes - 1) / kWgLanes);
+                c.max_wg = std::max<uint32_t>(c.max_wg, (d.himg.nsub + kHuffWg - 1) / kHuffWg);
+                if (d.himg.nsub > 1) c.merge_wgs = std::max<uint32_t>(c.merge_wgs, (d.himg.nsub - 1 + kHuffWg - 1) / kHuffWg);
                 const uint32_t T = 1u << d.log2_tile;
                 c.max_tiles = std::max<uint32_t>(c.max_tiles, (d.nmcu + T - 1) / T);
                 c.max_tile_blocks = std::max<uint32_t>(c.max_tile_blocks, T * d.bpm);
@@ -277,8 +277,11 @@ int allocate_work_buffers(mjx_batch *b)
     std::memset(b->h_mismatch, 0, mm);
     b->huff_lds = huff_lds_bytes(lut_cap);
     b->idct_lds = idct_lds_bytes(max_tile_blocks);
-    if (b->huff_lds > 160 * 1024 || b->idct_lds > 160 * 1024) return MJX_ERR_UNSUPPORTED_FORMAT;
-    if (configure_kernels(b->huff_lds, b->idct_lds) != 0) { (void)hipGetLastError(); return MJX_ERR_DEVICE; }
+    if (b->huff_lds + huff_window_bytes() + huff_stage_bytes() > 160 * 1024 || b->idct_lds > 160 * 1024) return MJX_ERR_UNSUPPORTED_FORMAT;
+    {
+        const size_t pad = std::max(b->ctx->spec_lds_pad, std::max(b->ctx->merge_lds_pad, b->ctx->write_lds_pad));
+        if (configure_kernels(b->huff_lds + huff_window_bytes() + huff_stage_bytes() + pad, b->idct_lds) != 0) { (void)hipGetLastError(); return MJX_ERR_DEVICE; }
+    }
     return MJX_OK;
 }
 
@@ -313,7 +316,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     fix_passes = std::min(fix_passes, kMaxFix);
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_SYNC)) {
         prof_begin(b, MJX_K_HUFF_SYNC);
-        launch_huff_spec(st, c.max_wg, nimg, b->huff_lds + b->ctx->spec_lds_pad, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, b->d_cps, c.nsub);
+        launch_huff_spec(st, c.max_wg, nimg, b->huff_lds, b->ctx->spec_lds_pad, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, b->d_cps);
         prof_end(b);
     }
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_FIX)) {
@@ -321,8 +324,8 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         if (c.merge_wgs > 0) {
             for (int k = 0; k < fix_passes; k++) {
                 prof_begin(b, MJX_K_HUFF_FIX);
-                launch_huff_merge(st, c.merge_wgs, nimg, b->huff_lds + b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, b->d_cps,
-                                  c.nsub, b->d_mismatch + ci * kMaxFix + k);
+                launch_huff_merge(st, c.merge_wgs, nimg, b->huff_lds, b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, b->d_cps,
+                                  b->d_mismatch + ci * kMaxFix + k);
                 prof_end(b);
             }
             HIPOK(hipMemcpyAsync(b->h_mismatch + ci * kMaxFix, b->d_mismatch + ci * kMaxFix, kMaxFix * sizeof(uint32_t),
@@ -334,7 +337,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         launch_huff_scan(st, nimg, imgs, b->d_exit, b->d_blkbase, b->d_ebase, b->d_img_entries, b->d_img_flags);
         prof_end(b);
         prof_begin(b, MJX_K_HUFF_WRITE);
-        launch_huff_write(st, c.max_wg, nimg, b->huff_lds + b->ctx->write_lds_pad, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_blkbase, b->d_ebase,
+        launch_huff_write(st, c.max_wg, nimg, b->huff_lds, b->ctx->write_lds_pad, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_blkbase, b->d_ebase,
                           b->d_entries, b->d_tile_eoff, dcb, b->d_status, b->d_img_flags);
         prof_end(b);
         prof_begin(b, MJX_K_DC_SCAN);
@@ -425,7 +428,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
         inf.tile_blocks = d.tile_blocks;
         inf.ntiles = uint32_t((inf.nblocks + d.tile_blocks - 1) / d.tile_blocks);
         // every stream entry consumes at least 2 bits of scan (1-bit code + 1 value bit) and a block holds at most 63
-        inf.ent_cap = (std::min<uint64_t>(uint64_t(p.scan_len) * 4, inf.nblocks * 63) + 7) / 4 * 4;
+        inf.ent_cap = (std::min<uint64_t>(uint64_t(p.scan_len) * 4, inf.nblocks * 63) + 15) / 8 * 8;   // regions start on 32-byte sectors
         inf.scan_len = p.scan_len;
         inf.rgb_off = rgb_pool;
         inf.rgb_bytes = uint64_t(p.width) * p.height * 3;
@@ -445,17 +448,17 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
         HIPOK(hipMalloc(&b->d_images, std::max<size_t>(n, 1) * sizeof(DevImage)));
         HIPOK(hipMemcpy(b->d_images, b->himages.data(), n * sizeof(DevImage), hipMemcpyHostToDevice));
         HIPOK(hipMalloc(&b->d_scan, b->scan_pool_bytes + 256));    // slack: bit windows read up to 96 bytes past a scan
-        HIPOK(hipMalloc(&b->d_lut, std::max<size_t>(lut_pool, 8) * sizeof(uint16_t)));
+        HIPOK(hipMalloc(&b->d_lut, std::max<size_t>(lut_pool, 8) * sizeof(LutEntry)));
         HIPOK(hipMalloc(&b->d_qm, std::max<size_t>(nu, 1) * 192 * sizeof(float)));
         if (src) {
             if (src->scan_pool_bytes != scan_pool) return MJX_ERR_INVALID_ARG;
             for (size_t rep = 0; rep < times; rep++)
                 HIPOK(hipMemcpy(b->d_scan + rep * scan_pool, src->d_scan, scan_pool, hipMemcpyDeviceToDevice));
-            HIPOK(hipMemcpy(b->d_lut, src->d_lut, std::max<size_t>(lut_pool, 8) * sizeof(uint16_t), hipMemcpyDeviceToDevice));
+            HIPOK(hipMemcpy(b->d_lut, src->d_lut, std::max<size_t>(lut_pool, 8) * sizeof(LutEntry), hipMemcpyDeviceToDevice));
             HIPOK(hipMemcpy(b->d_qm, src->d_qm, std::max<size_t>(nu, 1) * 192 * sizeof(float), hipMemcpyDeviceToDevice));
         } else {
             std::vector<uint8_t> hs(scan_pool, 0xaa);
-            std::vector<uint16_t> hl(std::max<size_t>(lut_pool, 8), 0);
+            std::vector<LutEntry> hl(std::max<size_t>(lut_pool, 8), 0);
             std::vector<float> hq(std::max<size_t>(nu, 1) * 192, 0.f);
             std::vector<char> on_device(nu, 0);
             if (ds) for (size_t idx : ds->plan_index) on_device[idx] = 1;
@@ -463,7 +466,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
                 const ImagePlan &p = plans[k];
                 if (p.status != MJX_OK) continue;
                 if (!on_device[k]) std::memcpy(hs.data() + scan_off[k], p.scan, p.scan_len);
-                std::memcpy(hl.data() + lut_off[k], p.lut.data(), p.lut.size() * sizeof(uint16_t));
+                std::memcpy(hl.data() + lut_off[k], p.lut.data(), p.lut.size() * sizeof(LutEntry));
                 std::memcpy(hq.data() + k * 192, p.qmult, sizeof p.qmult);
             }
             HIPOK(hipMemcpy(b->d_scan, hs.data(), scan_pool, hipMemcpyHostToDevice));
@@ -488,7 +491,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
                     if (rc3 != MJX_OK) return rc3;
                 }
             }
-            HIPOK(hipMemcpy(b->d_lut, hl.data(), hl.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            HIPOK(hipMemcpy(b->d_lut, hl.data(), hl.size() * sizeof(LutEntry), hipMemcpyHostToDevice));
             HIPOK(hipMemcpy(b->d_qm, hq.data(), hq.size() * sizeof(float), hipMemcpyHostToDevice));
         }
         return allocate_work_buffers(b);

@@ -32,23 +32,33 @@ constexpr int kLutPrimaryBits = 10;
 constexpr int kLutPrimarySize = 1 << kLutPrimaryBits;
 constexpr int kMaxBlocksPerMcu = 12;           // 3 components x (2x2)
 
-// ---- decode table entry (uint16) ---------------------------------------------------------------
-//  direct : bit15 = 0 | size[14:11] | run[10:5] | len[4:0]      (len = total code length, 1..16)
-//  link   : bit15 = 1 | sub-table offset / 2 [14:4] (entries, relative to the table base) | nbits[3:0]
-//  invalid: 0
-constexpr uint16_t kLutLinkBit = 0x8000;
-MJX_HD constexpr uint16_t lut_direct(unsigned len, unsigned run, unsigned size)
+// ---- decode table entry (uint32) ---------------------------------------------------------------
+//  direct : 64 - adv [31:26] | zinc [25:19] | size [18:15] | len [14:10] | bad [1] | cnt [0]
+//             len  = code length (1..16), size = value bits, adv = len + size (bits the symbol consumes, <= 27)
+//             zinc = zig-zag positions the symbol advances: run + 1; 64 for EOB (saturates the block); 16 for ZRL
+//             cnt  = 1 for an AC symbol with size != 0 (it produces one entry of the compact coefficient stream)
+//             bad  = 1 for bit patterns no code matches (huffman.rs:156/162); such an entry consumes one bit
+//           The fields the synchronisation passes need are placed so that two instructions update the lane:
+//           x += e & kLutXMask  (bit budget of the current dword -= adv, entries += cnt)  and  r = sat_sub(r, zinc).
+//  link   : 0 [31:26] | byte offset of the sub-table from the table's base [25:4] | nbits [3:0]
+typedef uint32_t LutEntry;
+constexpr uint32_t kLutDirectMin = 1u << 26;         // direct entries are >= this (64 - adv >= 33), links below
+constexpr uint32_t kLutXMask = 0xfc000001u;
+constexpr uint32_t kLutBad = 2u, kLutCnt = 1u;
+MJX_HD constexpr LutEntry lut_direct(unsigned len, unsigned run, unsigned size, bool is_ac)
 {
-    return uint16_t((size << 11) | (run << 5) | len);
+    return ((64u - (len + size)) << 26) | ((run + 1u) << 19) | (size << 15) | (len << 10) | ((is_ac && size) ? kLutCnt : 0u);
 }
-MJX_HD constexpr uint16_t lut_link(unsigned offset, unsigned nbits) { return uint16_t(0x8000u | ((offset >> 1) << 4) | nbits); }
-MJX_HD constexpr unsigned lut_link_offset(unsigned e) { return ((e >> 4) & 0x7ffu) << 1; }
+MJX_HD constexpr LutEntry lut_invalid() { return lut_direct(1, 0, 0, false) | kLutBad; }
+MJX_HD constexpr LutEntry lut_link(unsigned offset_entries, unsigned nbits) { return ((offset_entries * 4u) << 4) | nbits; }
+MJX_HD constexpr bool lut_is_link(LutEntry e) { return e < kLutDirectMin; }
+MJX_HD constexpr unsigned lut_link_offset(LutEntry e) { return (e >> 4) / 4u; }      // entries
 
 // ---- per-subsequence synchronisation state -------------------------------------------------------------------
 // The first 8 bytes (what the next subsequence must start from) are read while other lanes may rewrite them, so they
 // form one naturally aligned 8-byte word; the counters are only consumed after the rounds have converged.
 struct alignas(8) SubseqState {
-    uint32_t p;    // bit position (relative to the image's scan) of the first symbol at/after the boundary
+    uint32_t p;    // bit position (relative to the image's scan) of the first symbol after the boundary
     uint8_t z;     // zig-zag index of the next coefficient (0 = next symbol is a DC code)
     uint8_t c;     // block index inside the MCU (selects the DC/AC table pair)
     uint16_t pad;
@@ -64,17 +74,20 @@ MJX_HD SubseqState make_state(uint32_t p, uint32_t z, uint32_t c, uint32_t n = 0
 }
 
 // Per-image constants the lane needs (lives in LDS on the device).
+// The blocks of an MCU cycle through btab: when a block ends the lane fetches the entry of the next one (one 8-byte
+// read) and has its table pair and the index of the block after it, with no comparisons.
+struct BlockTab {
+    uint32_t tabs;     // byte offset of the block's DC table | byte offset of its AC table << 16 (from the image's tables)
+    uint32_t next;     // block-in-MCU of the following block
+};
 struct HuffImage {
-    // The blocks of an MCU are ordered by component, so the table pair of block c follows from two thresholds:
-    // c < cfirst1 -> component 0, c < cfirst2 -> component 1, else component 2.  All five words are uniform per image
-    // (scalar registers on the device): no memory access when a block ends.
-    uint32_t ctab[3];                    // per component: dc table base | ac table base << 16 (entry offsets)
-    uint32_t cfirst1, cfirst2;           // first block-in-MCU of components 1 and 2 (= bpm when absent)
+    BlockTab btab[kMaxBlocksPerMcu];
     uint32_t bpm;                        // blocks per MCU
     uint32_t total_bits;                 // scan_len * 8
     uint32_t total_blocks;               // MCUs to decode * bpm
     uint32_t nsub;                       // ceil(total_bits / kSubseqBits)
 };
+static_assert(sizeof(HuffImage) % 16 == 0, "the decode tables follow HuffImage in LDS and are staged in 16-byte pieces");
 
 // ---- compact coefficient stream -------------------------------------------------------------------------------
 // One 32-bit entry per non-zero AC coefficient, in decode order:  value[15:0] | zig-zag position[21:16] | block[29:22]
@@ -91,15 +104,18 @@ struct NullSink {
     MJX_HD void block_done(uint32_t) const {}
     MJX_HD void bad_code(uint32_t) const {}
     MJX_HD void tick() const {}          // one call per decoded symbol (statistics in the CPU emulation)
+    MJX_HD void flush_groups() const {}
 };
 
 // ---- checkpoints: early merge of a re-decode with the path of the previous decode ----------------------
-// While decoding a subsequence the lane records its state at the first symbol at/after every 256-bit boundary
-// inside the subsequence.  A later re-decode of the same subsequence (its entry changed) compares its own state
-// at each boundary with the recorded one: equal (p, z, c) means the two decodes coincide from there on, so the
-// re-decode stops and inherits the old exit.  This is the self-synchronisation property used at a finer grain:
-// most re-decodes merge after a few dozen symbols instead of running all ~180.
-//   word 0: bit31 valid | n[30:16] | c[15:12] | z[11:6] | p - boundary [5:0]      word 1: m
+// While decoding a subsequence the lane records its state at the first symbol after every 256-bit boundary inside
+// the subsequence (strictly after: a lane notices a boundary when it moves on to the next dword of the stream).  A
+// later re-decode of the same subsequence (its entry changed) compares its own state at each boundary with the
+// recorded one: equal (p, z, c) means the two decodes coincide from there on, so the re-decode stops and inherits
+// the old exit.  This is the self-synchronisation property used at a finer grain: most re-decodes merge after ~100
+// symbols instead of running all ~800.
+//   word 0: bit31 valid | n[30:16] | next block-in-MCU [15:12] | 64 - z [11:5] | t [4:0]      word 1: m
+//   (at a boundary the lane's dword position is the boundary itself, so t stands for p)
 //   n, m = blocks / stream entries from the checkpoint to the end of the subsequence (after the decode's fix-up);
 //   while a decode is running they temporarily hold the counts from the start to the checkpoint.
 constexpr int kCpBits = 256;
@@ -113,101 +129,193 @@ struct NoCheckpoints {
     MJX_HD void set(uint32_t, uint32_t, uint32_t) const {}        // both words
 };
 
-// Registers of one lane's decoder: position + a three-dword look-ahead window of the big-endian bitstream.
-// w2 is fetched one refill early and kept *raw* (BitSrc::raw32); it is only converted (BitSrc::fix, the byte swap of
-// a little-endian load) when it moves into w1 at the next refill, so nothing consumes a global-memory load for a
-// whole dword of symbols (~6) and its latency stays off the lane's critical path.
+// Registers of one lane's decoder.  The stream is seen through two big-endian dwords w0 w1 and a queue q[] of
+// BitSrc::kAhead dwords fetched ahead and kept *raw* (byte-swapped only when they move into w1).  A wave executes the
+// refill path on almost every symbol (some lane always runs out), and each execution has to wait for the load of
+// the execution kAhead back (loads retire in order, per wave): with one dword ahead every symbol would expose a
+// full L2 round trip, with three the wave covers it with three symbols' worth of work.  The lane's position is
+//     p = 8 * (wn - 8) - t,      t = bits of w0 not yet consumed (0..31),      wn - 8 = byte offset of w1,
+// so the next 32 bits of the stream are the funnel shift {w0,w1} >> t.  t lives in the top six bits of x and the
+// stream-entry count m in the low 26, so one add of the masked table entry moves both; t < 0 (sign of x) = the lane
+// has moved into w1 and refills.  Everything that depends on p alone (end of the subsequence, checkpoints) is only
+// looked at on that refill: boundaries are multiples of 32 bits.
+constexpr int kMaxAhead = 4;
 struct LaneState {
-    uint32_t p, z, c, n, m;   // bit position, zig-zag index, block-in-MCU, blocks completed, stream entries produced
-    uint32_t tab;             // table pair of block c (see HuffImage::ctab)
-    uint32_t wi, o;           // dword index of w0, bit offset inside it
-    uint32_t w0, w1, w2;
+    uint32_t x;             // t [31:26] (signed) | m [25:0]
+    uint32_t r;             // coefficients left in the current block: 64 - zig-zag index
+    uint32_t n;             // blocks completed
+    uint32_t cnext;         // block-in-MCU of the block after the current one
+    uint32_t base, acb;     // byte offset of the table of the next symbol / of the current block's AC table
+    uint32_t wn;            // byte offset of the dword after w1 (= of q[0])
+    uint32_t w0, w1;
+    uint32_t q[kMaxAhead];
 };
+MJX_HD uint32_t lane_t(const LaneState &st) { return st.x >> 26; }
+MJX_HD uint32_t lane_m(const LaneState &st) { return st.x & 0x3ffffffu; }
+MJX_HD uint32_t lane_pos(const LaneState &st) { return 8u * (st.wn - 8u) - lane_t(st); }
+MJX_HD uint32_t lane_z(const LaneState &st) { return 64u - st.r; }
+MJX_HD uint32_t lane_c(const LaneState &st, const HuffImage &img) { return (st.cnext ? st.cnext : img.bpm) - 1u; }
+// byte offset of the first dword a lane fetches after it has left the bits below `bit` (bit rounded up to a dword)
+MJX_HD uint32_t wn_after(uint32_t bit) { return 4u * ((bit + 31u) >> 5) + 12u; }
 
-MJX_HD uint32_t block_tab(const HuffImage &img, uint32_t c)
+MJX_HD uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh)      // low 32 bits of {hi,lo} >> sh, sh in 0..31
 {
-    return c < img.cfirst1 ? img.ctab[0] : (c < img.cfirst2 ? img.ctab[1] : img.ctab[2]);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return uint32_t(((uint64_t(hi) << 32) | lo) >> (sh & 31));
+#endif
+}
+MJX_HD uint32_t sat_sub(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_elementwise_sub_sat(a, b);
+#else
+    return a > b ? a - b : 0u;
+#endif
+}
+MJX_HD uint32_t bits_field(uint32_t v, uint32_t off, uint32_t width)   // width 0 -> 0
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ubfe(v, off, width);
+#else
+    return width ? (v >> (off & 31)) & (0xffffffffu >> (32 - width)) : 0u;
+#endif
+}
+MJX_HD LutEntry lut_at(const LutEntry *lut, uint32_t byte_off)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    // On the device the table offsets a lane carries (BlockTab::tabs, patched by stage_tables) are absolute LDS
+    // addresses, so the lookup address is one shift-add of the code bits.
+    (void)lut;
+    return *(const __attribute__((address_space(3))) LutEntry *)(byte_off);
+#else
+    return *reinterpret_cast<const LutEntry *>(reinterpret_cast<const unsigned char *>(lut) + byte_off);
+#endif
 }
 
+// The refill every bit source performs unless it has its own: the window moves on one dword, the queue moves up,
+// one more dword is requested.
+template <class BitSrc>
+MJX_HD void refill_generic(const BitSrc &bits, LaneState &st)
+{
+    st.w0 = st.w1;
+    st.w1 = BitSrc::fix(st.q[0]);
+    for (int i = 0; i + 1 < BitSrc::kAhead; i++) st.q[i] = st.q[i + 1];
+    st.q[BitSrc::kAhead - 1] = bits.raw32(st.wn + 4u * uint32_t(BitSrc::kAhead - 1));
+}
+
+//   BitSrc::be32(b)  -> big-endian dword at byte offset b of the image's scan (0xAAAAAAAA past the end,
+//                       huffman.rs:236-246); raw32(b) / fix(raw) = the same in two steps (load, then byte order)
 template <class BitSrc>
 MJX_HD void lane_begin(LaneState &st, const BitSrc &bits, const HuffImage &img, SubseqState entry)
 {
-    st.p = entry.p; st.z = entry.z; st.c = entry.c; st.n = 0; st.m = 0;
-    st.tab = block_tab(img, st.c);
-    st.wi = st.p >> 5; st.o = st.p & 31;
-    st.w0 = bits.be32(st.wi); st.w1 = bits.be32(st.wi + 1); st.w2 = bits.raw32(st.wi + 2);
+    const uint32_t wi1 = (entry.p + 31u) >> 5;                   // dwords lying completely below p, rounded up
+    st.wn = 4u * wi1 + 8u;
+    st.x = (32u * wi1 - entry.p) << 26;
+    st.r = 64u - entry.z;
+    st.n = 0;
+    const BlockTab bt = img.btab[entry.c];
+    st.cnext = bt.next;
+    st.acb = bt.tabs >> 16;
+    st.base = entry.z ? st.acb : (bt.tabs & 0xffffu);
+    st.w0 = wi1 ? bits.be32(st.wn - 12u) : 0u;                   // p == 0: all of w0 is "consumed", nothing to load
+    st.w1 = bits.be32(st.wn - 8u);
+    for (int i = 0; i < BitSrc::kAhead; i++) st.q[i] = bits.raw32(st.wn - 4u + 4u * uint32_t(i));
 }
 
 // One Huffman symbol: table lookup, EXTEND, coefficient placement, state update, window refill.
+// Returns true when the lane moved on to the next dword of the stream (the caller then looks at lane_event).
 template <bool WRITE, class BitSrc, class Sink>
-MJX_HD void symbol_step(LaneState &st, const BitSrc &bits, const uint16_t *lut, const HuffImage &img, uint32_t &blk,
+MJX_HD bool symbol_step(LaneState &st, const BitSrc &bits, const LutEntry *lut, const HuffImage &img, uint32_t &blk,
                         Sink &sink)
 {
-    const uint32_t w = st.o ? ((st.w0 << st.o) | (st.w1 >> (32 - st.o))) : st.w0;   // next 32 bits of the stream
-    const uint32_t base = st.z ? (st.tab >> 16) : (st.tab & 0xffff);
-    uint32_t e = lut[base + (w >> (32 - kLutPrimaryBits))];
-    if (e & kLutLinkBit) {
-        const uint32_t nb = e & 15, off = lut_link_offset(e);
-        e = lut[base + off + ((w << kLutPrimaryBits) >> (32 - nb))];
+    const uint32_t w = funnel(st.w0, st.w1, lane_t(st));                          // next 32 bits of the stream
+    const uint32_t base = st.base;
+    LutEntry e = lut_at(lut, base + (w >> (32 - kLutPrimaryBits)) * 4u);
+    st.base = st.acb;                                                             // (overridden when the block ends)
+    if (lut_is_link(e)) {
+        const uint32_t nb = e & 15u;
+        e = lut_at(lut, base + (e >> 4) + bits_field(w, 32u - kLutPrimaryBits - nb, nb) * 4u);
     }
-    uint32_t len = e & 31;
-    const uint32_t run = (e >> 5) & 63, size = (e >> 11) & 15;
     sink.tick();
-    if (len == 0) {                                                               // no code matches (huffman.rs:156/162)
-        if (WRITE) sink.bad_code(blk);
-        len = 1;
-    }
-    uint32_t pos = st.z + run;
-    pos = pos > 63 ? 63 : pos;
+    const uint32_t r_old = st.r;
+    st.r = sat_sub(st.r, (e >> 19) & 127u);
     if (WRITE) {
+        if (e & kLutBad) sink.bad_code(blk);
+        const uint32_t len = (e >> 10) & 31u, size = (e >> 15) & 15u;
         const uint32_t v = w << len;                                              // value bits, left aligned
         const uint32_t vb = (v >> 1) >> (31 - size);                              // size == 0 -> 0
         const int32_t val = int32_t(vb) - int32_t(((1u << size) - 1u) & ((v >> 31) - 1u));   // EXTEND, T.81 F.2
-        if (st.z == 0) sink.dc(blk, val);
-        else if (size) sink.ac(blk, pos, val);
+        if (r_old == 64) sink.dc(blk, val);
+        else if (e & kLutCnt) sink.ac(blk, 63u - st.r, val);
     }
-    st.m += (st.z != 0 && size != 0) ? 1u : 0u;
-    st.z = pos + 1;
-    if (st.z == 64) {
-        st.z = 0;
-        st.c = (st.c + 1 == img.bpm) ? 0 : st.c + 1;
-        st.tab = block_tab(img, st.c);
+    st.x += e & kLutXMask;
+    if (st.r == 0) {
+        const BlockTab bt = img.btab[st.cnext];
+        st.r = 64;
+        st.cnext = bt.next;
+        st.base = bt.tabs & 0xffffu;
+        st.acb = bt.tabs >> 16;
         st.n++;
         blk++;
         if (WRITE) sink.block_done(blk);
     }
-    const uint32_t adv = len + size;
-    st.p += adv;
-    st.o += adv;
-    if (st.o >= 32) {
-        st.o -= 32;
-        st.wi++;
-        st.w0 = st.w1;
-        st.w1 = BitSrc::fix(st.w2);
-        st.w2 = bits.raw32(st.wi + 2);
+    if (int32_t(st.x) < 0) {
+        st.x ^= 0x80000000u;                                                      // t += 32
+        bits.refill(st);
+        st.wn += 4;
+        return true;
     }
+    return false;
 }
 
-// Checkpoint test at a symbol start.  Returns true when the lane's state equals the one recorded by the previous
-// decode of this subsequence at the same 256-bit boundary (the decodes coincide from here on); otherwise records the
-// state (with the blocks completed so far) and advances to the next boundary.
-template <bool COMPARE, class CpStore>
-MJX_HD bool checkpoint_merge(const LaneState &st, CpStore &cps, uint32_t &k, uint32_t &cp_bit, uint32_t &n_rest,
-                             uint32_t &m_rest)
+// What a lane looks at when it moves on to a new dword: the end of its subsequence and the checkpoints.
+struct LaneEvents {
+    uint32_t next_wn;       // st.wn at/after which the next event is due
+    uint32_t end_wn;        // ... at/after which the lane has left its subsequence
+    uint32_t k;             // index of the next checkpoint
+    bool merged;            // the re-decode met the previous decode's path: the exit is the previous exit
+};
+template <int CP>
+MJX_HD void events_begin(LaneEvents &ev, uint32_t sub_start, uint32_t end_bit)
 {
-    const uint32_t state = (st.p - cp_bit) | (st.z << 6) | (st.c << 12) | kCpValid;
-    if (COMPARE) {
-        const uint32_t old = cps.get(k);
-        if ((old & kCpStateMask) == state) {
-            n_rest = (old >> 16) & 0x7fffu;
-            m_rest = cps.get_m(k);
-            return true;
+    ev.end_wn = wn_after(end_bit);
+    ev.k = 0;
+    ev.merged = false;
+    ev.next_wn = CP ? wn_after(sub_start + kCpBits) : ev.end_wn;
+    if (ev.next_wn > ev.end_wn) ev.next_wn = ev.end_wn;
+}
+// Returns true when the lane is finished.  Otherwise (a checkpoint boundary was crossed): compares with the state the
+// previous decode recorded there (CP == 2; equal = the decodes coincide from here on), or records the lane's state
+// with the counts so far and moves to the next boundary.
+template <int CP, class CpStore>
+MJX_HD bool lane_event(LaneState &st, LaneEvents &ev, const HuffImage &img, CpStore &cps)
+{
+    if (st.wn < ev.next_wn) return false;
+    if (st.wn >= ev.end_wn) return true;
+    if (CP) {
+        const uint32_t state = lane_t(st) | (st.r << 5) | (st.cnext << 12) | kCpValid;
+        if (CP == 2) {
+            const uint32_t old = cps.get(ev.k);
+            if ((old & kCpStateMask) == state) {
+                st.n += (old >> 16) & 0x7fffu;
+                st.x += cps.get_m(ev.k);
+                ev.merged = true;
+                return true;
+            }
         }
+        cps.set(ev.k, state | (st.n << 16), lane_m(st));
+        ev.k++;
+        ev.next_wn += kCpBits / 8;
+        if (ev.next_wn > ev.end_wn) ev.next_wn = ev.end_wn;
     }
-    cps.set(k, state | (st.n << 16), st.m);
-    k++;
-    cp_bit += kCpBits;
     return false;
+}
+MJX_HD SubseqState lane_exit(const LaneState &st, const LaneEvents &ev, const HuffImage &img, const SubseqState &old_exit)
+{
+    if (ev.merged) return make_state(old_exit.p, old_exit.z, old_exit.c, st.n, lane_m(st));
+    return make_state(lane_pos(st), lane_z(st), lane_c(st, img), st.n, lane_m(st));
 }
 
 // counts-so-far -> counts-to-the-end for the checkpoints this decode recorded
@@ -220,43 +328,40 @@ MJX_HD void checkpoint_fixup(CpStore &cps, uint32_t k, uint32_t n_total, uint32_
     }
 }
 
-// Decode from `entry` until the bit position reaches `end_bit`.
-//   BitSrc::be32(i)  -> big-endian dword i of the image's scan (0xAAAAAAAA past the end, huffman.rs:236-246);
-//                       raw32(i) / fix(raw) = the same in two steps (load, then byte order)
+// Decode the symbols of one subsequence: those that start in (sub_start, end_bit] (end_bit rounded up to a dword: the
+// last subsequence of a scan may run up to 31 bits into the 0xAA padding the reference would read as well), from
+// `entry` (the first of them).
 //   lut              -> the image's decode tables
 //   WRITE            -> emit coefficients for blocks < img.total_blocks through `sink`, starting at block `blk`
 //   CP               -> 0: no checkpoints; 1: record checkpoints in `cps`; 2: record and merge with the previous
 //                       decode of this subsequence (`sub_start` = its first bit, `old_exit` = that decode's exit)
 template <bool WRITE, int CP, class BitSrc, class Sink, class CpStore>
-MJX_HD SubseqState decode_subseq(const BitSrc &bits, const uint16_t *lut, const HuffImage &img, SubseqState entry,
+MJX_HD SubseqState decode_subseq(const BitSrc &bits, const LutEntry *lut, const HuffImage &img, SubseqState entry,
                                  uint32_t end_bit, uint32_t blk, Sink &sink, CpStore &cps, uint32_t sub_start,
                                  SubseqState old_exit)
 {
+    if (entry.p > end_bit) return make_state(entry.p, entry.z, entry.c);           // nothing starts inside
     LaneState st;
+    LaneEvents ev;
     lane_begin(st, bits, img, entry);
-    uint32_t cp_bit = sub_start + kCpBits, k = 0;
-    while (st.p < end_bit) {
-        if (WRITE && blk >= img.total_blocks) break;
-        if (CP && st.p >= cp_bit) {
-            uint32_t n_rest, m_rest;
-            if (checkpoint_merge<CP == 2>(st, cps, k, cp_bit, n_rest, m_rest)) {
-                st.n += n_rest;
-                st.m += m_rest;
-                st.p = old_exit.p; st.z = old_exit.z; st.c = old_exit.c;
-                break;
-            }
-        }
-        symbol_step<WRITE>(st, bits, lut, img, blk, sink);
+    events_begin<CP>(ev, sub_start, end_bit);
+    bool running = !(WRITE && blk >= img.total_blocks);
+    while (running) {                               // (one back edge: a second one makes the compiler split the loop)
+        const bool crossed = symbol_step<WRITE>(st, bits, lut, img, blk, sink);
+        bool done = WRITE && blk >= img.total_blocks;
+        if (crossed) done = lane_event<CP>(st, ev, img, cps) || done;
+        running = !done;
     }
-    if (CP) checkpoint_fixup(cps, k, st.n, st.m);
-    return make_state(st.p, st.z, st.c, st.n, st.m);
+    bits.drain(st);
+    if (CP) checkpoint_fixup(cps, ev.k, st.n, lane_m(st));
+    return lane_exit(st, ev, img, old_exit);
 }
 
 #if !defined(__HIP_DEVICE_COMPILE__)
 // ---- host-side table construction (mjx_lut.cpp) ---------------------------------------------------
 // Appends the two-level decode table for one DHT table to `out` (uint16 entries) and returns its size in
 // entries, or a negative MJX_ERR_* code.  `is_dc`: symbols are DC size categories (run = 0).
-int build_decode_table(const uint8_t bits[16], const uint8_t *vals, bool is_dc, uint16_t *out, int cap);
+int build_decode_table(const uint8_t bits[16], const uint8_t *vals, bool is_dc, LutEntry *out, int cap);
 #endif
 
 }   // namespace mjx

@@ -6,7 +6,12 @@
 
 namespace mjx {
 
-constexpr int kWgLanes = 256;                                   // lanes (= subsequences) per k_huff_spec / k_huff_write workgroup
+constexpr int kWgLanes = 256;                                   // lanes of the scan / prefix-sum workgroups
+#ifndef MJX_HUFF_WG
+#define MJX_HUFF_WG 512
+#endif
+constexpr int kHuffWg = MJX_HUFF_WG;                            // lanes (= subsequences) per k_huff_spec / merge / write workgroup:
+                                                                // the decode tables in LDS are shared by kHuffWg / 64 waves
 constexpr int kDcSegMcus = 2048;                                // MCUs per DC-prediction segment (k_dc_sums / k_dc_apply)
 
 // One image of a chunk, as the kernels see it (HBM, read-only during decode).
@@ -17,8 +22,8 @@ struct DevImage {
     uint64_t ent_off;       // entries into the compact coefficient stream pool (start of the image's region)
     uint64_t rgb_off;       // bytes into the RGB pool
     uint32_t scan_padded;   // bytes that may be read at scan_off (multiple of 16; tail filled with 0xAA)
-    uint32_t lut_off;       // entries into the decode-table pool (multiple of 8)
-    uint32_t lut_n;         // entries (multiple of 8)
+    uint32_t lut_off;       // entries into the decode-table pool (multiple of 4)
+    uint32_t lut_n;         // entries (multiple of 4)
     uint32_t sub_off;       // index of subsequence 0 in the per-subsequence arrays
     uint32_t qm_off;        // floats into the dequant-multiplier pool (3 x 64 per image)
     uint32_t width, height, mcux, mcuy, nmcu;
@@ -61,20 +66,22 @@ inline uint32_t tile_mcus(uint32_t bpm, uint32_t hmax)
 size_t huff_lds_bytes(uint32_t lut_cap_entries);
 size_t idct_lds_bytes(uint32_t max_tile_blocks);
 int configure_kernels(size_t huff_lds, size_t idct_lds);
+size_t huff_window_bytes();     // LDS the windowed entropy kernels need on top of huff_lds_bytes()
+size_t huff_stage_bytes();      // ... and the write pass's entry rings
 void launch_destuff_count(hipStream_t st, uint32_t max_seg, uint32_t nimg, const DestuffImg *imgs, const uint8_t *raw,
                           uint32_t *segcount);
 void launch_destuff_scatter(hipStream_t st, uint32_t max_seg, uint32_t nimg, const DestuffImg *imgs, const uint8_t *raw,
                             const uint32_t *segbase, uint8_t *pool);
-void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
-                      const uint8_t *scan_pool, const uint16_t *lut_pool, SubseqState *entry, SubseqState *exit_,
-                      uint32_t *cps, uint32_t cp_stride);
-void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
-                       const uint8_t *scan_pool, const uint16_t *lut_pool, SubseqState *entry, SubseqState *exit_,
-                       uint32_t *cps, uint32_t cp_stride, uint32_t *mismatches);
+void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
+                      const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
+                      uint32_t *cps);
+void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
+                       const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
+                       uint32_t *cps, uint32_t *mismatches);
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,
                       uint32_t *ebase, uint32_t *img_entries, uint32_t *img_flags);
-void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
-                       const uint8_t *scan_pool, const uint16_t *lut_pool, const SubseqState *entry,
+void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
+                       const uint8_t *scan_pool, const LutEntry *lut_pool, const SubseqState *entry,
                        const uint32_t *blkbase, const uint32_t *ebase, uint32_t *entries, uint32_t *tile_eoff,
                        int32_t *dcbuf, int *status, const uint32_t *img_flags);
 void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int32_t *dcbuf,

@@ -2,11 +2,11 @@
 //
 //   stage A (entropy, replaces HuffmanDecoder::next_block + the MCU loop, reference
 //            src/jpeg/huffman.rs:146-254 and src/jpeg/decoder.rs:195-215):
-//     k_huff_sync   speculative decode of every 128-byte subsequence + intra-workgroup synchronisation
-//     k_huff_fix    inter-workgroup synchronisation pass
-//     k_huff_scan   per-image exclusive scan of completed-block counts
-//     k_huff_write  final decode from the synchronised entry states, scattering coefficients
-//     k_dc_scan     DC prediction (decoder.rs:208-210) as a per-component prefix sum
+//     k_huff_spec   speculative decode of every 512-byte subsequence, recording exit states and checkpoints
+//     k_huff_merge  one synchronisation round: re-decode the subsequences whose entry changed until they merge
+//     k_huff_scan   per-image exclusive scan of completed-block / stream-entry counts
+//     k_huff_write  final decode from the synchronised entry states into the compact coefficient stream
+//     k_dc_sums / k_dc_apply   DC prediction (decoder.rs:208-210) as a per-component prefix sum
 //   stage B (pixels, replaces decoder.rs:227-235, 239-331 and src/transform.rs:55-87):
 //     k_idct_color  dequant + un-zigzag + 8x8 float IDCT + chroma replication + YCbCr->RGB + packed store
 //
@@ -25,72 +25,87 @@ namespace mjx {
 // The image's de-stuffed scan in HBM as big-endian dwords; bytes past the padded end read 0xAA (huffman.rs:236-246).
 // Every lane walks its own 512-byte subsequence, so a lane's loads hit one 128-byte line 32 times in a row (L2 / MALL
 // resident: a chunk's scans are ~1 MB per 4K image).
+#ifndef MJX_AHEAD
+#define MJX_AHEAD 1
+#endif
 struct GlobalBits {
-    const uint32_t *words;
-    uint32_t nwords;
-    // No bounds test: a lane reads at most 3 dwords past the last scan byte, and every image's region in the pool ends
+    // One dword ahead: a deeper queue does not help, because moving a queue up touches the newest (still in flight)
+    // dword at the very next refill.
+    static constexpr int kAhead = MJX_AHEAD;
+    const unsigned char *bytes;     // wave-uniform base: loads are `base + 32-bit lane offset`, no 64-bit address math
+    // No bounds test: a lane reads at most 6 dwords past the last scan byte, and every image's region in the pool ends
     // with >= 16 bytes of 0xAA (mjx_api.hip build_batch), so the padding *is* the out-of-range value.
-    __device__ __forceinline__ uint32_t be32(uint32_t i) const { return __builtin_bswap32(words[i]); }
-    __device__ __forceinline__ uint32_t raw32(uint32_t i) const { return words[i]; }
+    __device__ __forceinline__ uint32_t raw32(uint32_t byte_off) const { return *reinterpret_cast<const uint32_t *>(bytes + byte_off); }
+    __device__ __forceinline__ uint32_t be32(uint32_t byte_off) const { return __builtin_bswap32(raw32(byte_off)); }
     static __device__ __forceinline__ uint32_t fix(uint32_t raw) { return __builtin_bswap32(raw); }
+    __device__ __forceinline__ void refill(LaneState &st) const { refill_generic(*this, st); }
+    __device__ __forceinline__ void drain(LaneState &) const {}
 };
 
 // Checkpoint words live in HBM in blocks of 256 consecutive subsequences; inside a block they are row-major by word
-// (row 2k = state word of checkpoint k, row 2k+1 = its entry count, rows 256 words apart), so the lanes of a wave
-// touch adjacent words of a row and a workgroup's checkpoints stay within one 30 KB region.  In merge rounds the previous decode's state
-// word is requested one boundary ahead (~45 symbols), so the comparison at the boundary does not expose a round trip.
-constexpr uint32_t kCpRow = 256;
-__device__ __forceinline__ uint32_t *cps_slot(uint32_t *g_cps, uint32_t idx)
+// (row 2k = state word of checkpoint k, row 2k+1 = its entry count, rows 1 KiB apart), so the lanes of a wave touch
+// adjacent words of a row and a workgroup's checkpoints stay within one 30 KB region.  In merge rounds the previous
+// decode's state word is requested one boundary ahead (~45 symbols), so the comparison at the boundary does not
+// expose a round trip.  Addresses are `uniform base + 32-bit lane offset` (a chunk's checkpoints stay far below
+// 4 GiB: its stream capacity is capped in plan_chunks).
+constexpr uint32_t kCpRow = 256, kCpRowBytes = kCpRow * 4;
+__device__ __forceinline__ uint32_t cps_byte_off(uint32_t idx)
 {
-    return g_cps + size_t(idx / kCpRow) * (2 * kNumCp * kCpRow) + idx % kCpRow;
+    return (idx / kCpRow) * (2 * kNumCp * kCpRowBytes) + (idx % kCpRow) * 4;
 }
 
 struct GlobalCps {
-    uint32_t *g;            // cps_slot(g_cps, subsequence index in the chunk)
-    uint32_t stride;        // kCpRow
+    unsigned char *base;    // the chunk's checkpoint array (wave-uniform)
+    uint32_t off;           // cps_byte_off(subsequence index in the chunk)
     uint32_t next;          // prefetched state word of the previous decode
-    __device__ __forceinline__ void prime() { next = g[0]; }
+    __device__ __forceinline__ uint32_t &word(uint32_t row) const { return *reinterpret_cast<uint32_t *>(base + (off + row * kCpRowBytes)); }
+    __device__ __forceinline__ void prime() { next = word(0); }
     __device__ __forceinline__ uint32_t get(uint32_t k)
     {
         const uint32_t v = next;
-        if (k + 1 < uint32_t(kNumCp)) next = g[2 * (k + 1) * stride];
+        if (k + 1 < uint32_t(kNumCp)) next = word(2 * (k + 1));
         return v;
     }
-    __device__ __forceinline__ uint32_t get_m(uint32_t k) const { return g[(2 * k + 1) * stride]; }
-    __device__ __forceinline__ uint32_t get_plain(uint32_t k) const { return g[2 * k * stride]; }
-    __device__ __forceinline__ uint32_t get_m_plain(uint32_t k) const { return g[(2 * k + 1) * stride]; }
+    __device__ __forceinline__ uint32_t get_m(uint32_t k) const { return word(2 * k + 1); }
+    __device__ __forceinline__ uint32_t get_plain(uint32_t k) const { return word(2 * k); }
+    __device__ __forceinline__ uint32_t get_m_plain(uint32_t k) const { return word(2 * k + 1); }
     __device__ __forceinline__ void set(uint32_t k, uint32_t v, uint32_t m) const
     {
-        g[2 * k * stride] = v;
-        g[(2 * k + 1) * stride] = m;
+        word(2 * k) = v;
+        word(2 * k + 1) = m;
     }
 };
 
 struct __attribute__((packed, aligned(4))) Entry4 { uint32_t a, b, c, d; };
 
 // Sink of the write pass: the compact coefficient stream (see coef_entry), DC differences, tile offsets.
-// Entries are buffered four at a time in registers so that the lane issues one 16-byte store per four non-zero
-// coefficients instead of one 2-byte store each; a lane's stream region is contiguous, so its lines fill completely.
+// A lane's stream region is contiguous but it fills slowly (one 128-byte line per ~45 symbols), so what reaches HBM
+// is what each store instruction carried.  Entries are staged in a ring of kStageRing dwords per lane in LDS and go
+// out as whole 32-byte sectors (two back-to-back 16-byte stores) aligned to the sector grid of the image's region.
+// The wave writes its sectors out together every kFlushEvery symbols (wave-uniform branch): a symbol adds at most
+// one entry, so at most 7 + kFlushEvery < kStageRing entries wait in a ring.  Only a lane's first partial group goes
+// out dword-wise as it is produced, its last partial group at the end.
+// DC differences (one per block, 30x rarer) are stored as they come.
+constexpr uint32_t kStageRing = 16, kFlushEvery = 8, kGroup = 8;
 struct StreamSink {
-    uint32_t *entries;      // the image's entry region
+    uint32_t *entries;      // the image's entry region (32-byte aligned)
     int32_t *dcbuf;         // the image's DC differences (one int32 per block)
     uint32_t *tile_eoff;    // the image's tile offsets (+ sentinel)
     int *status;
+    uint32_t *ring;         // the lane's kStageRing dwords of LDS
     uint32_t off;           // entries produced so far (next entry index)
-    uint32_t nbuf;          // entries waiting in b0..b3 (oldest first ends in b3 after four pushes)
-    uint32_t b0, b1, b2, b3;
-    uint32_t ndc;           // DC differences waiting in d0..d3 (a lane's blocks are consecutive)
-    uint32_t d0, d1, d2, d3;
-    uint32_t last_dc_blk;
+    uint32_t flushed;       // entries below this index are in HBM (a multiple of kGroup once past the first group)
+    uint32_t direct_end;    // first group boundary at/after the lane's first entry: entries below it go out one by one
     uint32_t next_tile_blk, tile_idx, tile_blocks, total_blocks, ntiles;
+    __device__ __forceinline__ void begin(uint32_t first_entry)
+    {
+        off = first_entry;
+        direct_end = (first_entry + kGroup - 1) & ~(kGroup - 1);
+        flushed = direct_end;
+    }
     __device__ __forceinline__ void dc(uint32_t b, int v)
     {
-        d0 = d1; d1 = d2; d2 = d3; d3 = uint32_t(v);
-        last_dc_blk = b;
-        if (++ndc == 4) {
-            *reinterpret_cast<Entry4 *>(dcbuf + (b - 3)) = Entry4{d0, d1, d2, d3};
-            ndc = 0;
-        }
+        dcbuf[b] = v;
         if (b == next_tile_blk) {           // first block of a stage-B tile: remember where its entries start
             tile_eoff[tile_idx] = off;
             tile_idx++;
@@ -99,11 +114,23 @@ struct StreamSink {
     }
     __device__ __forceinline__ void ac(uint32_t b, unsigned pos, int v)
     {
-        b0 = b1; b1 = b2; b2 = b3; b3 = coef_entry(v, pos, b);
+        const uint32_t e = coef_entry(v, pos, b);
+        ring[off & (kStageRing - 1)] = e;
+        if (off < direct_end) entries[off] = e;
         off++;
-        if (++nbuf == 4) {
-            *reinterpret_cast<Entry4 *>(entries + (off - 4)) = Entry4{b0, b1, b2, b3};
-            nbuf = 0;
+    }
+    // wave-uniform call: every lane writes out its complete groups
+    __device__ __forceinline__ void flush_groups()
+    {
+        while (__builtin_amdgcn_ballot_w64(flushed + kGroup <= off)) {
+            if (flushed + kGroup <= off) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(ring + (flushed & (kStageRing - 1)));
+                uint4 *dst = reinterpret_cast<uint4 *>(entries + flushed);
+                const uint4 a = src[0], c = src[1];
+                dst[0] = a;
+                dst[1] = c;
+                flushed += kGroup;
+            }
         }
     }
     __device__ __forceinline__ void block_done(uint32_t next_blk)
@@ -112,31 +139,29 @@ struct StreamSink {
     }
     __device__ __forceinline__ void flush()
     {
-        if (nbuf == 3) entries[off - 3] = b1;
-        if (nbuf >= 2) entries[off - 2] = b2;
-        if (nbuf >= 1) entries[off - 1] = b3;
-        nbuf = 0;
-        if (ndc == 3) dcbuf[last_dc_blk - 2] = int32_t(d1);
-        if (ndc >= 2) dcbuf[last_dc_blk - 1] = int32_t(d2);
-        if (ndc >= 1) dcbuf[last_dc_blk] = int32_t(d3);
-        ndc = 0;
+        flush_groups();
+        for (uint32_t i = flushed; i < off; i++) entries[i] = ring[i & (kStageRing - 1)];    // (empty if off < flushed)
     }
     __device__ __forceinline__ void bad_code(uint32_t) const { atomicOr(status, 1); }
     __device__ __forceinline__ void tick() const {}
 };
 
 // Decode tables + per-image constants into LDS (dynamic LDS: HuffImage, then the tables).
-__device__ __forceinline__ void stage_tables(const DevImage &im, const uint16_t *lut_pool, unsigned char *smem,
-                                             const HuffImage *&himg, const uint16_t *&lut)
+__device__ __forceinline__ void stage_tables(const DevImage &im, const LutEntry *lut_pool, unsigned char *smem,
+                                             const HuffImage *&himg, const LutEntry *&lut)
 {
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     HuffImage *h = reinterpret_cast<HuffImage *>(smem);
-    uint16_t *l = reinterpret_cast<uint16_t *>(smem + sizeof(HuffImage));
+    LutEntry *l = reinterpret_cast<LutEntry *>(smem + sizeof(HuffImage));
     for (uint32_t i = tid; i < sizeof(HuffImage) / 4; i += nthr)
         reinterpret_cast<uint32_t *>(h)[i] = reinterpret_cast<const uint32_t *>(&im.himg)[i];
     const uint4 *lsrc = reinterpret_cast<const uint4 *>(lut_pool + im.lut_off);
     uint4 *ldst = reinterpret_cast<uint4 *>(l);
-    for (uint32_t g = tid; g < im.lut_n / 8; g += nthr) ldst[g] = lsrc[g];
+    for (uint32_t g = tid; g < im.lut_n / 4; g += nthr) ldst[g] = lsrc[g];
+    __syncthreads();
+    // table offsets -> absolute LDS addresses (see lut_at); the workgroup's LDS stays below 64 KiB
+    if (tid < uint32_t(kMaxBlocksPerMcu))
+        h->btab[tid].tabs += uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)(l))) * 0x10001u;
     __syncthreads();
     himg = h;
     lut = l;
@@ -148,32 +173,32 @@ __device__ __forceinline__ uint32_t subseq_end(const HuffImage &h, uint32_t s)
     return e < h.total_bits ? e : h.total_bits;
 }
 
-// Per-lane window of the bitstream in LDS.  A lane that read its bits straight from HBM would issue one L2 request
-// per dword and expose an L2 / MALL round trip at almost every symbol (some lane of the wave always needs a refill),
-// and in the write pass such loads would also queue behind the scattered stores (loads and stores retire in issue
-// order on vmcnt).  Instead every lane owns kWinDwords big-endian dwords in LDS; the wave restages all its windows
-// together (wave-uniform branch, 16-byte loads) whenever one lane is about to run out, about every 120 symbols.
-#ifndef MJX_WRITE_WIN
-#define MJX_WRITE_WIN true
+// Per-lane window of the bitstream in LDS.  A lane that read its bits straight from HBM would wait for an L2 round
+// trip on almost every symbol: some lane of the wave always needs a refill, loads retire in order per wave, and the
+// freshly requested dword cannot be moved up a register queue before it has landed.  (In the write pass such loads
+// would also queue behind the scattered stores.)  Instead every lane owns kWinDwords big-endian dwords in LDS; the
+// wave restages all its windows together (wave-uniform branch, 16-byte loads) whenever one lane is about to run
+// out, about every 60 symbols, and the per-symbol refills only touch LDS.
+#ifndef MJX_WIN_DWORDS
+#define MJX_WIN_DWORDS 12
 #endif
-#ifndef MJX_SPEC_WIN
-#define MJX_SPEC_WIN 0
-#endif
-constexpr bool kSpecWin = MJX_SPEC_WIN != 0;   // spec / merge read bits through LDS windows (1) or straight from HBM (0)
-constexpr int kWinDwords = 24;
-constexpr int kWinStride = kWinDwords + 1;      // odd stride: lane l, dword k -> bank (25 l + k) % 32, conflict-free per k
+constexpr int kWinDwords = MJX_WIN_DWORDS;
+constexpr int kWinStride = kWinDwords + 1;      // odd stride: lanes spread over all banks
 struct LdsWindow {
-    const uint32_t *lds;    // lane's window
-    uint32_t wbase;         // stream dword index of lds[0]
-    __device__ __forceinline__ uint32_t be32(uint32_t i) const { return lds[i - wbase]; }
-    __device__ __forceinline__ uint32_t raw32(uint32_t i) const { return lds[i - wbase]; }
+    static constexpr int kAhead = 1;
+    const unsigned char *lds;    // lane's window
+    uint32_t wbase;              // stream byte offset of the window's first dword
+    __device__ __forceinline__ uint32_t be32(uint32_t byte_off) const { return *reinterpret_cast<const uint32_t *>(lds + (byte_off - wbase)); }
+    __device__ __forceinline__ uint32_t raw32(uint32_t byte_off) const { return be32(byte_off); }
     static __device__ __forceinline__ uint32_t fix(uint32_t raw) { return raw; }
+    __device__ __forceinline__ void refill(LaneState &st) const { refill_generic(*this, st); }
+    __device__ __forceinline__ void drain(LaneState &) const {}
 };
 __device__ __forceinline__ void window_fill(uint32_t *lds, const GlobalBits &g, uint32_t wbase)
 {
 #pragma unroll
     for (int q = 0; q < kWinDwords / 4; q++) {
-        uint4 v = *reinterpret_cast<const uint4 *>(g.words + wbase + 4 * q);    // 4-byte aligned 16-byte load
+        uint4 v = *reinterpret_cast<const uint4 *>(g.bytes + wbase + 16 * q);    // 4-byte aligned 16-byte load
         lds[4 * q] = __builtin_bswap32(v.x);
         lds[4 * q + 1] = __builtin_bswap32(v.y);
         lds[4 * q + 2] = __builtin_bswap32(v.z);
@@ -181,81 +206,81 @@ __device__ __forceinline__ void window_fill(uint32_t *lds, const GlobalBits &g, 
     }
 }
 
-// The decode loop shared by the three entropy kernels.  All lanes of the wave step together; a lane that is done
-// (reached its end bit, merged with its previous decode, or ran past the last block in the write pass) idles.
+// Decode loop over LDS windows.  All lanes of the wave step together; a lane that is done (left its subsequence,
+// merged with its previous decode, or ran past the last block in the write pass) idles.
 //   WRITE  emit coefficients through `sink`      CP  0: none, 1: record checkpoints, 2: record + merge (see mjx_huff.h)
-template <bool WRITE, int CP, bool USE_WIN, class Sink, class CpStore>
+template <bool WRITE, int CP, class Sink, class CpStore>
 __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry, uint32_t end_bit, uint32_t blk,
-                                                   const GlobalBits &g, uint32_t *my_win, const uint16_t *lut,
+                                                   const GlobalBits &g, uint32_t *my_win, const LutEntry *lut,
                                                    const HuffImage &h, Sink &sink, CpStore &cps, uint32_t sub_start,
                                                    SubseqState old_exit)
 {
-    LdsWindow win{my_win, entry.p >> 5};
-    if (USE_WIN) window_fill(my_win, g, win.wbase);
     LaneState st;
-    if (USE_WIN) lane_begin(st, win, h, entry);
-    else lane_begin(st, g, h, entry);
-    const uint32_t total_blocks = h.total_blocks;
-    uint32_t cp_bit = sub_start + kCpBits, k = 0;
-    bool running = live;
-    for (;;) {
-        bool active = running && st.p < end_bit;
-        if (WRITE) active = active && blk < total_blocks;
-        if (!__any(active)) break;
-        if (USE_WIN && __any(active && st.wi + 3 >= win.wbase + kWinDwords)) {   // wave-uniform: restage every window
-            win.wbase = st.wi;
-            window_fill(my_win, g, win.wbase);
-        }
-        if (active) {
-            bool merged = false;
-            if (CP && st.p >= cp_bit) {
-                uint32_t n_rest, m_rest;
-                if (checkpoint_merge<CP == 2>(st, cps, k, cp_bit, n_rest, m_rest)) {
-                    st.n += n_rest;
-                    st.m += m_rest;
-                    st.p = old_exit.p; st.z = old_exit.z; st.c = old_exit.c;
-                    merged = true;
-                    running = false;
-                }
-            }
-            if (!merged) {
-                if (USE_WIN) symbol_step<WRITE>(st, win, lut, h, blk, sink);
-                else symbol_step<WRITE>(st, g, lut, h, blk, sink);
-            }
-        }
+    LaneEvents ev;
+    {
+        const uint32_t first = 4u * ((entry.p + 31u) >> 5);                     // byte offset of the lane's w1
+        LdsWindow win{reinterpret_cast<const unsigned char *>(my_win), first ? first - 4u : 0u};
+        window_fill(my_win, g, win.wbase);
+        lane_begin(st, win, h, entry);
     }
-    if (CP && live) checkpoint_fixup(cps, k, st.n, st.m);
-    return make_state(st.p, st.z, st.c, st.n, st.m);
+    events_begin<CP>(ev, sub_start, end_bit);
+    uint32_t wbase = st.wn - 12u;
+    if (st.wn == 8u) wbase = 0;
+    const uint32_t total_blocks = h.total_blocks;
+    bool running = live && entry.p <= end_bit && !(WRITE && blk >= total_blocks);
+    const bool started = running;
+    for (uint32_t it = 1;; it++) {
+        if (!__builtin_amdgcn_ballot_w64(running)) break;
+        if (__builtin_amdgcn_ballot_w64(running && st.wn >= wbase + 4u * kWinDwords)) {   // wave-uniform: restage every window
+            wbase = st.wn;                                                      // (w0, w1, q are in registers)
+            window_fill(my_win, g, wbase);
+        }
+        if (running) {
+            const LdsWindow win{reinterpret_cast<const unsigned char *>(my_win), wbase};
+            const bool crossed = symbol_step<WRITE>(st, win, lut, h, blk, sink);
+            bool done = WRITE && blk >= total_blocks;
+            if (crossed) done = lane_event<CP>(st, ev, h, cps) || done;
+            running = !done;
+        }
+        if (WRITE && it % kFlushEvery == 0) sink.flush_groups();               // wave-uniform
+    }
+    if (!started) return make_state(entry.p, entry.z, entry.c);
+    if (CP) checkpoint_fixup(cps, ev.k, st.n, lane_m(st));
+    return lane_exit(st, ev, h, old_exit);
 }
 
+#ifndef MJX_SPEC_WIN
+#define MJX_SPEC_WIN 1
+#endif
+constexpr bool kSpecWin = MJX_SPEC_WIN != 0;    // spec / merge read their bits through LDS windows (1) or straight from HBM (0)
+
 // k_huff_spec: every lane decodes its subsequence from the guess "a block starts exactly here", recording its exit
-// state and a checkpoint every 256 bits.  Lanes do the same amount of work (+-3 %), so plain lock-step is efficient.
-extern "C" __global__ __launch_bounds__(256) void k_huff_spec(const DevImage *images, const uint8_t *scan_pool,
-                                                               const uint16_t *lut_pool, SubseqState *g_entry,
-                                                               SubseqState *g_exit, uint32_t *g_cps, uint32_t cp_stride)
+// state and a checkpoint every 256 bits.  Lanes do the same amount of work (+-3 %), so the plain per-lane loop
+// (exec-masked by the compiler) is efficient.
+extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_spec(const DevImage *images, const uint8_t *scan_pool,
+                                                                   const LutEntry *lut_pool, SubseqState *g_entry,
+                                                                   SubseqState *g_exit, uint32_t *g_cps, uint32_t win_off)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint32_t s_win[kSpecWin ? kWgLanes * kWinStride : 1];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // HuffImage, tables, [windows]
+    uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
     const DevImage &im = images[blockIdx.y];
-    if (!im.valid || blockIdx.x * kWgLanes >= im.himg.nsub) return;
+    if (!im.valid || blockIdx.x * kHuffWg >= im.himg.nsub) return;
     const HuffImage *h;
-    const uint16_t *lut;
+    const LutEntry *lut;
     stage_tables(im, lut_pool, smem, h, lut);
-    const uint32_t s = blockIdx.x * kWgLanes + threadIdx.x;
+    const uint32_t s = blockIdx.x * kHuffWg + threadIdx.x;
     const bool live = s < h->nsub;
-    const GlobalBits bits{reinterpret_cast<const uint32_t *>(scan_pool + im.scan_off), im.scan_padded / 4};
+    if (!kSpecWin && !live) return;
+    const GlobalBits bits{scan_pool + im.scan_off};
     const SubseqState e = make_state(live ? s * kSubseqBits : 0u, 0, 0);
     NullSink sink;
-    GlobalCps cps{cps_slot(g_cps, im.sub_off + s), kCpRow, 0};
-    // lanes do equal work, so the plain per-lane loop (exec-masked by the compiler) is the cheapest form
-    SubseqState x = e;
-    if (kSpecWin) x = wave_decode<false, 1, true>(live, e, live ? subseq_end(*h, s) : 0u, 0, bits, s_win + threadIdx.x * kWinStride,
-                                                  lut, *h, sink, cps, s * kSubseqBits, e);
-    else if (live) x = decode_subseq<false, 1>(bits, lut, *h, e, subseq_end(*h, s), 0, sink, cps, s * kSubseqBits, e);
-    if (live) {
-        g_entry[im.sub_off + s] = e;
-        g_exit[im.sub_off + s] = x;
-    }
+    GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + (live ? s : 0u)), 0};
+    SubseqState x;
+    if (kSpecWin) x = wave_decode<false, 1>(live, e, live ? subseq_end(*h, s) : 0u, 0, bits, s_win + threadIdx.x * kWinStride, lut, *h, sink, cps, s * kSubseqBits, e);
+    else x = decode_subseq<false, 1>(bits, lut, *h, e, subseq_end(*h, s), 0, sink, cps, s * kSubseqBits, e);
+    if (!live) return;
+    g_entry[im.sub_off + s] = e;
+    g_exit[im.sub_off + s] = x;
 }
 
 // k_huff_merge: one synchronisation round.  Subsequence s must start where s-1 ended: if entry[s] differs from
@@ -264,16 +289,14 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_spec(const DevImage *im
 // fixed point entry[s] == exit[s-1] for all s, which (entry[0] being the true start) is the true decode; `mismatches`
 // counts the re-decoded items of this round.  Exits are read while other lanes may be rewriting them (8-byte aligned
 // accesses): a stale read only defers the repair to the next round, and the zero-count round is race-free by definition.
-extern "C" __global__ __launch_bounds__(256) void k_huff_merge(const DevImage *images, const uint8_t *scan_pool,
-                                                                const uint16_t *lut_pool, SubseqState *g_entry,
-                                                                SubseqState *g_exit, uint32_t *g_cps, uint32_t cp_stride,
-                                                                uint32_t *mismatches)
+extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_merge(const DevImage *images, const uint8_t *scan_pool,
+                                                                const LutEntry *lut_pool, SubseqState *g_entry,
+                                                                SubseqState *g_exit, uint32_t *g_cps, uint32_t *mismatches)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint32_t s_win[kSpecWin ? kWgLanes * kWinStride : 1];
     const DevImage &im = images[blockIdx.y];
-    if (!im.valid || blockIdx.x * kWgLanes + 1 >= im.himg.nsub) return;
-    const uint32_t s = blockIdx.x * kWgLanes + threadIdx.x + 1;
+    if (!im.valid || blockIdx.x * kHuffWg + 1 >= im.himg.nsub) return;
+    const uint32_t s = blockIdx.x * kHuffWg + threadIdx.x + 1;
     bool need = false;
     SubseqState prev = make_state(0, 0, 0);
     if (s < im.himg.nsub) {
@@ -282,26 +305,19 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_merge(const DevImage *i
     }
     if (!__syncthreads_or(need)) return;                                   // nothing to repair in this workgroup
     const HuffImage *h;
-    const uint16_t *lut;
+    const LutEntry *lut;
     stage_tables(im, lut_pool, smem, h, lut);
     const unsigned long long m = __ballot(need);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(mismatches, uint32_t(__popcll(m)));
-    if (!m) return;                                                        // wave-uniform
-    const GlobalBits bits{reinterpret_cast<const uint32_t *>(scan_pool + im.scan_off), im.scan_padded / 4};
+    if (!need) return;
+    const GlobalBits bits{scan_pool + im.scan_off};
     const SubseqState e = make_state(prev.p, prev.z, prev.c);
-    SubseqState old_exit = make_state(0, 0, 0);
-    GlobalCps cps{cps_slot(g_cps, im.sub_off + (need ? s : 0u)), kCpRow, 0};
-    if (need) {
-        old_exit = g_exit[im.sub_off + s];
-        g_entry[im.sub_off + s] = e;
-        cps.prime();
-    }
+    const SubseqState old_exit = g_exit[im.sub_off + s];
+    GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + s), 0};
+    g_entry[im.sub_off + s] = e;
+    cps.prime();
     NullSink sink;
-    SubseqState x = e;
-    if (kSpecWin) x = wave_decode<false, 2, true>(need, e, need ? subseq_end(*h, s) : 0u, 0, bits, s_win + threadIdx.x * kWinStride,
-                                                  lut, *h, sink, cps, s * kSubseqBits, old_exit);
-    else if (need) x = decode_subseq<false, 2>(bits, lut, *h, e, subseq_end(*h, s), 0, sink, cps, s * kSubseqBits, old_exit);
-    if (need) g_exit[im.sub_off + s] = x;
+    g_exit[im.sub_off + s] = decode_subseq<false, 2>(bits, lut, *h, e, subseq_end(*h, s), 0, sink, cps, s * kSubseqBits, old_exit);
 }
 
 // Workgroup-wide exclusive scan helper (256 lanes): returns the exclusive prefix of v, total in *total.
@@ -432,21 +448,21 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *im
     }
 }
 
-extern "C" __global__ __launch_bounds__(256) void k_huff_write(const DevImage *images, const uint8_t *scan_pool,
-                                                                const uint16_t *lut_pool, const SubseqState *g_entry,
+extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImage *images, const uint8_t *scan_pool,
+                                                                const LutEntry *lut_pool, const SubseqState *g_entry,
                                                                 const uint32_t *g_blkbase, const uint32_t *g_ebase,
                                                                 uint32_t *entries, uint32_t *tile_eoff, int32_t *dcbuf,
-                                                                int *status, const uint32_t *img_flags)
+                                                                int *status, const uint32_t *img_flags, uint32_t win_off)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint32_t s_win[kWgLanes * kWinStride];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // HuffImage, tables, windows
+    uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
     const DevImage &im = images[blockIdx.y];
-    if (!im.valid || blockIdx.x * kWgLanes >= im.himg.nsub || img_flags[im.status_idx]) return;
+    if (!im.valid || blockIdx.x * kHuffWg >= im.himg.nsub || img_flags[im.status_idx]) return;
     const HuffImage *h;
-    const uint16_t *lut;
+    const LutEntry *lut;
     stage_tables(im, lut_pool, smem, h, lut);
-    const uint32_t s = blockIdx.x * kWgLanes + threadIdx.x;
-    const GlobalBits gbits{reinterpret_cast<const uint32_t *>(scan_pool + im.scan_off), im.scan_padded / 4};
+    const uint32_t s = blockIdx.x * kHuffWg + threadIdx.x;
+    const GlobalBits gbits{scan_pool + im.scan_off};
     const bool live = s < h->nsub;
     SubseqState e = make_state(0, 0, 0);
     uint32_t blk = 0, end_bit = 0, ebase = 0;
@@ -461,12 +477,8 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_write(const DevImage *i
     sink.dcbuf = dcbuf + im.coef_off;
     sink.tile_eoff = tile_eoff + im.tile_off;
     sink.status = status + im.status_idx;
-    sink.off = ebase;
-    sink.nbuf = 0;
-    sink.b0 = sink.b1 = sink.b2 = sink.b3 = 0;
-    sink.ndc = 0;
-    sink.d0 = sink.d1 = sink.d2 = sink.d3 = 0;
-    sink.last_dc_blk = 0;
+    sink.ring = s_win + kHuffWg * kWinStride + threadIdx.x * kStageRing;
+    sink.begin(ebase);
     sink.tile_blocks = im.tile_blocks;
     sink.total_blocks = h->total_blocks;
     sink.ntiles = (h->total_blocks + im.tile_blocks - 1) / im.tile_blocks;
@@ -476,7 +488,7 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_write(const DevImage *i
         sink.next_tile_blk = sink.tile_idx * im.tile_blocks;
     }
     NoCheckpoints nocp;
-    wave_decode<true, 0, MJX_WRITE_WIN>(live, e, end_bit, blk, gbits, s_win + threadIdx.x * kWinStride, lut, *h, sink, nocp, 0, e);
+    wave_decode<true, 0>(live, e, end_bit, blk, gbits, s_win + threadIdx.x * kWinStride, lut, *h, sink, nocp, 0, e);
     sink.flush();
 }
 
@@ -1067,17 +1079,20 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
 // ------------------------------------------------------------------------------------------------
 // host launchers (declared in mjx_kernels.h)
 // ------------------------------------------------------------------------------------------------
-size_t huff_lds_bytes(uint32_t lut_cap_entries) { return sizeof(HuffImage) + size_t(lut_cap_entries) * 2 + 16; }
+size_t huff_lds_bytes(uint32_t lut_cap_entries) { return (sizeof(HuffImage) + size_t(lut_cap_entries) * sizeof(LutEntry) + 15) / 16 * 16; }
+size_t huff_window_bytes() { return size_t(kHuffWg) * kWinStride * 4; }
+size_t huff_stage_bytes() { return size_t(kHuffWg) * kStageRing * 4; }    // the write pass's entry rings
 
 size_t idct_lds_bytes(uint32_t max_tile_blocks) { return size_t(max_tile_blocks) * kPixStride * 4; }
 
 int configure_kernels(size_t huff_lds, size_t idct_lds)
 {
     hipError_t e = hipSuccess;
-    if (huff_lds > 64 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_spec), hipFuncAttributeMaxDynamicSharedMemorySize, int(huff_lds));
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_merge), hipFuncAttributeMaxDynamicSharedMemorySize, int(huff_lds));
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_write), hipFuncAttributeMaxDynamicSharedMemorySize, int(huff_lds));
+    if (huff_lds > 64 * 1024) {   // tables + windows + occupancy padding of the largest entropy launch
+        const int cap = int(huff_lds);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_spec), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_merge), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_write), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     }
     if (e == hipSuccess && idct_lds > 64 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_idct_color<0>), hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
@@ -1099,18 +1114,20 @@ void launch_destuff_scatter(hipStream_t st, uint32_t max_seg, uint32_t nimg, con
     hipLaunchKernelGGL(k_destuff_scatter, dim3(max_seg, nimg), dim3(256), 0, st, imgs, raw, segbase, pool);
 }
 
-void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
-                      const uint8_t *scan_pool, const uint16_t *lut_pool, SubseqState *entry, SubseqState *exit_,
-                      uint32_t *cps, uint32_t cp_stride)
+void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
+                      const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
+                      uint32_t *cps)
 {
-    hipLaunchKernelGGL(k_huff_spec, dim3(max_wg, nimg), dim3(kWgLanes), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, cp_stride);
+    const size_t lds = tables_lds + (kSpecWin ? huff_window_bytes() : 0) + pad_lds;
+    hipLaunchKernelGGL(k_huff_spec, dim3(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, uint32_t(tables_lds));
 }
 
-void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
-                       const uint8_t *scan_pool, const uint16_t *lut_pool, SubseqState *entry, SubseqState *exit_,
-                       uint32_t *cps, uint32_t cp_stride, uint32_t *mismatches)
+void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
+                       const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
+                       uint32_t *cps, uint32_t *mismatches)
 {
-    hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kWgLanes), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, cp_stride, mismatches);
+    const size_t lds = tables_lds + pad_lds;
+    hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches);
 }
 
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,
@@ -1119,12 +1136,13 @@ void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, con
     hipLaunchKernelGGL(k_huff_scan, dim3(nimg), dim3(kWgLanes), 0, st, images, exit_, blkbase, ebase, img_entries, img_flags);
 }
 
-void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t lds, const DevImage *images,
-                       const uint8_t *scan_pool, const uint16_t *lut_pool, const SubseqState *entry,
+void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
+                       const uint8_t *scan_pool, const LutEntry *lut_pool, const SubseqState *entry,
                        const uint32_t *blkbase, const uint32_t *ebase, uint32_t *entries, uint32_t *tile_eoff,
                        int32_t *dcbuf, int *status, const uint32_t *img_flags)
 {
-    hipLaunchKernelGGL(k_huff_write, dim3(max_wg, nimg), dim3(kWgLanes), lds, st, images, scan_pool, lut_pool, entry, blkbase, ebase, entries, tile_eoff, dcbuf, status, img_flags);
+    const size_t lds = tables_lds + huff_window_bytes() + huff_stage_bytes() + pad_lds;
+    hipLaunchKernelGGL(k_huff_write, dim3(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, blkbase, ebase, entries, tile_eoff, dcbuf, status, img_flags, uint32_t(tables_lds));
 }
 
 void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int32_t *dcbuf,

@@ -12,18 +12,18 @@
 
 namespace mjx {
 
-static uint16_t entry_for_symbol(unsigned len, uint8_t sym, bool is_dc)
+static LutEntry entry_for_symbol(unsigned len, uint8_t sym, bool is_dc)
 {
     if (is_dc) {
-        if (sym > 15) return 0;                      // read_n_bits asserts n <= 16 (huffman.rs:202); 16 is unusable
-        return lut_direct(len, 0, sym);
+        if (sym > 15) return lut_invalid();          // read_n_bits asserts n <= 16 (huffman.rs:202); 16 is unusable
+        return lut_direct(len, 0, sym, false);
     }
     const unsigned r = sym >> 4, s = sym & 15;
-    if (sym == 0x00) return lut_direct(len, 63, 0);  // EOB
-    return lut_direct(len, r, s);                    // includes ZRL (r = 15, s = 0) and the degenerate r/0 symbols
+    if (sym == 0x00) return lut_direct(len, 63, 0, true);  // EOB
+    return lut_direct(len, r, s, true);              // includes ZRL (r = 15, s = 0) and the degenerate r/0 symbols
 }
 
-int build_decode_table(const uint8_t bits[16], const uint8_t *vals, bool is_dc, uint16_t *out, int cap)
+int build_decode_table(const uint8_t bits[16], const uint8_t *vals, bool is_dc, LutEntry *out, int cap)
 {
     // canonical code assignment
     struct Code { uint16_t code; uint8_t len, sym; };
@@ -42,7 +42,7 @@ int build_decode_table(const uint8_t bits[16], const uint8_t *vals, bool is_dc, 
     }
     if (ncodes == 0) return -MJX_ERR_BAD_HUFFMAN;
     if (cap < kLutPrimarySize) return -MJX_ERR_NOMEM;
-    std::memset(out, 0, sizeof(uint16_t) * kLutPrimarySize);
+    for (int k = 0; k < kLutPrimarySize; k++) out[k] = lut_invalid();
     int used = kLutPrimarySize;
 
     // longest code under each primary prefix that needs a sub-table
@@ -57,17 +57,17 @@ int build_decode_table(const uint8_t bits[16], const uint8_t *vals, bool is_dc, 
     }
     for (int i = 0; i < ncodes; i++) {
         const Code &c = codes[i];
-        const uint16_t e = entry_for_symbol(c.len, c.sym, is_dc);
+        const LutEntry e = entry_for_symbol(c.len, c.sym, is_dc);
         if (c.len <= kLutPrimaryBits) {
             const unsigned first = unsigned(c.code) << (kLutPrimaryBits - c.len), count = 1u << (kLutPrimaryBits - c.len);
             for (unsigned k = 0; k < count; k++) out[first + k] = e;
         } else {
             const unsigned prefix = c.code >> (c.len - kLutPrimaryBits);
             const unsigned nb = maxlen[prefix] - kLutPrimaryBits;        // 1..6
-            if (!(out[prefix] & kLutLinkBit)) {
-                if (used + (1 << nb) > cap || used > 0xffe) return -MJX_ERR_NOMEM;     // offsets are even, < 4096
+            if (!lut_is_link(out[prefix])) {
+                if (used + (1 << nb) > cap) return -MJX_ERR_NOMEM;
                 out[prefix] = lut_link(unsigned(used), nb);
-                std::memset(out + used, 0, sizeof(uint16_t) << nb);
+                for (int k = 0; k < (1 << nb); k++) out[used + k] = lut_invalid();
                 used += 1 << nb;
             }
             const unsigned sub = lut_link_offset(out[prefix]);

@@ -140,7 +140,7 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p)
     // decode tables: each distinct (class, slot) used by the scan is built once
     int dc_base[4] = {-1, -1, -1, -1}, ac_base[4] = {-1, -1, -1, -1};
     p.lut.clear();
-    uint16_t tmp[kLutPrimarySize + 4096];
+    static thread_local LutEntry tmp[kLutPrimarySize + 4096];
     auto add_table = [&](const mjx_hufftab &t, bool is_dc) -> int {
         const int n = build_decode_table(t.bits, t.vals, is_dc, tmp, int(sizeof tmp / sizeof tmp[0]));
         if (n < 0) return n;
@@ -161,15 +161,15 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p)
             ac_base[k.ta] = b;
         }
     }
-    if (p.lut.size() > 0xffff) return fail(MJX_ERR_BAD_HUFFMAN);
-    while (p.lut.size() % 8) p.lut.push_back(0);                                    // 16-byte granules for staging
+    // table offsets become 16-bit LDS addresses on the device; four tables of a baseline scan need < 24 KB
+    if (p.lut.size() * sizeof(LutEntry) > 0x7fff) return fail(MJX_ERR_BAD_HUFFMAN);
+    while (p.lut.size() % 4) p.lut.push_back(0);                                    // 16-byte granules for staging
     std::memset(&p.himg, 0, sizeof p.himg);
-    for (uint32_t c = 0; c < 3; c++) {
-        const mjx_comp &k = d.comp[c < p.ncomp ? c : 0];
-        p.himg.ctab[c] = uint32_t(dc_base[k.td]) | (uint32_t(ac_base[k.ta]) << 16);
+    for (uint32_t b = 0; b < p.bpm; b++) {
+        const mjx_comp &k = d.comp[p.blk_comp[b]];
+        p.himg.btab[b].tabs = uint32_t(dc_base[k.td]) * uint32_t(sizeof(LutEntry)) | (uint32_t(ac_base[k.ta]) * uint32_t(sizeof(LutEntry)) << 16);
+        p.himg.btab[b].next = b + 1 == p.bpm ? 0 : b + 1;
     }
-    p.himg.cfirst1 = p.ncomp > 1 ? p.h[0] * p.v[0] : p.bpm;
-    p.himg.cfirst2 = p.ncomp > 2 ? p.himg.cfirst1 + p.h[1] * p.v[1] : p.bpm;
     p.himg.bpm = p.bpm;
     p.himg.total_bits = uint32_t(p.scan_len * 8);
     p.himg.total_blocks = p.nmcu * p.bpm;

@@ -20,19 +20,22 @@ using namespace mjx;
 
 namespace {
 struct HostBits {
+    static constexpr int kAhead = 3;
     const uint8_t *p;
     size_t n;
-    uint32_t be32(uint32_t i) const
+    uint32_t be32(uint32_t byte_off) const
     {
         uint32_t w = 0;
         for (int k = 0; k < 4; k++) {
-            const size_t idx = size_t(i) * 4 + k;
+            const size_t idx = size_t(byte_off) + k;
             w = (w << 8) | (idx < n ? p[idx] : 0xaau);
         }
         return w;
     }
-    uint32_t raw32(uint32_t i) const { return be32(i); }
+    uint32_t raw32(uint32_t byte_off) const { return be32(byte_off); }
     static uint32_t fix(uint32_t raw) { return raw; }
+    void refill(LaneState &st) const { refill_generic(*this, st); }
+    void drain(LaneState &) const {}
 };
 // Mirrors the device sink of k_huff_write: AC entries appended to the compact stream, DC differences per block,
 // the stream offset of every tile's first block.
