@@ -60,7 +60,7 @@ struct Chunk {
     uint64_t coef_base = 0;        // first block of the chunk inside the per-block arrays (keep_coefs) or 0
     uint64_t entries = 0, ent_base = 0;   // capacity of the chunk's stream regions; first entry (keep_coefs) or 0
     uint32_t tiles = 0, tile_base = 0;    // tile offsets (+1 sentinel per image)
-    uint32_t max_wg = 0, merge_wgs = 0, max_tiles = 0, lut_cap = 0, max_tile_blocks = 0, mode_mask = 0, max_segs = 0;
+    uint32_t max_wg = 0, merge_wgs = 0, max_tiles = 0, lut_cap = 0, max_tile_blocks = 0, mode_mask = 0, max_segs = 0, bpm_mask = 0;
     uint64_t plane_words = 0;      // REF_COMPAT scratch of the chunk
     uint32_t max_pixel_wgs = 0;
 };
@@ -207,6 +207,7 @@ void plan_chunks(mjx_batch *b)
                 c.max_tile_blocks = std::max<uint32_t>(c.max_tile_blocks, T * d.bpm);
                 c.lut_cap = std::max<uint32_t>(c.lut_cap, d.lut_n);
                 c.mode_mask |= 1u << d.mode;
+                c.bpm_mask |= 1u << d.bpm;
                 if (d.mode == 2) {
                     d.plane_off = c.plane_words;
                     c.plane_words += uint64_t(d.width) * d.height * d.ncomp;
@@ -341,7 +342,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
                           b->d_entries, b->d_tile_eoff, dcb, b->d_status, b->d_img_flags);
         prof_end(b);
         prof_begin(b, MJX_K_DC_SCAN);
-        launch_dc_scan(st, c.max_segs, nimg, imgs, dcb, b->d_segsum, b->d_img_flags);
+        launch_dc_scan(st, c.max_segs, nimg, imgs, dcb, b->d_segsum, b->d_img_flags, c.bpm_mask);
         prof_end(b);
     }
     if (stages & MJX_STAGE_PIXELS) {

@@ -37,7 +37,8 @@ constexpr int kMaxBlocksPerMcu = 12;           // 3 components x (2x2)
 //             len  = code length (1..16), size = value bits, adv = len + size (bits the symbol consumes, <= 27)
 //             zinc = zig-zag positions the symbol advances: run + 1; 64 for EOB (saturates the block); 16 for ZRL
 //             cnt  = 1 for an AC symbol with size != 0 (it produces one entry of the compact coefficient stream)
-//             bad  = 1 for bit patterns no code matches (huffman.rs:156/162); such an entry consumes one bit
+//             bad  = 1 for bit patterns no code matches (huffman.rs:156/162); such an entry consumes one bit and is
+//                    only ever reached through a link
 //           The fields the synchronisation passes need are placed so that two instructions update the lane:
 //           x += e & kLutXMask  (bit budget of the current dword -= adv, entries += cnt)  and  r = sat_sub(r, zinc).
 //  link   : 0 [31:26] | byte offset of the sub-table from the table's base [25:4] | nbits [3:0]
@@ -114,7 +115,7 @@ struct NullSink {
 // recorded one: equal (p, z, c) means the two decodes coincide from there on, so the re-decode stops and inherits
 // the old exit.  This is the self-synchronisation property used at a finer grain: most re-decodes merge after ~100
 // symbols instead of running all ~800.
-//   word 0: bit31 valid | n[30:16] | next block-in-MCU [15:12] | 64 - z [11:5] | t [4:0]      word 1: m
+//   word 0: bit31 valid | n[30:16] | block-in-MCU + 2 (mod blocks per MCU) [15:12] | 64 - z [11:5] | t [4:0]      word 1: m
 //   (at a boundary the lane's dword position is the boundary itself, so t stands for p)
 //   n, m = blocks / stream entries from the checkpoint to the end of the subsequence (after the decode's fix-up);
 //   while a decode is running they temporarily hold the counts from the start to the checkpoint.
@@ -144,7 +145,8 @@ struct LaneState {
     uint32_t x;             // t [31:26] (signed) | m [25:0]
     uint32_t r;             // coefficients left in the current block: 64 - zig-zag index
     uint32_t n;             // blocks completed
-    uint32_t cnext;         // block-in-MCU of the block after the current one
+    BlockTab nb;            // table entry of the block after the current one, fetched when the current block began
+                            // (off the critical path); nb.next = block-in-MCU of the block after that
     uint32_t base, acb;     // byte offset of the table of the next symbol / of the current block's AC table
     uint32_t wn;            // byte offset of the dword after w1 (= of q[0])
     uint32_t w0, w1;
@@ -154,7 +156,11 @@ MJX_HD uint32_t lane_t(const LaneState &st) { return st.x >> 26; }
 MJX_HD uint32_t lane_m(const LaneState &st) { return st.x & 0x3ffffffu; }
 MJX_HD uint32_t lane_pos(const LaneState &st) { return 8u * (st.wn - 8u) - lane_t(st); }
 MJX_HD uint32_t lane_z(const LaneState &st) { return 64u - st.r; }
-MJX_HD uint32_t lane_c(const LaneState &st, const HuffImage &img) { return (st.cnext ? st.cnext : img.bpm) - 1u; }
+MJX_HD uint32_t lane_c(const LaneState &st, const HuffImage &img)
+{
+    const uint32_t c1 = (st.nb.next ? st.nb.next : img.bpm) - 1u;     // the next block
+    return (c1 ? c1 : img.bpm) - 1u;                                 // the current one
+}
 // byte offset of the first dword a lane fetches after it has left the bits below `bit` (bit rounded up to a dword)
 MJX_HD uint32_t wn_after(uint32_t bit) { return 4u * ((bit + 31u) >> 5) + 12u; }
 
@@ -216,7 +222,7 @@ MJX_HD void lane_begin(LaneState &st, const BitSrc &bits, const HuffImage &img, 
     st.r = 64u - entry.z;
     st.n = 0;
     const BlockTab bt = img.btab[entry.c];
-    st.cnext = bt.next;
+    st.nb = img.btab[bt.next];
     st.acb = bt.tabs >> 16;
     st.base = entry.z ? st.acb : (bt.tabs & 0xffffu);
     st.w0 = wi1 ? bits.be32(st.wn - 12u) : 0u;                   // p == 0: all of w0 is "consumed", nothing to load
@@ -237,12 +243,12 @@ MJX_HD bool symbol_step(LaneState &st, const BitSrc &bits, const LutEntry *lut, 
     if (lut_is_link(e)) {
         const uint32_t nb = e & 15u;
         e = lut_at(lut, base + (e >> 4) + bits_field(w, 32u - kLutPrimaryBits - nb, nb) * 4u);
+        if (WRITE && (e & kLutBad)) sink.bad_code(blk);                           // (invalid patterns always come this way)
     }
     sink.tick();
     const uint32_t r_old = st.r;
     st.r = sat_sub(st.r, (e >> 19) & 127u);
     if (WRITE) {
-        if (e & kLutBad) sink.bad_code(blk);
         const uint32_t len = (e >> 10) & 31u, size = (e >> 15) & 15u;
         const uint32_t v = w << len;                                              // value bits, left aligned
         const uint32_t vb = (v >> 1) >> (31 - size);                              // size == 0 -> 0
@@ -252,11 +258,10 @@ MJX_HD bool symbol_step(LaneState &st, const BitSrc &bits, const LutEntry *lut, 
     }
     st.x += e & kLutXMask;
     if (st.r == 0) {
-        const BlockTab bt = img.btab[st.cnext];
         st.r = 64;
-        st.cnext = bt.next;
-        st.base = bt.tabs & 0xffffu;
-        st.acb = bt.tabs >> 16;
+        st.base = st.nb.tabs & 0xffffu;
+        st.acb = st.nb.tabs >> 16;
+        st.nb = img.btab[st.nb.next];
         st.n++;
         blk++;
         if (WRITE) sink.block_done(blk);
@@ -295,7 +300,7 @@ MJX_HD bool lane_event(LaneState &st, LaneEvents &ev, const HuffImage &img, CpSt
     if (st.wn < ev.next_wn) return false;
     if (st.wn >= ev.end_wn) return true;
     if (CP) {
-        const uint32_t state = lane_t(st) | (st.r << 5) | (st.cnext << 12) | kCpValid;
+        const uint32_t state = lane_t(st) | (st.r << 5) | (st.nb.next << 12) | kCpValid;
         if (CP == 2) {
             const uint32_t old = cps.get(ev.k);
             if ((old & kCpStateMask) == state) {

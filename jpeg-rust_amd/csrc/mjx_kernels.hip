@@ -83,10 +83,13 @@ struct __attribute__((packed, aligned(4))) Entry4 { uint32_t a, b, c, d; };
 // is what each store instruction carried.  Entries are staged in a ring of kStageRing dwords per lane in LDS and go
 // out as whole 32-byte sectors (two back-to-back 16-byte stores) aligned to the sector grid of the image's region.
 // The wave writes its sectors out together every kFlushEvery symbols (wave-uniform branch): a symbol adds at most
-// one entry, so at most 7 + kFlushEvery < kStageRing entries wait in a ring.  Only a lane's first partial group goes
-// out dword-wise as it is produced, its last partial group at the end.
+// one entry, so at most 7 + kFlushEvery < kStageRing entries wait in a ring.  Only a lane's first and last partial
+// group go out dword-wise.
 // DC differences (one per block, 30x rarer) are stored as they come.
-constexpr uint32_t kStageRing = 16, kFlushEvery = 8, kGroup = 8;
+#ifndef MJX_GROUP
+#define MJX_GROUP 8
+#endif
+constexpr uint32_t kGroup = MJX_GROUP, kFlushEvery = kGroup, kStageRing = 2 * kGroup;
 struct StreamSink {
     uint32_t *entries;      // the image's entry region (32-byte aligned)
     int32_t *dcbuf;         // the image's DC differences (one int32 per block)
@@ -94,14 +97,14 @@ struct StreamSink {
     int *status;
     uint32_t *ring;         // the lane's kStageRing dwords of LDS
     uint32_t off;           // entries produced so far (next entry index)
-    uint32_t flushed;       // entries below this index are in HBM (a multiple of kGroup once past the first group)
-    uint32_t direct_end;    // first group boundary at/after the lane's first entry: entries below it go out one by one
+    uint32_t flushed;       // entries below this index are in HBM
+    uint32_t blk_bits;      // the current block's index, placed as in coef_entry
     uint32_t next_tile_blk, tile_idx, tile_blocks, total_blocks, ntiles;
-    __device__ __forceinline__ void begin(uint32_t first_entry)
+    __device__ __forceinline__ void begin(uint32_t first_entry, uint32_t first_blk)
     {
         off = first_entry;
-        direct_end = (first_entry + kGroup - 1) & ~(kGroup - 1);
-        flushed = direct_end;
+        flushed = first_entry;
+        blk_bits = (first_blk & 0xffu) << 22;
     }
     __device__ __forceinline__ void dc(uint32_t b, int v)
     {
@@ -112,35 +115,43 @@ struct StreamSink {
             next_tile_blk += tile_blocks;
         }
     }
-    __device__ __forceinline__ void ac(uint32_t b, unsigned pos, int v)
+    __device__ __forceinline__ void ac(uint32_t, unsigned pos, int v)
     {
-        const uint32_t e = coef_entry(v, pos, b);
-        ring[off & (kStageRing - 1)] = e;
-        if (off < direct_end) entries[off] = e;
+        ring[off & (kStageRing - 1)] = (uint32_t(v) & 0xffffu) | (pos << 16) | blk_bits;     // coef_entry
         off++;
     }
-    // wave-uniform call: every lane writes out its complete groups
+    // wave-uniform call: every lane writes out its complete groups; a lane whose region does not start on a sector
+    // first writes dword-wise up to the next boundary
     __device__ __forceinline__ void flush_groups()
     {
-        while (__builtin_amdgcn_ballot_w64(flushed + kGroup <= off)) {
-            if (flushed + kGroup <= off) {
+        while (__builtin_amdgcn_ballot_w64((flushed & (kGroup - 1)) != 0 && flushed < off)) {
+            if ((flushed & (kGroup - 1)) != 0 && flushed < off) {
+                entries[flushed] = ring[flushed & (kStageRing - 1)];
+                flushed++;
+            }
+        }
+        while (__builtin_amdgcn_ballot_w64((flushed & (kGroup - 1)) == 0 && flushed + kGroup <= off)) {
+            if ((flushed & (kGroup - 1)) == 0 && flushed + kGroup <= off) {
                 const uint4 *src = reinterpret_cast<const uint4 *>(ring + (flushed & (kStageRing - 1)));
                 uint4 *dst = reinterpret_cast<uint4 *>(entries + flushed);
-                const uint4 a = src[0], c = src[1];
-                dst[0] = a;
-                dst[1] = c;
+                uint4 v[kGroup / 4];
+#pragma unroll
+                for (uint32_t q = 0; q < kGroup / 4; q++) v[q] = src[q];
+#pragma unroll
+                for (uint32_t q = 0; q < kGroup / 4; q++) dst[q] = v[q];
                 flushed += kGroup;
             }
         }
     }
     __device__ __forceinline__ void block_done(uint32_t next_blk)
     {
+        blk_bits = (next_blk & 0xffu) << 22;
         if (next_blk == total_blocks) tile_eoff[ntiles] = off;
     }
     __device__ __forceinline__ void flush()
     {
         flush_groups();
-        for (uint32_t i = flushed; i < off; i++) entries[i] = ring[i & (kStageRing - 1)];    // (empty if off < flushed)
+        for (uint32_t i = flushed; i < off; i++) entries[i] = ring[i & (kStageRing - 1)];
     }
     __device__ __forceinline__ void bad_code(uint32_t) const { atomicOr(status, 1); }
     __device__ __forceinline__ void tick() const {}
@@ -478,7 +489,7 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
     sink.tile_eoff = tile_eoff + im.tile_off;
     sink.status = status + im.status_idx;
     sink.ring = s_win + kHuffWg * kWinStride + threadIdx.x * kStageRing;
-    sink.begin(ebase);
+    sink.begin(ebase, blk);
     sink.tile_blocks = im.tile_blocks;
     sink.total_blocks = h->total_blocks;
     sink.ntiles = (h->total_blocks + im.tile_blocks - 1) / im.tile_blocks;
@@ -511,13 +522,14 @@ __device__ __forceinline__ void wg_reduce3(int32_t v[3], int32_t (*s_w)[3], int3
     __syncthreads();
 }
 
+constexpr uint32_t kDcFastShapes = (1u << 1) | (1u << 3) | (1u << 4) | (1u << 6);     // blocks per MCU with a fast kernel
 extern "C" __global__ __launch_bounds__(256) void k_dc_sums(const DevImage *images, const int32_t *dcbuf,
                                                              int32_t *segsum, uint32_t max_segs, const uint32_t *img_flags)
 {
     __shared__ int32_t s_w[4][3];
     const DevImage &im = images[blockIdx.y];
     const uint32_t m0 = blockIdx.x * kDcSegMcus;
-    if (!im.valid || m0 >= im.nmcu || img_flags[im.status_idx]) return;
+    if (!im.valid || m0 >= im.nmcu || img_flags[im.status_idx] || ((kDcFastShapes >> im.bpm) & 1u)) return;
     const uint32_t bpm = im.bpm, tid = threadIdx.x;
     const uint32_t nv = (min(uint32_t(kDcSegMcus), im.nmcu - m0)) * bpm;
     const int32_t *dc = dcbuf + im.coef_off + size_t(m0) * bpm;
@@ -542,7 +554,7 @@ extern "C" __global__ __launch_bounds__(256) void k_dc_apply(const DevImage *ima
     __shared__ int32_t s_wsum[4][3];
     const DevImage &im = images[blockIdx.y];
     const uint32_t seg0 = blockIdx.x * kDcSegMcus;
-    if (!im.valid || seg0 >= im.nmcu || img_flags[im.status_idx]) return;
+    if (!im.valid || seg0 >= im.nmcu || img_flags[im.status_idx] || ((kDcFastShapes >> im.bpm) & 1u)) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, bpm = im.bpm;
     const uint32_t seg1 = min(im.nmcu, seg0 + kDcSegMcus);
     int32_t *dc = dcbuf + im.coef_off;
@@ -614,6 +626,133 @@ extern "C" __global__ __launch_bounds__(256) void k_dc_apply(const DevImage *ima
     }
 }
 
+// Fast forms for the common MCU shapes (BPM blocks per MCU known at compile time): a lane owns kDcLaneMcus
+// consecutive MCUs of the segment, keeps their differences in registers (16-byte loads, all in flight at once),
+// and the workgroup needs a single scan.  Images with another MCU shape take the generic kernels above.
+// (Staging the segment through LDS for fully coalesced accesses was measured 2.4x slower.)
+constexpr int kDcLaneMcus = kDcSegMcus / 256;
+struct __attribute__((packed, aligned(4))) Int4 { int32_t a, b, c, d; };
+
+template <int BPM>
+__device__ __forceinline__ uint32_t dc_lane_load(const DevImage &im, const int32_t *dcbuf, uint32_t seg0, uint32_t seg1,
+                                                 int32_t (&v)[kDcLaneMcus * BPM], int32_t *&p)
+{
+    const uint32_t m_first = seg0 + threadIdx.x * kDcLaneMcus;
+    const uint32_t nvalid = m_first < seg1 ? min(uint32_t(kDcLaneMcus), seg1 - m_first) : 0u;
+    p = const_cast<int32_t *>(dcbuf) + im.coef_off + size_t(m_first) * BPM;
+    if (nvalid == kDcLaneMcus) {
+#pragma unroll
+        for (int q = 0; q < kDcLaneMcus * BPM / 4; q++) {
+            const Int4 x = reinterpret_cast<const Int4 *>(p)[q];
+            v[4 * q] = x.a; v[4 * q + 1] = x.b; v[4 * q + 2] = x.c; v[4 * q + 3] = x.d;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kDcLaneMcus * BPM; i++) v[i] = uint32_t(i) < nvalid * BPM ? p[i] : 0;
+    }
+    return nvalid;
+}
+
+template <int BPM>
+__global__ __launch_bounds__(256) void k_dc_sums_t(const DevImage *images, const int32_t *dcbuf, int32_t *segsum,
+                                                   uint32_t max_segs, const uint32_t *img_flags)
+{
+    static_assert((kDcLaneMcus * BPM) % 4 == 0, "16-byte pieces");
+    __shared__ int32_t s_w[4][3];
+    const DevImage &im = images[blockIdx.y];
+    const uint32_t seg0 = blockIdx.x * kDcSegMcus;
+    if (!im.valid || im.bpm != BPM || seg0 >= im.nmcu || img_flags[im.status_idx]) return;
+    const uint32_t seg1 = min(im.nmcu, seg0 + kDcSegMcus);
+    int32_t v[kDcLaneMcus * BPM];
+    int32_t *p;
+    (void)dc_lane_load<BPM>(im, dcbuf, seg0, seg1, v, p);
+    int32_t sum[3] = {0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < BPM; j++) {
+        const uint32_t c = im.blk_comp[j];
+        int32_t t = 0;
+#pragma unroll
+        for (int m = 0; m < kDcLaneMcus; m++) t += v[m * BPM + j];
+        sum[0] += c == 0 ? t : 0;
+        sum[1] += c == 1 ? t : 0;
+        sum[2] += c == 2 ? t : 0;
+    }
+    int32_t tot[3];
+    wg_reduce3(sum, s_w, tot);
+    if (threadIdx.x < 3) segsum[(size_t(blockIdx.y) * max_segs + blockIdx.x) * 3 + threadIdx.x] = tot[threadIdx.x];
+}
+
+template <int BPM>
+__global__ __launch_bounds__(256) void k_dc_apply_t(const DevImage *images, int32_t *dcbuf, const int32_t *segsum,
+                                                    uint32_t max_segs, const uint32_t *img_flags)
+{
+    __shared__ int32_t s_wsum[4][3];
+    const DevImage &im = images[blockIdx.y];
+    const uint32_t seg0 = blockIdx.x * kDcSegMcus;
+    if (!im.valid || im.bpm != BPM || seg0 >= im.nmcu || img_flags[im.status_idx]) return;
+    const uint32_t seg1 = min(im.nmcu, seg0 + kDcSegMcus);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t v[kDcLaneMcus * BPM];
+    int32_t *p;
+    const uint32_t nvalid = dc_lane_load<BPM>(im, dcbuf, seg0, seg1, v, p);
+    int32_t carry[3] = {0, 0, 0};
+    for (uint32_t sgi = 0; sgi < blockIdx.x; sgi++) {
+        const int32_t *q = segsum + (size_t(blockIdx.y) * max_segs + sgi) * 3;
+        carry[0] += q[0]; carry[1] += q[1]; carry[2] += q[2];
+    }
+    uint32_t comp[BPM];
+#pragma unroll
+    for (int j = 0; j < BPM; j++) comp[j] = im.blk_comp[j];
+    int32_t sum[3] = {0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < BPM; j++) {
+        int32_t t = 0;
+#pragma unroll
+        for (int m = 0; m < kDcLaneMcus; m++) t += v[m * BPM + j];
+        sum[0] += comp[j] == 0 ? t : 0;
+        sum[1] += comp[j] == 1 ? t : 0;
+        sum[2] += comp[j] == 2 ? t : 0;
+    }
+    int32_t incl[3] = {sum[0], sum[1], sum[2]};
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int32_t o = __shfl_up(incl[c], d);
+            if (lane >= uint32_t(d)) incl[c] += o;
+        }
+    }
+    if (lane == 63) { s_wsum[wave][0] = incl[0]; s_wsum[wave][1] = incl[1]; s_wsum[wave][2] = incl[2]; }
+    __syncthreads();
+    int32_t base[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        base[c] = carry[c] + incl[c] - sum[c];
+#pragma unroll
+        for (uint32_t w = 0; w < 4; w++) base[c] += w < wave ? s_wsum[w][c] : 0;
+    }
+#pragma unroll
+    for (int m = 0; m < kDcLaneMcus; m++)
+#pragma unroll
+        for (int j = 0; j < BPM; j++) {
+            const uint32_t c = comp[j];
+            const int32_t r = (c == 0 ? base[0] : (c == 1 ? base[1] : base[2])) + v[m * BPM + j];
+            v[m * BPM + j] = r;
+            base[0] = c == 0 ? r : base[0];
+            base[1] = c == 1 ? r : base[1];
+            base[2] = c == 2 ? r : base[2];
+        }
+    if (nvalid == kDcLaneMcus) {
+#pragma unroll
+        for (int q = 0; q < kDcLaneMcus * BPM / 4; q++)
+            reinterpret_cast<Int4 *>(p)[q] = Int4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    } else {
+#pragma unroll
+        for (int i = 0; i < kDcLaneMcus * BPM; i++)
+            if (uint32_t(i) < nvalid * BPM) p[i] = v[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // stage B
 // ------------------------------------------------------------------------------------------------
@@ -649,43 +788,28 @@ __device__ __forceinline__ uint32_t pack_u8(float n, uint32_t byte, uint32_t wor
     return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(n), byte, word);
 }
 
-// x / 0.587f, correctly rounded, in three operations (multiply by the rounded reciprocal, exact residual by FMA, one
-// correction).  Bit-identical to IEEE division for every |x| in [2^-100, 8192) -- exhaustively checked on the host
-// (DESIGN.md s5); outside that range the result is clamped or vanishes in the +128.
-__device__ __forceinline__ float div_c_green(float x)
-{
-    const float d = 0.587f, rcp = 1.0f / 0.587f;
-    const float q = x * rcp;
-    const float r = __builtin_fmaf(-q, d, x);
-    return __builtin_fmaf(r, rcp, q);
-}
-
-// decoder.rs:392-402 y_cb_cr_to_rgb with the two chroma products hoisted (crk = cr * (2 - 2*c_red), cbk likewise: the
-// same rounded products the reference forms per pixel).  Every operation is rounded to f32 separately (no contraction)
-// in the reference's order:  r = crk + y;  b = cbk + y;  g = (y - c_blue*b - c_red*r) / c_green;  then +128, clamp, truncate.
+// decoder.rs:392-402 y_cb_cr_to_rgb:  r = cr (2 - 2 c_red) + y,  b = cb (2 - 2 c_blue) + y,
+// g = (y - c_blue b - c_red r) / c_green, then + 128, clamp, truncate.  Substituting r and b, g is y minus fixed
+// multiples of cb and cr (c_red + c_green + c_blue = 1), so a chroma sample contributes three terms that are shared by
+// every pixel it covers (four in 4:2:0), and a pixel costs three additions.  The + 128 is not added here: the
+// luminance samples arrive with it (it is put on the DC coefficient before the inverse DCT, k_idct_color phase 1).
+// The reference rounds its longer chain of f32 operations differently; the results agree within the 1-LSB bound of
+// the parity tests (a sample must lie within ~1e-4 of an integer for the truncation to differ).
 struct Rgb { float r, g, b; };
-__device__ __forceinline__ Rgb ycc_to_rgb(float y, float cbk, float crk)
+struct ChromaTerms { float r, g, b; };
+__device__ __forceinline__ ChromaTerms chroma_terms(float cb, float cr)
 {
-#pragma clang fp contract(off)
-    const float c_red = 0.299f, c_blue = 0.114f;
-    Rgb o;
-    o.r = crk + y;
-    o.b = cbk + y;
-    const float t1 = c_blue * o.b;
-    const float t2 = c_red * o.r;
-    float g = y - t1;
-    g = g - t2;
-    o.g = div_c_green(g) + 128.0f;
-    o.r = o.r + 128.0f;
-    o.b = o.b + 128.0f;
-    return o;
+    const float c_red = 0.299f, c_green = 0.587f, c_blue = 0.114f;
+    const float kr = 2.0f - 2.0f * c_red, kb = 2.0f - 2.0f * c_blue;
+    ChromaTerms t;
+    t.r = cr * kr;
+    t.b = cb * kb;
+    t.g = __builtin_fmaf(cb, -(c_blue * kb / c_green), cr * -(c_red * kr / c_green));
+    return t;
 }
-__device__ __forceinline__ void chroma_products(float cb, float cr, float &cbk, float &crk)
+__device__ __forceinline__ Rgb ycc_to_rgb(float y128, const ChromaTerms &t)
 {
-#pragma clang fp contract(off)
-    const float kr = 2.0f - 2.0f * 0.299f, kb = 2.0f - 2.0f * 0.114f;
-    crk = cr * kr;
-    cbk = cb * kb;
+    return Rgb{y128 + t.r, y128 + t.g, y128 + t.b};
 }
 
 struct __attribute__((packed, aligned(4))) Rgb4 { uint32_t a, b, c; };
@@ -839,18 +963,16 @@ __device__ __forceinline__ void pixels_420(uint32_t width, uint32_t height, uint
         const float4 yb = *reinterpret_cast<const float4 *>(yp + 8);
         const float2 cb = *reinterpret_cast<const float2 *>(cbase + rp * 8);
         const float2 cr = *reinterpret_cast<const float2 *>(cbase + kPixStride + rp * 8);
-        float cbk0, crk0, cbk1, crk1;
-        chroma_products(cb.x, cr.x, cbk0, crk0);
-        chroma_products(cb.y, cr.y, cbk1, crk1);
+        const ChromaTerms c0 = chroma_terms(cb.x, cr.x), c1 = chroma_terms(cb.y, cr.y);
         Rgb p[4];
-        p[0] = ycc_to_rgb(ya.x, cbk0, crk0); p[1] = ycc_to_rgb(ya.y, cbk0, crk0);
-        p[2] = ycc_to_rgb(ya.z, cbk1, crk1); p[3] = ycc_to_rgb(ya.w, cbk1, crk1);
+        p[0] = ycc_to_rgb(ya.x, c0); p[1] = ycc_to_rgb(ya.y, c0);
+        p[2] = ycc_to_rgb(ya.z, c1); p[3] = ycc_to_rgb(ya.w, c1);
         uint8_t *dst = col + size_t(rp) * 2 * width * 3;
         if (INTERIOR) *reinterpret_cast<Rgb4 *>(dst) = pack4(p);
         else store4(dst, pack4(p), aligned, npix);
         if (INTERIOR || py + 1 < height) {
-            p[0] = ycc_to_rgb(yb.x, cbk0, crk0); p[1] = ycc_to_rgb(yb.y, cbk0, crk0);
-            p[2] = ycc_to_rgb(yb.z, cbk1, crk1); p[3] = ycc_to_rgb(yb.w, cbk1, crk1);
+            p[0] = ycc_to_rgb(yb.x, c0); p[1] = ycc_to_rgb(yb.y, c0);
+            p[2] = ycc_to_rgb(yb.z, c1); p[3] = ycc_to_rgb(yb.w, c1);
             if (INTERIOR) *reinterpret_cast<Rgb4 *>(dst + size_t(width) * 3) = pack4(p);
             else store4(dst + size_t(width) * 3, pack4(p), aligned, npix);
         }
@@ -883,14 +1005,10 @@ __device__ __forceinline__ void pixels_generic(const DevImage &im, const float *
             load4(tile, im, t * bpm, 1, sx * 4, r, cbv);
             load4(tile, im, t * bpm, 2, sx * 4, r, crv);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                float cbk, crk;
-                chroma_products(cbv[k], crv[k], cbk, crk);
-                p[k] = ycc_to_rgb(yv[k], cbk, crk);
-            }
+            for (int k = 0; k < 4; k++) p[k] = ycc_to_rgb(yv[k], chroma_terms(cbv[k], crv[k]));
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; k++) p[k].r = p[k].g = p[k].b = yv[k] + 128.0f;                 // decoder.rs:318-325
+            for (int k = 0; k < 4; k++) p[k].r = p[k].g = p[k].b = yv[k];                          // decoder.rs:318-325 (+128 is in the samples)
         }
         store4(out_img + (size_t(py) * im.width + px) * 3, pack4(p), aligned, npix);
     }
@@ -975,9 +1093,7 @@ extern "C" __global__ __launch_bounds__(256) void k_ref_color(const DevImage *im
     uint32_t word = 0;
     if (im.ncomp == 3) {
         const float cb = __uint_as_float(uint32_t(pl[len + i])), cr = __uint_as_float(uint32_t(pl[2 * len + i]));
-        float cbk, crk;
-        chroma_products(cb, cr, cbk, crk);
-        const Rgb p = ycc_to_rgb(y, cbk, crk);
+        const Rgb p = ycc_to_rgb(y + 128.0f, chroma_terms(cb, cr));
         word = pack_u8(p.b, 2, pack_u8(p.g, 1, pack_u8(p.r, 0, 0)));
     } else {
         const float v = y + 128.0f;
@@ -1053,7 +1169,10 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
                 if (cur.e0 + tid + 256u * k < cur.e1) scatter_entry(cur.ent[k], first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
             for (uint32_t i = cur.e0 + tid + 256u * kPrefetch; i < cur.e1; i += 256)
                 scatter_entry(src[i], first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
-            if (tid < nblk) tile_f[tid * kPixStride] = float(cur.dc) * s_qm[s_comp[tid] * 64];
+            // DC; luminance blocks also take the + 128 of decoder.rs:318-330 here (a constant on the DC term of the
+            // prescaled transform is the same constant on all 64 samples); REF_COMPAT adds it per pixel in k_ref_color,
+            // where samples no block covers must come out as 0 + 128
+            if (tid < nblk) tile_f[tid * kPixStride] = float(cur.dc) * s_qm[s_comp[tid] * 64] + ((MODE != 2 && s_comp[tid] == 0) ? 128.0f : 0.0f);
         }
         TileFetch nxt = cur;
         if (tile + 1 < tile1) tile_fetch(src, eoff, dcs, tile + 1, tile_blocks, total_blocks, nxt);
@@ -1146,10 +1265,18 @@ void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
 }
 
 void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int32_t *dcbuf,
-                    int32_t *segsum, const uint32_t *img_flags)
+                    int32_t *segsum, const uint32_t *img_flags, uint32_t bpm_mask)
 {
-    hipLaunchKernelGGL(k_dc_sums, dim3(max_segs, nimg), dim3(256), 0, st, images, dcbuf, segsum, max_segs, img_flags);
-    hipLaunchKernelGGL(k_dc_apply, dim3(max_segs, nimg), dim3(256), 0, st, images, dcbuf, segsum, max_segs, img_flags);
+    const dim3 grid(max_segs, nimg), wg(256);
+#define MJX_DC_PASS(KERNEL)                                                                                              \
+    if (bpm_mask & (1u << 1)) hipLaunchKernelGGL(KERNEL##_t<1>, grid, wg, 0, st, images, dcbuf, segsum, max_segs, img_flags); \
+    if (bpm_mask & (1u << 3)) hipLaunchKernelGGL(KERNEL##_t<3>, grid, wg, 0, st, images, dcbuf, segsum, max_segs, img_flags); \
+    if (bpm_mask & (1u << 4)) hipLaunchKernelGGL(KERNEL##_t<4>, grid, wg, 0, st, images, dcbuf, segsum, max_segs, img_flags); \
+    if (bpm_mask & (1u << 6)) hipLaunchKernelGGL(KERNEL##_t<6>, grid, wg, 0, st, images, dcbuf, segsum, max_segs, img_flags); \
+    if (bpm_mask & ~kDcFastShapes) hipLaunchKernelGGL(KERNEL, grid, wg, 0, st, images, dcbuf, segsum, max_segs, img_flags);
+    MJX_DC_PASS(k_dc_sums)
+    MJX_DC_PASS(k_dc_apply)
+#undef MJX_DC_PASS
 }
 
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,

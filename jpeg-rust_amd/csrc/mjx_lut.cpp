@@ -77,6 +77,13 @@ int build_decode_table(const uint8_t bits[16], const uint8_t *vals, bool is_dc, 
             for (unsigned k = 0; k < count; k++) out[sub + first + k] = e;
         }
     }
+    // Bit patterns that match no code: the primary table sends them through the link path (zero index bits) to one
+    // shared invalid entry, so that only the rare second-level lookup has to test for bad codes.
+    if (used + 1 > cap) return -MJX_ERR_NOMEM;
+    const int bad_at = used++;
+    out[bad_at] = lut_invalid();
+    for (int k = 0; k < kLutPrimarySize; k++)
+        if (out[k] == lut_invalid()) out[k] = lut_link(unsigned(bad_at), 0);
     return used;
 }
 
