@@ -199,7 +199,7 @@ void plan_chunks(mjx_batch *b)
                 c.entries += inf.ent_cap;
                 c.tiles += inf.ntiles + 1;
                 c.nsub += d.himg.nsub;
-                c.blocks += inf.nblocks;
+                c.blocks += (inf.nblocks + 7) & ~uint64_t(7);          // regions of DC differences start on 32-byte sectors
                 c.max_wg = std::max<uint32_t>(c.max_wg, (d.himg.nsub + kHuffWg - 1) / kHuffWg);
                 if (d.himg.nsub > 1) c.merge_wgs = std::max<uint32_t>(c.merge_wgs, (d.himg.nsub - 1 + kHuffWg - 1) / kHuffWg);
                 const uint32_t T = 1u << d.log2_tile;

@@ -28,7 +28,10 @@ namespace mjx {
 #endif
 constexpr int kSubseqBytes = MJX_SUBSEQ_BYTES;  // bytes of scan per lane
 constexpr int kSubseqBits = kSubseqBytes * 8;
-constexpr int kLutPrimaryBits = 10;
+#ifndef MJX_LUT_BITS
+#define MJX_LUT_BITS 9
+#endif
+constexpr int kLutPrimaryBits = MJX_LUT_BITS;
 constexpr int kLutPrimarySize = 1 << kLutPrimaryBits;
 constexpr int kMaxBlocksPerMcu = 12;           // 3 components x (2x2)
 

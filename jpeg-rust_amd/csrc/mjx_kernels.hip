@@ -78,80 +78,99 @@ struct GlobalCps {
 
 struct __attribute__((packed, aligned(4))) Entry4 { uint32_t a, b, c, d; };
 
-// Sink of the write pass: the compact coefficient stream (see coef_entry), DC differences, tile offsets.
-// A lane's stream region is contiguous but it fills slowly (one 128-byte line per ~45 symbols), so what reaches HBM
-// is what each store instruction carried.  Entries are staged in a ring of kStageRing dwords per lane in LDS and go
-// out as whole 32-byte sectors (two back-to-back 16-byte stores) aligned to the sector grid of the image's region.
-// The wave writes its sectors out together every kFlushEvery symbols (wave-uniform branch): a symbol adds at most
-// one entry, so at most 7 + kFlushEvery < kStageRing entries wait in a ring.  Only a lane's first and last partial
-// group go out dword-wise.
-// DC differences (one per block, 30x rarer) are stored as they come.
-#ifndef MJX_GROUP
-#define MJX_GROUP 8
-#endif
-constexpr uint32_t kGroup = MJX_GROUP, kFlushEvery = kGroup, kStageRing = 2 * kGroup;
+// A lane's contiguous run of output dwords, staged in a ring of 2 * GROUP dwords in LDS and written to HBM as whole
+// aligned groups of GROUP dwords (16-byte stores back to back).  The lane's region fills slowly (a 128-byte line of
+// stream entries per ~45 symbols, ~20 us), longer than a dirty line survives in L2, so what reaches HBM is what each
+// store instruction carried: dword stores cost a 32-byte sector each (and an instruction per symbol step), grouped
+// stores write every sector once.  flush_groups() is called by the whole wave every kFlushEvery symbols
+// (wave-uniform branch); the caller guarantees that at most GROUP dwords are pushed between two calls, so the
+// ring never overflows.  A run that does not start on a group boundary first goes dword-wise up to the next one.
+constexpr uint32_t kFlushEvery = 8;
+template <uint32_t GROUP>
+struct LaneRing {
+    static constexpr uint32_t kRing = 2 * GROUP;
+    uint32_t *ring;         // the lane's kRing dwords of LDS
+    uint32_t *out;          // the image's region (aligned to GROUP dwords)
+    uint32_t off;           // next index
+    uint32_t flushed;       // indices below this are in HBM
+    __device__ __forceinline__ void begin(uint32_t *lds, uint32_t *region, uint32_t first)
+    {
+        ring = lds;
+        out = region;
+        off = flushed = first;
+    }
+    __device__ __forceinline__ void push(uint32_t v)
+    {
+        ring[off & (kRing - 1)] = v;
+        off++;
+    }
+    __device__ __forceinline__ void flush_groups()
+    {
+        while (__builtin_amdgcn_ballot_w64((flushed & (GROUP - 1)) != 0 && flushed < off)) {
+            if ((flushed & (GROUP - 1)) != 0 && flushed < off) {
+                out[flushed] = ring[flushed & (kRing - 1)];
+                flushed++;
+            }
+        }
+        while (__builtin_amdgcn_ballot_w64((flushed & (GROUP - 1)) == 0 && flushed + GROUP <= off)) {
+            if ((flushed & (GROUP - 1)) == 0 && flushed + GROUP <= off) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(ring + (flushed & (kRing - 1)));
+                uint4 *dst = reinterpret_cast<uint4 *>(out + flushed);
+                uint4 v[GROUP / 4];
+#pragma unroll
+                for (uint32_t q = 0; q < GROUP / 4; q++) v[q] = src[q];
+#pragma unroll
+                for (uint32_t q = 0; q < GROUP / 4; q++) dst[q] = v[q];
+                flushed += GROUP;
+            }
+        }
+    }
+    __device__ __forceinline__ void flush_all()
+    {
+        flush_groups();
+        for (uint32_t i = flushed; i < off; i++) out[i] = ring[i & (kRing - 1)];
+        flushed = off;
+    }
+};
+
+// Sink of the write pass: the compact coefficient stream (see coef_entry), DC differences (one per block), tile
+// offsets.  A symbol adds at most one stream entry, a block takes at least two symbols: the rings below hold.
+constexpr uint32_t kAcGroup = 8, kDcGroup = 4;                 // 32-byte sectors of entries, 16 bytes of DC differences
+static_assert(kAcGroup >= kFlushEvery && 2 * kDcGroup >= kFlushEvery, "ring capacity between two flushes");
 struct StreamSink {
-    uint32_t *entries;      // the image's entry region (32-byte aligned)
-    int32_t *dcbuf;         // the image's DC differences (one int32 per block)
+    LaneRing<kAcGroup> ac_ring;     // index = entry index in the image's stream region
+    LaneRing<kDcGroup> dc_ring;     // index = block index in the image
     uint32_t *tile_eoff;    // the image's tile offsets (+ sentinel)
     int *status;
-    uint32_t *ring;         // the lane's kStageRing dwords of LDS
-    uint32_t off;           // entries produced so far (next entry index)
-    uint32_t flushed;       // entries below this index are in HBM
     uint32_t blk_bits;      // the current block's index, placed as in coef_entry
     uint32_t next_tile_blk, tile_idx, tile_blocks, total_blocks, ntiles;
-    __device__ __forceinline__ void begin(uint32_t first_entry, uint32_t first_blk)
-    {
-        off = first_entry;
-        flushed = first_entry;
-        blk_bits = (first_blk & 0xffu) << 22;
-    }
     __device__ __forceinline__ void dc(uint32_t b, int v)
     {
-        dcbuf[b] = v;
+        dc_ring.push(uint32_t(v));          // (b == dc_ring.off - 1: a lane's blocks are consecutive)
         if (b == next_tile_blk) {           // first block of a stage-B tile: remember where its entries start
-            tile_eoff[tile_idx] = off;
+            tile_eoff[tile_idx] = ac_ring.off;
             tile_idx++;
             next_tile_blk += tile_blocks;
         }
     }
     __device__ __forceinline__ void ac(uint32_t, unsigned pos, int v)
     {
-        ring[off & (kStageRing - 1)] = (uint32_t(v) & 0xffffu) | (pos << 16) | blk_bits;     // coef_entry
-        off++;
+        ac_ring.push((uint32_t(v) & 0xffffu) | (pos << 16) | blk_bits);     // coef_entry
     }
-    // wave-uniform call: every lane writes out its complete groups; a lane whose region does not start on a sector
-    // first writes dword-wise up to the next boundary
-    __device__ __forceinline__ void flush_groups()
+    __device__ __forceinline__ void flush_groups()          // wave-uniform call
     {
-        while (__builtin_amdgcn_ballot_w64((flushed & (kGroup - 1)) != 0 && flushed < off)) {
-            if ((flushed & (kGroup - 1)) != 0 && flushed < off) {
-                entries[flushed] = ring[flushed & (kStageRing - 1)];
-                flushed++;
-            }
-        }
-        while (__builtin_amdgcn_ballot_w64((flushed & (kGroup - 1)) == 0 && flushed + kGroup <= off)) {
-            if ((flushed & (kGroup - 1)) == 0 && flushed + kGroup <= off) {
-                const uint4 *src = reinterpret_cast<const uint4 *>(ring + (flushed & (kStageRing - 1)));
-                uint4 *dst = reinterpret_cast<uint4 *>(entries + flushed);
-                uint4 v[kGroup / 4];
-#pragma unroll
-                for (uint32_t q = 0; q < kGroup / 4; q++) v[q] = src[q];
-#pragma unroll
-                for (uint32_t q = 0; q < kGroup / 4; q++) dst[q] = v[q];
-                flushed += kGroup;
-            }
-        }
+        ac_ring.flush_groups();
+        dc_ring.flush_groups();
     }
     __device__ __forceinline__ void block_done(uint32_t next_blk)
     {
         blk_bits = (next_blk & 0xffu) << 22;
-        if (next_blk == total_blocks) tile_eoff[ntiles] = off;
+        if (next_blk == total_blocks) tile_eoff[ntiles] = ac_ring.off;
     }
     __device__ __forceinline__ void flush()
     {
-        flush_groups();
-        for (uint32_t i = flushed; i < off; i++) entries[i] = ring[i & (kStageRing - 1)];
+        ac_ring.flush_all();
+        dc_ring.flush_all();
     }
     __device__ __forceinline__ void bad_code(uint32_t) const { atomicOr(status, 1); }
     __device__ __forceinline__ void tick() const {}
@@ -170,7 +189,7 @@ __device__ __forceinline__ void stage_tables(const DevImage &im, const LutEntry 
     uint4 *ldst = reinterpret_cast<uint4 *>(l);
     for (uint32_t g = tid; g < im.lut_n / 4; g += nthr) ldst[g] = lsrc[g];
     __syncthreads();
-    // table offsets -> absolute LDS addresses (see lut_at); the workgroup's LDS stays below 64 KiB
+    // table offsets -> absolute LDS addresses (see lut_at); the tables come first in the workgroup's LDS, below 64 KiB
     if (tid < uint32_t(kMaxBlocksPerMcu))
         h->btab[tid].tabs += uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)(l))) * 0x10001u;
     __syncthreads();
@@ -189,9 +208,9 @@ __device__ __forceinline__ uint32_t subseq_end(const HuffImage &h, uint32_t s)
 // freshly requested dword cannot be moved up a register queue before it has landed.  (In the write pass such loads
 // would also queue behind the scattered stores.)  Instead every lane owns kWinDwords big-endian dwords in LDS; the
 // wave restages all its windows together (wave-uniform branch, 16-byte loads) whenever one lane is about to run
-// out, about every 60 symbols, and the per-symbol refills only touch LDS.
+// out, about every 40 symbols, and the per-symbol refills only touch LDS.
 #ifndef MJX_WIN_DWORDS
-#define MJX_WIN_DWORDS 12
+#define MJX_WIN_DWORDS 8
 #endif
 constexpr int kWinDwords = MJX_WIN_DWORDS;
 constexpr int kWinStride = kWinDwords + 1;      // odd stride: lanes spread over all banks
@@ -484,17 +503,21 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
         end_bit = subseq_end(*h, s);
     }
     StreamSink sink;
-    sink.entries = entries + im.ent_off;
-    sink.dcbuf = dcbuf + im.coef_off;
     sink.tile_eoff = tile_eoff + im.tile_off;
     sink.status = status + im.status_idx;
-    sink.ring = s_win + kHuffWg * kWinStride + threadIdx.x * kStageRing;
-    sink.begin(ebase, blk);
+    const uint32_t first_start = blk + (e.z ? 1u : 0u);                    // first block whose DC this lane decodes
+    {
+        uint32_t *rings = s_win + kHuffWg * kWinStride;
+        sink.ac_ring.begin(rings + threadIdx.x * LaneRing<kAcGroup>::kRing, entries + im.ent_off, ebase);
+        rings += kHuffWg * LaneRing<kAcGroup>::kRing;
+        sink.dc_ring.begin(rings + threadIdx.x * LaneRing<kDcGroup>::kRing,
+                           reinterpret_cast<uint32_t *>(dcbuf + im.coef_off), first_start);
+    }
+    sink.blk_bits = (blk & 0xffu) << 22;
     sink.tile_blocks = im.tile_blocks;
     sink.total_blocks = h->total_blocks;
     sink.ntiles = (h->total_blocks + im.tile_blocks - 1) / im.tile_blocks;
     {
-        const uint32_t first_start = blk + (e.z ? 1u : 0u);                // first block whose DC this lane decodes
         sink.tile_idx = (first_start + im.tile_blocks - 1) / im.tile_blocks;
         sink.next_tile_blk = sink.tile_idx * im.tile_blocks;
     }
@@ -1200,7 +1223,7 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
 // ------------------------------------------------------------------------------------------------
 size_t huff_lds_bytes(uint32_t lut_cap_entries) { return (sizeof(HuffImage) + size_t(lut_cap_entries) * sizeof(LutEntry) + 15) / 16 * 16; }
 size_t huff_window_bytes() { return size_t(kHuffWg) * kWinStride * 4; }
-size_t huff_stage_bytes() { return size_t(kHuffWg) * kStageRing * 4; }    // the write pass's entry rings
+size_t huff_stage_bytes() { return size_t(kHuffWg) * (LaneRing<kAcGroup>::kRing + LaneRing<kDcGroup>::kRing) * 4; }    // the write pass's rings
 
 size_t idct_lds_bytes(uint32_t max_tile_blocks) { return size_t(max_tile_blocks) * kPixStride * 4; }
 

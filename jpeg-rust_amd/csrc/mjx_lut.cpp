@@ -3,7 +3,7 @@
 // Replaces HuffmanTable::from_size_data_tables / make_code_table (reference src/jpeg/huffman.rs:37-98):
 // canonical codes are assigned exactly as T.81 Figure C.2 does (code <<= 1 per length step, +1 per symbol);
 // instead of a sorted Vec<HuffmanCode> searched linearly per length (huffman.rs:60-76, 211-227) the codes are
-// expanded into a 2^10-entry primary table plus small sub-tables for longer codes, with the symbol's
+// expanded into a 2^9-entry primary table plus small sub-tables for longer codes, with the symbol's
 // run / size already decoded and the reference's EOB / ZRL behaviour folded in (see mjx_huff.h).
 #include "mjx.h"
 #include "mjx_huff.h"
@@ -63,7 +63,7 @@ int build_decode_table(const uint8_t bits[16], const uint8_t *vals, bool is_dc, 
             for (unsigned k = 0; k < count; k++) out[first + k] = e;
         } else {
             const unsigned prefix = c.code >> (c.len - kLutPrimaryBits);
-            const unsigned nb = maxlen[prefix] - kLutPrimaryBits;        // 1..6
+            const unsigned nb = maxlen[prefix] - kLutPrimaryBits;        // 1..7
             if (!lut_is_link(out[prefix])) {
                 if (used + (1 << nb) > cap) return -MJX_ERR_NOMEM;
                 out[prefix] = lut_link(unsigned(used), nb);
