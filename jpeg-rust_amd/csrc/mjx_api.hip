@@ -201,7 +201,7 @@ void plan_chunks(mjx_batch *b)
                 c.nsub += d.himg.nsub;
                 c.blocks += (inf.nblocks + 7) & ~uint64_t(7);          // regions of DC differences start on 32-byte sectors
                 c.max_wg = std::max<uint32_t>(c.max_wg, (d.himg.nsub + kHuffWg - 1) / kHuffWg);
-                if (d.himg.nsub > 1) c.merge_wgs = std::max<uint32_t>(c.merge_wgs, (d.himg.nsub - 1 + kHuffWg - 1) / kHuffWg);
+                if (d.himg.nsub > 1) c.merge_wgs = std::max<uint32_t>(c.merge_wgs, (d.himg.nsub - 1 + kMergeWg - 1) / kMergeWg);
                 const uint32_t T = 1u << d.log2_tile;
                 c.max_tiles = std::max<uint32_t>(c.max_tiles, (d.nmcu + T - 1) / T);
                 c.max_tile_blocks = std::max<uint32_t>(c.max_tile_blocks, T * d.bpm);

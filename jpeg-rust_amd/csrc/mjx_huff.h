@@ -297,13 +297,14 @@ MJX_HD void events_begin(LaneEvents &ev, uint32_t sub_start, uint32_t end_bit)
 // Returns true when the lane is finished.  Otherwise (a checkpoint boundary was crossed): compares with the state the
 // previous decode recorded there (CP == 2; equal = the decodes coincide from here on), or records the lane's state
 // with the counts so far and moves to the next boundary.
+MJX_HD uint32_t cp_state_word(const LaneState &st) { return lane_t(st) | (st.r << 5) | (st.nb.next << 12) | kCpValid; }
 template <int CP, class CpStore>
 MJX_HD bool lane_event(LaneState &st, LaneEvents &ev, const HuffImage &img, CpStore &cps)
 {
     if (st.wn < ev.next_wn) return false;
     if (st.wn >= ev.end_wn) return true;
     if (CP) {
-        const uint32_t state = lane_t(st) | (st.r << 5) | (st.nb.next << 12) | kCpValid;
+        const uint32_t state = cp_state_word(st);
         if (CP == 2) {
             const uint32_t old = cps.get(ev.k);
             if ((old & kCpStateMask) == state) {

@@ -314,40 +314,128 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_spec(const DevImage
 }
 
 // k_huff_merge: one synchronisation round.  Subsequence s must start where s-1 ended: if entry[s] differs from
-// exit[s-1] the lane re-decodes s from the corrected entry until it meets the path recorded by the previous decode of
-// s (checkpoint match: median ~100 of ~800 symbols) or reaches the end.  A round that re-decodes nothing proves the
+// exit[s-1], s is re-decoded from the corrected entry until it meets the path recorded by the previous decode of s
+// (checkpoint match: median ~100 of ~800 symbols) or reaches the end.  A round that re-decodes nothing proves the
 // fixed point entry[s] == exit[s-1] for all s, which (entry[0] being the true start) is the true decode; `mismatches`
 // counts the re-decoded items of this round.  Exits are read while other lanes may be rewriting them (8-byte aligned
 // accesses): a stale read only defers the repair to the next round, and the zero-count round is race-free by definition.
-extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_merge(const DevImage *images, const uint8_t *scan_pool,
+//
+// Re-decodes differ in length by an order of magnitude, so they advance in slices of one checkpoint interval (256
+// bits, ~50 symbols, the same work for every lane) and between slices the workgroup packs its unfinished items into
+// its lowest lanes through LDS; waves left without items skip the slice.  An item between slices is just
+// (s, p, z, c, n, m, k): the lane that picks it up stages the 48 bytes of stream the slice can touch in its LDS
+// window and rebuilds the decoder registers from p, z, c.
+constexpr int kMergeWin = 12, kMergeStride = kMergeWin + 1, kItemDwords = 6;
+extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevImage *images, const uint8_t *scan_pool,
                                                                 const LutEntry *lut_pool, SubseqState *g_entry,
-                                                                SubseqState *g_exit, uint32_t *g_cps, uint32_t *mismatches)
+                                                                SubseqState *g_exit, uint32_t *g_cps, uint32_t *mismatches,
+                                                                uint32_t win_off)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // HuffImage, tables, windows (= item exchange)
+    __shared__ uint32_t s_cnt[kMergeWg / 64];
+    uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
     const DevImage &im = images[blockIdx.y];
-    if (!im.valid || blockIdx.x * kHuffWg + 1 >= im.himg.nsub) return;
-    const uint32_t s = blockIdx.x * kHuffWg + threadIdx.x + 1;
-    bool need = false;
-    SubseqState prev = make_state(0, 0, 0);
-    if (s < im.himg.nsub) {
-        prev = g_exit[im.sub_off + s - 1];
-        need = !same_entry(prev, g_entry[im.sub_off + s]);
+    if (!im.valid || blockIdx.x * kMergeWg + 1 >= im.himg.nsub) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t it_s = blockIdx.x * kMergeWg + tid + 1, it_p = 0, it_zc = 0, it_n = 0, it_m = 0, it_k = 0;
+    bool active = false;
+    if (it_s < im.himg.nsub) {
+        const SubseqState prev = g_exit[im.sub_off + it_s - 1];
+        active = !same_entry(prev, g_entry[im.sub_off + it_s]);
+        it_p = prev.p;
+        it_zc = prev.z | (uint32_t(prev.c) << 8);
+        if (active) g_entry[im.sub_off + it_s] = make_state(prev.p, prev.z, prev.c);
     }
-    if (!__syncthreads_or(need)) return;                                   // nothing to repair in this workgroup
+    if (!__syncthreads_or(active)) return;                                 // nothing to repair in this workgroup
     const HuffImage *h;
     const LutEntry *lut;
     stage_tables(im, lut_pool, smem, h, lut);
-    const unsigned long long m = __ballot(need);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(mismatches, uint32_t(__popcll(m)));
-    if (!need) return;
-    const GlobalBits bits{scan_pool + im.scan_off};
-    const SubseqState e = make_state(prev.p, prev.z, prev.c);
-    const SubseqState old_exit = g_exit[im.sub_off + s];
-    GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + s), 0};
-    g_entry[im.sub_off + s] = e;
-    cps.prime();
-    NullSink sink;
-    g_exit[im.sub_off + s] = decode_subseq<false, 2>(bits, lut, *h, e, subseq_end(*h, s), 0, sink, cps, s * kSubseqBits, old_exit);
+    {
+        const unsigned long long mm = __ballot(active);
+        if (lane == 0 && mm) atomicAdd(mismatches, uint32_t(__popcll(mm)));
+    }
+    const unsigned char *bytes = scan_pool + im.scan_off;
+    uint32_t *my_win = s_win + tid * kMergeStride;
+    for (;;) {
+        if (active) {                                                      // one slice
+            const uint32_t sub_start = it_s * kSubseqBits, end_bit = subseq_end(*h, it_s);
+            const GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + it_s), 0};
+            bool fin = false;
+            SubseqState x = make_state(it_p, it_zc & 0xffu, it_zc >> 8, it_n, it_m);
+            if (it_p <= end_bit) {                                         // (else nothing starts inside s)
+                const uint32_t old_word = it_k < uint32_t(kNumCp) ? cps.get_plain(it_k) : 0u;   // requested early
+                const uint32_t wi1 = (it_p + 31u) >> 5, wbase = wi1 ? 4u * wi1 - 4u : 0u;
+#pragma unroll
+                for (int q = 0; q < kMergeWin / 4; q++) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(bytes + wbase + 16 * q);
+                    my_win[4 * q] = __builtin_bswap32(v.x);
+                    my_win[4 * q + 1] = __builtin_bswap32(v.y);
+                    my_win[4 * q + 2] = __builtin_bswap32(v.z);
+                    my_win[4 * q + 3] = __builtin_bswap32(v.w);
+                }
+                const LdsWindow win{reinterpret_cast<const unsigned char *>(my_win), wbase};
+                LaneState st;
+                lane_begin(st, win, *h, x);
+                st.n = it_n;
+                st.x += it_m;
+                const uint32_t end_wn = wn_after(end_bit);
+                uint32_t stop_wn = wn_after(sub_start + (it_k + 1) * kCpBits);
+                stop_wn = stop_wn < end_wn ? stop_wn : end_wn;
+                uint32_t blk = 0;
+                NullSink sink;
+                while (st.wn < stop_wn) (void)symbol_step<false>(st, win, lut, *h, blk, sink);
+                if (st.wn >= end_wn) {                                     // left the subsequence without merging
+                    fin = true;
+                    x = make_state(lane_pos(st), lane_z(st), lane_c(st, *h), st.n, lane_m(st));
+                } else {
+                    const uint32_t state = cp_state_word(st);
+                    if ((old_word & kCpStateMask) == state) {              // met the previous decode's path
+                        const SubseqState old_exit = g_exit[im.sub_off + it_s];
+                        fin = true;
+                        x = make_state(old_exit.p, old_exit.z, old_exit.c, st.n + ((old_word >> 16) & 0x7fffu),
+                                       lane_m(st) + cps.get_m_plain(it_k));
+                    } else {
+                        cps.set(it_k, state | (st.n << 16), lane_m(st));
+                        it_k++;
+                        it_p = lane_pos(st);
+                        it_zc = lane_z(st) | (lane_c(st, *h) << 8);
+                        it_n = st.n;
+                        it_m = lane_m(st);
+                    }
+                }
+            } else {
+                fin = true;
+            }
+            if (fin) {
+                checkpoint_fixup(cps, it_k, x.n, x.m);
+                g_exit[im.sub_off + it_s] = x;
+                active = false;
+            }
+        }
+        // pack the unfinished items into the lowest lanes
+        const unsigned long long mask = __ballot(active);
+        if (lane == 0) s_cnt[wave] = uint32_t(__popcll(mask));
+        __syncthreads();                                                   // (also: every lane is done with its window)
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kMergeWg / 64; w++) {
+            const uint32_t c = s_cnt[w];
+            before += w < wave ? c : 0u;
+            total += c;
+        }
+        if (total == 0) break;
+        if (active) {
+            uint32_t *slot = s_win + (before + __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u))) * kItemDwords;
+            slot[0] = it_s; slot[1] = it_p; slot[2] = it_zc; slot[3] = it_n; slot[4] = it_m; slot[5] = it_k;
+        }
+        __syncthreads();
+        active = tid < total;
+        if (active) {
+            const uint32_t *slot = s_win + tid * kItemDwords;
+            it_s = slot[0]; it_p = slot[1]; it_zc = slot[2]; it_n = slot[3]; it_m = slot[4]; it_k = slot[5];
+        }
+        __syncthreads();                                                   // the exchange area becomes windows again
+    }
 }
 
 // Workgroup-wide exclusive scan helper (256 lanes): returns the exclusive prefix of v, total in *total.
@@ -1268,8 +1356,8 @@ void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
                        const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
                        uint32_t *cps, uint32_t *mismatches)
 {
-    const size_t lds = tables_lds + pad_lds;
-    hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches);
+    const size_t lds = tables_lds + size_t(kMergeWg) * kMergeStride * 4 + pad_lds;
+    hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches, uint32_t(tables_lds));
 }
 
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,
