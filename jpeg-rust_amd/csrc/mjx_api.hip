@@ -86,7 +86,8 @@ struct mjx_batch {
     SubseqState *d_entry = nullptr, *d_exit = nullptr;
     uint32_t *d_blkbase = nullptr;
     uint32_t *d_cps = nullptr;          // [kNumCp][chunk subsequences]
-    uint32_t *d_pull = nullptr;         // [kMaxFix][chunk images] item counters of k_huff_merge
+    uint32_t *d_pull = nullptr;         // [chunk images] straggler counts of k_huff_merge (per round)
+    uint32_t *d_items = nullptr;        // [max_nsub][6] stragglers handed from k_huff_merge to k_huff_merge_tail
     uint32_t max_nsub = 1, max_chunk_images = 1;
     int32_t *d_segsum = nullptr;
     uint32_t *d_entries = nullptr;      // compact coefficient stream
@@ -130,7 +131,7 @@ void release(mjx_batch *b)
     (void)hipFree(b->d_entries); (void)hipFree(b->d_tile_eoff); (void)hipFree(b->d_ebase); (void)hipFree(b->d_img_entries); (void)hipFree(b->d_img_flags);
     (void)hipFree(b->d_dc); (void)hipFree(b->d_rgb); (void)hipFree(b->d_status);
     (void)hipFree(b->d_planes);
-    (void)hipFree(b->d_mismatch); (void)hipFree(b->d_segsum); (void)hipFree(b->d_cps); (void)hipFree(b->d_pull);
+    (void)hipFree(b->d_mismatch); (void)hipFree(b->d_segsum); (void)hipFree(b->d_cps); (void)hipFree(b->d_pull); (void)hipFree(b->d_items);
     if (b->h_mismatch) (void)hipHostFree(b->h_mismatch);
     delete b;
 }
@@ -255,6 +256,7 @@ int allocate_work_buffers(mjx_batch *b)
     b->max_nsub = max_nsub;
     b->max_chunk_images = uint32_t(max_imgs);
     HIPOK(hipMalloc(&b->d_pull, max_imgs * kMaxFix * sizeof(uint32_t)));
+    HIPOK(hipMalloc(&b->d_items, size_t(max_nsub) * 6 * sizeof(uint32_t)));
     HIPOK(hipMalloc(&b->d_segsum, max_segsum * 3 * sizeof(int32_t)));
     {
         uint64_t max_planes = 0;
@@ -326,7 +328,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
             for (int k = 0; k < fix_passes; k++) {
                 prof_begin(b, MJX_K_HUFF_FIX);
                 launch_huff_merge(st, c.merge_wgs, nimg, b->huff_lds, b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, b->d_cps,
-                                  b->d_mismatch + ci * kMaxFix + k);
+                                  b->d_mismatch + ci * kMaxFix + k, b->d_items, b->d_pull);
                 prof_end(b);
             }
             HIPOK(hipMemcpyAsync(b->h_mismatch + ci * kMaxFix, b->d_mismatch + ci * kMaxFix, kMaxFix * sizeof(uint32_t),

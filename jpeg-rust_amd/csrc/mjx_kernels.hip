@@ -325,11 +325,82 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_spec(const DevImage
 // its lowest lanes through LDS; waves left without items skip the slice.  An item between slices is just
 // (s, p, z, c, n, m, k): the lane that picks it up stages the 48 bytes of stream the slice can touch in its LDS
 // window and rebuilds the decoder registers from p, z, c.
+// The slowest few per cent of the items need all sixteen slices; left in place they would hold their workgroup's
+// LDS (and with it the CU's occupancy) for a single wave's worth of work.  So k_huff_merge runs kHeadSlices slices and
+// appends what is still unfinished to a per-image list in HBM; k_huff_merge_tail picks the lists up with one-wave
+// workgroups (ten per CU) and runs every item to its end.
 constexpr int kMergeWin = 12, kMergeStride = kMergeWin + 1, kItemDwords = 6;
+#ifndef MJX_HEAD_SLICES
+#define MJX_HEAD_SLICES 6
+#endif
+constexpr int kHeadSlices = MJX_HEAD_SLICES;
+struct MergeItem { uint32_t s, p, zc, n, m, k; };
+
+// One slice of one item: decode from (p, z, c) to the next checkpoint boundary (or the end of the subsequence).
+// Returns true when the item is finished (its exit and checkpoints are final), false when `it` holds the progress.
+__device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, const HuffImage &h, const LutEntry *lut,
+                                            const unsigned char *bytes, uint32_t *my_win, SubseqState *g_exit,
+                                            uint32_t *g_cps)
+{
+    const uint32_t sub_start = it.s * kSubseqBits, end_bit = subseq_end(h, it.s);
+    const GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + it.s), 0};
+    bool fin = false;
+    SubseqState x = make_state(it.p, it.zc & 0xffu, it.zc >> 8, it.n, it.m);
+    if (it.p <= end_bit) {                                         // (else nothing starts inside s)
+        const uint32_t old_word = it.k < uint32_t(kNumCp) ? cps.get_plain(it.k) : 0u;   // requested early
+        const uint32_t wi1 = (it.p + 31u) >> 5, wbase = wi1 ? 4u * wi1 - 4u : 0u;
+#pragma unroll
+        for (int q = 0; q < kMergeWin / 4; q++) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(bytes + wbase + 16 * q);
+            my_win[4 * q] = __builtin_bswap32(v.x);
+            my_win[4 * q + 1] = __builtin_bswap32(v.y);
+            my_win[4 * q + 2] = __builtin_bswap32(v.z);
+            my_win[4 * q + 3] = __builtin_bswap32(v.w);
+        }
+        const LdsWindow win{reinterpret_cast<const unsigned char *>(my_win), wbase};
+        LaneState st;
+        lane_begin(st, win, h, x);
+        st.n = it.n;
+        st.x += it.m;
+        const uint32_t end_wn = wn_after(end_bit);
+        uint32_t stop_wn = wn_after(sub_start + (it.k + 1) * kCpBits);
+        stop_wn = stop_wn < end_wn ? stop_wn : end_wn;
+        uint32_t blk = 0;
+        NullSink sink;
+        while (st.wn < stop_wn) (void)symbol_step<false>(st, win, lut, h, blk, sink);
+        if (st.wn >= end_wn) {                                     // left the subsequence without merging
+            fin = true;
+            x = make_state(lane_pos(st), lane_z(st), lane_c(st, h), st.n, lane_m(st));
+        } else {
+            const uint32_t state = cp_state_word(st);
+            if ((old_word & kCpStateMask) == state) {              // met the previous decode's path
+                const SubseqState old_exit = g_exit[im.sub_off + it.s];
+                fin = true;
+                x = make_state(old_exit.p, old_exit.z, old_exit.c, st.n + ((old_word >> 16) & 0x7fffu),
+                               lane_m(st) + cps.get_m_plain(it.k));
+            } else {
+                cps.set(it.k, state | (st.n << 16), lane_m(st));
+                it.k++;
+                it.p = lane_pos(st);
+                it.zc = lane_z(st) | (lane_c(st, h) << 8);
+                it.n = st.n;
+                it.m = lane_m(st);
+            }
+        }
+    } else {
+        fin = true;
+    }
+    if (fin) {
+        checkpoint_fixup(cps, it.k, x.n, x.m);
+        g_exit[im.sub_off + it.s] = x;
+    }
+    return fin;
+}
+
 extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevImage *images, const uint8_t *scan_pool,
                                                                 const LutEntry *lut_pool, SubseqState *g_entry,
                                                                 SubseqState *g_exit, uint32_t *g_cps, uint32_t *mismatches,
-                                                                uint32_t win_off)
+                                                                uint32_t win_off, uint32_t *g_items, uint32_t *g_item_count)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // HuffImage, tables, windows (= item exchange)
     __shared__ uint32_t s_cnt[kMergeWg / 64];
@@ -337,14 +408,14 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
     const DevImage &im = images[blockIdx.y];
     if (!im.valid || blockIdx.x * kMergeWg + 1 >= im.himg.nsub) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t it_s = blockIdx.x * kMergeWg + tid + 1, it_p = 0, it_zc = 0, it_n = 0, it_m = 0, it_k = 0;
+    MergeItem it{blockIdx.x * kMergeWg + tid + 1, 0, 0, 0, 0, 0};
     bool active = false;
-    if (it_s < im.himg.nsub) {
-        const SubseqState prev = g_exit[im.sub_off + it_s - 1];
-        active = !same_entry(prev, g_entry[im.sub_off + it_s]);
-        it_p = prev.p;
-        it_zc = prev.z | (uint32_t(prev.c) << 8);
-        if (active) g_entry[im.sub_off + it_s] = make_state(prev.p, prev.z, prev.c);
+    if (it.s < im.himg.nsub) {
+        const SubseqState prev = g_exit[im.sub_off + it.s - 1];
+        active = !same_entry(prev, g_entry[im.sub_off + it.s]);
+        it.p = prev.p;
+        it.zc = prev.z | (uint32_t(prev.c) << 8);
+        if (active) g_entry[im.sub_off + it.s] = make_state(prev.p, prev.z, prev.c);
     }
     if (!__syncthreads_or(active)) return;                                 // nothing to repair in this workgroup
     const HuffImage *h;
@@ -356,64 +427,21 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
     }
     const unsigned char *bytes = scan_pool + im.scan_off;
     uint32_t *my_win = s_win + tid * kMergeStride;
-    for (;;) {
-        if (active) {                                                      // one slice
-            const uint32_t sub_start = it_s * kSubseqBits, end_bit = subseq_end(*h, it_s);
-            const GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + it_s), 0};
-            bool fin = false;
-            SubseqState x = make_state(it_p, it_zc & 0xffu, it_zc >> 8, it_n, it_m);
-            if (it_p <= end_bit) {                                         // (else nothing starts inside s)
-                const uint32_t old_word = it_k < uint32_t(kNumCp) ? cps.get_plain(it_k) : 0u;   // requested early
-                const uint32_t wi1 = (it_p + 31u) >> 5, wbase = wi1 ? 4u * wi1 - 4u : 0u;
-#pragma unroll
-                for (int q = 0; q < kMergeWin / 4; q++) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(bytes + wbase + 16 * q);
-                    my_win[4 * q] = __builtin_bswap32(v.x);
-                    my_win[4 * q + 1] = __builtin_bswap32(v.y);
-                    my_win[4 * q + 2] = __builtin_bswap32(v.z);
-                    my_win[4 * q + 3] = __builtin_bswap32(v.w);
-                }
-                const LdsWindow win{reinterpret_cast<const unsigned char *>(my_win), wbase};
-                LaneState st;
-                lane_begin(st, win, *h, x);
-                st.n = it_n;
-                st.x += it_m;
-                const uint32_t end_wn = wn_after(end_bit);
-                uint32_t stop_wn = wn_after(sub_start + (it_k + 1) * kCpBits);
-                stop_wn = stop_wn < end_wn ? stop_wn : end_wn;
-                uint32_t blk = 0;
-                NullSink sink;
-                while (st.wn < stop_wn) (void)symbol_step<false>(st, win, lut, *h, blk, sink);
-                if (st.wn >= end_wn) {                                     // left the subsequence without merging
-                    fin = true;
-                    x = make_state(lane_pos(st), lane_z(st), lane_c(st, *h), st.n, lane_m(st));
-                } else {
-                    const uint32_t state = cp_state_word(st);
-                    if ((old_word & kCpStateMask) == state) {              // met the previous decode's path
-                        const SubseqState old_exit = g_exit[im.sub_off + it_s];
-                        fin = true;
-                        x = make_state(old_exit.p, old_exit.z, old_exit.c, st.n + ((old_word >> 16) & 0x7fffu),
-                                       lane_m(st) + cps.get_m_plain(it_k));
-                    } else {
-                        cps.set(it_k, state | (st.n << 16), lane_m(st));
-                        it_k++;
-                        it_p = lane_pos(st);
-                        it_zc = lane_z(st) | (lane_c(st, *h) << 8);
-                        it_n = st.n;
-                        it_m = lane_m(st);
-                    }
-                }
-            } else {
-                fin = true;
+    for (int slice = 0;; slice++) {
+        if (active) active = !merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps);
+        const unsigned long long mask = __ballot(active);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+        if (slice + 1 == kHeadSlices) {                                    // hand the stragglers to k_huff_merge_tail
+            uint32_t base = 0;
+            if (lane == 0 && mask) base = atomicAdd(g_item_count + blockIdx.y, uint32_t(__popcll(mask)));
+            base = __shfl(base, 0);
+            if (active) {
+                uint32_t *slot = g_items + (size_t(im.sub_off) + base + rank) * kItemDwords;
+                slot[0] = it.s; slot[1] = it.p; slot[2] = it.zc; slot[3] = it.n; slot[4] = it.m; slot[5] = it.k;
             }
-            if (fin) {
-                checkpoint_fixup(cps, it_k, x.n, x.m);
-                g_exit[im.sub_off + it_s] = x;
-                active = false;
-            }
+            break;
         }
         // pack the unfinished items into the lowest lanes
-        const unsigned long long mask = __ballot(active);
         if (lane == 0) s_cnt[wave] = uint32_t(__popcll(mask));
         __syncthreads();                                                   // (also: every lane is done with its window)
         uint32_t before = 0, total = 0;
@@ -425,17 +453,40 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
         }
         if (total == 0) break;
         if (active) {
-            uint32_t *slot = s_win + (before + __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u))) * kItemDwords;
-            slot[0] = it_s; slot[1] = it_p; slot[2] = it_zc; slot[3] = it_n; slot[4] = it_m; slot[5] = it_k;
+            uint32_t *slot = s_win + (before + rank) * kItemDwords;
+            slot[0] = it.s; slot[1] = it.p; slot[2] = it.zc; slot[3] = it.n; slot[4] = it.m; slot[5] = it.k;
         }
         __syncthreads();
         active = tid < total;
         if (active) {
             const uint32_t *slot = s_win + tid * kItemDwords;
-            it_s = slot[0]; it_p = slot[1]; it_zc = slot[2]; it_n = slot[3]; it_m = slot[4]; it_k = slot[5];
+            it.s = slot[0]; it.p = slot[1]; it.zc = slot[2]; it.n = slot[3]; it.m = slot[4]; it.k = slot[5];
         }
         __syncthreads();                                                   // the exchange area becomes windows again
     }
+}
+
+extern "C" __global__ __launch_bounds__(64) void k_huff_merge_tail(const DevImage *images, const uint8_t *scan_pool,
+                                                                    const LutEntry *lut_pool, SubseqState *g_exit,
+                                                                    uint32_t *g_cps, uint32_t win_off,
+                                                                    const uint32_t *g_items, const uint32_t *g_item_count)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // HuffImage, tables, 64 windows
+    uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
+    const DevImage &im = images[blockIdx.y];
+    if (!im.valid) return;
+    const uint32_t count = g_item_count[blockIdx.y];
+    if (blockIdx.x * 64 >= count) return;
+    const HuffImage *h;
+    const LutEntry *lut;
+    stage_tables(im, lut_pool, smem, h, lut);
+    const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= count) return;
+    const uint32_t *slot = g_items + (size_t(im.sub_off) + j) * kItemDwords;
+    MergeItem it{slot[0], slot[1], slot[2], slot[3], slot[4], slot[5]};
+    const unsigned char *bytes = scan_pool + im.scan_off;
+    uint32_t *my_win = s_win + threadIdx.x * kMergeStride;
+    while (!merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps)) {}
 }
 
 // Workgroup-wide exclusive scan helper (256 lanes): returns the exclusive prefix of v, total in *total.
@@ -1354,10 +1405,13 @@ void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tab
 
 void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                        const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
-                       uint32_t *cps, uint32_t *mismatches)
+                       uint32_t *cps, uint32_t *mismatches, uint32_t *items, uint32_t *item_count)
 {
+    (void)hipMemsetAsync(item_count, 0, size_t(nimg) * sizeof(uint32_t), st);
     const size_t lds = tables_lds + size_t(kMergeWg) * kMergeStride * 4 + pad_lds;
-    hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches, uint32_t(tables_lds));
+    hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches, uint32_t(tables_lds), items, item_count);
+    const size_t tail_lds = tables_lds + size_t(64) * kMergeStride * 4;
+    hipLaunchKernelGGL(k_huff_merge_tail, dim3(max_wg * (kMergeWg / 64), nimg), dim3(64), tail_lds, st, images, scan_pool, lut_pool, exit_, cps, uint32_t(tables_lds), items, item_count);
 }
 
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,
