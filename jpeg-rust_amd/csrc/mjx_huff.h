@@ -240,6 +240,10 @@ MJX_HD bool symbol_step(LaneState &st, const BitSrc &bits, const LutEntry *lut, 
                         Sink &sink)
 {
     const uint32_t w = funnel(st.w0, st.w1, lane_t(st));                          // next 32 bits of the stream
+    // A source whose reads are cheap but not free to wait for (an LDS window) is asked for the dword after w1 on every
+    // step, together with the table lookup; a refill then has it at hand instead of waiting for its own read.
+    uint32_t eager = 0;
+    if (BitSrc::kEager) eager = bits.raw32(st.wn - 4u);
     const uint32_t base = st.base;
     LutEntry e = lut_at(lut, base + (w >> (32 - kLutPrimaryBits)) * 4u);
     st.base = st.acb;                                                             // (overridden when the block ends)
@@ -271,7 +275,12 @@ MJX_HD bool symbol_step(LaneState &st, const BitSrc &bits, const LutEntry *lut, 
     }
     if (int32_t(st.x) < 0) {
         st.x ^= 0x80000000u;                                                      // t += 32
-        bits.refill(st);
+        if (BitSrc::kEager) {
+            st.w0 = st.w1;
+            st.w1 = BitSrc::fix(eager);
+        } else {
+            bits.refill(st);
+        }
         st.wn += 4;
         return true;
     }

@@ -32,6 +32,7 @@ struct GlobalBits {
     // One dword ahead: a deeper queue does not help, because moving a queue up touches the newest (still in flight)
     // dword at the very next refill.
     static constexpr int kAhead = MJX_AHEAD;
+    static constexpr bool kEager = false;
     const unsigned char *bytes;     // wave-uniform base: loads are `base + 32-bit lane offset`, no 64-bit address math
     // No bounds test: a lane reads at most 6 dwords past the last scan byte, and every image's region in the pool ends
     // with >= 16 bytes of 0xAA (mjx_api.hip build_batch), so the padding *is* the out-of-range value.
@@ -215,7 +216,8 @@ __device__ __forceinline__ uint32_t subseq_end(const HuffImage &h, uint32_t s)
 constexpr int kWinDwords = MJX_WIN_DWORDS;
 constexpr int kWinStride = kWinDwords + 1;      // odd stride: lanes spread over all banks
 struct LdsWindow {
-    static constexpr int kAhead = 1;
+    static constexpr int kAhead = 0;         // no look-ahead queue: the dword after w1 is read on every step (kEager)
+    static constexpr bool kEager = true;
     const unsigned char *lds;    // lane's window
     uint32_t wbase;              // stream byte offset of the window's first dword
     __device__ __forceinline__ uint32_t be32(uint32_t byte_off) const { return *reinterpret_cast<const uint32_t *>(lds + (byte_off - wbase)); }
@@ -261,8 +263,8 @@ __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry,
     const bool started = running;
     for (uint32_t it = 1;; it++) {
         if (!__builtin_amdgcn_ballot_w64(running)) break;
-        if (__builtin_amdgcn_ballot_w64(running && st.wn >= wbase + 4u * kWinDwords)) {   // wave-uniform: restage every window
-            wbase = st.wn;                                                      // (w0, w1, q are in registers)
+        if (__builtin_amdgcn_ballot_w64(running && st.wn - 4u >= wbase + 4u * kWinDwords)) {   // wave-uniform: restage every window
+            wbase = st.wn - 4u;                                                 // (w0, w1 are in registers; wn - 4 is read next)
             window_fill(my_win, g, wbase);
         }
         if (running) {

@@ -21,6 +21,7 @@ using namespace mjx;
 namespace {
 struct HostBits {
     static constexpr int kAhead = 3;
+    static constexpr bool kEager = false;
     const uint8_t *p;
     size_t n;
     uint32_t be32(uint32_t byte_off) const
