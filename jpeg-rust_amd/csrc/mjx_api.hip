@@ -85,7 +85,7 @@ struct mjx_batch {
     float *d_qm = nullptr;
     SubseqState *d_entry = nullptr, *d_exit = nullptr;
     uint32_t *d_blkbase = nullptr;
-    uint32_t *d_cps = nullptr;          // [kNumCp][chunk subsequences]
+    uint32_t *d_cps = nullptr;          // [chunk subsequences / 256][2 kMaxCp][256] checkpoint words
     uint32_t *d_pull = nullptr;         // [chunk images] straggler counts of k_huff_merge (per round)
     uint32_t *d_items = nullptr;        // [max_nsub][6] stragglers handed from k_huff_merge to k_huff_merge_tail
     uint32_t max_nsub = 1, max_chunk_images = 1;
@@ -250,7 +250,7 @@ int allocate_work_buffers(mjx_batch *b)
     HIPOK(hipMalloc(&b->d_entry, size_t(max_nsub) * sizeof(SubseqState)));
     HIPOK(hipMalloc(&b->d_exit, size_t(max_nsub) * sizeof(SubseqState)));
     HIPOK(hipMalloc(&b->d_blkbase, size_t(max_nsub) * sizeof(uint32_t)));
-    HIPOK(hipMalloc(&b->d_cps, (size_t(max_nsub) + 256) / 256 * 256 * kNumCp * 2 * sizeof(uint32_t)));
+    HIPOK(hipMalloc(&b->d_cps, (size_t(max_nsub) + 256) / 256 * 256 * kMaxCp * 2 * sizeof(uint32_t)));
     size_t max_imgs = 1;
     for (const Chunk &c : b->chunks) max_imgs = std::max(max_imgs, c.count);
     b->max_nsub = max_nsub;

@@ -26,8 +26,20 @@ namespace mjx {
 #ifndef MJX_SUBSEQ_BYTES
 #define MJX_SUBSEQ_BYTES 512
 #endif
-constexpr int kSubseqBytes = MJX_SUBSEQ_BYTES;  // bytes of scan per lane
+constexpr int kSubseqBytes = MJX_SUBSEQ_BYTES;  // bytes of scan per lane, at least (HuffImage::sub_bits is the image's value)
 constexpr int kSubseqBits = kSubseqBytes * 8;
+constexpr int kMaxSubseqBits = 2 * kSubseqBits;
+constexpr int kCpBits = 256;                   // bits between two checkpoints of a subsequence
+#ifndef MJX_HUFF_WG
+#define MJX_HUFF_WG 512
+#endif
+#ifndef MJX_MERGE_WG
+#define MJX_MERGE_WG 512
+#endif
+constexpr int kMergeWg = MJX_MERGE_WG;                          // ... per k_huff_merge workgroup
+constexpr int kHuffWg = MJX_HUFF_WG;                            // lanes (= subsequences) per k_huff_spec / merge / write workgroup:
+                                                                // the decode tables in LDS are shared by kHuffWg / 64 waves
+
 #ifndef MJX_LUT_BITS
 #define MJX_LUT_BITS 9
 #endif
@@ -89,8 +101,26 @@ struct HuffImage {
     uint32_t bpm;                        // blocks per MCU
     uint32_t total_bits;                 // scan_len * 8
     uint32_t total_blocks;               // MCUs to decode * bpm
-    uint32_t nsub;                       // ceil(total_bits / kSubseqBits)
+    uint32_t nsub;                       // ceil(total_bits / sub_bits)
+    uint32_t sub_bits;                   // bits per subsequence: a multiple of kCpBits in [kSubseqBits, kMaxSubseqBits]
+    uint32_t pad_[3];
 };
+
+// Subsequence length of an image.  512 bytes per lane is the sweet spot, but a workgroup's LDS (tables, windows,
+// rings) is allocated for all its lanes: an image of 4.1 workgroups' worth of 512-byte subsequences would hold five
+// workgroups' LDS, the fifth for a single wave's work.  When at most 25 % longer subsequences make the image fit into
+// one workgroup less, they are chosen instead.
+MJX_HD uint32_t choose_subseq_bits(uint32_t total_bits)
+{
+#ifdef MJX_FORCE_SUBSEQ_BITS
+    return MJX_FORCE_SUBSEQ_BITS;
+#endif
+    const uint32_t nsub = (total_bits + kSubseqBits - 1) / uint32_t(kSubseqBits), nwg = nsub / uint32_t(kHuffWg);
+    if (nwg == 0 || nsub % uint32_t(kHuffWg) == 0) return kSubseqBits;
+    const uint32_t lanes = nwg * uint32_t(kHuffWg);
+    const uint32_t bits = ((total_bits + lanes - 1) / lanes + kCpBits - 1) / kCpBits * kCpBits;
+    return (bits >= uint32_t(kSubseqBits) && bits <= uint32_t(kSubseqBits) * 5 / 4) ? bits : uint32_t(kSubseqBits);
+}
 static_assert(sizeof(HuffImage) % 16 == 0, "the decode tables follow HuffImage in LDS and are staged in 16-byte pieces");
 
 // ---- compact coefficient stream -------------------------------------------------------------------------------
@@ -122,8 +152,7 @@ struct NullSink {
 //   (at a boundary the lane's dword position is the boundary itself, so t stands for p)
 //   n, m = blocks / stream entries from the checkpoint to the end of the subsequence (after the decode's fix-up);
 //   while a decode is running they temporarily hold the counts from the start to the checkpoint.
-constexpr int kCpBits = 256;
-constexpr int kNumCp = kSubseqBits / kCpBits - 1;
+constexpr int kMaxCp = kMaxSubseqBits / kCpBits - 1;      // checkpoints of the longest subsequence
 constexpr uint32_t kCpValid = 0x80000000u, kCpStateMask = 0x8000ffffu;
 struct NoCheckpoints {
     MJX_HD uint32_t get(uint32_t) const { return 0; }             // word 0 of checkpoint k (may prefetch k+1)
@@ -336,13 +365,20 @@ MJX_HD SubseqState lane_exit(const LaneState &st, const LaneEvents &ev, const Hu
     return make_state(lane_pos(st), lane_z(st), lane_c(st, img), st.n, lane_m(st));
 }
 
-// counts-so-far -> counts-to-the-end for the checkpoints this decode recorded
+// counts-so-far -> counts-to-the-end for the checkpoints this decode recorded (four at a time: the loads of a group
+// are in flight together)
 template <class CpStore>
 MJX_HD void checkpoint_fixup(CpStore &cps, uint32_t k, uint32_t n_total, uint32_t m_total)
 {
-    for (uint32_t j = 0; j < k; j++) {
-        const uint32_t wv = cps.get_plain(j);
-        cps.set(j, (wv & kCpStateMask) | ((n_total - ((wv >> 16) & 0x7fffu)) << 16), m_total - cps.get_m_plain(j));
+    for (uint32_t j0 = 0; j0 < k; j0 += 4) {
+        uint32_t wv[4], mv[4];
+        for (uint32_t q = 0; q < 4; q++) {
+            wv[q] = j0 + q < k ? cps.get_plain(j0 + q) : 0u;
+            mv[q] = j0 + q < k ? cps.get_m_plain(j0 + q) : 0u;
+        }
+        for (uint32_t q = 0; q < 4; q++)
+            if (j0 + q < k)
+                cps.set(j0 + q, (wv[q] & kCpStateMask) | ((n_total - ((wv[q] >> 16) & 0x7fffu)) << 16), m_total - mv[q]);
     }
 }
 

@@ -7,15 +7,6 @@
 namespace mjx {
 
 constexpr int kWgLanes = 256;                                   // lanes of the scan / prefix-sum workgroups
-#ifndef MJX_HUFF_WG
-#define MJX_HUFF_WG 512
-#endif
-#ifndef MJX_MERGE_WG
-#define MJX_MERGE_WG 512
-#endif
-constexpr int kMergeWg = MJX_MERGE_WG;                          // ... per k_huff_merge workgroup
-constexpr int kHuffWg = MJX_HUFF_WG;                            // lanes (= subsequences) per k_huff_spec / merge / write workgroup:
-                                                                // the decode tables in LDS are shared by kHuffWg / 64 waves
 constexpr int kDcSegMcus = 2048;                                // MCUs per DC-prediction segment (k_dc_sums / k_dc_apply)
 
 // One image of a chunk, as the kernels see it (HBM, read-only during decode).

@@ -17,6 +17,10 @@
 
 #include "mjx_kernels.h"
 
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 namespace mjx {
 
 // ------------------------------------------------------------------------------------------------
@@ -52,7 +56,7 @@ struct GlobalBits {
 constexpr uint32_t kCpRow = 256, kCpRowBytes = kCpRow * 4;
 __device__ __forceinline__ uint32_t cps_byte_off(uint32_t idx)
 {
-    return (idx / kCpRow) * (2 * kNumCp * kCpRowBytes) + (idx % kCpRow) * 4;
+    return (idx / kCpRow) * (2 * kMaxCp * kCpRowBytes) + (idx % kCpRow) * 4;
 }
 
 struct GlobalCps {
@@ -64,7 +68,7 @@ struct GlobalCps {
     __device__ __forceinline__ uint32_t get(uint32_t k)
     {
         const uint32_t v = next;
-        if (k + 1 < uint32_t(kNumCp)) next = word(2 * (k + 1));
+        if (k + 1 < uint32_t(kMaxCp)) next = word(2 * (k + 1));
         return v;
     }
     __device__ __forceinline__ uint32_t get_m(uint32_t k) const { return word(2 * k + 1); }
@@ -200,7 +204,7 @@ __device__ __forceinline__ void stage_tables(const DevImage &im, const LutEntry 
 
 __device__ __forceinline__ uint32_t subseq_end(const HuffImage &h, uint32_t s)
 {
-    const uint32_t e = (s + 1) * uint32_t(kSubseqBits);
+    const uint32_t e = (s + 1) * h.sub_bits;
     return e < h.total_bits ? e : h.total_bits;
 }
 
@@ -223,7 +227,7 @@ struct LdsWindow {
     __device__ __forceinline__ uint32_t be32(uint32_t byte_off) const { return *reinterpret_cast<const uint32_t *>(lds + (byte_off - wbase)); }
     __device__ __forceinline__ uint32_t raw32(uint32_t byte_off) const { return be32(byte_off); }
     static __device__ __forceinline__ uint32_t fix(uint32_t raw) { return raw; }
-    __device__ __forceinline__ void refill(LaneState &st) const { refill_generic(*this, st); }
+    __device__ __forceinline__ void refill(LaneState &) const {}          // (kEager: symbol_step moves the window itself)
     __device__ __forceinline__ void drain(LaneState &) const {}
 };
 __device__ __forceinline__ void window_fill(uint32_t *lds, const GlobalBits &g, uint32_t wbase)
@@ -304,12 +308,13 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_spec(const DevImage
     const bool live = s < h->nsub;
     if (!kSpecWin && !live) return;
     const GlobalBits bits{scan_pool + im.scan_off};
-    const SubseqState e = make_state(live ? s * kSubseqBits : 0u, 0, 0);
+    const uint32_t sub_start = s * h->sub_bits;
+    const SubseqState e = make_state(live ? sub_start : 0u, 0, 0);
     NullSink sink;
     GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + (live ? s : 0u)), 0};
     SubseqState x;
-    if (kSpecWin) x = wave_decode<false, 1>(live, e, live ? subseq_end(*h, s) : 0u, 0, bits, s_win + threadIdx.x * kWinStride, lut, *h, sink, cps, s * kSubseqBits, e);
-    else x = decode_subseq<false, 1>(bits, lut, *h, e, subseq_end(*h, s), 0, sink, cps, s * kSubseqBits, e);
+    if (kSpecWin) x = wave_decode<false, 1>(live, e, live ? subseq_end(*h, s) : 0u, 0, bits, s_win + threadIdx.x * kWinStride, lut, *h, sink, cps, sub_start, e);
+    else x = decode_subseq<false, 1>(bits, lut, *h, e, subseq_end(*h, s), 0, sink, cps, sub_start, e);
     if (!live) return;
     g_entry[im.sub_off + s] = e;
     g_exit[im.sub_off + s] = x;
@@ -337,19 +342,22 @@ constexpr int kMergeWin = 12, kMergeStride = kMergeWin + 1, kItemDwords = 6;
 #endif
 constexpr int kHeadSlices = MJX_HEAD_SLICES;
 struct MergeItem { uint32_t s, p, zc, n, m, k; };
+#ifdef MJX_DEBUG_COUNTS
+__device__ unsigned long long g_dbg[64];
+#endif
 
 // One slice of one item: decode from (p, z, c) to the next checkpoint boundary (or the end of the subsequence).
 // Returns true when the item is finished (its exit and checkpoints are final), false when `it` holds the progress.
 __device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, const HuffImage &h, const LutEntry *lut,
-                                            const unsigned char *bytes, uint32_t *my_win, SubseqState *g_exit,
-                                            uint32_t *g_cps)
+                                            const unsigned char *bytes, uint32_t *my_win, const SubseqState *g_exit,
+                                            uint32_t *g_cps, SubseqState &x)
 {
-    const uint32_t sub_start = it.s * kSubseqBits, end_bit = subseq_end(h, it.s);
+    const uint32_t sub_start = it.s * h.sub_bits, end_bit = subseq_end(h, it.s);
     const GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + it.s), 0};
     bool fin = false;
-    SubseqState x = make_state(it.p, it.zc & 0xffu, it.zc >> 8, it.n, it.m);
+    x = make_state(it.p, it.zc & 0xffu, it.zc >> 8, it.n, it.m);
     if (it.p <= end_bit) {                                         // (else nothing starts inside s)
-        const uint32_t old_word = it.k < uint32_t(kNumCp) ? cps.get_plain(it.k) : 0u;   // requested early
+        const uint32_t old_word = it.k < uint32_t(kMaxCp) ? cps.get_plain(it.k) : 0u;   // requested early
         const uint32_t wi1 = (it.p + 31u) >> 5, wbase = wi1 ? 4u * wi1 - 4u : 0u;
 #pragma unroll
         for (int q = 0; q < kMergeWin / 4; q++) {
@@ -371,11 +379,17 @@ __device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, c
         NullSink sink;
         while (st.wn < stop_wn) (void)symbol_step<false>(st, win, lut, h, blk, sink);
         if (st.wn >= end_wn) {                                     // left the subsequence without merging
+#ifdef MJX_DEBUG_COUNTS
+            atomicAdd(&g_dbg[32 + (it.k < 31 ? it.k : 31)], 1ull);
+#endif
             fin = true;
             x = make_state(lane_pos(st), lane_z(st), lane_c(st, h), st.n, lane_m(st));
         } else {
             const uint32_t state = cp_state_word(st);
             if ((old_word & kCpStateMask) == state) {              // met the previous decode's path
+#ifdef MJX_DEBUG_COUNTS
+                atomicAdd(&g_dbg[it.k < 31 ? it.k : 31], 1ull);
+#endif
                 const SubseqState old_exit = g_exit[im.sub_off + it.s];
                 fin = true;
                 x = make_state(old_exit.p, old_exit.z, old_exit.c, st.n + ((old_word >> 16) & 0x7fffu),
@@ -392,11 +406,17 @@ __device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, c
     } else {
         fin = true;
     }
-    if (fin) {
-        checkpoint_fixup(cps, it.k, x.n, x.m);
-        g_exit[im.sub_off + it.s] = x;
-    }
     return fin;
+}
+// A finished item: its exit, and the counts of the checkpoints it recorded turned from "so far" into "to the end".
+__device__ __forceinline__ void merge_finish(const MergeItem &it, const DevImage &im, const SubseqState &x,
+                                             SubseqState *g_exit, uint32_t *g_cps)
+{
+    const GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + it.s), 0};
+#ifndef MJX_EXPERIMENT_NO_FIXUP
+    checkpoint_fixup(cps, it.k, x.n, x.m);
+#endif
+    g_exit[im.sub_off + it.s] = x;
 }
 
 extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevImage *images, const uint8_t *scan_pool,
@@ -430,7 +450,13 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
     const unsigned char *bytes = scan_pool + im.scan_off;
     uint32_t *my_win = s_win + tid * kMergeStride;
     for (int slice = 0;; slice++) {
-        if (active) active = !merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps);
+        if (active) {
+            SubseqState x;
+            if (merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x)) {
+                merge_finish(it, im, x, g_exit, g_cps);
+                active = false;
+            }
+        }
         const unsigned long long mask = __ballot(active);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
         if (slice + 1 == kHeadSlices) {                                    // hand the stragglers to k_huff_merge_tail
@@ -475,20 +501,39 @@ extern "C" __global__ __launch_bounds__(64) void k_huff_merge_tail(const DevImag
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // HuffImage, tables, 64 windows
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
-    const DevImage &im = images[blockIdx.y];
+    // Workgroup (image, group): the image is the fast grid dimension, so that the groups that have items -- the first
+    // few of every image -- are consecutive workgroup ids and spread over all XCDs and CUs; with the group as the fast
+    // dimension they recur with the period of the grid and land on a fraction of the CUs.
+    const uint32_t img = blockIdx.x, group = blockIdx.y;
+    const DevImage &im = images[img];
     if (!im.valid) return;
-    const uint32_t count = g_item_count[blockIdx.y];
-    if (blockIdx.x * 64 >= count) return;
+    const uint32_t count = g_item_count[img];
+    if (group * 64 >= count) return;
     const HuffImage *h;
     const LutEntry *lut;
     stage_tables(im, lut_pool, smem, h, lut);
-    const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t j = group * 64 + threadIdx.x;
     if (j >= count) return;
     const uint32_t *slot = g_items + (size_t(im.sub_off) + j) * kItemDwords;
     MergeItem it{slot[0], slot[1], slot[2], slot[3], slot[4], slot[5]};
     const unsigned char *bytes = scan_pool + im.scan_off;
     uint32_t *my_win = s_win + threadIdx.x * kMergeStride;
-    while (!merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps)) {}
+    // every lane runs its item to the end first; the read-modify-write of the recorded checkpoints then happens once
+    // for the whole wave instead of after every slice for the lanes that happen to finish there
+    SubseqState x;
+#ifdef MJX_DEBUG_COUNTS
+    const unsigned long long t0 = wall_clock64();
+    unsigned long long nsl = 1;
+    while (!merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x)) nsl++;
+    const unsigned long long t1 = wall_clock64();
+    atomicAdd(&g_dbg[60], nsl);
+    atomicAdd(&g_dbg[61], 1ull);
+    atomicMax(&g_dbg[62], t1 - t0);
+    atomicAdd(&g_dbg[63], t1 - t0);
+#else
+    while (!merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x)) {}
+#endif
+    merge_finish(it, im, x, g_exit, g_cps);
 }
 
 // Workgroup-wide exclusive scan helper (256 lanes): returns the exclusive prefix of v, total in *total.
@@ -1413,7 +1458,26 @@ void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
     const size_t lds = tables_lds + size_t(kMergeWg) * kMergeStride * 4 + pad_lds;
     hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches, uint32_t(tables_lds), items, item_count);
     const size_t tail_lds = tables_lds + size_t(64) * kMergeStride * 4;
-    hipLaunchKernelGGL(k_huff_merge_tail, dim3(max_wg * (kMergeWg / 64), nimg), dim3(64), tail_lds, st, images, scan_pool, lut_pool, exit_, cps, uint32_t(tables_lds), items, item_count);
+    hipLaunchKernelGGL(k_huff_merge_tail, dim3(nimg, max_wg * (kMergeWg / 64)), dim3(64), tail_lds, st, images, scan_pool, lut_pool, exit_, cps, uint32_t(tables_lds), items, item_count);
+    if (std::getenv("MJX_DEBUG_MERGE")) {
+        (void)hipStreamSynchronize(st);
+        std::vector<uint32_t> hc(nimg);
+        (void)hipMemcpy(hc.data(), item_count, nimg * 4, hipMemcpyDeviceToHost);
+        unsigned long long tot = 0; uint32_t mx = 0;
+        for (uint32_t v : hc) { tot += v; mx = v > mx ? v : mx; }
+        std::fprintf(stderr, "merge round: exported items total %llu max/image %u (images %u)\n", tot, mx, nimg);
+#ifdef MJX_DEBUG_COUNTS
+        unsigned long long hd[64];
+        (void)hipMemcpyFromSymbol(hd, HIP_SYMBOL(g_dbg), sizeof hd);
+        std::fprintf(stderr, "  merged at k:");
+        for (int i = 0; i < 20; i++) std::fprintf(stderr, " %llu", hd[i]);
+        std::fprintf(stderr, "\n  ended at k:");
+        for (int i = 0; i < 20; i++) std::fprintf(stderr, " %llu", hd[32 + i]);
+        std::fprintf(stderr, "\n  tail: lane-slices %llu lanes %llu max ticks %llu avg ticks %llu (100 MHz clock)\n", hd[60], hd[61], hd[62], hd[61] ? hd[63] / hd[61] : 0ull);
+        unsigned long long z[64] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof z);
+#endif
+    }
 }
 
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,

@@ -173,7 +173,8 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p)
     p.himg.bpm = p.bpm;
     p.himg.total_bits = uint32_t(p.scan_len * 8);
     p.himg.total_blocks = p.nmcu * p.bpm;
-    p.himg.nsub = (p.himg.total_bits + kSubseqBits - 1) / kSubseqBits;
+    p.himg.sub_bits = choose_subseq_bits(p.himg.total_bits);
+    p.himg.nsub = (p.himg.total_bits + p.himg.sub_bits - 1) / p.himg.sub_bits;
 
     // dequantisation x IDCT prescale, zig-zag order (reference: decoder.rs:230-232 multiplies by the raw table;
     // the AAN row/column factors and the 1/8 are folded in here so the kernel does one multiply per coefficient)

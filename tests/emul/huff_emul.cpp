@@ -96,20 +96,20 @@ extern "C" int emul_decode_coefs(const uint8_t *jpeg, size_t len, int layout, in
     const HostBits bits{plan.scan, plan.scan_len};
     const uint32_t nsub = img.nsub;
     std::vector<SubseqState> g_entry(nsub), g_exit(nsub);
-    std::vector<uint32_t> g_cps(size_t(nsub) * kNumCp * 2, 0xdeadbeefu);  // uninitialised on the device
+    std::vector<uint32_t> g_cps(size_t(nsub) * kMaxCp * 2, 0xdeadbeefu);  // uninitialised on the device
     TickSink ns;
     NoCheckpoints nocp;
     std::vector<std::vector<long>> iter_ticks;
     const char *dump = std::getenv("MJX_EMUL_DUMP");
-    auto end_of = [&](uint32_t s) { uint64_t e = uint64_t(s + 1) * kSubseqBits; return uint32_t(e < img.total_bits ? e : img.total_bits); };
+    auto end_of = [&](uint32_t s) { uint64_t e = uint64_t(s + 1) * img.sub_bits; return uint32_t(e < img.total_bits ? e : img.total_bits); };
     long redecodes = 0, rounds = 0;
 
     iter_ticks.emplace_back();
     for (uint32_t s = 0; s < nsub; s++) {                                  // k_huff_spec
-        const SubseqState e = make_state(s * uint32_t(kSubseqBits), 0, 0);
-        HostCps hc{g_cps.data() + size_t(s) * kNumCp * 2};
+        const SubseqState e = make_state(s * img.sub_bits, 0, 0);
+        HostCps hc{g_cps.data() + size_t(s) * kMaxCp * 2};
         const long t0 = ns.ticks;
-        g_exit[s] = decode_subseq<false, 1>(bits, plan.lut.data(), img, e, end_of(s), 0, ns, hc, s * kSubseqBits, e);
+        g_exit[s] = decode_subseq<false, 1>(bits, plan.lut.data(), img, e, end_of(s), 0, ns, hc, s * img.sub_bits, e);
         g_entry[s] = e;
         iter_ticks[0].push_back(ns.ticks - t0);
     }
@@ -123,9 +123,9 @@ extern "C" int emul_decode_coefs(const uint8_t *jpeg, size_t len, int layout, in
             if (same_entry(prev, g_entry[s])) continue;
             const SubseqState e = make_state(prev.p, prev.z, prev.c);
             g_entry[s] = e;
-            HostCps hc{g_cps.data() + size_t(s) * kNumCp * 2};
+            HostCps hc{g_cps.data() + size_t(s) * kMaxCp * 2};
             const long t0 = ns.ticks;
-            g_exit[s] = decode_subseq<false, 2>(bits, plan.lut.data(), img, e, end_of(s), 0, ns, hc, s * kSubseqBits, g_exit[s]);
+            g_exit[s] = decode_subseq<false, 2>(bits, plan.lut.data(), img, e, end_of(s), 0, ns, hc, s * img.sub_bits, g_exit[s]);
             iter_ticks.back().push_back(ns.ticks - t0);
             redone++;
         }
