@@ -43,6 +43,7 @@ def parse_args():
     ap.add_argument("--chunk-images", type=int, default=0)
     ap.add_argument("--stages", default="all", choices=["all", "pixels"], help="pixels = stage-B-only sweep on resident coefficients")
     ap.add_argument("--device-destuff", action="store_true", help="upload stuffed scans; FF00 compaction on the GPU at upload")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2], help="2 = odd chunks on a second HIP stream (stage B of one chunk overlaps stage A of the next; per-kernel times then include the contention)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
@@ -162,6 +163,8 @@ def main():
     with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
         datas = list(ex.map(lambda s: mjx.synth_jpeg(args.width, args.height, args.subsampling, args.quality, s), seeds))
 
+    if args.streams == 2:
+        os.environ["MJX_STREAMS"] = "2"
     ctx = mjx.Context(device, profiling=True)
     scans = [mjx.ParsedScan(d, device_destuff=args.device_destuff) for d in datas]
     keep = args.stages == "pixels"
@@ -214,7 +217,7 @@ def main():
                                   {"420": "4:2:0", "422": "4:2:2", "444": "4:4:4", "440": "4:4:0", "gray": "greyscale"}[args.subsampling],
                                   args.quality, period, args.stages),
                    "images_per_gpu": per_gpu, "width": args.width, "height": args.height, "subsampling": args.subsampling,
-                   "quality": args.quality, "layout": "standard", "sharding": "image i -> gpu i %% %d, no collective" % world},
+                   "quality": args.quality, "layout": "standard", "streams": args.streams, "sharding": "image i -> gpu i %% %d, no collective" % world},
         "kernels": kernels,
     }
     if kernels:

@@ -29,6 +29,8 @@ using namespace mjx;
 struct mjx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // odd chunks run here (MJX_STREAMS=2): one chunk's stage B overlaps the next one's stage A
+    int nstreams = 1;
     bool profiling = false;
     int fix_passes = 4;            // synchronisation rounds enqueued up front (the last one must re-decode nothing)
     // Extra dynamic LDS for k_huff_spec: caps it at 5 workgroups (20 waves) per CU.  Every lane streams its own
@@ -105,6 +107,16 @@ struct mjx_batch {
     size_t huff_lds = 0, idct_lds = 0;
     bool decoded_entropy = false;
     int last_chunk_resident = -1;
+    bool resident_second = false;   // ... and it lives in the second scratch set
+    // second set of per-chunk scratch for the chunks that run on ctx->stream2 (null = single stream)
+    struct Alt {
+        SubseqState *d_entry = nullptr, *d_exit = nullptr;
+        uint32_t *d_blkbase = nullptr, *d_ebase = nullptr, *d_cps = nullptr, *d_pull = nullptr, *d_items = nullptr;
+        int32_t *d_segsum = nullptr, *d_dc = nullptr;
+        unsigned long long *d_planes = nullptr;
+        uint32_t *d_entries = nullptr, *d_tile_eoff = nullptr;
+    } alt;
+    bool dual = false;
     uint64_t scan_bytes = 0, rgb_bytes = 0, coef_bytes = 0, pixels = 0;
     // profiling
     std::vector<EventPair> events;
@@ -132,6 +144,12 @@ void release(mjx_batch *b)
     (void)hipFree(b->d_dc); (void)hipFree(b->d_rgb); (void)hipFree(b->d_status);
     (void)hipFree(b->d_planes);
     (void)hipFree(b->d_mismatch); (void)hipFree(b->d_segsum); (void)hipFree(b->d_cps); (void)hipFree(b->d_pull); (void)hipFree(b->d_items);
+    if (b->dual) {
+        (void)hipFree(b->alt.d_entry); (void)hipFree(b->alt.d_exit); (void)hipFree(b->alt.d_blkbase); (void)hipFree(b->alt.d_ebase);
+        (void)hipFree(b->alt.d_cps); (void)hipFree(b->alt.d_pull); (void)hipFree(b->alt.d_items); (void)hipFree(b->alt.d_segsum);
+        (void)hipFree(b->alt.d_planes);
+        if (!b->opts.keep_coefs) { (void)hipFree(b->alt.d_entries); (void)hipFree(b->alt.d_tile_eoff); (void)hipFree(b->alt.d_dc); }
+    }
     if (b->h_mismatch) (void)hipHostFree(b->h_mismatch);
     delete b;
 }
@@ -278,6 +296,28 @@ int allocate_work_buffers(mjx_batch *b)
     HIPOK(hipMalloc(&b->d_mismatch, mm));
     HIPOK(hipHostMalloc(reinterpret_cast<void **>(&b->h_mismatch), mm, hipHostMallocDefault));
     std::memset(b->h_mismatch, 0, mm);
+    if (b->ctx->nstreams == 2 && b->chunks.size() > 1) {          // second scratch set for the chunks on stream2
+        mjx_batch::Alt &a = b->alt;
+        b->dual = true;
+        HIPOK(hipMalloc(&a.d_entry, size_t(max_nsub) * sizeof(SubseqState)));
+        HIPOK(hipMalloc(&a.d_exit, size_t(max_nsub) * sizeof(SubseqState)));
+        HIPOK(hipMalloc(&a.d_blkbase, size_t(max_nsub) * sizeof(uint32_t)));
+        HIPOK(hipMalloc(&a.d_ebase, size_t(max_nsub) * sizeof(uint32_t)));
+        HIPOK(hipMalloc(&a.d_cps, (size_t(max_nsub) + 256) / 256 * 256 * kMaxCp * 2 * sizeof(uint32_t)));
+        HIPOK(hipMalloc(&a.d_pull, max_imgs * kMaxFix * sizeof(uint32_t)));
+        HIPOK(hipMalloc(&a.d_items, size_t(max_nsub) * 6 * sizeof(uint32_t)));
+        HIPOK(hipMalloc(&a.d_segsum, max_segsum * 3 * sizeof(int32_t)));
+        uint64_t max_planes = 0;
+        for (const Chunk &c : b->chunks) max_planes = std::max(max_planes, c.plane_words);
+        if (max_planes) HIPOK(hipMalloc(&a.d_planes, size_t(max_planes) * 8));
+        if (b->opts.keep_coefs) {
+            a.d_entries = b->d_entries; a.d_tile_eoff = b->d_tile_eoff; a.d_dc = b->d_dc;
+        } else {
+            HIPOK(hipMalloc(&a.d_entries, size_t(max_entries) * 4 + 64));
+            HIPOK(hipMalloc(&a.d_tile_eoff, size_t(max_tiles_arr) * 4 + 16));
+            HIPOK(hipMalloc(&a.d_dc, size_t(coef_blocks) * sizeof(int32_t) + 64));
+        }
+    }
     b->huff_lds = huff_lds_bytes(lut_cap);
     b->idct_lds = idct_lds_bytes(max_tile_blocks);
     if (b->huff_lds + huff_window_bytes() + huff_stage_bytes() > 160 * 1024 || b->idct_lds > 160 * 1024) return MJX_ERR_UNSUPPORTED_FORMAT;
@@ -288,73 +328,83 @@ int allocate_work_buffers(mjx_batch *b)
     return MJX_OK;
 }
 
-void prof_begin(mjx_batch *b, int kind)
+void prof_begin(mjx_batch *b, int kind, hipStream_t st)
 {
     if (!b->ctx->profiling) return;
     EventPair e;
     if (!b->event_pool.empty()) { e = b->event_pool.back(); b->event_pool.pop_back(); }
     else { (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); }
     e.kind = kind;
-    (void)hipEventRecord(e.a, b->ctx->stream);
+    (void)hipEventRecord(e.a, st);
     b->events.push_back(e);
 }
-void prof_end(mjx_batch *b)
+void prof_end(mjx_batch *b, hipStream_t st)
 {
     if (!b->ctx->profiling) return;
-    (void)hipEventRecord(b->events.back().b, b->ctx->stream);
+    (void)hipEventRecord(b->events.back().b, st);
 }
 
 // Enqueue one chunk.  `fix_passes` inter-workgroup passes are launched; the mismatch count of the last one is copied
 // to the pinned mirror and examined in mjx_batch_wait.  `phases` selects which parts of the entropy stage run
 // (the repair path of mjx_batch_wait continues fix passes without restarting the speculative decode).
 enum { PH_SYNC = 1, PH_FIX = 2, PH_TAIL = 4, PH_ENTROPY_ALL = 7 };
-int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned phases = PH_ENTROPY_ALL)
+int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned phases = PH_ENTROPY_ALL, bool force_first = false)
 {
     const Chunk &c = b->chunks[ci];
     if (c.count == 0 || c.nsub == 0) return MJX_OK;
-    hipStream_t st = b->ctx->stream;
+    const bool second = b->dual && (ci & 1) && !force_first;
+    hipStream_t st = second ? b->ctx->stream2 : b->ctx->stream;
+#define SCR(x) (second ? b->alt.x : b->x)
     const DevImage *imgs = b->d_images + c.first;
     const uint32_t nimg = uint32_t(c.count);
-    int32_t *dcb = b->d_dc;              // image offsets already include the chunk base
+    int32_t *dcb = SCR(d_dc);              // image offsets already include the chunk base
     fix_passes = std::min(fix_passes, kMaxFix);
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_SYNC)) {
-        prof_begin(b, MJX_K_HUFF_SYNC);
-        launch_huff_spec(st, c.max_wg, nimg, b->huff_lds, b->ctx->spec_lds_pad, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, b->d_cps);
-        prof_end(b);
+        prof_begin(b, MJX_K_HUFF_SYNC, st);
+        launch_huff_spec(st, c.max_wg, nimg, b->huff_lds, b->ctx->spec_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps));
+        prof_end(b, st);
     }
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_FIX)) {
         HIPOK(hipMemsetAsync(b->d_mismatch + ci * kMaxFix, 0, kMaxFix * sizeof(uint32_t), st));
         if (c.merge_wgs > 0) {
             for (int k = 0; k < fix_passes; k++) {
-                prof_begin(b, MJX_K_HUFF_FIX);
-                launch_huff_merge(st, c.merge_wgs, nimg, b->huff_lds, b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_exit, b->d_cps,
-                                  b->d_mismatch + ci * kMaxFix + k, b->d_items, b->d_pull);
-                prof_end(b);
+                prof_begin(b, MJX_K_HUFF_FIX, st);
+                launch_huff_merge(st, c.merge_wgs, nimg, b->huff_lds, b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps),
+                                  b->d_mismatch + ci * kMaxFix + k, SCR(d_items), SCR(d_pull));
+                prof_end(b, st);
             }
             HIPOK(hipMemcpyAsync(b->h_mismatch + ci * kMaxFix, b->d_mismatch + ci * kMaxFix, kMaxFix * sizeof(uint32_t),
                                  hipMemcpyDeviceToHost, st));
         }
     }
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_TAIL)) {
-        prof_begin(b, MJX_K_HUFF_SCAN);
-        launch_huff_scan(st, nimg, imgs, b->d_exit, b->d_blkbase, b->d_ebase, b->d_img_entries, b->d_img_flags);
-        prof_end(b);
-        prof_begin(b, MJX_K_HUFF_WRITE);
-        launch_huff_write(st, c.max_wg, nimg, b->huff_lds, b->ctx->write_lds_pad, imgs, b->d_scan, b->d_lut, b->d_entry, b->d_blkbase, b->d_ebase,
-                          b->d_entries, b->d_tile_eoff, dcb, b->d_status, b->d_img_flags);
-        prof_end(b);
-        prof_begin(b, MJX_K_DC_SCAN);
-        launch_dc_scan(st, c.max_segs, nimg, imgs, dcb, b->d_segsum, b->d_img_flags, c.bpm_mask);
-        prof_end(b);
+        prof_begin(b, MJX_K_HUFF_SCAN, st);
+        launch_huff_scan(st, nimg, imgs, SCR(d_exit), SCR(d_blkbase), SCR(d_ebase), b->d_img_entries, b->d_img_flags);
+        prof_end(b, st);
+        prof_begin(b, MJX_K_HUFF_WRITE, st);
+        launch_huff_write(st, c.max_wg, nimg, b->huff_lds, b->ctx->write_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_blkbase), SCR(d_ebase),
+                          SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_status, b->d_img_flags);
+        prof_end(b, st);
+        prof_begin(b, MJX_K_DC_SCAN, st);
+        launch_dc_scan(st, c.max_segs, nimg, imgs, dcb, SCR(d_segsum), b->d_img_flags, c.bpm_mask);
+        prof_end(b, st);
     }
     if (stages & MJX_STAGE_PIXELS) {
-        prof_begin(b, MJX_K_IDCT_COLOR);
-        if (c.plane_words) HIPOK(hipMemsetAsync(b->d_planes, 0, size_t(c.plane_words) * 8, st));
-        launch_idct_color(st, (c.max_tiles + kTilesPerWgHost - 1) / kTilesPerWgHost, nimg, b->idct_lds, imgs, b->d_entries, b->d_tile_eoff, dcb, b->d_qm, b->d_rgb, c.mode_mask, b->d_planes, b->d_img_flags);
-        if (c.plane_words) launch_ref_color(st, c.max_pixel_wgs, nimg, imgs, b->d_planes, b->d_rgb, b->d_img_flags);
-        prof_end(b);
+        prof_begin(b, MJX_K_IDCT_COLOR, st);
+        if (c.plane_words) HIPOK(hipMemsetAsync(SCR(d_planes), 0, size_t(c.plane_words) * 8, st));
+        launch_idct_color(st, (c.max_tiles + kTilesPerWgHost - 1) / kTilesPerWgHost, nimg, b->idct_lds, imgs, SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_qm, b->d_rgb, c.mode_mask, SCR(d_planes), b->d_img_flags);
+        if (c.plane_words) launch_ref_color(st, c.max_pixel_wgs, nimg, imgs, SCR(d_planes), b->d_rgb, b->d_img_flags);
+        prof_end(b, st);
     }
     HIPOK(hipGetLastError());
+    return MJX_OK;
+#undef SCR
+}
+
+int sync_streams(const mjx_batch *b)
+{
+    HIPOK(hipStreamSynchronize(b->ctx->stream));
+    if (b->ctx->stream2) HIPOK(hipStreamSynchronize(b->ctx->stream2));
     return MJX_OK;
 }
 
@@ -524,6 +574,8 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     if (!c) return MJX_ERR_NOMEM;
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MJX_ERR_DEVICE; }
+    if (const char *e = std::getenv("MJX_STREAMS")) c->nstreams = std::atoi(e) == 2 ? 2 : 1;
+    if (c->nstreams == 2 && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) c->nstreams = 1;
     if (const char *e = std::getenv("MJX_SPEC_LDS_PAD")) c->spec_lds_pad = size_t(std::atoi(e));
     if (const char *e = std::getenv("MJX_MERGE_LDS_PAD")) c->merge_lds_pad = size_t(std::atoi(e));
     if (const char *e = std::getenv("MJX_WRITE_LDS_PAD")) c->write_lds_pad = size_t(std::atoi(e));
@@ -541,6 +593,7 @@ extern "C" void mjx_ctx_destroy(mjx_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
     delete ctx;
 }
 
@@ -666,7 +719,7 @@ extern "C" void mjx_batch_free(mjx_batch *b)
 {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
-    (void)hipStreamSynchronize(b->ctx->stream);
+    (void)sync_streams(b);
     release(b);
 }
 
@@ -686,6 +739,7 @@ extern "C" int mjx_batch_decode(mjx_batch *b, unsigned stages)
     if (stages & MJX_STAGE_ENTROPY) {
         b->decoded_entropy = true;
         b->last_chunk_resident = int(b->chunks.size()) - 1;
+        b->resident_second = b->dual && ((b->chunks.size() - 1) & 1);
     }
     return MJX_OK;
 }
@@ -694,7 +748,7 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
 {
     if (!b) return MJX_ERR_INVALID_ARG;
     HIPOK(hipSetDevice(b->ctx->device));
-    HIPOK(hipStreamSynchronize(b->ctx->stream));
+    { const int rc0 = sync_streams(b); if (rc0 != MJX_OK) return rc0; }
     collect_events(b);
     // Fixed-point check: the last inter-workgroup pass of every chunk must have found nothing to repair.  If it did
     // (pathological stream that stays unsynchronised across a whole 32 KiB workgroup span), redo that chunk with
@@ -708,19 +762,20 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
             // repair: restart this chunk's synchronisation (its state arrays may have been reused by a later chunk),
             // then keep running fix passes -- each one extends the verified prefix -- until one finds nothing.
             HIPOK(hipMemsetAsync(b->d_status + c.first, 0, c.count * sizeof(int), b->ctx->stream));
-            int rc = run_chunk(b, ci, MJX_STAGE_ENTROPY, 0, PH_SYNC);
+            int rc = run_chunk(b, ci, MJX_STAGE_ENTROPY, 0, PH_SYNC, true);
             if (rc != MJX_OK) return rc;
             for (;;) {
-                rc = run_chunk(b, ci, MJX_STAGE_ENTROPY, kMaxFix, PH_FIX);
+                rc = run_chunk(b, ci, MJX_STAGE_ENTROPY, kMaxFix, PH_FIX, true);
                 if (rc != MJX_OK) return rc;
                 HIPOK(hipStreamSynchronize(b->ctx->stream));
                 if (b->h_mismatch[ci * kMaxFix + kMaxFix - 1] == 0) break;
             }
-            rc = run_chunk(b, ci, MJX_STAGE_ALL, 0, PH_TAIL);
+            rc = run_chunk(b, ci, MJX_STAGE_ALL, 0, PH_TAIL, true);
             if (rc != MJX_OK) return rc;
             HIPOK(hipStreamSynchronize(b->ctx->stream));
             collect_events(b);
             b->last_chunk_resident = int(ci);
+            b->resident_second = false;
         }
     }
     std::vector<int> dev(b->info.size());
@@ -771,7 +826,7 @@ extern "C" int mjx_batch_copy_rgb(mjx_batch *b, size_t i, uint8_t *host_rgb)
     const ImageInfo &inf = b->info[i];
     if (inf.status != MJX_OK) return inf.status;
     HIPOK(hipSetDevice(b->ctx->device));
-    HIPOK(hipStreamSynchronize(b->ctx->stream));
+    { const int rcs = sync_streams(b); if (rcs != MJX_OK) return rcs; }
     HIPOK(hipMemcpy(host_rgb, b->d_rgb + inf.rgb_off, size_t(inf.rgb_bytes), hipMemcpyDeviceToHost));
     return MJX_OK;
 }
@@ -786,16 +841,19 @@ extern "C" int mjx_batch_copy_coefs(mjx_batch *b, size_t i, int16_t *host_coefs,
     if (!b->decoded_entropy) return MJX_ERR_INVALID_ARG;
     if (!b->opts.keep_coefs && int(inf.chunk) != b->last_chunk_resident) return MJX_ERR_INVALID_ARG;
     HIPOK(hipSetDevice(b->ctx->device));
-    HIPOK(hipStreamSynchronize(b->ctx->stream));
+    { const int rcs = sync_streams(b); if (rcs != MJX_OK) return rcs; }
     // expand the compact stream (entries + tile offsets + predicted DCs) into dense zig-zag blocks on the host
     std::vector<uint32_t> eoff(size_t(inf.ntiles) + 1);
-    HIPOK(hipMemcpy(eoff.data(), b->d_tile_eoff + inf.tile_off, eoff.size() * 4, hipMemcpyDeviceToHost));
+    const bool sec = b->resident_second && !b->opts.keep_coefs;
+    const uint32_t *tile_eoff = sec ? b->alt.d_tile_eoff : b->d_tile_eoff, *entries = sec ? b->alt.d_entries : b->d_entries;
+    const int32_t *dcs = sec ? b->alt.d_dc : b->d_dc;
+    HIPOK(hipMemcpy(eoff.data(), tile_eoff + inf.tile_off, eoff.size() * 4, hipMemcpyDeviceToHost));
     const uint32_t nent = eoff.back();
     if (nent > inf.ent_cap) return MJX_ERR_DEVICE;
     std::vector<uint32_t> ent(size_t(nent) + 1);
-    if (nent) HIPOK(hipMemcpy(ent.data(), b->d_entries + inf.ent_off, size_t(nent) * 4, hipMemcpyDeviceToHost));
+    if (nent) HIPOK(hipMemcpy(ent.data(), entries + inf.ent_off, size_t(nent) * 4, hipMemcpyDeviceToHost));
     std::vector<int32_t> dc(size_t(inf.nblocks));
-    HIPOK(hipMemcpy(dc.data(), b->d_dc + inf.coef_off, dc.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPOK(hipMemcpy(dc.data(), dcs + inf.coef_off, dc.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     std::memset(host_coefs, 0, size_t(inf.nblocks) * 128);
     for (uint32_t t = 0; t < inf.ntiles; t++) {
         const uint32_t first = t * inf.tile_blocks;
@@ -821,7 +879,7 @@ extern "C" int mjx_batch_bytes(const mjx_batch *b, uint64_t *scan_bytes, uint64_
         uint64_t total = 0;
         if (b->decoded_entropy) {
             HIPOK(hipSetDevice(b->ctx->device));
-            HIPOK(hipStreamSynchronize(b->ctx->stream));
+            { const int rcs = sync_streams(b); if (rcs != MJX_OK) return rcs; }
             std::vector<uint32_t> cnt(b->info.size());
             if (!cnt.empty()) HIPOK(hipMemcpy(cnt.data(), b->d_img_entries, cnt.size() * 4, hipMemcpyDeviceToHost));
             for (size_t i = 0; i < cnt.size(); i++)
@@ -836,7 +894,7 @@ extern "C" int mjx_batch_kernel_ms(mjx_batch *b, double ms[MJX_K_COUNT], uint64_
 {
     if (!b) return MJX_ERR_INVALID_ARG;
     HIPOK(hipSetDevice(b->ctx->device));
-    HIPOK(hipStreamSynchronize(b->ctx->stream));
+    { const int rcs = sync_streams(b); if (rcs != MJX_OK) return rcs; }
     collect_events(b);
     for (int k = 0; k < MJX_K_COUNT; k++) {
         if (ms) ms[k] = b->ms[k];
