@@ -230,6 +230,36 @@ def test_repair_path_when_the_enqueued_rounds_do_not_converge(mjx, orc, data_dir
     assert out.returncode == 0 and "repair ok" in out.stdout, out.stdout + out.stderr
 
 
+def test_two_streams_give_the_same_bytes(mjx, orc, data_dir, tmp_path):
+    """MJX_STREAMS=2 runs odd chunks on a second stream with their own scratch buffers; a five-chunk batch without
+    kept coefficients must produce the same RGB as the oracle allows, and the last chunk's coefficients stay readable."""
+    import subprocess, sys
+    root = os.path.dirname(data_dir.rstrip('/')).rsplit('/tests', 1)[0]
+    script = tmp_path / "streams.py"
+    script.write_text(
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "import __graft_entry__ as ge, oracle_binding as orc\n"
+        "mjx = ge.load_package()\n"
+        "ctx = mjx.Context(0)\n"
+        "datas = [mjx.synth_jpeg(1920, 1080, '420', 75, seed=s) for s in range(4)] + [mjx.synth_jpeg(640, 480, '422', 60, seed=9),\n"
+        "         mjx.synth_jpeg(333, 217, '444', 85, seed=5), mjx.synth_jpeg(64, 48, 'gray', 50, seed=6), mjx.synth_jpeg(3840, 2160, '420', 75, seed=7),\n"
+        "         mjx.synth_jpeg(100, 100, '420', 30, seed=8)]\n"
+        "b = mjx.Batch(ctx, [mjx.ParsedScan(d) for d in datas], chunk_images=2)\n"
+        "b.decode(); b.wait()\n"
+        "refs = [orc.decode(d, layout=orc.LAYOUT_STD) for d in datas]\n"
+        "for i, ref in enumerate(refs):\n"
+        "    assert b.status(i) == 0\n"
+        "    assert np.abs(b.rgb(i).astype(int) - ref.rgb.astype(int)).max() <= 1, i\n"
+        "assert np.array_equal(b.coefs(len(datas) - 1), orc.interleave(refs[-1]))\n"
+        "b.decode(); b.wait()\n"
+        "assert np.abs(b.rgb(7).astype(int) - refs[7].rgb.astype(int)).max() <= 1\n"
+        "print('streams ok')\n" % (root, root))
+    env = dict(os.environ, MJX_STREAMS="2")
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "streams ok" in out.stdout, out.stdout + out.stderr
+
+
 PIL_FIXTURES = {"opt_420_q85.jpg": True, "opt_444_q40.jpg": True, "opt_422_q95.jpg": False, "std_420_q100.jpg": False,
                 "opt_gray_q70.jpg": False, "opt_420_q10.jpg": True, "std_420_big.jpg": False}
 
