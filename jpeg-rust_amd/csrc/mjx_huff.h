@@ -112,9 +112,6 @@ struct HuffImage {
 // one workgroup less, they are chosen instead.
 MJX_HD uint32_t choose_subseq_bits(uint32_t total_bits)
 {
-#ifdef MJX_FORCE_SUBSEQ_BITS
-    return MJX_FORCE_SUBSEQ_BITS;
-#endif
     const uint32_t nsub = (total_bits + kSubseqBits - 1) / uint32_t(kSubseqBits), nwg = nsub / uint32_t(kHuffWg);
     if (nwg == 0 || nsub % uint32_t(kHuffWg) == 0) return kSubseqBits;
     const uint32_t lanes = nwg * uint32_t(kHuffWg);
@@ -162,17 +159,14 @@ struct NoCheckpoints {
     MJX_HD void set(uint32_t, uint32_t, uint32_t) const {}        // both words
 };
 
-// Registers of one lane's decoder.  The stream is seen through two big-endian dwords w0 w1 and a queue q[] of
-// BitSrc::kAhead dwords fetched ahead and kept *raw* (byte-swapped only when they move into w1).  A wave executes the
-// refill path on almost every symbol (some lane always runs out), and each execution has to wait for the load of
-// the execution kAhead back (loads retire in order, per wave): with one dword ahead every symbol would expose a
-// full L2 round trip, with three the wave covers it with three symbols' worth of work.  The lane's position is
+// Registers of one lane's decoder.  The stream is seen through two big-endian dwords w0 w1; the lane's position is
 //     p = 8 * (wn - 8) - t,      t = bits of w0 not yet consumed (0..31),      wn - 8 = byte offset of w1,
 // so the next 32 bits of the stream are the funnel shift {w0,w1} >> t.  t lives in the top six bits of x and the
 // stream-entry count m in the low 26, so one add of the masked table entry moves both; t < 0 (sign of x) = the lane
-// has moved into w1 and refills.  Everything that depends on p alone (end of the subsequence, checkpoints) is only
+// has moved into w1 and takes the next dword.  That dword (at wn - 4) is read on every step together with the table
+// lookup -- the bit source is an LDS window on the device, so the read is cheap but not free to wait for -- and is at
+// hand when a refill needs it.  Everything that depends on p alone (end of the subsequence, checkpoints) is only
 // looked at on that refill: boundaries are multiples of 32 bits.
-constexpr int kMaxAhead = 4;
 struct LaneState {
     uint32_t x;             // t [31:26] (signed) | m [25:0]
     uint32_t r;             // coefficients left in the current block: 64 - zig-zag index
@@ -180,9 +174,8 @@ struct LaneState {
     BlockTab nb;            // table entry of the block after the current one, fetched when the current block began
                             // (off the critical path); nb.next = block-in-MCU of the block after that
     uint32_t base, acb;     // byte offset of the table of the next symbol / of the current block's AC table
-    uint32_t wn;            // byte offset of the dword after w1 (= of q[0])
+    uint32_t wn;            // byte offset of the dword after w1, + 4
     uint32_t w0, w1;
-    uint32_t q[kMaxAhead];
 };
 MJX_HD uint32_t lane_t(const LaneState &st) { return st.x >> 26; }
 MJX_HD uint32_t lane_m(const LaneState &st) { return st.x & 0x3ffffffu; }
@@ -232,19 +225,8 @@ MJX_HD LutEntry lut_at(const LutEntry *lut, uint32_t byte_off)
 #endif
 }
 
-// The refill every bit source performs unless it has its own: the window moves on one dword, the queue moves up,
-// one more dword is requested.
-template <class BitSrc>
-MJX_HD void refill_generic(const BitSrc &bits, LaneState &st)
-{
-    st.w0 = st.w1;
-    st.w1 = BitSrc::fix(st.q[0]);
-    for (int i = 0; i + 1 < BitSrc::kAhead; i++) st.q[i] = st.q[i + 1];
-    st.q[BitSrc::kAhead - 1] = bits.raw32(st.wn + 4u * uint32_t(BitSrc::kAhead - 1));
-}
-
 //   BitSrc::be32(b)  -> big-endian dword at byte offset b of the image's scan (0xAAAAAAAA past the end,
-//                       huffman.rs:236-246); raw32(b) / fix(raw) = the same in two steps (load, then byte order)
+//                       huffman.rs:236-246)
 template <class BitSrc>
 MJX_HD void lane_begin(LaneState &st, const BitSrc &bits, const HuffImage &img, SubseqState entry)
 {
@@ -259,7 +241,6 @@ MJX_HD void lane_begin(LaneState &st, const BitSrc &bits, const HuffImage &img, 
     st.base = entry.z ? st.acb : (bt.tabs & 0xffffu);
     st.w0 = wi1 ? bits.be32(st.wn - 12u) : 0u;                   // p == 0: all of w0 is "consumed", nothing to load
     st.w1 = bits.be32(st.wn - 8u);
-    for (int i = 0; i < BitSrc::kAhead; i++) st.q[i] = bits.raw32(st.wn - 4u + 4u * uint32_t(i));
 }
 
 // One Huffman symbol: table lookup, EXTEND, coefficient placement, state update, window refill.
@@ -269,10 +250,7 @@ MJX_HD bool symbol_step(LaneState &st, const BitSrc &bits, const LutEntry *lut, 
                         Sink &sink)
 {
     const uint32_t w = funnel(st.w0, st.w1, lane_t(st));                          // next 32 bits of the stream
-    // A source whose reads are cheap but not free to wait for (an LDS window) is asked for the dword after w1 on every
-    // step, together with the table lookup; a refill then has it at hand instead of waiting for its own read.
-    uint32_t eager = 0;
-    if (BitSrc::kEager) eager = bits.raw32(st.wn - 4u);
+    const uint32_t ahead = bits.be32(st.wn - 4u);                                 // the dword after w1 (see LaneState)
     const uint32_t base = st.base;
     LutEntry e = lut_at(lut, base + (w >> (32 - kLutPrimaryBits)) * 4u);
     st.base = st.acb;                                                             // (overridden when the block ends)
@@ -304,12 +282,8 @@ MJX_HD bool symbol_step(LaneState &st, const BitSrc &bits, const LutEntry *lut, 
     }
     if (int32_t(st.x) < 0) {
         st.x ^= 0x80000000u;                                                      // t += 32
-        if (BitSrc::kEager) {
-            st.w0 = st.w1;
-            st.w1 = BitSrc::fix(eager);
-        } else {
-            bits.refill(st);
-        }
+        st.w0 = st.w1;
+        st.w1 = ahead;
         st.wn += 4;
         return true;
     }
@@ -406,7 +380,6 @@ MJX_HD SubseqState decode_subseq(const BitSrc &bits, const LutEntry *lut, const 
         if (crossed) done = lane_event<CP>(st, ev, img, cps) || done;
         running = !done;
     }
-    bits.drain(st);
     if (CP) checkpoint_fixup(cps, ev.k, st.n, lane_m(st));
     return lane_exit(st, ev, img, old_exit);
 }

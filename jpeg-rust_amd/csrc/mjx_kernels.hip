@@ -17,34 +17,17 @@
 
 #include "mjx_kernels.h"
 
-#include <cstdio>
-#include <cstdlib>
-#include <vector>
-
 namespace mjx {
 
 // ------------------------------------------------------------------------------------------------
 // stage A building blocks
 // ------------------------------------------------------------------------------------------------
-// The image's de-stuffed scan in HBM as big-endian dwords; bytes past the padded end read 0xAA (huffman.rs:236-246).
-// Every lane walks its own 512-byte subsequence, so a lane's loads hit one 128-byte line 32 times in a row (L2 / MALL
-// resident: a chunk's scans are ~1 MB per 4K image).
-#ifndef MJX_AHEAD
-#define MJX_AHEAD 1
-#endif
+// The image's de-stuffed scan in HBM; bytes past the padded end read 0xAA (huffman.rs:236-246).
 struct GlobalBits {
-    // One dword ahead: a deeper queue does not help, because moving a queue up touches the newest (still in flight)
-    // dword at the very next refill.
-    static constexpr int kAhead = MJX_AHEAD;
-    static constexpr bool kEager = false;
     const unsigned char *bytes;     // wave-uniform base: loads are `base + 32-bit lane offset`, no 64-bit address math
-    // No bounds test: a lane reads at most 6 dwords past the last scan byte, and every image's region in the pool ends
-    // with >= 16 bytes of 0xAA (mjx_api.hip build_batch), so the padding *is* the out-of-range value.
-    __device__ __forceinline__ uint32_t raw32(uint32_t byte_off) const { return *reinterpret_cast<const uint32_t *>(bytes + byte_off); }
-    __device__ __forceinline__ uint32_t be32(uint32_t byte_off) const { return __builtin_bswap32(raw32(byte_off)); }
-    static __device__ __forceinline__ uint32_t fix(uint32_t raw) { return __builtin_bswap32(raw); }
-    __device__ __forceinline__ void refill(LaneState &st) const { refill_generic(*this, st); }
-    __device__ __forceinline__ void drain(LaneState &) const {}
+    // No bounds test on the loads from it: a window is staged at most 48 bytes past the last scan byte, and every
+    // image's region in the pool ends with >= 16 bytes of 0xAA (mjx_api.hip build_batch; the pool itself has 256
+    // bytes of slack), so the padding *is* the out-of-range value for every dword a lane can decode from.
 };
 
 // Checkpoint words live in HBM in blocks of 256 consecutive subsequences; inside a block they are row-major by word
@@ -220,15 +203,9 @@ __device__ __forceinline__ uint32_t subseq_end(const HuffImage &h, uint32_t s)
 constexpr int kWinDwords = MJX_WIN_DWORDS;
 constexpr int kWinStride = kWinDwords + 1;      // odd stride: lanes spread over all banks
 struct LdsWindow {
-    static constexpr int kAhead = 0;         // no look-ahead queue: the dword after w1 is read on every step (kEager)
-    static constexpr bool kEager = true;
     const unsigned char *lds;    // lane's window
     uint32_t wbase;              // stream byte offset of the window's first dword
     __device__ __forceinline__ uint32_t be32(uint32_t byte_off) const { return *reinterpret_cast<const uint32_t *>(lds + (byte_off - wbase)); }
-    __device__ __forceinline__ uint32_t raw32(uint32_t byte_off) const { return be32(byte_off); }
-    static __device__ __forceinline__ uint32_t fix(uint32_t raw) { return raw; }
-    __device__ __forceinline__ void refill(LaneState &) const {}          // (kEager: symbol_step moves the window itself)
-    __device__ __forceinline__ void drain(LaneState &) const {}
 };
 __device__ __forceinline__ void window_fill(uint32_t *lds, const GlobalBits &g, uint32_t wbase)
 {
@@ -285,11 +262,6 @@ __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry,
     return lane_exit(st, ev, h, old_exit);
 }
 
-#ifndef MJX_SPEC_WIN
-#define MJX_SPEC_WIN 1
-#endif
-constexpr bool kSpecWin = MJX_SPEC_WIN != 0;    // spec / merge read their bits through LDS windows (1) or straight from HBM (0)
-
 // k_huff_spec: every lane decodes its subsequence from the guess "a block starts exactly here", recording its exit
 // state and a checkpoint every 256 bits.  Lanes do the same amount of work (+-3 %), so the plain per-lane loop
 // (exec-masked by the compiler) is efficient.
@@ -306,15 +278,12 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_spec(const DevImage
     stage_tables(im, lut_pool, smem, h, lut);
     const uint32_t s = blockIdx.x * kHuffWg + threadIdx.x;
     const bool live = s < h->nsub;
-    if (!kSpecWin && !live) return;
     const GlobalBits bits{scan_pool + im.scan_off};
     const uint32_t sub_start = s * h->sub_bits;
     const SubseqState e = make_state(live ? sub_start : 0u, 0, 0);
     NullSink sink;
     GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + (live ? s : 0u)), 0};
-    SubseqState x;
-    if (kSpecWin) x = wave_decode<false, 1>(live, e, live ? subseq_end(*h, s) : 0u, 0, bits, s_win + threadIdx.x * kWinStride, lut, *h, sink, cps, sub_start, e);
-    else x = decode_subseq<false, 1>(bits, lut, *h, e, subseq_end(*h, s), 0, sink, cps, sub_start, e);
+    const SubseqState x = wave_decode<false, 1>(live, e, live ? subseq_end(*h, s) : 0u, 0, bits, s_win + threadIdx.x * kWinStride, lut, *h, sink, cps, sub_start, e);
     if (!live) return;
     g_entry[im.sub_off + s] = e;
     g_exit[im.sub_off + s] = x;
@@ -342,9 +311,6 @@ constexpr int kMergeWin = 12, kMergeStride = kMergeWin + 1, kItemDwords = 6;
 #endif
 constexpr int kHeadSlices = MJX_HEAD_SLICES;
 struct MergeItem { uint32_t s, p, zc, n, m, k; };
-#ifdef MJX_DEBUG_COUNTS
-__device__ unsigned long long g_dbg[64];
-#endif
 
 // One slice of one item: decode from (p, z, c) to the next checkpoint boundary (or the end of the subsequence).
 // Returns true when the item is finished (its exit and checkpoints are final), false when `it` holds the progress.
@@ -379,17 +345,11 @@ __device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, c
         NullSink sink;
         while (st.wn < stop_wn) (void)symbol_step<false>(st, win, lut, h, blk, sink);
         if (st.wn >= end_wn) {                                     // left the subsequence without merging
-#ifdef MJX_DEBUG_COUNTS
-            atomicAdd(&g_dbg[32 + (it.k < 31 ? it.k : 31)], 1ull);
-#endif
             fin = true;
             x = make_state(lane_pos(st), lane_z(st), lane_c(st, h), st.n, lane_m(st));
         } else {
             const uint32_t state = cp_state_word(st);
             if ((old_word & kCpStateMask) == state) {              // met the previous decode's path
-#ifdef MJX_DEBUG_COUNTS
-                atomicAdd(&g_dbg[it.k < 31 ? it.k : 31], 1ull);
-#endif
                 const SubseqState old_exit = g_exit[im.sub_off + it.s];
                 fin = true;
                 x = make_state(old_exit.p, old_exit.z, old_exit.c, st.n + ((old_word >> 16) & 0x7fffu),
@@ -413,9 +373,7 @@ __device__ __forceinline__ void merge_finish(const MergeItem &it, const DevImage
                                              SubseqState *g_exit, uint32_t *g_cps)
 {
     const GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + it.s), 0};
-#ifndef MJX_EXPERIMENT_NO_FIXUP
     checkpoint_fixup(cps, it.k, x.n, x.m);
-#endif
     g_exit[im.sub_off + it.s] = x;
 }
 
@@ -521,18 +479,7 @@ extern "C" __global__ __launch_bounds__(64) void k_huff_merge_tail(const DevImag
     // every lane runs its item to the end first; the read-modify-write of the recorded checkpoints then happens once
     // for the whole wave instead of after every slice for the lanes that happen to finish there
     SubseqState x;
-#ifdef MJX_DEBUG_COUNTS
-    const unsigned long long t0 = wall_clock64();
-    unsigned long long nsl = 1;
-    while (!merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x)) nsl++;
-    const unsigned long long t1 = wall_clock64();
-    atomicAdd(&g_dbg[60], nsl);
-    atomicAdd(&g_dbg[61], 1ull);
-    atomicMax(&g_dbg[62], t1 - t0);
-    atomicAdd(&g_dbg[63], t1 - t0);
-#else
     while (!merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x)) {}
-#endif
     merge_finish(it, im, x, g_exit, g_cps);
 }
 
@@ -1446,7 +1393,7 @@ void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tab
                       const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
                       uint32_t *cps)
 {
-    const size_t lds = tables_lds + (kSpecWin ? huff_window_bytes() : 0) + pad_lds;
+    const size_t lds = tables_lds + huff_window_bytes() + pad_lds;
     hipLaunchKernelGGL(k_huff_spec, dim3(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, uint32_t(tables_lds));
 }
 
@@ -1459,25 +1406,6 @@ void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
     hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches, uint32_t(tables_lds), items, item_count);
     const size_t tail_lds = tables_lds + size_t(64) * kMergeStride * 4;
     hipLaunchKernelGGL(k_huff_merge_tail, dim3(nimg, max_wg * (kMergeWg / 64)), dim3(64), tail_lds, st, images, scan_pool, lut_pool, exit_, cps, uint32_t(tables_lds), items, item_count);
-    if (std::getenv("MJX_DEBUG_MERGE")) {
-        (void)hipStreamSynchronize(st);
-        std::vector<uint32_t> hc(nimg);
-        (void)hipMemcpy(hc.data(), item_count, nimg * 4, hipMemcpyDeviceToHost);
-        unsigned long long tot = 0; uint32_t mx = 0;
-        for (uint32_t v : hc) { tot += v; mx = v > mx ? v : mx; }
-        std::fprintf(stderr, "merge round: exported items total %llu max/image %u (images %u)\n", tot, mx, nimg);
-#ifdef MJX_DEBUG_COUNTS
-        unsigned long long hd[64];
-        (void)hipMemcpyFromSymbol(hd, HIP_SYMBOL(g_dbg), sizeof hd);
-        std::fprintf(stderr, "  merged at k:");
-        for (int i = 0; i < 20; i++) std::fprintf(stderr, " %llu", hd[i]);
-        std::fprintf(stderr, "\n  ended at k:");
-        for (int i = 0; i < 20; i++) std::fprintf(stderr, " %llu", hd[32 + i]);
-        std::fprintf(stderr, "\n  tail: lane-slices %llu lanes %llu max ticks %llu avg ticks %llu (100 MHz clock)\n", hd[60], hd[61], hd[62], hd[61] ? hd[63] / hd[61] : 0ull);
-        unsigned long long z[64] = {0};
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof z);
-#endif
-    }
 }
 
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,

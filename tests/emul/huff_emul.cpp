@@ -20,8 +20,6 @@ using namespace mjx;
 
 namespace {
 struct HostBits {
-    static constexpr int kAhead = 3;
-    static constexpr bool kEager = false;
     const uint8_t *p;
     size_t n;
     uint32_t be32(uint32_t byte_off) const
@@ -33,10 +31,6 @@ struct HostBits {
         }
         return w;
     }
-    uint32_t raw32(uint32_t byte_off) const { return be32(byte_off); }
-    static uint32_t fix(uint32_t raw) { return raw; }
-    void refill(LaneState &st) const { refill_generic(*this, st); }
-    void drain(LaneState &) const {}
 };
 // Mirrors the device sink of k_huff_write: AC entries appended to the compact stream, DC differences per block,
 // the stream offset of every tile's first block.
