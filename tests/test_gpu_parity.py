@@ -66,6 +66,16 @@ def test_synthetic_standard_layout(mjx, orc, gpu_ctx, w, h, sub, quality):
     _check(ref, coefs, rgb, "%dx%d %s q%d" % (w, h, sub, quality))
 
 
+@pytest.mark.parametrize("w,h,sub,quality", [(1920, 1080, "420", 40), (1920, 1080, "420", 88), (1920, 1080, "444", 60),
+                                             (2560, 1440, "420", 75), (2560, 1440, "422", 90), (1600, 1200, "420", 95)])
+def test_scan_sizes_around_the_workgroup_boundaries(mjx, orc, gpu_ctx, w, h, sub, quality):
+    """Scans of 0.1 .. 1.5 MB: the per-image subsequence length (512 .. 640 bytes, chosen so that the image fills whole
+    512-lane workgroups) takes different values, with and without a remainder workgroup."""
+    data = mjx.synth_jpeg(w, h, sub, quality, seed=w + quality)
+    (ref, coefs, rgb), = _decode_both(mjx, orc, gpu_ctx, [data])
+    _check(ref, coefs, rgb, "%dx%d %s q%d" % (w, h, sub, quality))
+
+
 def test_heterogeneous_batch_and_chunking(mjx, orc, gpu_ctx, data_dir):
     datas = [open(os.path.join(data_dir, n), "rb").read() for n in FIXTURES]
     datas += [mjx.synth_jpeg(w, h, s, 75, seed=i) for i, (w, h, s) in enumerate(CASES[:10])]

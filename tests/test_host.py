@@ -119,7 +119,8 @@ def test_emulated_parallel_decode_equals_oracle_T0(mjx, orc, emul, name, layout)
 
 
 @pytest.mark.parametrize("w,h,sub,q", [(64, 48, "444", 75), (64, 48, "422", 30), (61, 45, "420", 95), (100, 60, "gray", 75),
-                                       (48, 64, "440", 75), (750, 595, "420", 50), (1920, 1080, "420", 75)])
+                                       (48, 64, "440", 75), (750, 595, "420", 50), (1920, 1080, "420", 75),
+                                      (1920, 1080, "420", 90), (2560, 1440, "420", 60)])
 def test_emulated_decode_synthetic(mjx, orc, emul, w, h, sub, q):
     data = mjx.synth_jpeg(w, h, sub, q, seed=w + h)
     for wg in (0, 1):                        # merge rounds on a snapshot (concurrent lanes) / in place (one lane)
