@@ -72,6 +72,11 @@ typedef struct mjx_scan_desc {
     mjx_hufftab dc[4], ac[4];      /* .huffman_dc_tables() / .huffman_ac_tables() decoder.rs:71-77 */
     uint8_t dc_present, ac_present;
     uint8_t scan_is_stuffed;       /* 1: `scan` still holds FF00 pairs; mjx_batch_create de-stuffs on the device */
+    /* Restart intervals (T.81 B.2.4.4) -- beyond the reference, which panics on DRI (jpeg/mod.rs:424-428; strict_ref keeps
+       that).  mjx_parse removes the RSTn markers from `scan` and lists where each further interval begins. */
+    uint16_t restart_interval;     /* MCUs per interval, 0 = none */
+    uint32_t n_restart;            /* entries of restart_offsets */
+    const uint32_t *restart_offsets; /* byte offset in `scan` of the first byte of interval 1, 2, ... (interval 0 starts at 0) */
     void *owner_;                  /* internal: storage behind `scan` when filled by mjx_parse */
 } mjx_scan_desc;
 

@@ -62,7 +62,7 @@ struct Chunk {
     uint64_t coef_base = 0;        // first block of the chunk inside the per-block arrays (keep_coefs) or 0
     uint64_t entries = 0, ent_base = 0;   // capacity of the chunk's stream regions; first entry (keep_coefs) or 0
     uint32_t tiles = 0, tile_base = 0;    // tile offsets (+1 sentinel per image)
-    uint32_t max_wg = 0, merge_wgs = 0, max_tiles = 0, lut_cap = 0, max_tile_blocks = 0, mode_mask = 0, max_segs = 0, bpm_mask = 0;
+    uint32_t max_wg = 0, merge_wgs = 0, max_tiles = 0, lut_cap = 0, max_tile_blocks = 0, mode_mask = 0, max_segs = 0, bpm_mask = 0, max_restart_segs = 0;
     uint64_t plane_words = 0;      // REF_COMPAT scratch of the chunk
     uint32_t max_pixel_wgs = 0;
 };
@@ -85,6 +85,8 @@ struct mjx_batch {
     size_t scan_pool_bytes = 0;
     LutEntry *d_lut = nullptr;
     float *d_qm = nullptr;
+    uint32_t *d_segs = nullptr;         // restart segments of the unique images: (first subsequence, first bit) pairs
+    std::vector<uint32_t> h_segs;       // host copy (mjx_batch_tile rebuilds plans from it)
     SubseqState *d_entry = nullptr, *d_exit = nullptr;
     uint32_t *d_blkbase = nullptr;
     uint32_t *d_cps = nullptr;          // [chunk subsequences / 256][2 kMaxCp][256] checkpoint words
@@ -138,7 +140,7 @@ void release(mjx_batch *b)
     if (b->ctx) (void)hipSetDevice(b->ctx->device);
     for (auto &e : b->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : b->event_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    (void)hipFree(b->d_images); (void)hipFree(b->d_scan); (void)hipFree(b->d_lut); (void)hipFree(b->d_qm);
+    (void)hipFree(b->d_images); (void)hipFree(b->d_scan); (void)hipFree(b->d_lut); (void)hipFree(b->d_qm); (void)hipFree(b->d_segs);
     (void)hipFree(b->d_entry); (void)hipFree(b->d_exit); (void)hipFree(b->d_blkbase);
     (void)hipFree(b->d_entries); (void)hipFree(b->d_tile_eoff); (void)hipFree(b->d_ebase); (void)hipFree(b->d_img_entries); (void)hipFree(b->d_img_flags);
     (void)hipFree(b->d_dc); (void)hipFree(b->d_rgb); (void)hipFree(b->d_status);
@@ -162,6 +164,8 @@ void fill_dev_image(const ImagePlan &p, DevImage &d)
     d.width = p.width; d.height = p.height; d.mcux = p.mcux; d.mcuy = p.mcuy; d.nmcu = p.nmcu;
     d.ncomp = p.ncomp; d.bpm = p.bpm; d.hmax = p.hmax; d.vmax = p.vmax;
     d.valid = 1;
+    d.nseg = p.nseg;
+    d.restart_mcus = p.restart_mcus;
     uint32_t t = tile_mcus(p.bpm, p.hmax), l2 = 0;
     while ((1u << (l2 + 1)) <= t) l2++;
     d.log2_tile = l2;
@@ -227,6 +231,7 @@ void plan_chunks(mjx_batch *b)
                 c.lut_cap = std::max<uint32_t>(c.lut_cap, d.lut_n);
                 c.mode_mask |= 1u << d.mode;
                 c.bpm_mask |= 1u << d.bpm;
+                if (d.nseg > 1) c.max_restart_segs = std::max(c.max_restart_segs, d.nseg);
                 if (d.mode == 2) {
                     d.plane_off = c.plane_words;
                     c.plane_words += uint64_t(d.width) * d.height * d.ncomp;
@@ -361,7 +366,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     fix_passes = std::min(fix_passes, kMaxFix);
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_SYNC)) {
         prof_begin(b, MJX_K_HUFF_SYNC, st);
-        launch_huff_spec(st, c.max_wg, nimg, b->huff_lds, b->ctx->spec_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps));
+        launch_huff_spec(st, c.max_wg, nimg, b->huff_lds, b->ctx->spec_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps), b->d_segs);
         prof_end(b, st);
     }
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_FIX)) {
@@ -370,7 +375,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
             for (int k = 0; k < fix_passes; k++) {
                 prof_begin(b, MJX_K_HUFF_FIX, st);
                 launch_huff_merge(st, c.merge_wgs, nimg, b->huff_lds, b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps),
-                                  b->d_mismatch + ci * kMaxFix + k, SCR(d_items), SCR(d_pull));
+                                  b->d_mismatch + ci * kMaxFix + k, SCR(d_items), SCR(d_pull), b->d_segs);
                 prof_end(b, st);
             }
             HIPOK(hipMemcpyAsync(b->h_mismatch + ci * kMaxFix, b->d_mismatch + ci * kMaxFix, kMaxFix * sizeof(uint32_t),
@@ -383,10 +388,10 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         prof_end(b, st);
         prof_begin(b, MJX_K_HUFF_WRITE, st);
         launch_huff_write(st, c.max_wg, nimg, b->huff_lds, b->ctx->write_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_blkbase), SCR(d_ebase),
-                          SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_status, b->d_img_flags);
+                          SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_status, b->d_img_flags, b->d_segs, SCR(d_exit));
         prof_end(b, st);
         prof_begin(b, MJX_K_DC_SCAN, st);
-        launch_dc_scan(st, c.max_segs, nimg, imgs, dcb, SCR(d_segsum), b->d_img_flags, c.bpm_mask);
+        launch_dc_scan(st, c.max_segs, nimg, imgs, dcb, SCR(d_segsum), b->d_img_flags, c.bpm_mask, c.max_restart_segs);
         prof_end(b, st);
     }
     if (stages & MJX_STAGE_PIXELS) {
@@ -446,8 +451,9 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
     b->himages.resize(n);
     // pools for the unique images
     std::vector<uint64_t> scan_off(nu, 0);
-    std::vector<uint32_t> scan_padded(nu, 0), lut_off(nu, 0), lut_n(nu, 0);
+    std::vector<uint32_t> scan_padded(nu, 0), lut_off(nu, 0), lut_n(nu, 0), seg_off(nu, 0);
     size_t scan_pool = 0, lut_pool = 0;
+    b->h_segs.clear();
     for (size_t k = 0; k < nu; k++) {
         if (plans[k].status != MJX_OK) continue;
         scan_off[k] = scan_pool;
@@ -456,6 +462,8 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
         lut_off[k] = uint32_t(lut_pool);
         lut_n[k] = uint32_t(plans[k].lut.size());
         lut_pool += plans[k].lut.size();
+        seg_off[k] = uint32_t(b->h_segs.size() / 2);
+        b->h_segs.insert(b->h_segs.end(), plans[k].seg.begin(), plans[k].seg.end());
     }
     scan_pool = align_up(std::max<size_t>(scan_pool, 16), 256);
     b->scan_pool_bytes = scan_pool * times;
@@ -476,12 +484,17 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
         d.lut_off = lut_off[k];
         d.lut_n = lut_n[k];
         d.qm_off = uint32_t(k * 192);
+        d.seg_off = seg_off[k];
         inf.width = p.width; inf.height = p.height; inf.bpm = p.bpm; inf.nmcu = p.nmcu;
         inf.nblocks = uint64_t(p.nmcu) * p.bpm;
         inf.tile_blocks = d.tile_blocks;
         inf.ntiles = uint32_t((inf.nblocks + d.tile_blocks - 1) / d.tile_blocks);
         // every stream entry consumes at least 2 bits of scan (1-bit code + 1 value bit) and a block holds at most 63
         inf.ent_cap = (std::min<uint64_t>(uint64_t(p.scan_len) * 4, inf.nblocks * 63) + 15) / 8 * 8;   // regions start on 32-byte sectors
+        // with restart intervals the lanes fill what the synchronisation passes counted (up to one entry per two bits of
+        // scan, garbage after a segment's last block included) with null entries: see k_huff_write
+        if (p.restart_mcus) inf.ent_cap = (uint64_t(p.scan_len) * 4 + 64 + 15) / 8 * 8;
+        d.ent_cap = uint32_t(std::min<uint64_t>(inf.ent_cap, 0xffffffffu));
         inf.scan_len = p.scan_len;
         inf.rgb_off = rgb_pool;
         inf.rgb_bytes = uint64_t(p.width) * p.height * 3;
@@ -503,6 +516,8 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
         HIPOK(hipMalloc(&b->d_scan, b->scan_pool_bytes + 256));    // slack: bit windows read up to 96 bytes past a scan
         HIPOK(hipMalloc(&b->d_lut, std::max<size_t>(lut_pool, 8) * sizeof(LutEntry)));
         HIPOK(hipMalloc(&b->d_qm, std::max<size_t>(nu, 1) * 192 * sizeof(float)));
+        HIPOK(hipMalloc(&b->d_segs, std::max<size_t>(b->h_segs.size(), 2) * sizeof(uint32_t)));
+        if (!b->h_segs.empty()) HIPOK(hipMemcpy(b->d_segs, b->h_segs.data(), b->h_segs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         if (src) {
             if (src->scan_pool_bytes != scan_pool) return MJX_ERR_INVALID_ARG;
             for (size_t rep = 0; rep < times; rep++)
@@ -709,6 +724,9 @@ extern "C" int mjx_batch_tile(mjx_ctx *ctx, const mjx_batch *src, size_t times, 
         p.nbx = d.nbx;
         p.nby = d.nby;
         p.lut.assign(d.lut_n, 0);                         // sizes only: the pool is copied device-to-device
+        p.nseg = d.nseg;
+        p.restart_mcus = d.restart_mcus;
+        p.seg.assign(src->h_segs.begin() + size_t(d.seg_off) * 2, src->h_segs.begin() + size_t(d.seg_off) * 2 + 2 * (size_t(d.nseg) + 1));
         p.scan = nullptr;
         p.scan_len = src->info[k].scan_len;
     }

@@ -36,6 +36,11 @@ struct DevImage {
     uint8_t ref_xf[4], ref_yf[4];
     uint32_t nbx, nby;
     uint64_t plane_off;     // 64-bit words into the plane scratch (ncomp planes of width*height words)
+    // restart intervals: nseg segments of restart_mcus MCUs; (first subsequence, first bit) pairs + sentinel at seg_off
+    uint32_t seg_off;       // index (in pairs) into the segment pool
+    uint32_t nseg;          // 1 = no restart interval
+    uint32_t restart_mcus;
+    uint32_t ent_cap;       // entries the image's stream region holds
 };
 
 // Device-side de-stuffing (jpeg/mod.rs:371-385 on the GPU): one image of an upload.
@@ -69,18 +74,18 @@ void launch_destuff_scatter(hipStream_t st, uint32_t max_seg, uint32_t nimg, con
                             const uint32_t *segbase, uint8_t *pool);
 void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                       const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
-                      uint32_t *cps);
+                      uint32_t *cps, const uint32_t *segs);
 void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                        const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
-                       uint32_t *cps, uint32_t *mismatches, uint32_t *items, uint32_t *item_count);
+                       uint32_t *cps, uint32_t *mismatches, uint32_t *items, uint32_t *item_count, const uint32_t *segs);
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,
                       uint32_t *ebase, uint32_t *img_entries, uint32_t *img_flags);
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                        const uint8_t *scan_pool, const LutEntry *lut_pool, const SubseqState *entry,
                        const uint32_t *blkbase, const uint32_t *ebase, uint32_t *entries, uint32_t *tile_eoff,
-                       int32_t *dcbuf, int *status, const uint32_t *img_flags);
+                       int32_t *dcbuf, int *status, const uint32_t *img_flags, const uint32_t *segs, const SubseqState *exit_);
 void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int32_t *dcbuf,
-                    int32_t *segsum, const uint32_t *img_flags, uint32_t bpm_mask);
+                    int32_t *segsum, const uint32_t *img_flags, uint32_t bpm_mask, uint32_t max_restart_segs);
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint32_t *entries, const uint32_t *tile_eoff, const int32_t *dcbuf, const float *qmult,
                        uint8_t *rgb, uint32_t mode_mask, unsigned long long *planes, const uint32_t *img_flags);

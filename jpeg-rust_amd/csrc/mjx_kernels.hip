@@ -185,10 +185,39 @@ __device__ __forceinline__ void stage_tables(const DevImage &im, const LutEntry 
     lut = l;
 }
 
-__device__ __forceinline__ uint32_t subseq_end(const HuffImage &h, uint32_t s)
+// Where subsequence s of an image lies.  Without restart intervals the scan is one segment cut every sub_bits bits.
+// With them every interval is a segment of its own: segs[g] = (first subsequence, first bit) of
+// segment g, subsequences do not straddle segments, and a segment's first subsequence starts in the known state
+// (block 0 of an MCU, DC code next) -- it needs no synchronisation.
+struct SubLoc {
+    uint32_t start, end;        // bits: the subsequence owns the symbols that start in (start, end] (and at start, if first)
+    uint32_t seg;               // segment index
+    uint32_t seg_sub0;          // first subsequence of the segment
+};
+__device__ __forceinline__ SubLoc locate_sub(const DevImage &im, const HuffImage &h, const uint32_t *segs, uint32_t s)
 {
-    const uint32_t e = (s + 1) * h.sub_bits;
-    return e < h.total_bits ? e : h.total_bits;
+    SubLoc l;
+    if (im.nseg <= 1) {                                                    // wave-uniform
+        l.seg = 0;
+        l.seg_sub0 = 0;
+        l.start = s * h.sub_bits;
+        const uint32_t e = l.start + h.sub_bits;
+        l.end = e < h.total_bits ? e : h.total_bits;
+        return l;
+    }
+    const uint2 *sg = reinterpret_cast<const uint2 *>(segs) + im.seg_off;
+    uint32_t lo = 0, hi = im.nseg;                                         // largest g with sg[g].x <= s
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sg[mid].x <= s) lo = mid; else hi = mid;
+    }
+    const uint2 a = sg[lo], nx = sg[lo + 1];
+    l.seg = lo;
+    l.seg_sub0 = a.x;
+    l.start = a.y + (s - a.x) * h.sub_bits;
+    const uint32_t e = l.start + h.sub_bits;
+    l.end = e < nx.y ? e : nx.y;
+    return l;
 }
 
 // Per-lane window of the bitstream in LDS.  A lane that read its bits straight from HBM would wait for an L2 round
@@ -224,7 +253,7 @@ __device__ __forceinline__ void window_fill(uint32_t *lds, const GlobalBits &g, 
 //   WRITE  emit coefficients through `sink`      CP  0: none, 1: record checkpoints, 2: record + merge (see mjx_huff.h)
 template <bool WRITE, int CP, class Sink, class CpStore>
 __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry, uint32_t end_bit, uint32_t blk,
-                                                   const GlobalBits &g, uint32_t *my_win, const LutEntry *lut,
+                                                   uint32_t blk_limit, const GlobalBits &g, uint32_t *my_win, const LutEntry *lut,
                                                    const HuffImage &h, Sink &sink, CpStore &cps, uint32_t sub_start,
                                                    SubseqState old_exit)
 {
@@ -239,7 +268,7 @@ __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry,
     events_begin<CP>(ev, sub_start, end_bit);
     uint32_t wbase = st.wn - 12u;
     if (st.wn == 8u) wbase = 0;
-    const uint32_t total_blocks = h.total_blocks;
+    const uint32_t total_blocks = blk_limit;                               // (write pass: first block the lane must not write)
     bool running = live && entry.p <= end_bit && !(WRITE && blk >= total_blocks);
     const bool started = running;
     for (uint32_t it = 1;; it++) {
@@ -267,7 +296,8 @@ __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry,
 // (exec-masked by the compiler) is efficient.
 extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_spec(const DevImage *images, const uint8_t *scan_pool,
                                                                    const LutEntry *lut_pool, SubseqState *g_entry,
-                                                                   SubseqState *g_exit, uint32_t *g_cps, uint32_t win_off)
+                                                                   SubseqState *g_exit, uint32_t *g_cps, uint32_t win_off,
+                                                                   const uint32_t *segs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // HuffImage, tables, [windows]
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
@@ -279,11 +309,11 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_spec(const DevImage
     const uint32_t s = blockIdx.x * kHuffWg + threadIdx.x;
     const bool live = s < h->nsub;
     const GlobalBits bits{scan_pool + im.scan_off};
-    const uint32_t sub_start = s * h->sub_bits;
-    const SubseqState e = make_state(live ? sub_start : 0u, 0, 0);
+    const SubLoc loc = locate_sub(im, *h, segs, live ? s : 0u);
+    const SubseqState e = make_state(live ? loc.start : 0u, 0, 0);
     NullSink sink;
     GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + (live ? s : 0u)), 0};
-    const SubseqState x = wave_decode<false, 1>(live, e, live ? subseq_end(*h, s) : 0u, 0, bits, s_win + threadIdx.x * kWinStride, lut, *h, sink, cps, sub_start, e);
+    const SubseqState x = wave_decode<false, 1>(live, e, live ? loc.end : 0u, 0, 0xffffffffu, bits, s_win + threadIdx.x * kWinStride, lut, *h, sink, cps, loc.start, e);
     if (!live) return;
     g_entry[im.sub_off + s] = e;
     g_exit[im.sub_off + s] = x;
@@ -316,9 +346,10 @@ struct MergeItem { uint32_t s, p, zc, n, m, k; };
 // Returns true when the item is finished (its exit and checkpoints are final), false when `it` holds the progress.
 __device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, const HuffImage &h, const LutEntry *lut,
                                             const unsigned char *bytes, uint32_t *my_win, const SubseqState *g_exit,
-                                            uint32_t *g_cps, SubseqState &x)
+                                            uint32_t *g_cps, SubseqState &x, const uint32_t *segs)
 {
-    const uint32_t sub_start = it.s * h.sub_bits, end_bit = subseq_end(h, it.s);
+    const SubLoc loc = locate_sub(im, h, segs, it.s);
+    const uint32_t sub_start = loc.start, end_bit = loc.end;
     const GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + it.s), 0};
     bool fin = false;
     x = make_state(it.p, it.zc & 0xffu, it.zc >> 8, it.n, it.m);
@@ -380,7 +411,8 @@ __device__ __forceinline__ void merge_finish(const MergeItem &it, const DevImage
 extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevImage *images, const uint8_t *scan_pool,
                                                                 const LutEntry *lut_pool, SubseqState *g_entry,
                                                                 SubseqState *g_exit, uint32_t *g_cps, uint32_t *mismatches,
-                                                                uint32_t win_off, uint32_t *g_items, uint32_t *g_item_count)
+                                                                uint32_t win_off, uint32_t *g_items, uint32_t *g_item_count,
+                                                                const uint32_t *segs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // HuffImage, tables, windows (= item exchange)
     __shared__ uint32_t s_cnt[kMergeWg / 64];
@@ -393,6 +425,7 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
     if (it.s < im.himg.nsub) {
         const SubseqState prev = g_exit[im.sub_off + it.s - 1];
         active = !same_entry(prev, g_entry[im.sub_off + it.s]);
+        if (im.nseg > 1 && locate_sub(im, im.himg, segs, it.s).seg_sub0 == it.s) active = false;   // a segment's first: entry known
         it.p = prev.p;
         it.zc = prev.z | (uint32_t(prev.c) << 8);
         if (active) g_entry[im.sub_off + it.s] = make_state(prev.p, prev.z, prev.c);
@@ -410,7 +443,7 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
     for (int slice = 0;; slice++) {
         if (active) {
             SubseqState x;
-            if (merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x)) {
+            if (merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x, segs)) {
                 merge_finish(it, im, x, g_exit, g_cps);
                 active = false;
             }
@@ -455,7 +488,8 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
 extern "C" __global__ __launch_bounds__(64) void k_huff_merge_tail(const DevImage *images, const uint8_t *scan_pool,
                                                                     const LutEntry *lut_pool, SubseqState *g_exit,
                                                                     uint32_t *g_cps, uint32_t win_off,
-                                                                    const uint32_t *g_items, const uint32_t *g_item_count)
+                                                                    const uint32_t *g_items, const uint32_t *g_item_count,
+                                                                    const uint32_t *segs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // HuffImage, tables, 64 windows
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
@@ -479,7 +513,7 @@ extern "C" __global__ __launch_bounds__(64) void k_huff_merge_tail(const DevImag
     // every lane runs its item to the end first; the read-modify-write of the recorded checkpoints then happens once
     // for the whole wave instead of after every slice for the lanes that happen to finish there
     SubseqState x;
-    while (!merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x)) {}
+    while (!merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x, segs)) {}
     merge_finish(it, im, x, g_exit, g_cps);
 }
 
@@ -607,7 +641,9 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *im
         img_entries[im.status_idx] = total_m;      // upper bound of the entries the write pass produces
         // The scan ends before every MCU is decoded (truncated file): the reference would go on decoding its 0xAA
         // padding (huffman.rs:236-246); here the image is reported as truncated and skipped by the later kernels.
-        img_flags[im.status_idx] = total_n < im.himg.total_blocks ? 1u : 0u;
+        // (With restart intervals the count includes what follows a segment's last block; missing intervals are found on
+        // the host, mjx_plan.cpp.)
+        img_flags[im.status_idx] = (im.nseg <= 1 && total_n < im.himg.total_blocks) ? 1u : 0u;
     }
 }
 
@@ -615,9 +651,10 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
                                                                 const LutEntry *lut_pool, const SubseqState *g_entry,
                                                                 const uint32_t *g_blkbase, const uint32_t *g_ebase,
                                                                 uint32_t *entries, uint32_t *tile_eoff, int32_t *dcbuf,
-                                                                int *status, const uint32_t *img_flags, uint32_t win_off)
+                                                                int *status, const uint32_t *img_flags, uint32_t win_off,
+                                                                const uint32_t *segs, const SubseqState *g_exit)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // HuffImage, tables, windows
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // HuffImage, tables, windows, rings
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
     const DevImage &im = images[blockIdx.y];
     if (!im.valid || blockIdx.x * kHuffWg >= im.himg.nsub || img_flags[im.status_idx]) return;
@@ -628,12 +665,24 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
     const GlobalBits gbits{scan_pool + im.scan_off};
     const bool live = s < h->nsub;
     SubseqState e = make_state(0, 0, 0);
-    uint32_t blk = 0, end_bit = 0, ebase = 0;
+    uint32_t blk = 0, end_bit = 0, ebase = 0, blk_limit = h->total_blocks, pad_to = 0;
     if (live) {
+        const SubLoc loc = locate_sub(im, *h, segs, s);
         e = g_entry[im.sub_off + s];
         blk = g_blkbase[im.sub_off + s];
         ebase = g_ebase[im.sub_off + s];
-        end_bit = subseq_end(*h, s);
+        end_bit = loc.end;
+        if (im.nseg > 1) {
+            // blocks are counted from the segment's first one (restart_mcus MCUs per segment); the lane stops at the
+            // segment's last block, and fills the rest of what the synchronisation passes counted for it -- garbage
+            // after that block included -- with null entries, so that the stream has no holes (a null entry lands on a
+            // DC slot in stage B and is overwritten by the DC)
+            const uint32_t seg_blocks = im.restart_mcus * im.bpm, seg_first = loc.seg * seg_blocks;
+            blk = seg_first + (blk - g_blkbase[im.sub_off + loc.seg_sub0]);
+            blk_limit = min(seg_first + seg_blocks, h->total_blocks);
+            pad_to = ebase + g_exit[im.sub_off + s].m;
+            pad_to = pad_to < im.ent_cap ? pad_to : im.ent_cap;
+        }
     }
     StreamSink sink;
     sink.tile_eoff = tile_eoff + im.tile_off;
@@ -655,7 +704,13 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
         sink.next_tile_blk = sink.tile_idx * im.tile_blocks;
     }
     NoCheckpoints nocp;
-    wave_decode<true, 0>(live, e, end_bit, blk, gbits, s_win + threadIdx.x * kWinStride, lut, *h, sink, nocp, 0, e);
+    wave_decode<true, 0>(live, e, end_bit, blk, blk_limit, gbits, s_win + threadIdx.x * kWinStride, lut, *h, sink, nocp, 0, e);
+    if (im.nseg > 1) {                                                     // wave-uniform
+        for (uint32_t it = 1; __builtin_amdgcn_ballot_w64(sink.ac_ring.off < pad_to); it++) {
+            if (sink.ac_ring.off < pad_to) sink.ac_ring.push(sink.blk_bits);
+            if (it % kFlushEvery == 0) sink.flush_groups();
+        }
+    }
     sink.flush();
 }
 
@@ -685,7 +740,7 @@ extern "C" __global__ __launch_bounds__(256) void k_dc_sums(const DevImage *imag
     __shared__ int32_t s_w[4][3];
     const DevImage &im = images[blockIdx.y];
     const uint32_t m0 = blockIdx.x * kDcSegMcus;
-    if (!im.valid || m0 >= im.nmcu || img_flags[im.status_idx] || ((kDcFastShapes >> im.bpm) & 1u)) return;
+    if (!im.valid || m0 >= im.nmcu || img_flags[im.status_idx] || ((kDcFastShapes >> im.bpm) & 1u) || im.nseg > 1) return;
     const uint32_t bpm = im.bpm, tid = threadIdx.x;
     const uint32_t nv = (min(uint32_t(kDcSegMcus), im.nmcu - m0)) * bpm;
     const int32_t *dc = dcbuf + im.coef_off + size_t(m0) * bpm;
@@ -710,7 +765,7 @@ extern "C" __global__ __launch_bounds__(256) void k_dc_apply(const DevImage *ima
     __shared__ int32_t s_wsum[4][3];
     const DevImage &im = images[blockIdx.y];
     const uint32_t seg0 = blockIdx.x * kDcSegMcus;
-    if (!im.valid || seg0 >= im.nmcu || img_flags[im.status_idx] || ((kDcFastShapes >> im.bpm) & 1u)) return;
+    if (!im.valid || seg0 >= im.nmcu || img_flags[im.status_idx] || ((kDcFastShapes >> im.bpm) & 1u) || im.nseg > 1) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, bpm = im.bpm;
     const uint32_t seg1 = min(im.nmcu, seg0 + kDcSegMcus);
     int32_t *dc = dcbuf + im.coef_off;
@@ -817,7 +872,7 @@ __global__ __launch_bounds__(256) void k_dc_sums_t(const DevImage *images, const
     __shared__ int32_t s_w[4][3];
     const DevImage &im = images[blockIdx.y];
     const uint32_t seg0 = blockIdx.x * kDcSegMcus;
-    if (!im.valid || im.bpm != BPM || seg0 >= im.nmcu || img_flags[im.status_idx]) return;
+    if (!im.valid || im.bpm != BPM || seg0 >= im.nmcu || img_flags[im.status_idx] || im.nseg > 1) return;
     const uint32_t seg1 = min(im.nmcu, seg0 + kDcSegMcus);
     int32_t v[kDcLaneMcus * BPM];
     int32_t *p;
@@ -845,7 +900,7 @@ __global__ __launch_bounds__(256) void k_dc_apply_t(const DevImage *images, int3
     __shared__ int32_t s_wsum[4][3];
     const DevImage &im = images[blockIdx.y];
     const uint32_t seg0 = blockIdx.x * kDcSegMcus;
-    if (!im.valid || im.bpm != BPM || seg0 >= im.nmcu || img_flags[im.status_idx]) return;
+    if (!im.valid || im.bpm != BPM || seg0 >= im.nmcu || img_flags[im.status_idx] || im.nseg > 1) return;
     const uint32_t seg1 = min(im.nmcu, seg0 + kDcSegMcus);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int32_t v[kDcLaneMcus * BPM];
@@ -906,6 +961,31 @@ __global__ __launch_bounds__(256) void k_dc_apply_t(const DevImage *images, int3
 #pragma unroll
         for (int i = 0; i < kDcLaneMcus * BPM; i++)
             if (uint32_t(i) < nvalid * BPM) p[i] = v[i];
+    }
+}
+
+// Restart intervals: the DC predictors start again at 0 in every interval (T.81 E.2.4), so the
+// prediction is independent per interval: one lane walks the blocks of one interval.
+extern "C" __global__ __launch_bounds__(256) void k_dc_restart(const DevImage *images, int32_t *dcbuf,
+                                                                const uint32_t *img_flags)
+{
+    const DevImage &im = images[blockIdx.y];
+    if (!im.valid || im.nseg <= 1 || img_flags[im.status_idx]) return;
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= im.nseg) return;
+    const uint32_t seg_blocks = im.restart_mcus * im.bpm, b0 = g * seg_blocks;
+    const uint32_t b1 = min(b0 + seg_blocks, im.himg.total_blocks);
+    int32_t *dc = dcbuf + im.coef_off;
+    int32_t p0 = 0, p1 = 0, p2 = 0;
+    uint32_t j = 0;
+    for (uint32_t b = b0; b < b1; b++) {
+        const uint32_t c = im.blk_comp[j];
+        const int32_t r = (c == 0 ? p0 : (c == 1 ? p1 : p2)) + dc[b];
+        dc[b] = r;
+        p0 = c == 0 ? r : p0;
+        p1 = c == 1 ? r : p1;
+        p2 = c == 2 ? r : p2;
+        j = j + 1 == im.bpm ? 0 : j + 1;
     }
 }
 
@@ -1391,21 +1471,21 @@ void launch_destuff_scatter(hipStream_t st, uint32_t max_seg, uint32_t nimg, con
 
 void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                       const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
-                      uint32_t *cps)
+                      uint32_t *cps, const uint32_t *segs)
 {
     const size_t lds = tables_lds + huff_window_bytes() + pad_lds;
-    hipLaunchKernelGGL(k_huff_spec, dim3(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, uint32_t(tables_lds));
+    hipLaunchKernelGGL(k_huff_spec, dim3(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, uint32_t(tables_lds), segs);
 }
 
 void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                        const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
-                       uint32_t *cps, uint32_t *mismatches, uint32_t *items, uint32_t *item_count)
+                       uint32_t *cps, uint32_t *mismatches, uint32_t *items, uint32_t *item_count, const uint32_t *segs)
 {
     (void)hipMemsetAsync(item_count, 0, size_t(nimg) * sizeof(uint32_t), st);
     const size_t lds = tables_lds + size_t(kMergeWg) * kMergeStride * 4 + pad_lds;
-    hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches, uint32_t(tables_lds), items, item_count);
+    hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches, uint32_t(tables_lds), items, item_count, segs);
     const size_t tail_lds = tables_lds + size_t(64) * kMergeStride * 4;
-    hipLaunchKernelGGL(k_huff_merge_tail, dim3(nimg, max_wg * (kMergeWg / 64)), dim3(64), tail_lds, st, images, scan_pool, lut_pool, exit_, cps, uint32_t(tables_lds), items, item_count);
+    hipLaunchKernelGGL(k_huff_merge_tail, dim3(nimg, max_wg * (kMergeWg / 64)), dim3(64), tail_lds, st, images, scan_pool, lut_pool, exit_, cps, uint32_t(tables_lds), items, item_count, segs);
 }
 
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,
@@ -1417,14 +1497,14 @@ void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, con
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                        const uint8_t *scan_pool, const LutEntry *lut_pool, const SubseqState *entry,
                        const uint32_t *blkbase, const uint32_t *ebase, uint32_t *entries, uint32_t *tile_eoff,
-                       int32_t *dcbuf, int *status, const uint32_t *img_flags)
+                       int32_t *dcbuf, int *status, const uint32_t *img_flags, const uint32_t *segs, const SubseqState *exit_)
 {
     const size_t lds = tables_lds + huff_window_bytes() + huff_stage_bytes() + pad_lds;
-    hipLaunchKernelGGL(k_huff_write, dim3(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, blkbase, ebase, entries, tile_eoff, dcbuf, status, img_flags, uint32_t(tables_lds));
+    hipLaunchKernelGGL(k_huff_write, dim3(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, blkbase, ebase, entries, tile_eoff, dcbuf, status, img_flags, uint32_t(tables_lds), segs, exit_);
 }
 
 void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int32_t *dcbuf,
-                    int32_t *segsum, const uint32_t *img_flags, uint32_t bpm_mask)
+                    int32_t *segsum, const uint32_t *img_flags, uint32_t bpm_mask, uint32_t max_restart_segs)
 {
     const dim3 grid(max_segs, nimg), wg(256);
 #define MJX_DC_PASS(KERNEL)                                                                                              \
@@ -1436,6 +1516,7 @@ void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevI
     MJX_DC_PASS(k_dc_sums)
     MJX_DC_PASS(k_dc_apply)
 #undef MJX_DC_PASS
+    if (max_restart_segs) hipLaunchKernelGGL(k_dc_restart, dim3((max_restart_segs + 255) / 256, nimg), wg, 0, st, images, dcbuf, img_flags);
 }
 
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,

@@ -42,6 +42,7 @@ struct ParserState {
     bool have_frame = false;
     unsigned width = 0, height = 0;
     std::vector<FrameComp> frame;
+    unsigned restart_interval = 0;     // DRI (accepted unless strict_ref)
     mjx_scan_desc *d;
 };
 
@@ -148,13 +149,21 @@ void read_sos(const ByteView &f, size_t pos, ParserState &st, bool strict, bool 
         d->comp[c] = mjx_comp{sc[c].id, fc->h, fc->v, fc->tq, sc[c].td, sc[c].ta};
     }
 
-    // everything after the SOS header, FF00 -> FF, markers (EOI...) kept verbatim
+    // everything after the SOS header, FF00 -> FF, markers (EOI...) kept verbatim -- except RSTn when a restart
+    // interval is defined: those are taken out and the offset of the byte that follows is recorded
     const size_t total = f.size();
     const size_t remain = i < total ? total - i : 0;
-    uint8_t *buf = static_cast<uint8_t *>(std::malloc(remain + 32));
-    if (!buf) throw ParseError{MJX_ERR_NOMEM};
-    size_t w = 0;
     const uint8_t *src = remain ? f.span(i, remain) : nullptr;
+    const bool restarts = st.restart_interval != 0;
+    if (restarts) keep_stuffed = false;                  // the device compaction does not know about RSTn
+    size_t max_rst = 0;
+    for (size_t k = 0; restarts && k + 1 < remain; k++) max_rst += (src[k] == 0xff && (src[k + 1] & 0xf8) == 0xd0);
+    const size_t scan_room = (remain + 32 + 3) & ~size_t(3);
+    uint8_t *buf = static_cast<uint8_t *>(std::malloc(scan_room + max_rst * sizeof(uint32_t) + 4));
+    if (!buf) throw ParseError{MJX_ERR_NOMEM};
+    uint32_t *rst = reinterpret_cast<uint32_t *>(buf + scan_room);
+    uint32_t nrst = 0;
+    size_t w = 0;
     if (keep_stuffed) {                                  // the GPU compacts FF00 pairs (mjx_batch_create)
         if (remain) std::memcpy(buf, src, remain);
         w = remain;
@@ -168,12 +177,19 @@ void read_sos(const ByteView &f, size_t pos, ParserState &st, bool strict, bool 
                 if (strict) { std::free(buf); throw ParseError{MJX_ERR_TRUNCATED}; }
             } else if (src[k + 1] == 0x00) {
                 k++;
+            } else if (restarts && (src[k + 1] & 0xf8) == 0xd0) {
+                w--;                                    // drop FF Dn; the next interval starts at the following byte
+                k++;
+                rst[nrst++] = uint32_t(w);
             }
         }
     }
     std::memset(buf + w, 0xaa, 32);                     // huffman.rs:236-246: bytes past the end read as 0xaa
     d->scan = buf;
     d->scan_len = w;
+    d->restart_interval = uint16_t(st.restart_interval);
+    d->n_restart = nrst;
+    d->restart_offsets = nrst ? rst : nullptr;
     d->owner_ = buf;
 }
 
@@ -205,7 +221,11 @@ void walk(const uint8_t *jpeg, size_t len, const mjx_opts &opts, mjx_scan_desc *
         case Seg::SOF0: read_sof0(f, i, st, strict); break;
         case Seg::DHT: read_dht(f, i, body, out); break;
         case Seg::SOS: read_sos(f, i, st, strict, opts.device_destuff != 0); return;                        // :415-417 returns after the first scan
-        case Seg::DRI: throw ParseError{MJX_ERR_DRI_UNSUPPORTED};                 // :424-428
+        case Seg::DRI:                                                             // :424-428 panics; T.81 B.2.4.4 otherwise
+            if (strict) throw ParseError{MJX_ERR_DRI_UNSUPPORTED};
+            if (body < 2) throw ParseError{MJX_ERR_TRUNCATED};
+            st.restart_interval = f.be16(i);
+            break;
         case Seg::APP0:                                                            // :429-443 absolute offsets up to vec[15]
             (void)f.span(i, 6);
             if (strict && len < 16) throw ParseError{MJX_ERR_TRUNCATED};

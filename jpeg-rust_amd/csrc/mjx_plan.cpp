@@ -174,7 +174,33 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p)
     p.himg.total_bits = uint32_t(p.scan_len * 8);
     p.himg.total_blocks = p.nmcu * p.bpm;
     p.himg.sub_bits = choose_subseq_bits(p.himg.total_bits);
-    p.himg.nsub = (p.himg.total_bits + p.himg.sub_bits - 1) / p.himg.sub_bits;
+    p.restart_mcus = d.restart_interval;
+    p.seg.clear();
+    if (p.restart_mcus == 0) {
+        p.nseg = 1;
+        p.himg.nsub = (p.himg.total_bits + p.himg.sub_bits - 1) / p.himg.sub_bits;
+        p.seg = {0u, 0u, p.himg.nsub, p.himg.total_bits};
+    } else {
+        // Each restart interval is decoded on its own: its first subsequence starts in a known state, subsequences do
+        // not straddle intervals, and the DC predictors start again (T.81 E.2.4).  REF_COMPAT has no meaning here: the
+        // reference panics on DRI (jpeg/mod.rs:424-428).
+        if (p.layout == MJX_LAYOUT_REF_COMPAT) return fail(MJX_ERR_DRI_UNSUPPORTED);
+        p.nseg = (p.nmcu + p.restart_mcus - 1) / p.restart_mcus;
+        if (d.n_restart + 1 < p.nseg) return fail(MJX_ERR_TRUNCATED);              // fewer RSTn markers than intervals
+        uint32_t sub = 0;
+        for (uint32_t g = 0; g <= p.nseg; g++) {
+            const uint64_t byte0 = g == 0 ? 0 : (g - 1 < d.n_restart ? d.restart_offsets[g - 1] : p.scan_len);
+            if (byte0 > p.scan_len || (g > 0 && byte0 * 8 < p.seg[2 * (g - 1) + 1])) return fail(MJX_ERR_INVALID_ARG);
+            const uint32_t bit0 = g == p.nseg ? p.himg.total_bits : uint32_t(byte0 * 8);
+            if (g > 0) {
+                const uint32_t len = bit0 - p.seg[2 * (g - 1) + 1];
+                sub += len ? (len + p.himg.sub_bits - 1) / p.himg.sub_bits : 1u;
+            }
+            p.seg.push_back(sub);
+            p.seg.push_back(bit0);
+        }
+        p.himg.nsub = sub;
+    }
 
     // dequantisation x IDCT prescale, zig-zag order (reference: decoder.rs:230-232 multiplies by the raw table;
     // the AAN row/column factors and the 1/8 are folded in here so the kernel does one multiply per coefficient)

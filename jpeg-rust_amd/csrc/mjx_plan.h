@@ -33,6 +33,12 @@ struct ImagePlan {
     // REF_COMPAT placement (decoder.rs:239-250): replication factors per component, block grid of the image
     uint32_t ref_xf[3] = {1, 1, 1}, ref_yf[3] = {1, 1, 1};
     uint32_t nbx = 0, nby = 0;
+    // Restart intervals: the scan is a sequence of independent segments of restart_mcus MCUs each.
+    // seg[g] = (first subsequence, first bit) of segment g, plus a sentinel (nsub, total_bits).  One segment when the
+    // image has no restart interval.
+    uint32_t restart_mcus = 0;
+    std::vector<uint32_t> seg;                     // 2 * (nseg + 1) words
+    uint32_t nseg = 1;
 };
 
 // decoder.rs:259-288 get_indices: raster counter (x, y) of a component's blocks -> block position (bug-for-bug, Q3).

@@ -348,6 +348,7 @@ typedef struct {
     int ncomp_frame;
     orc_framecomp fcomp[256];
     int width, height;
+    int restart_interval;      /* MCUs per restart interval (ext_dri), 0 = none */
 } orc_parse;
 
 /* decoder.rs:259-288 get_indices.  usize arithmetic: underflow panics. */
@@ -459,6 +460,14 @@ static void orc_jpeg_decode(orc_env *env, const orc_opts *opts, const orc_parse 
                 memcpy(dst, blk, sizeof blk);
                 dst[0] = (int16_t)dcv;
             }
+        }
+        if (ps->restart_interval > 0 && (m + 1) % (size_t)ps->restart_interval == 0 && m + 1 < num_read) {
+            /* ext_dri: byte-align, expect RSTn (the markers stay in the copied buffer: only FF00 pairs were compacted) */
+            orc_shift_and_fix(&hd, (size_t)((8 - hd.total_bits % 8) % 8));
+            const uint32_t mk = hd.current >> 16;
+            if ((mk & 0xfff8u) != 0xffd0u) orc_panic(env, ORC_ERR_UNSUPPORTED, "restart marker expected");
+            orc_shift_and_fix(&hd, 16);
+            prev_dc[0] = prev_dc[1] = prev_dc[2] = 0;
         }
     }
     out->bits_used = (size_t)hd.total_bits;
@@ -709,7 +718,9 @@ static void orc_parse_and_decode(orc_env *env, const uint8_t *vec, size_t len, c
             return;                                              /* :417 */
         }
         case 0xdd: /* DRI :424-428 */
-            orc_panic(env, opts->strict_ref ? ORC_ERR_REF_PANIC : ORC_ERR_UNSUPPORTED, "got to restart interval def");
+            if (!opts->ext_dri) orc_panic(env, opts->strict_ref ? ORC_ERR_REF_PANIC : ORC_ERR_UNSUPPORTED, "got to restart interval def");
+            PANIC_IF(data_length < 2 || i + 2 > len, "DRI segment out of bounds");    /* extension: Lr = 4, Ri */
+            ps->restart_interval = (vec[i] << 8) | vec[i + 1];
             break;
         case 0xe0: /* APP0 :429-443: reads fixed absolute offsets vec[7], vec[8], vec[10..14], vec[14], vec[15] */
             PANIC_IF(i + 6 > len, "APP0 identifier out of bounds");
@@ -727,7 +738,7 @@ static void orc_parse_and_decode(orc_env *env, const uint8_t *vec, size_t len, c
 
 int orc_decode(const uint8_t *jpeg, size_t len, const orc_opts *opts, orc_image *out)
 {
-    static const orc_opts defaults = {0, ORC_LAYOUT_REF, 0, 0, 0};
+    static const orc_opts defaults = {0, ORC_LAYOUT_REF, 0, 0, 0, 0};
     const orc_opts *volatile o = opts ? opts : &defaults;
     memset(out, 0, sizeof *out);
     orc_env *env = (orc_env *)calloc(1, sizeof(orc_env));

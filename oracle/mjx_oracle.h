@@ -47,6 +47,9 @@ typedef struct {
                          0: same result via per-length first-code table */
     int ext_1bit;     /* NOT reference behaviour: also try 1-bit codes (the reference starts at length 2, huffman.rs:211,
                          SURVEY Q8, and panics on such tables).  Only used to check the GPU path's superset behaviour. */
+    int ext_dri;      /* NOT reference behaviour: accept DRI / RSTn restart intervals (T.81 B.2.4.4, E.2.4) instead of panicking
+                         like jpeg/mod.rs:424-428: after every Ri MCUs the bit reader moves to the next byte boundary, skips the
+                         RSTn marker and the DC predictors start again from 0.  Used to check the GPU path's SURVEY s8(f)-3 row. */
 } orc_opts;
 
 typedef struct {

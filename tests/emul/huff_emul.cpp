@@ -86,6 +86,7 @@ extern "C" int emul_decode_coefs(const uint8_t *jpeg, size_t len, int layout, in
     ImagePlan plan;
     rc = plan_image(d, opts, plan);
     if (rc) { mjx_free_scan(&d); return rc; }
+    if (plan.restart_mcus) { mjx_free_scan(&d); return MJX_ERR_DRI_UNSUPPORTED; }   // (restart intervals: GPU tests only)
     const HuffImage &img = plan.himg;
     const HostBits bits{plan.scan, plan.scan_len};
     const uint32_t nsub = img.nsub;

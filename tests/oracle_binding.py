@@ -13,7 +13,7 @@ OK, ERR_REF_PANIC, ERR_UNSUPPORTED, ERR_NO_SCAN, ERR_NOMEM = range(5)
 
 class Opts(ctypes.Structure):
     _fields_ = [("strict_ref", ctypes.c_int), ("layout", ctypes.c_int), ("faithful_cos", ctypes.c_int),
-                ("faithful_huff", ctypes.c_int), ("ext_1bit", ctypes.c_int)]
+                ("faithful_huff", ctypes.c_int), ("ext_1bit", ctypes.c_int), ("ext_dri", ctypes.c_int)]
 
 
 class Img(ctypes.Structure):
@@ -55,9 +55,9 @@ class Decoded:
     pass
 
 
-def decode(data, layout=LAYOUT_REF, strict_ref=False, faithful_cos=False, faithful_huff=False, ext_1bit=False):
+def decode(data, layout=LAYOUT_REF, strict_ref=False, faithful_cos=False, faithful_huff=False, ext_1bit=False, ext_dri=False):
     """-> object with rgb [H,W,3] u8, coefs (list per component of int16 [blocks,64]), hv (blocks per MCU per comp)."""
-    o = Opts(int(strict_ref), int(layout), int(faithful_cos), int(faithful_huff), int(ext_1bit))
+    o = Opts(int(strict_ref), int(layout), int(faithful_cos), int(faithful_huff), int(ext_1bit), int(ext_dri))
     im = Img()
     rc = lib().orc_decode(bytes(data), len(data), ctypes.byref(o), ctypes.byref(im))
     if rc != OK:

@@ -289,6 +289,54 @@ def test_libjpeg_written_files(mjx, orc, gpu_ctx, name):
     batch.close()
 
 
+# ---- restart intervals (beyond the reference, which panics on DRI) -------------------------------
+DRI_FIXTURES = ["dri_420_r5", "dri_444_r1", "dri_422_rows", "dri_gray_r7", "dri_420_720p_rows", "dri_420_r300"]
+
+
+@pytest.mark.parametrize("name", DRI_FIXTURES)
+def test_restart_intervals(mjx, orc, gpu_ctx, name):
+    """Every restart interval is an independent segment (own subsequences, known start state, DC predictors from 0).
+    Checked against the oracle's ext_dri extension, which is pinned by the libjpeg twin without restart markers."""
+    d = os.path.join(os.path.dirname(__file__), "golden", "pil")
+    data = open(os.path.join(d, name + ".jpg"), "rb").read()
+    plain = open(os.path.join(d, name + "_plain.jpg"), "rb").read()
+    batch = mjx.Batch(gpu_ctx, [mjx.ParsedScan(data), mjx.ParsedScan(plain)], keep_coefs=True)
+    batch.decode()
+    batch.wait()
+    assert batch.status(0) == mjx.OK and batch.status(1) == mjx.OK
+    ref = orc.decode(data, layout=orc.LAYOUT_STD, ext_dri=True)
+    _check(ref, batch.coefs(0), batch.rgb(0), name)
+    assert np.array_equal(batch.coefs(0), batch.coefs(1)) and np.array_equal(batch.rgb(0), batch.rgb(1))
+    batch.close()
+
+
+def test_restart_intervals_mixed_batch_and_errors(mjx, orc, gpu_ctx, data_dir):
+    d = os.path.join(os.path.dirname(__file__), "golden", "pil")
+    dri = [open(os.path.join(d, n + ".jpg"), "rb").read() for n in DRI_FIXTURES]
+    others = [open(os.path.join(data_dir, n), "rb").read() for n in FIXTURES] + [mjx.synth_jpeg(1920, 1080, "420", 75, seed=1)]
+    datas = [dri[0], others[0], dri[4], others[1], dri[3], others[-1], dri[5]]
+    res_dri = {id(x) for x in dri}
+    batch = mjx.Batch(gpu_ctx, [mjx.ParsedScan(x) for x in datas], keep_coefs=True, chunk_images=3)
+    batch.decode()
+    batch.wait()
+    for i, x in enumerate(datas):
+        ref = orc.decode(x, layout=orc.LAYOUT_STD, ext_dri=id(x) in res_dri)
+        assert batch.status(i) == mjx.OK
+        _check(ref, batch.coefs(i), batch.rgb(i), "mixed %d" % i)
+    batch.close()
+    # an interval's marker missing: fewer segments than the MCU count needs -> reported, not decoded
+    x = bytearray(dri[0])
+    k = x.rindex(b"\xff\xd0") if b"\xff\xd0" in x else None
+    cut = bytes(x[:k] + x[k + 2:])
+    b2 = mjx.Batch(gpu_ctx, [mjx.ParsedScan(cut)], keep_coefs=True)
+    assert b2.status(0) == mjx.ERR_TRUNCATED
+    b2.close()
+    # REF_COMPAT has no restart intervals (the reference panics on DRI)
+    b3 = mjx.Batch(gpu_ctx, [mjx.ParsedScan(dri[0])], layout=mjx.LAYOUT_REF_COMPAT)
+    assert b3.status(0) == mjx.ERR_DRI_UNSUPPORTED
+    b3.close()
+
+
 # ---- SURVEY s8(f) row 2: byte de-stuffing on the device ---------------------------------------------------------------
 def test_device_side_destuffing_matches_host_destuffing(mjx, orc, gpu_ctx, data_dir):
     datas = [open(os.path.join(data_dir, n), "rb").read() for n in FIXTURES]          # lena.jpeg holds 464 FF00 pairs

@@ -67,7 +67,8 @@ def test_parse_error_codes_mirror_the_reference_panics(mjx):
     assert _code(mjx, _read("huff_simple0.jpg"), False) == mjx.OK                         # skipped
     sos = good.index(b"\xff\xda")
     dri = good[:sos] + b"\xff\xdd\x00\x04\x00\x08" + good[sos:]
-    assert _code(mjx, dri, True) == mjx.ERR_DRI_UNSUPPORTED and _code(mjx, dri, False) == mjx.ERR_DRI_UNSUPPORTED
+    assert _code(mjx, dri, True) == mjx.ERR_DRI_UNSUPPORTED                                # mod.rs:424-428 panics
+    assert _code(mjx, dri, False) == mjx.OK                                                # accepted
     assert _code(mjx, good[:sos], False) == mjx.ERR_NO_SCAN                               # image_data() == None
     assert _code(mjx, good[:100], False) == mjx.ERR_TRUNCATED
     assert _code(mjx, b"\x00\x01\x02\x03", True) == mjx.ERR_UNSUPPORTED_MARKER            # "Unhandled byte marker"
@@ -217,4 +218,39 @@ def test_progressive_and_restart_files_are_rejected(mjx):
     prog = open(os.path.join(PIL_DIR, "progressive.jpg"), "rb").read()
     rst = open(os.path.join(PIL_DIR, "restart.jpg"), "rb").read()
     assert _code(mjx, prog, False) == mjx.ERR_UNSUPPORTED_FORMAT and _code(mjx, prog, True) == mjx.ERR_UNSUPPORTED_MARKER
-    assert _code(mjx, rst, False) == mjx.ERR_DRI_UNSUPPORTED          # jpeg/mod.rs:424-428
+    assert _code(mjx, rst, True) == mjx.ERR_DRI_UNSUPPORTED           # jpeg/mod.rs:424-428
+    assert _code(mjx, rst, False) == mjx.OK                           # restart intervals are decoded
+
+
+DRI_FIXTURES = ["dri_420_r5", "dri_444_r1", "dri_422_rows", "dri_gray_r7", "dri_420_720p_rows", "dri_420_r300"]
+
+
+@pytest.mark.parametrize("name", DRI_FIXTURES)
+def test_restart_markers_are_parsed_out_of_the_scan(mjx, orc, name):
+    """mjx_parse removes the RSTn markers and lists where the intervals begin; the oracle's ext_dri extension is pinned by
+    the libjpeg twin of every file (same picture saved without restart markers = same quantised coefficients)."""
+    data = open(os.path.join(PIL_DIR, name + ".jpg"), "rb").read()
+    plain = open(os.path.join(PIL_DIR, name + "_plain.jpg"), "rb").read()
+    scan = mjx.ParsedScan(data)
+    d = scan.desc
+    n_markers = sum(data.count(bytes([0xff, 0xd0 + k])) for k in range(8))
+    assert d.restart_interval > 0 and d.n_restart == n_markers
+    offs = [d.restart_offsets[k] for k in range(d.n_restart)]
+    assert offs == sorted(offs) and offs[-1] <= d.scan_len
+    sos = data.index(b"\xff\xda")
+    raw = data[sos + 2 + int.from_bytes(data[sos + 2:sos + 4], "big"):]
+    want, want_offs, k = bytearray(), [], 0
+    while k < len(raw):                                               # FF00 -> FF, FF Dn dropped (offset recorded)
+        if raw[k] == 0xff and k + 1 < len(raw) and raw[k + 1] == 0x00:
+            want.append(0xff); k += 2
+        elif raw[k] == 0xff and k + 1 < len(raw) and 0xd0 <= raw[k + 1] <= 0xd7:
+            want_offs.append(len(want)); k += 2
+        else:
+            want.append(raw[k]); k += 1
+    assert bytes(scan.scan_bytes()) == bytes(want) and offs == want_offs
+    assert scan.validate() == mjx.OK
+    ref = orc.decode(data, layout=orc.LAYOUT_STD, ext_dri=True)
+    twin = orc.decode(plain, layout=orc.LAYOUT_STD)
+    assert np.array_equal(orc.interleave(ref), orc.interleave(twin)) and np.array_equal(ref.rgb, twin.rgb)
+    with pytest.raises(orc.OracleError):
+        orc.decode(data, layout=orc.LAYOUT_STD)                       # the reference itself panics on DRI
