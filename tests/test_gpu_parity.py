@@ -181,6 +181,13 @@ def test_cli_writes_the_reference_ppm(mjx, orc, gpu_ctx, data_dir, tmp_path):
     assert np.abs(px - ref.rgb.astype(np.int32)).max() <= TOL
     rc = subprocess.call([cli, os.path.join(data_dir, "huff_simple0.jpg"), str(out), "--strict"])
     assert rc == mjx.ERR_UNSUPPORTED_MARKER
+    dri = os.path.join(os.path.dirname(__file__), "golden", "pil", "dri_422_rows.jpg")      # restart intervals, s8(f)-3
+    subprocess.check_call([cli, dri, str(out)])
+    tok = out.read_text().split()
+    ref = orc.decode(open(dri, "rb").read(), layout=orc.LAYOUT_STD, ext_dri=True)
+    assert tok[:4] == ["P3", "333", "222", "255"]
+    assert np.abs(np.array(tok[4:], dtype=np.int32).reshape(222, 333, 3) - ref.rgb.astype(np.int32)).max() <= TOL
+    assert subprocess.call([cli, dri, str(out), "--strict"]) == mjx.ERR_DRI_UNSUPPORTED
 
 
 # ---- hostile inputs: one bad image must not kill the batch, and nothing may fault on the device --------------------
