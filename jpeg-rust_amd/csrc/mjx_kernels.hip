@@ -675,8 +675,8 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
         if (im.nseg > 1) {
             // blocks are counted from the segment's first one (restart_mcus MCUs per segment); the lane stops at the
             // segment's last block, and fills the rest of what the synchronisation passes counted for it -- garbage
-            // after that block included -- with null entries, so that the stream has no holes (a null entry lands on a
-            // DC slot in stage B and is overwritten by the DC)
+            // after that block included -- with null entries (position 0, skipped by stage B), so that the stream has no
+            // holes
             const uint32_t seg_blocks = im.restart_mcus * im.bpm, seg_first = loc.seg * seg_blocks;
             blk = seg_first + (blk - g_blkbase[im.sub_off + loc.seg_sub0]);
             blk_limit = min(seg_first + seg_blocks, h->total_blocks);
@@ -706,6 +706,7 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
     NoCheckpoints nocp;
     wave_decode<true, 0>(live, e, end_bit, blk, blk_limit, gbits, s_win + threadIdx.x * kWinStride, lut, *h, sink, nocp, 0, e);
     if (im.nseg > 1) {                                                     // wave-uniform
+        sink.flush_groups();                                               // (the rings hold one flush period, no more)
         for (uint32_t it = 1; __builtin_amdgcn_ballot_w64(sink.ac_ring.off < pad_to); it++) {
             if (sink.ac_ring.off < pad_to) sink.ac_ring.push(sink.blk_bits);
             if (it % kFlushEvery == 0) sink.flush_groups();
@@ -978,14 +979,20 @@ extern "C" __global__ __launch_bounds__(256) void k_dc_restart(const DevImage *i
     int32_t *dc = dcbuf + im.coef_off;
     int32_t p0 = 0, p1 = 0, p2 = 0;
     uint32_t j = 0;
-    for (uint32_t b = b0; b < b1; b++) {
-        const uint32_t c = im.blk_comp[j];
-        const int32_t r = (c == 0 ? p0 : (c == 1 ? p1 : p2)) + dc[b];
-        dc[b] = r;
-        p0 = c == 0 ? r : p0;
-        p1 = c == 1 ? r : p1;
-        p2 = c == 2 ? r : p2;
-        j = j + 1 == im.bpm ? 0 : j + 1;
+    for (uint32_t b = b0; b < b1; b += 8) {                                // eight loads in flight, then the serial part
+        int32_t v[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) v[q] = b + q < b1 ? dc[b + q] : 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) {
+            const uint32_t c = im.blk_comp[j];
+            const int32_t r = (c == 0 ? p0 : (c == 1 ? p1 : p2)) + v[q];
+            if (b + q < b1) dc[b + q] = r;
+            p0 = c == 0 ? r : p0;
+            p1 = c == 1 ? r : p1;
+            p2 = c == 2 ? r : p2;
+            j = j + 1 == im.bpm ? 0 : j + 1;
+        }
     }
 }
 
@@ -1129,7 +1136,8 @@ __device__ __forceinline__ void scatter_entry(uint32_t e, uint32_t first_lo, uin
 {
     const uint32_t b = ((e >> 22) - first_lo) & 0xffu;
     const uint32_t pos = (e >> 16) & 63u;
-    if (b < nblk) tile_f[b * kPixStride + s_nat[pos]] = float(int32_t(int16_t(e & 0xffffu))) * s_qm[s_comp[b] * 64 + pos];
+    // pos == 0 marks a null entry (the write pass fills holes with them when restart intervals cut a lane short)
+    if (b < nblk && pos != 0) tile_f[b * kPixStride + s_nat[pos]] = float(int32_t(int16_t(e & 0xffffu))) * s_qm[s_comp[b] * 64 + pos];
 }
 
 // One lane = one 8x8 block: 16 x ds_read_b128 of its row, 8 column + 8 row transforms in registers, back to the row.
