@@ -187,17 +187,35 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p)
         if (p.layout == MJX_LAYOUT_REF_COMPAT) return fail(MJX_ERR_DRI_UNSUPPORTED);
         p.nseg = (p.nmcu + p.restart_mcus - 1) / p.restart_mcus;
         if (d.n_restart + 1 < p.nseg) return fail(MJX_ERR_TRUNCATED);              // fewer RSTn markers than intervals
-        uint32_t sub = 0;
+        std::vector<uint32_t> bit0(p.nseg + 1);
         for (uint32_t g = 0; g <= p.nseg; g++) {
             const uint64_t byte0 = g == 0 ? 0 : (g - 1 < d.n_restart ? d.restart_offsets[g - 1] : p.scan_len);
-            if (byte0 > p.scan_len || (g > 0 && byte0 * 8 < p.seg[2 * (g - 1) + 1])) return fail(MJX_ERR_INVALID_ARG);
-            const uint32_t bit0 = g == p.nseg ? p.himg.total_bits : uint32_t(byte0 * 8);
+            if (byte0 > p.scan_len) return fail(MJX_ERR_INVALID_ARG);
+            bit0[g] = g == p.nseg ? p.himg.total_bits : uint32_t(byte0 * 8);
+            if (g > 0 && bit0[g] < bit0[g - 1]) return fail(MJX_ERR_INVALID_ARG);
+        }
+        auto count = [&](uint32_t bits) {
+            uint32_t n = 0;
+            for (uint32_t g = 0; g < p.nseg; g++) {
+                const uint32_t len = bit0[g + 1] - bit0[g];
+                n += len ? (len + bits - 1) / bits : 1u;
+            }
+            return n;
+        };
+        // the same workgroup-filling rule as choose_subseq_bits, on the segmented count
+        uint32_t sub = count(p.himg.sub_bits);
+        const uint32_t nwg = sub / uint32_t(kHuffWg);
+        if (nwg > 0 && sub % uint32_t(kHuffWg) != 0)
+            for (uint32_t bits = p.himg.sub_bits + kCpBits; bits <= uint32_t(kSubseqBits) * 5 / 4; bits += kCpBits)
+                if (count(bits) <= nwg * uint32_t(kHuffWg)) { p.himg.sub_bits = bits; sub = count(bits); break; }
+        sub = 0;
+        for (uint32_t g = 0; g <= p.nseg; g++) {
             if (g > 0) {
-                const uint32_t len = bit0 - p.seg[2 * (g - 1) + 1];
+                const uint32_t len = bit0[g] - bit0[g - 1];
                 sub += len ? (len + p.himg.sub_bits - 1) / p.himg.sub_bits : 1u;
             }
             p.seg.push_back(sub);
-            p.seg.push_back(bit0);
+            p.seg.push_back(bit0[g]);
         }
         p.himg.nsub = sub;
     }
