@@ -33,12 +33,8 @@ struct mjx_ctx {
     int nstreams = 1;
     bool profiling = false;
     int fix_passes = 4;            // synchronisation rounds enqueued up front (the last one must re-decode nothing)
-    // Extra dynamic LDS for k_huff_spec: caps it at 5 workgroups (20 waves) per CU.  Every lane streams its own
-    // 512-byte subsequence, so the lines in flight grow with occupancy; past ~20 waves/CU they no longer fit the XCD's
-    // 4 MB L2 and the kernel slows down (measured: 5.5 ms at 32 waves/CU vs 3.5 ms at 20, 1024 x 4K).
-    size_t spec_lds_pad = 0;       // LDS padding = occupancy caps for experiments (MJX_*_LDS_PAD)
-    size_t merge_lds_pad = 0;      // the merge rounds are latency-bound on few lanes and prefer full occupancy
-    size_t write_lds_pad = 0;
+    // Extra dynamic LDS per entropy kernel = occupancy caps for experiments (MJX_SPEC/MERGE/WRITE_LDS_PAD); 0 in production.
+    size_t spec_lds_pad = 0, merge_lds_pad = 0, write_lds_pad = 0;
 };
 
 namespace {

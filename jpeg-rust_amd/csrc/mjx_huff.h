@@ -1,11 +1,11 @@
 // mjx_huff.h -- per-lane baseline-JPEG entropy decode, shared by the HIP kernels (device) and
 // the CPU emulation harness in tests/emul (host).  No wave/workgroup cooperation lives here:
-// one call decodes one fixed-size *subsequence* of the bitstream from a given entry state.
+// one call decodes one *subsequence* of the bitstream (512..640 bytes, fixed per image) from a given entry state.
 //
 // What it replaces in the reference (src/jpeg/huffman.rs): next_code (211-227) becomes a
 // two-level table lookup, read_n_bits + value_correction (198-208, 256-268) become a shift and a
 // branch-free EXTEND, next_block's EOB / ZRL / run clamps (164-189) are folded into the table so
-// the symbol step is uniform:  pos = min(z + run, 63); coef[pos] = value; z = pos + 1.
+// the symbol step is uniform:  pos = min(z + run, 63); coef[pos] = value; z = pos + 1   (kept as r = 64 - z, zinc = run + 1).
 //   * EOB (0x00)  -> run = 63, size 0 : jumps to the end of the block (huffman.rs:164-169)
 //   * ZRL (0xf0)  -> run = 15, size 0 : min(z+15,63)+1 == min(z+16,64)   (huffman.rs:170-175)
 //   * r/s         -> run = r,  size s : min(r, 64-len-1) zeros then the value (huffman.rs:183-189)
@@ -386,7 +386,7 @@ MJX_HD SubseqState decode_subseq(const BitSrc &bits, const LutEntry *lut, const 
 
 #if !defined(__HIP_DEVICE_COMPILE__)
 // ---- host-side table construction (mjx_lut.cpp) ---------------------------------------------------
-// Appends the two-level decode table for one DHT table to `out` (uint16 entries) and returns its size in
+// Appends the two-level decode table for one DHT table to `out` (LutEntry words) and returns its size in
 // entries, or a negative MJX_ERR_* code.  `is_dc`: symbols are DC size categories (run = 0).
 int build_decode_table(const uint8_t bits[16], const uint8_t *vals, bool is_dc, LutEntry *out, int cap);
 #endif
