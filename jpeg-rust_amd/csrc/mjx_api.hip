@@ -190,8 +190,10 @@ void plan_chunks(mjx_batch *b)
 {
     const size_t n = b->info.size();
     const bool keep = b->opts.keep_coefs != 0;
-    size_t per_chunk = b->opts.chunk_images ? b->opts.chunk_images : 1024;
-    per_chunk = std::min<size_t>(per_chunk, 65535);
+    // A chunk should give every kernel several rounds of workgroups per CU: by default it is closed after ~2 M
+    // subsequences (1 GiB of scan: 1024 4K images, 4096 1080p images); opts.chunk_images fixes the image count instead.
+    const size_t per_chunk = std::min<size_t>(b->opts.chunk_images ? b->opts.chunk_images : 65535, 65535);
+    const uint64_t sub_target = b->opts.chunk_images ? ~uint64_t(0) : (uint64_t(1) << 21);
     const uint64_t kMaxChunkEntries = (uint64_t(24) << 30) / 4;          // 24 GiB of stream capacity per chunk
     b->chunks.clear();
     uint64_t coef_running = 0, ent_running = 0;
@@ -205,7 +207,7 @@ void plan_chunks(mjx_batch *b)
         c.tile_base = keep ? tile_running : 0;
         while (i < n && c.count < per_chunk) {
             const ImageInfo &inf = b->info[i];
-            if (c.count > 0 && c.entries + inf.ent_cap > kMaxChunkEntries) break;
+            if (c.count > 0 && (c.entries + inf.ent_cap > kMaxChunkEntries || c.nsub >= sub_target)) break;
             DevImage &d = b->himages[i];
             if (inf.status == MJX_OK) {
                 d.sub_off = c.nsub;
