@@ -382,7 +382,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     }
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_TAIL)) {
         prof_begin(b, MJX_K_HUFF_SCAN, st);
-        launch_huff_scan(st, nimg, imgs, SCR(d_exit), SCR(d_blkbase), SCR(d_ebase), b->d_img_entries, b->d_img_flags);
+        launch_huff_scan(st, nimg, imgs, SCR(d_exit), SCR(d_blkbase), SCR(d_ebase), b->d_img_entries, b->d_img_flags, b->d_segs);
         prof_end(b, st);
         prof_begin(b, MJX_K_HUFF_WRITE, st);
         launch_huff_write(st, c.max_wg, nimg, b->huff_lds, b->ctx->write_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_blkbase), SCR(d_ebase),

@@ -618,7 +618,8 @@ extern "C" __global__ __launch_bounds__(256) void k_destuff_scatter(const Destuf
 // blkbase[s] / ebase[s] = blocks completed / stream entries produced before subsequence s (one workgroup per image).
 extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *images, const SubseqState *g_exit,
                                                                uint32_t *g_blkbase, uint32_t *g_ebase,
-                                                               uint32_t *img_entries, uint32_t *img_flags)
+                                                               uint32_t *img_entries, uint32_t *img_flags,
+                                                               const uint32_t *segs)
 {
     __shared__ uint32_t s_tmp[4];
     const DevImage &im = images[blockIdx.x];
@@ -637,13 +638,28 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *im
         run_n += g_exit[im.sub_off + s].n;
         run_m += g_exit[im.sub_off + s].m;
     }
+    // The scan ends before every MCU is decoded (truncated file): the reference would go on decoding its 0xAA padding
+    // (huffman.rs:236-246); here the image is reported as truncated and skipped by the later kernels.  With restart
+    // intervals every segment must hold its own blocks (restart_mcus MCUs, the last one what is left): a short segment
+    // would leave tiles without offsets.
+    __shared__ uint32_t s_short;
+    if (tid == 0) s_short = (im.nseg <= 1 && total_n < im.himg.total_blocks) ? 1u : 0u;
+    __threadfence_block();
+    __syncthreads();                                                       // g_blkbase of this image is complete
+    if (im.nseg > 1) {
+        const uint2 *sg = reinterpret_cast<const uint2 *>(segs) + im.seg_off;
+        const uint32_t seg_blocks = im.restart_mcus * im.bpm;
+        for (uint32_t g = tid; g < im.nseg; g += kWgLanes) {
+            const uint32_t s0 = sg[g].x, s1 = sg[g + 1].x;
+            const uint32_t n0 = g_blkbase[im.sub_off + s0], n1 = s1 < nsub ? g_blkbase[im.sub_off + s1] : total_n;
+            const uint32_t want = min(seg_blocks, im.himg.total_blocks - g * seg_blocks);
+            if (n1 - n0 < want) atomicOr(&s_short, 1u);
+        }
+        __syncthreads();
+    }
     if (tid == 0) {
         img_entries[im.status_idx] = total_m;      // upper bound of the entries the write pass produces
-        // The scan ends before every MCU is decoded (truncated file): the reference would go on decoding its 0xAA
-        // padding (huffman.rs:236-246); here the image is reported as truncated and skipped by the later kernels.
-        // (With restart intervals the count includes what follows a segment's last block; missing intervals are found on
-        // the host, mjx_plan.cpp.)
-        img_flags[im.status_idx] = (im.nseg <= 1 && total_n < im.himg.total_blocks) ? 1u : 0u;
+        img_flags[im.status_idx] = s_short;
     }
 }
 
@@ -1497,9 +1513,9 @@ void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
 }
 
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,
-                      uint32_t *ebase, uint32_t *img_entries, uint32_t *img_flags)
+                      uint32_t *ebase, uint32_t *img_entries, uint32_t *img_flags, const uint32_t *segs)
 {
-    hipLaunchKernelGGL(k_huff_scan, dim3(nimg), dim3(kWgLanes), 0, st, images, exit_, blkbase, ebase, img_entries, img_flags);
+    hipLaunchKernelGGL(k_huff_scan, dim3(nimg), dim3(kWgLanes), 0, st, images, exit_, blkbase, ebase, img_entries, img_flags, segs);
 }
 
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,

@@ -344,6 +344,37 @@ def test_restart_intervals_mixed_batch_and_errors(mjx, orc, gpu_ctx, data_dir):
     b3.close()
 
 
+def test_restart_intervals_hostile_inputs(mjx, orc, gpu_ctx):
+    """Corrupted files with restart intervals (stray / missing / moved markers, garbage inside intervals): nothing may
+    fault on the device, every image gets a status, and an intact image in the same batch is unaffected."""
+    d = os.path.join(os.path.dirname(__file__), "golden", "pil")
+    rng = np.random.default_rng(3)
+    good = open(os.path.join(d, "dri_422_rows.jpg"), "rb").read()
+    scans, n_ok_parse = [mjx.ParsedScan(good)], 0
+    for name in ("dri_420_r5", "dri_420_720p_rows", "dri_444_r1"):
+        base = open(os.path.join(d, name + ".jpg"), "rb").read()
+        sos = base.index(b"\xff\xda")
+        for k in range(12):
+            b = bytearray(base)
+            for _ in range(int(rng.integers(1, 10))):
+                b[int(rng.integers(sos + 14, len(b)))] = int(rng.choice([0xff, 0xd0, 0xd3, 0x00, int(rng.integers(0, 256))]))
+            try:
+                scans.append(mjx.ParsedScan(bytes(b)))
+                n_ok_parse += 1
+            except mjx.MjxError:
+                pass
+    assert n_ok_parse > 10
+    batch = mjx.Batch(gpu_ctx, scans, keep_coefs=True, chunk_images=7)
+    batch.decode()
+    batch.wait()
+    for i in range(1, len(scans)):
+        assert batch.status(i) in (mjx.OK, mjx.ERR_TRUNCATED, mjx.ERR_BAD_HUFFMAN, mjx.ERR_INVALID_ARG)
+    ref = orc.decode(good, layout=orc.LAYOUT_STD, ext_dri=True)
+    assert batch.status(0) == mjx.OK
+    _check(ref, batch.coefs(0), batch.rgb(0), "intact image next to corrupted ones")
+    batch.close()
+
+
 # ---- SURVEY s8(f) row 2: byte de-stuffing on the device ---------------------------------------------------------------
 def test_device_side_destuffing_matches_host_destuffing(mjx, orc, gpu_ctx, data_dir):
     datas = [open(os.path.join(data_dir, n), "rb").read() for n in FIXTURES]          # lena.jpeg holds 464 FF00 pairs

@@ -92,6 +92,21 @@ def test_parse_never_crashes_on_mutations(mjx):
         for data in (bytes(b), bytes(b[:cut])):
             for strict in (True, False):
                 assert 0 <= _code(mjx, data, strict) <= mjx.ERR_MISSING_TABLE
+    # a file with restart intervals: mutations anywhere (markers inside the scan included), parse + plan must stay in bounds
+    base = open(os.path.join(os.path.dirname(__file__), "golden", "pil", "dri_420_r5.jpg"), "rb").read()
+    for k in range(200):
+        b = bytearray(base)
+        for _ in range(int(rng.integers(1, 8))):
+            b[int(rng.integers(0, len(b)))] = int(rng.choice([0xff, 0xd0, 0xd7, 0x00, int(rng.integers(0, 256))]))
+        cut = int(rng.integers(1, len(b)))
+        for data in (bytes(b), bytes(b[:cut])):
+            try:
+                scan = mjx.ParsedScan(data)
+            except mjx.MjxError as e:
+                assert 0 < e.code <= mjx.ERR_MISSING_TABLE
+                continue
+            assert 0 <= scan.validate() <= mjx.ERR_MISSING_TABLE
+            scan.close()
 
 
 # ---- entropy algorithm on the CPU emulation ---------------------------------------------------------------
