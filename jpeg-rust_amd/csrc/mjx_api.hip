@@ -488,10 +488,12 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
         inf.tile_blocks = d.tile_blocks;
         inf.ntiles = uint32_t((inf.nblocks + d.tile_blocks - 1) / d.tile_blocks);
         // every stream entry consumes at least 2 bits of scan (1-bit code + 1 value bit) and a block holds at most 63
-        inf.ent_cap = (std::min<uint64_t>(uint64_t(p.scan_len) * 4, inf.nblocks * 63) + 15) / 8 * 8;   // regions start on 32-byte sectors
-        // with restart intervals the lanes fill what the synchronisation passes counted (up to one entry per two bits of
-        // scan, garbage after a segment's last block included) with null entries: see k_huff_write
-        if (p.restart_mcus) inf.ent_cap = (uint64_t(p.scan_len) * 4 + 64 + 15) / 8 * 8;
+        // every subsequence's run of entries is rounded up to a whole 32-byte group (null entries): see k_huff_write
+        const uint64_t group_pad = uint64_t(p.himg.nsub) * 8 + 16;
+        inf.ent_cap = (std::min<uint64_t>(uint64_t(p.scan_len) * 4, inf.nblocks * 63) + group_pad) / 8 * 8;   // regions start on 32-byte sectors
+        // with restart intervals the lanes also fill what the synchronisation passes counted after a segment's last block
+        // (garbage, up to one entry per two bits of scan)
+        if (p.restart_mcus) inf.ent_cap = (uint64_t(p.scan_len) * 4 + 64 + group_pad) / 8 * 8;
         d.ent_cap = uint32_t(std::min<uint64_t>(inf.ent_cap, 0xffffffffu));
         inf.scan_len = p.scan_len;
         inf.rgb_off = rgb_pool;

@@ -73,8 +73,11 @@ struct __attribute__((packed, aligned(4))) Entry4 { uint32_t a, b, c, d; };
 // stores write every sector once.  flush_groups() is called by the whole wave every kFlushEvery symbols
 // (wave-uniform branch); the caller guarantees that at most GROUP dwords are pushed between two calls, so the
 // ring never overflows.  A run that does not start on a group boundary first goes dword-wise up to the next one.
-constexpr uint32_t kFlushEvery = 8;
-template <uint32_t GROUP>
+#ifndef MJX_FLUSH_EVERY
+#define MJX_FLUSH_EVERY 8
+#endif
+constexpr uint32_t kFlushEvery = MJX_FLUSH_EVERY;
+template <uint32_t GROUP, bool ALIGNED = false>
 struct LaneRing {
     static constexpr uint32_t kRing = 2 * GROUP;
     uint32_t *ring;         // the lane's kRing dwords of LDS
@@ -92,24 +95,39 @@ struct LaneRing {
         ring[off & (kRing - 1)] = v;
         off++;
     }
+    __device__ __forceinline__ void store_group()
+    {
+        if constexpr (GROUP >= 4) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(ring + (flushed & (kRing - 1)));
+            uint4 *dst = reinterpret_cast<uint4 *>(out + flushed);
+            uint4 v[GROUP / 4];
+#pragma unroll
+            for (uint32_t q = 0; q < GROUP / 4; q++) v[q] = src[q];
+#pragma unroll
+            for (uint32_t q = 0; q < GROUP / 4; q++) dst[q] = v[q];
+        } else if constexpr (GROUP == 2) {
+            *reinterpret_cast<uint2 *>(out + flushed) = *reinterpret_cast<const uint2 *>(ring + (flushed & (kRing - 1)));
+        } else {
+            out[flushed] = ring[flushed & (kRing - 1)];
+        }
+        flushed += GROUP;
+    }
     __device__ __forceinline__ void flush_groups()
     {
-        while (__builtin_amdgcn_ballot_w64((flushed & (GROUP - 1)) != 0 && flushed < off)) {
-            if ((flushed & (GROUP - 1)) != 0 && flushed < off) {
-                out[flushed] = ring[flushed & (kRing - 1)];
-                flushed++;
+        if constexpr (ALIGNED) {
+            // the run starts on a group boundary and at most GROUP dwords arrive between two calls: one group at most
+            if (__builtin_amdgcn_ballot_w64(flushed + GROUP <= off)) {
+                if (flushed + GROUP <= off) store_group();
             }
-        }
-        while (__builtin_amdgcn_ballot_w64((flushed & (GROUP - 1)) == 0 && flushed + GROUP <= off)) {
-            if ((flushed & (GROUP - 1)) == 0 && flushed + GROUP <= off) {
-                const uint4 *src = reinterpret_cast<const uint4 *>(ring + (flushed & (kRing - 1)));
-                uint4 *dst = reinterpret_cast<uint4 *>(out + flushed);
-                uint4 v[GROUP / 4];
-#pragma unroll
-                for (uint32_t q = 0; q < GROUP / 4; q++) v[q] = src[q];
-#pragma unroll
-                for (uint32_t q = 0; q < GROUP / 4; q++) dst[q] = v[q];
-                flushed += GROUP;
+        } else {
+            while (__builtin_amdgcn_ballot_w64((flushed & (GROUP - 1)) != 0 && flushed < off)) {
+                if ((flushed & (GROUP - 1)) != 0 && flushed < off) {
+                    out[flushed] = ring[flushed & (kRing - 1)];
+                    flushed++;
+                }
+            }
+            while (__builtin_amdgcn_ballot_w64((flushed & (GROUP - 1)) == 0 && flushed + GROUP <= off)) {
+                if ((flushed & (GROUP - 1)) == 0 && flushed + GROUP <= off) store_group();
             }
         }
     }
@@ -123,10 +141,17 @@ struct LaneRing {
 
 // Sink of the write pass: the compact coefficient stream (see coef_entry), DC differences (one per block), tile
 // offsets.  A symbol adds at most one stream entry, a block takes at least two symbols: the rings below hold.
-constexpr uint32_t kAcGroup = 8, kDcGroup = 4;                 // 32-byte sectors of entries, 16 bytes of DC differences
+#ifndef MJX_AC_GROUP
+#define MJX_AC_GROUP 8
+#endif
+#ifndef MJX_DC_GROUP
+#define MJX_DC_GROUP 4
+#endif
+constexpr uint32_t kAcGroup = MJX_AC_GROUP, kDcGroup = MJX_DC_GROUP;                 // 32-byte sectors of entries, 16 bytes of DC differences
 static_assert(kAcGroup >= kFlushEvery && 2 * kDcGroup >= kFlushEvery, "ring capacity between two flushes");
+__device__ __forceinline__ uint32_t stream_run(uint32_t m) { return (m + kAcGroup - 1) & ~(kAcGroup - 1); }
 struct StreamSink {
-    LaneRing<kAcGroup> ac_ring;     // index = entry index in the image's stream region
+    LaneRing<kAcGroup, true> ac_ring;   // index = entry index in the image's stream region; runs are whole groups
     LaneRing<kDcGroup> dc_ring;     // index = block index in the image
     uint32_t *tile_eoff;    // the image's tile offsets (+ sentinel)
     int *status;
@@ -157,7 +182,7 @@ struct StreamSink {
     }
     __device__ __forceinline__ void flush()
     {
-        ac_ring.flush_all();
+        ac_ring.flush_groups();             // (the caller padded the run to a whole group)
         dc_ring.flush_all();
     }
     __device__ __forceinline__ void bad_code(uint32_t) const { atomicOr(status, 1); }
@@ -248,8 +273,12 @@ __device__ __forceinline__ void window_fill(uint32_t *lds, const GlobalBits &g, 
     }
 }
 
-// Decode loop over LDS windows.  All lanes of the wave step together; a lane that is done (left its subsequence,
-// merged with its previous decode, or ran past the last block in the write pass) idles.
+// Decode loop over LDS windows: a plain per-lane loop.  A lane that is done (left its subsequence, merged with its
+// previous decode, or ran past the last block in the write pass) drops out of the exec mask, so its state stays put in
+// its registers; the window restage and the ring flush are uniform over the lanes still active.  (These kernels are
+// bound by vector-instruction issue -- ~2 cycles per wave instruction on a SIMD-32 -- so the form of the loop
+// matters: an `if (running)` body inside a wave-uniform loop made the compiler copy the lane state in and out of
+// temporaries, 20 of 57 vector instructions per step.)
 //   WRITE  emit coefficients through `sink`      CP  0: none, 1: record checkpoints, 2: record + merge (see mjx_huff.h)
 template <bool WRITE, int CP, class Sink, class CpStore>
 __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry, uint32_t end_bit, uint32_t blk,
@@ -271,20 +300,21 @@ __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry,
     const uint32_t total_blocks = blk_limit;                               // (write pass: first block the lane must not write)
     bool running = live && entry.p <= end_bit && !(WRITE && blk >= total_blocks);
     const bool started = running;
-    for (uint32_t it = 1;; it++) {
-        if (!__builtin_amdgcn_ballot_w64(running)) break;
-        if (__builtin_amdgcn_ballot_w64(running && st.wn - 4u >= wbase + 4u * kWinDwords)) {   // wave-uniform: restage every window
-            wbase = st.wn - 4u;                                                 // (w0, w1 are in registers; wn - 4 is read next)
+    uint32_t it = 1;
+    while (running) {                                                          // per-lane loop: finished lanes are masked off
+        if (__builtin_amdgcn_ballot_w64(st.wn - 4u >= wbase + 4u * kWinDwords)) {       // uniform over the active lanes
+            wbase = st.wn - 4u;
             window_fill(my_win, g, wbase);
         }
-        if (running) {
-            const LdsWindow win{reinterpret_cast<const unsigned char *>(my_win), wbase};
-            const bool crossed = symbol_step<WRITE>(st, win, lut, h, blk, sink);
-            bool done = WRITE && blk >= total_blocks;
-            if (crossed) done = lane_event<CP>(st, ev, h, cps) || done;
-            running = !done;
+        const LdsWindow win{reinterpret_cast<const unsigned char *>(my_win), wbase};
+        const bool crossed = symbol_step<WRITE>(st, win, lut, h, blk, sink);
+        bool done = WRITE && blk >= total_blocks;
+        if (crossed) done = lane_event<CP>(st, ev, h, cps) || done;
+        running = !done;
+        if (WRITE) {
+            if (it % kFlushEvery == 0) sink.flush_groups();
+            it++;
         }
-        if (WRITE && it % kFlushEvery == 0) sink.flush_groups();               // wave-uniform
     }
     if (!started) return make_state(entry.p, entry.z, entry.c);
     if (CP) checkpoint_fixup(cps, ev.k, st.n, lane_m(st));
@@ -616,6 +646,7 @@ extern "C" __global__ __launch_bounds__(256) void k_destuff_scatter(const Destuf
 }
 
 // blkbase[s] / ebase[s] = blocks completed / stream entries produced before subsequence s (one workgroup per image).
+// A subsequence's run of stream entries is rounded up to whole store groups (the write pass fills up with null entries).
 extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *images, const SubseqState *g_exit,
                                                                uint32_t *g_blkbase, uint32_t *g_ebase,
                                                                uint32_t *img_entries, uint32_t *img_flags,
@@ -628,7 +659,7 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *im
     const uint32_t per = (nsub + kWgLanes - 1) / kWgLanes;
     const uint32_t a = min(nsub, tid * per), b = min(nsub, a + per);
     uint32_t sum_n = 0, sum_m = 0;
-    for (uint32_t s = a; s < b; s++) { sum_n += g_exit[im.sub_off + s].n; sum_m += g_exit[im.sub_off + s].m; }
+    for (uint32_t s = a; s < b; s++) { sum_n += g_exit[im.sub_off + s].n; sum_m += stream_run(g_exit[im.sub_off + s].m); }
     uint32_t total_n, total_m;
     uint32_t run_n = wg_exclusive_scan(sum_n, s_tmp, &total_n);
     uint32_t run_m = wg_exclusive_scan(sum_m, s_tmp, &total_m);
@@ -636,7 +667,7 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *im
         g_blkbase[im.sub_off + s] = run_n;
         g_ebase[im.sub_off + s] = run_m;
         run_n += g_exit[im.sub_off + s].n;
-        run_m += g_exit[im.sub_off + s].m;
+        run_m += stream_run(g_exit[im.sub_off + s].m);
     }
     // The scan ends before every MCU is decoded (truncated file): the reference would go on decoding its 0xAA padding
     // (huffman.rs:236-246); here the image is reported as truncated and skipped by the later kernels.  With restart
@@ -690,15 +721,17 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
         end_bit = loc.end;
         if (im.nseg > 1) {
             // blocks are counted from the segment's first one (restart_mcus MCUs per segment); the lane stops at the
-            // segment's last block, and fills the rest of what the synchronisation passes counted for it -- garbage
-            // after that block included -- with null entries (position 0, skipped by stage B), so that the stream has no
-            // holes
+            // segment's last block
             const uint32_t seg_blocks = im.restart_mcus * im.bpm, seg_first = loc.seg * seg_blocks;
             blk = seg_first + (blk - g_blkbase[im.sub_off + loc.seg_sub0]);
             blk_limit = min(seg_first + seg_blocks, h->total_blocks);
-            pad_to = ebase + g_exit[im.sub_off + s].m;
-            pad_to = pad_to < im.ent_cap ? pad_to : im.ent_cap;
         }
+        // the lane's run in the stream is what the synchronisation passes counted for it, rounded up to whole store
+        // groups: what it does not produce (group padding, blocks past the last one, garbage after a segment's last
+        // block) is filled with null entries (position 0, skipped by stage B), so the stream has no holes and every
+        // store is a whole aligned group
+        pad_to = ebase + stream_run(g_exit[im.sub_off + s].m);
+        pad_to = pad_to < im.ent_cap ? pad_to : im.ent_cap;
     }
     StreamSink sink;
     sink.tile_eoff = tile_eoff + im.tile_off;
@@ -721,12 +754,10 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
     }
     NoCheckpoints nocp;
     wave_decode<true, 0>(live, e, end_bit, blk, blk_limit, gbits, s_win + threadIdx.x * kWinStride, lut, *h, sink, nocp, 0, e);
-    if (im.nseg > 1) {                                                     // wave-uniform
-        sink.flush_groups();                                               // (the rings hold one flush period, no more)
-        for (uint32_t it = 1; __builtin_amdgcn_ballot_w64(sink.ac_ring.off < pad_to); it++) {
-            if (sink.ac_ring.off < pad_to) sink.ac_ring.push(sink.blk_bits);
-            if (it % kFlushEvery == 0) sink.flush_groups();
-        }
+    sink.flush_groups();                                                   // (the rings hold one flush period, no more)
+    for (uint32_t it = 1; __builtin_amdgcn_ballot_w64(sink.ac_ring.off < pad_to); it++) {
+        if (sink.ac_ring.off < pad_to) sink.ac_ring.push(sink.blk_bits);
+        if (it % kFlushEvery == 0) sink.flush_groups();
     }
     sink.flush();
 }
