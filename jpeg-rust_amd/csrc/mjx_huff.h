@@ -48,27 +48,30 @@ constexpr int kLutPrimarySize = 1 << kLutPrimaryBits;
 constexpr int kMaxBlocksPerMcu = 12;           // 3 components x (2x2)
 
 // ---- decode table entry (uint32) ---------------------------------------------------------------
-//  direct : 64 - adv [31:26] | zinc [25:19] | size [18:15] | len [14:10] | bad [1] | cnt [0]
-//             len  = code length (1..16), size = value bits, adv = len + size (bits the symbol consumes, <= 27)
+//  direct : 0 [31] | bad [30] | zinc [22:16] | 0 [15] | size [14:11] | cnt [8] | adv [4:0]
+//             adv  = code length + size: the bits the symbol consumes (1..27); size = value bits (0..11)
 //             zinc = zig-zag positions the symbol advances: run + 1; 64 for EOB (saturates the block); 16 for ZRL
 //             cnt  = 1 for an AC symbol with size != 0 (it produces one entry of the compact coefficient stream)
 //             bad  = 1 for bit patterns no code matches (huffman.rs:156/162); such an entry consumes one bit and is
 //                    only ever reached through a link
-//           The fields the synchronisation passes need are placed so that two instructions update the lane:
-//           x += e & kLutXMask  (bit budget of the current dword -= adv, entries += cnt)  and  r = sat_sub(r, zinc).
-//  link   : 0 [31:26] | byte offset of the sub-table from the table's base [25:4] | nbits [3:0]
+//           The fields are placed for the lane update (see LaneState and symbol_step; these kernels are bound by
+//           vector-instruction issue, so the count matters):
+//             x -= e & kLutXMask                     bits left in the current dword -= adv, stream entries += cnt
+//             r  = sat_sub(r, e & kLutZincMask)      r is kept scaled by 2^16
+//             value bits = bfe(window, -e, e >> 11)  offset (32 - adv) mod 32 and width size: the low five bits
+//  link   : 1 [31] | byte offset of the sub-table from the table's base [19:4] | nbits [3:0]
 typedef uint32_t LutEntry;
-constexpr uint32_t kLutDirectMin = 1u << 26;         // direct entries are >= this (64 - adv >= 33), links below
-constexpr uint32_t kLutXMask = 0xfc000001u;
-constexpr uint32_t kLutBad = 2u, kLutCnt = 1u;
+constexpr uint32_t kLutLink = 0x80000000u;
+constexpr uint32_t kLutXMask = 0x0000011fu, kLutZincMask = 0x007f0000u;
+constexpr uint32_t kLutBad = 1u << 30, kLutCnt = 1u << 8;
 MJX_HD constexpr LutEntry lut_direct(unsigned len, unsigned run, unsigned size, bool is_ac)
 {
-    return ((64u - (len + size)) << 26) | ((run + 1u) << 19) | (size << 15) | (len << 10) | ((is_ac && size) ? kLutCnt : 0u);
+    return ((run + 1u) << 16) | (size << 11) | ((is_ac && size) ? kLutCnt : 0u) | (len + size);
 }
 MJX_HD constexpr LutEntry lut_invalid() { return lut_direct(1, 0, 0, false) | kLutBad; }
-MJX_HD constexpr LutEntry lut_link(unsigned offset_entries, unsigned nbits) { return ((offset_entries * 4u) << 4) | nbits; }
-MJX_HD constexpr bool lut_is_link(LutEntry e) { return e < kLutDirectMin; }
-MJX_HD constexpr unsigned lut_link_offset(LutEntry e) { return (e >> 4) / 4u; }      // entries
+MJX_HD constexpr LutEntry lut_link(unsigned offset_entries, unsigned nbits) { return kLutLink | ((offset_entries * 4u) << 4) | nbits; }
+MJX_HD constexpr bool lut_is_link(LutEntry e) { return int32_t(e) < 0; }
+MJX_HD constexpr unsigned lut_link_offset(LutEntry e) { return ((e >> 4) & 0xffffu) / 4u; }      // entries
 
 // ---- per-subsequence synchronisation state -------------------------------------------------------------------
 // The first 8 bytes (what the next subsequence must start from) are read while other lanes may rewrite them, so they
@@ -122,7 +125,8 @@ static_assert(sizeof(HuffImage) % 16 == 0, "the decode tables follow HuffImage i
 
 // ---- compact coefficient stream -------------------------------------------------------------------------------
 // One 32-bit entry per non-zero AC coefficient, in decode order:  value[15:0] | zig-zag position[21:16] | block[29:22]
-// (low 8 bits of the block's index inside the image).  DC differences go to a separate array, one per block.
+// (low 8 bits of the block's index inside the image; bits 30-31 carry nothing and are not looked at).  DC differences
+// go to a separate array, one per block.
 MJX_HD constexpr uint32_t coef_entry(int val, uint32_t pos, uint32_t blk)
 {
     return (uint32_t(val) & 0xffffu) | (pos << 16) | ((blk & 0xffu) << 22);
@@ -130,8 +134,8 @@ MJX_HD constexpr uint32_t coef_entry(int val, uint32_t pos, uint32_t blk)
 
 // A sink that discards everything (synchronisation passes).
 struct NullSink {
-    MJX_HD void dc(uint32_t, int) const {}
-    MJX_HD void ac(uint32_t, unsigned, int) const {}
+    MJX_HD void dc(uint32_t, int) const {}                       // (block, value)
+    MJX_HD void ac(uint32_t, uint32_t, int) const {}             // (block, r after the symbol -- scaled, see LaneState --, value)
     MJX_HD void block_done(uint32_t) const {}
     MJX_HD void bad_code(uint32_t) const {}
     MJX_HD void tick() const {}          // one call per decoded symbol (statistics in the CPU emulation)
@@ -161,26 +165,30 @@ struct NoCheckpoints {
 
 // Registers of one lane's decoder.  The stream is seen through two big-endian dwords w0 w1; the lane's position is
 //     p = 8 * (wn - 8) - t,      t = bits of w0 not yet consumed (0..31),      wn - 8 = byte offset of w1,
-// so the next 32 bits of the stream are the funnel shift {w0,w1} >> t.  t lives in the top six bits of x and the
-// stream-entry count m in the low 26, so one add of the masked table entry moves both; t < 0 (sign of x) = the lane
-// has moved into w1 and takes the next dword.  That dword (at wn - 4) is read on every step together with the table
-// lookup -- the bit source is an LDS window on the device, so the read is cheap but not free to wait for -- and is at
-// hand when a refill needs it.  Everything that depends on p alone (end of the subsequence, checkpoints) is only
-// looked at on that refill: boundaries are multiples of 32 bits.
+// so the next 32 bits of the stream are the funnel shift {w0,w1} >> t (the shifter reads the low five bits of x).
+// t lives in the low byte of x and a down-counter of the stream entries in the upper 24 bits, so one subtraction of
+// the masked table entry moves both; a low byte above 31 (the borrow went through it) = the lane has moved into w1
+// and takes the next dword: x += 32 puts t back into 0..31 and returns the borrow.  That dword (at wn - 4) is read on
+// every step together with the table lookup -- the bit source is an LDS window on the device, so the read is cheap
+// but not free to wait for -- and is at hand when a refill needs it.  Everything that depends on p alone (end of the
+// subsequence, checkpoints) is only looked at on that refill: boundaries are multiples of 32 bits.
+constexpr uint32_t kLaneM0 = 0xffffffu;    // the entry counter starts here and counts down
+constexpr uint32_t kRShift = 16, kRBlock = 64u << kRShift;
 struct LaneState {
-    uint32_t x;             // t [31:26] (signed) | m [25:0]
-    uint32_t r;             // coefficients left in the current block: 64 - zig-zag index
+    uint32_t x;             // kLaneM0 - m [31:8] | t [7:0]
+    uint32_t r;             // coefficients left in the current block (64 - zig-zag index), scaled by 2^16
     uint32_t n;             // blocks completed
     BlockTab nb;            // table entry of the block after the current one, fetched when the current block began
                             // (off the critical path); nb.next = block-in-MCU of the block after that
-    uint32_t base, acb;     // byte offset of the table of the next symbol / of the current block's AC table
+    uint32_t dcb, acb;      // byte offsets of the current block's DC / AC table (the DC table is used while r == 64)
     uint32_t wn;            // byte offset of the dword after w1, + 4
     uint32_t w0, w1;
 };
-MJX_HD uint32_t lane_t(const LaneState &st) { return st.x >> 26; }
-MJX_HD uint32_t lane_m(const LaneState &st) { return st.x & 0x3ffffffu; }
+MJX_HD uint32_t lane_t(const LaneState &st) { return st.x & 31u; }
+MJX_HD uint32_t lane_m(const LaneState &st) { return kLaneM0 - (st.x >> 8); }
+MJX_HD void lane_add_m(LaneState &st, uint32_t m) { st.x -= m << 8; }
 MJX_HD uint32_t lane_pos(const LaneState &st) { return 8u * (st.wn - 8u) - lane_t(st); }
-MJX_HD uint32_t lane_z(const LaneState &st) { return 64u - st.r; }
+MJX_HD uint32_t lane_z(const LaneState &st) { return 64u - (st.r >> kRShift); }
 MJX_HD uint32_t lane_c(const LaneState &st, const HuffImage &img)
 {
     const uint32_t c1 = (st.nb.next ? st.nb.next : img.bpm) - 1u;     // the next block
@@ -200,7 +208,9 @@ MJX_HD uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh)      // low 32 bit
 MJX_HD uint32_t sat_sub(uint32_t a, uint32_t b)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_elementwise_sub_sat(a, b);
+    uint32_t d;                                                      // (opaque to the compiler: it would turn the test
+    asm("v_sub_u32_e64 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));   // "difference == 0" into "a <= b" and a copy)
+    return d;
 #else
     return a > b ? a - b : 0u;
 #endif
@@ -210,7 +220,16 @@ MJX_HD uint32_t bits_field(uint32_t v, uint32_t off, uint32_t width)   // width 
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_ubfe(v, off, width);
 #else
-    return width ? (v >> (off & 31)) & (0xffffffffu >> (32 - width)) : 0u;
+    return (width & 31u) ? (v >> (off & 31u)) & (0xffffffffu >> (32u - (width & 31u))) : 0u;
+#endif
+}
+MJX_HD int32_t bits_field_signed(uint32_t v, uint32_t off, uint32_t width)   // sign-extended from the field's top bit; width 0 -> 0
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sbfe(int32_t(v), off, width);
+#else
+    const uint32_t f = bits_field(v, off, width);
+    return (width & 31u) && (f >> ((width & 31u) - 1u)) ? int32_t(f) - int32_t(1u << (width & 31u)) : int32_t(f);
 #endif
 }
 MJX_HD LutEntry lut_at(const LutEntry *lut, uint32_t byte_off)
@@ -225,20 +244,30 @@ MJX_HD LutEntry lut_at(const LutEntry *lut, uint32_t byte_off)
 #endif
 }
 
-//   BitSrc::be32(b)  -> big-endian dword at byte offset b of the image's scan (0xAAAAAAAA past the end,
-//                       huffman.rs:236-246)
+// Slot of the primary table the next kLutPrimaryBits bits select.  The primary tables start on multiples of their
+// size (mjx_plan.cpp lays the tables out that way; on the device the tables sit at the start of the workgroup's LDS,
+// itself aligned), so the index is OR-ed in.
+MJX_HD uint32_t lut_slot(uint32_t base, uint32_t w)
+{
+    return ((w >> (32 - kLutPrimaryBits - 2)) & uint32_t((kLutPrimarySize - 1) * 4)) | base;
+}
+
+//   BitSrc::be32(b)   -> big-endian dword at byte offset b of the image's scan (0xAAAAAAAA past the end,
+//                        huffman.rs:236-246)
+//   BitSrc::ahead(b)  -> the same for b = wn - 4, the dword a lane reads on every step (a source may keep a read
+//                        pointer for it: advance() is called whenever wn moves on by 4)
 template <class BitSrc>
 MJX_HD void lane_begin(LaneState &st, const BitSrc &bits, const HuffImage &img, SubseqState entry)
 {
     const uint32_t wi1 = (entry.p + 31u) >> 5;                   // dwords lying completely below p, rounded up
     st.wn = 4u * wi1 + 8u;
-    st.x = (32u * wi1 - entry.p) << 26;
-    st.r = 64u - entry.z;
+    st.x = (kLaneM0 << 8) | (32u * wi1 - entry.p);
+    st.r = (64u - entry.z) << kRShift;
     st.n = 0;
     const BlockTab bt = img.btab[entry.c];
     st.nb = img.btab[bt.next];
     st.acb = bt.tabs >> 16;
-    st.base = entry.z ? st.acb : (bt.tabs & 0xffffu);
+    st.dcb = bt.tabs & 0xffffu;
     st.w0 = wi1 ? bits.be32(st.wn - 12u) : 0u;                   // p == 0: all of w0 is "consumed", nothing to load
     st.w1 = bits.be32(st.wn - 8u);
 }
@@ -246,45 +275,47 @@ MJX_HD void lane_begin(LaneState &st, const BitSrc &bits, const HuffImage &img, 
 // One Huffman symbol: table lookup, EXTEND, coefficient placement, state update, window refill.
 // Returns true when the lane moved on to the next dword of the stream (the caller then looks at lane_event).
 template <bool WRITE, class BitSrc, class Sink>
-MJX_HD bool symbol_step(LaneState &st, const BitSrc &bits, const LutEntry *lut, const HuffImage &img, uint32_t &blk,
+MJX_HD bool symbol_step(LaneState &st, BitSrc &bits, const LutEntry *lut, const HuffImage &img, uint32_t &blk,
                         Sink &sink)
 {
-    const uint32_t w = funnel(st.w0, st.w1, lane_t(st));                          // next 32 bits of the stream
-    const uint32_t ahead = bits.be32(st.wn - 4u);                                 // the dword after w1 (see LaneState)
-    const uint32_t base = st.base;
-    LutEntry e = lut_at(lut, base + (w >> (32 - kLutPrimaryBits)) * 4u);
-    st.base = st.acb;                                                             // (overridden when the block ends)
+    const uint32_t w = funnel(st.w0, st.w1, st.x);                                // next 32 bits of the stream
+    const uint32_t ahead = bits.ahead(st.wn - 4u);                                // the dword after w1 (see LaneState)
+    const uint32_t base = st.r == kRBlock ? st.dcb : st.acb;                      // (tables are aligned: see lut_slot)
+    LutEntry e = lut_at(lut, lut_slot(base, w));
     if (lut_is_link(e)) {
         const uint32_t nb = e & 15u;
-        e = lut_at(lut, base + (e >> 4) + bits_field(w, 32u - kLutPrimaryBits - nb, nb) * 4u);
+        e = lut_at(lut, base + bits_field(e, 4, 16) + bits_field(w, 32u - kLutPrimaryBits - nb, nb) * 4u);
         if (WRITE && (e & kLutBad)) sink.bad_code(blk);                           // (invalid patterns always come this way)
     }
     sink.tick();
     const uint32_t r_old = st.r;
-    st.r = sat_sub(st.r, (e >> 19) & 127u);
+    st.r = sat_sub(st.r, e & kLutZincMask);
     if (WRITE) {
-        const uint32_t len = (e >> 10) & 31u, size = (e >> 15) & 15u;
-        const uint32_t v = w << len;                                              // value bits, left aligned
-        const uint32_t vb = (v >> 1) >> (31 - size);                              // size == 0 -> 0
-        const int32_t val = int32_t(vb) - int32_t(((1u << size) - 1u) & ((v >> 31) - 1u));   // EXTEND, T.81 F.2
-        if (r_old == 64) sink.dc(blk, val);
-        else if (e & kLutCnt) sink.ac(blk, 63u - st.r, val);
+        // EXTEND (T.81 F.2, huffman.rs:256-268) without a comparison: g = the value bits sign-extended from their leading
+        // bit; flipping everything above them gives the value itself (leading bit 1) or value - 1 (leading bit 0)
+        const uint32_t size = e >> 11;                                            // (the low five bits count)
+        const int32_t g = bits_field_signed(w, 0u - e, size);
+        const int32_t hflip = g ^ int32_t(0xffffffffu << (size & 31u));
+        const int32_t val = hflip - (hflip >> 31);
+        if (r_old == kRBlock) sink.dc(blk, val);
+        else if (e & kLutCnt) sink.ac(blk, st.r, val);
     }
-    st.x += e & kLutXMask;
+    st.x -= e & kLutXMask;
     if (st.r == 0) {
-        st.r = 64;
-        st.base = st.nb.tabs & 0xffffu;
+        st.r = kRBlock;
+        st.dcb = st.nb.tabs & 0xffffu;
         st.acb = st.nb.tabs >> 16;
         st.nb = img.btab[st.nb.next];
         st.n++;
         blk++;
         if (WRITE) sink.block_done(blk);
     }
-    if (int32_t(st.x) < 0) {
-        st.x ^= 0x80000000u;                                                      // t += 32
+    if ((st.x & 0xffu) > 31u) {
+        st.x += 32u;                                                              // t += 32, the borrow goes back
         st.w0 = st.w1;
         st.w1 = ahead;
         st.wn += 4;
+        bits.advance();
         return true;
     }
     return false;
@@ -309,7 +340,7 @@ MJX_HD void events_begin(LaneEvents &ev, uint32_t sub_start, uint32_t end_bit)
 // Returns true when the lane is finished.  Otherwise (a checkpoint boundary was crossed): compares with the state the
 // previous decode recorded there (CP == 2; equal = the decodes coincide from here on), or records the lane's state
 // with the counts so far and moves to the next boundary.
-MJX_HD uint32_t cp_state_word(const LaneState &st) { return lane_t(st) | (st.r << 5) | (st.nb.next << 12) | kCpValid; }
+MJX_HD uint32_t cp_state_word(const LaneState &st) { return lane_t(st) | (st.r >> (kRShift - 5)) | (st.nb.next << 12) | kCpValid; }
 template <int CP, class CpStore>
 MJX_HD bool lane_event(LaneState &st, LaneEvents &ev, const HuffImage &img, CpStore &cps)
 {
@@ -321,7 +352,7 @@ MJX_HD bool lane_event(LaneState &st, LaneEvents &ev, const HuffImage &img, CpSt
             const uint32_t old = cps.get(ev.k);
             if ((old & kCpStateMask) == state) {
                 st.n += (old >> 16) & 0x7fffu;
-                st.x += cps.get_m(ev.k);
+                lane_add_m(st, cps.get_m(ev.k));
                 ev.merged = true;
                 return true;
             }
@@ -332,6 +363,16 @@ MJX_HD bool lane_event(LaneState &st, LaneEvents &ev, const HuffImage &img, CpSt
         if (ev.next_wn > ev.end_wn) ev.next_wn = ev.end_wn;
     }
     return false;
+}
+// The recording half of lane_event for decodes that never merge (CP == 1), for callers that test the boundaries
+// themselves: the lane has reached ev.next_wn and is still inside its subsequence.
+template <class CpStore>
+MJX_HD void checkpoint_record(const LaneState &st, LaneEvents &ev, CpStore &cps)
+{
+    cps.set(ev.k, cp_state_word(st) | (st.n << 16), lane_m(st));
+    ev.k++;
+    ev.next_wn += kCpBits / 8;
+    if (ev.next_wn > ev.end_wn) ev.next_wn = ev.end_wn;
 }
 MJX_HD SubseqState lane_exit(const LaneState &st, const LaneEvents &ev, const HuffImage &img, const SubseqState &old_exit)
 {
@@ -364,7 +405,7 @@ MJX_HD void checkpoint_fixup(CpStore &cps, uint32_t k, uint32_t n_total, uint32_
 //   CP               -> 0: no checkpoints; 1: record checkpoints in `cps`; 2: record and merge with the previous
 //                       decode of this subsequence (`sub_start` = its first bit, `old_exit` = that decode's exit)
 template <bool WRITE, int CP, class BitSrc, class Sink, class CpStore>
-MJX_HD SubseqState decode_subseq(const BitSrc &bits, const LutEntry *lut, const HuffImage &img, SubseqState entry,
+MJX_HD SubseqState decode_subseq(BitSrc bits, const LutEntry *lut, const HuffImage &img, SubseqState entry,
                                  uint32_t end_bit, uint32_t blk, Sink &sink, CpStore &cps, uint32_t sub_start,
                                  SubseqState old_exit)
 {

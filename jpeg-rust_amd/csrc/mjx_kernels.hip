@@ -98,13 +98,12 @@ struct LaneRing {
     __device__ __forceinline__ void store_group()
     {
         if constexpr (GROUP >= 4) {
+            static_assert(GROUP == 4 || GROUP == 8, "one or two 16-byte stores");
             const uint4 *src = reinterpret_cast<const uint4 *>(ring + (flushed & (kRing - 1)));
             uint4 *dst = reinterpret_cast<uint4 *>(out + flushed);
-            uint4 v[GROUP / 4];
-#pragma unroll
-            for (uint32_t q = 0; q < GROUP / 4; q++) v[q] = src[q];
-#pragma unroll
-            for (uint32_t q = 0; q < GROUP / 4; q++) dst[q] = v[q];
+            const uint4 v0 = src[0], v1 = src[GROUP / 4 - 1];
+            dst[0] = v0;
+            if constexpr (GROUP == 8) dst[1] = v1;
         } else if constexpr (GROUP == 2) {
             *reinterpret_cast<uint2 *>(out + flushed) = *reinterpret_cast<const uint2 *>(ring + (flushed & (kRing - 1)));
         } else {
@@ -155,20 +154,22 @@ struct StreamSink {
     LaneRing<kDcGroup> dc_ring;     // index = block index in the image
     uint32_t *tile_eoff;    // the image's tile offsets (+ sentinel)
     int *status;
-    uint32_t blk_bits;      // the current block's index, placed as in coef_entry
+    uint32_t blk_bits;      // the current block's index, placed as in coef_entry (bits above the field: don't care),
+                            // + 63 << 16: minus the scaled r = position
     uint32_t next_tile_blk, tile_idx, tile_blocks, total_blocks, ntiles;
+    static __device__ __forceinline__ uint32_t block_bits(uint32_t blk) { return ((blk & 0xffu) << 22) + (63u << kRShift); }
     __device__ __forceinline__ void dc(uint32_t b, int v)
     {
-        dc_ring.push(uint32_t(v));          // (b == dc_ring.off - 1: a lane's blocks are consecutive)
+        dc_ring.push(uint32_t(v));                  // (b == dc_ring.off - 1: a lane's blocks are consecutive)
         if (b == next_tile_blk) {           // first block of a stage-B tile: remember where its entries start
             tile_eoff[tile_idx] = ac_ring.off;
             tile_idx++;
             next_tile_blk += tile_blocks;
         }
     }
-    __device__ __forceinline__ void ac(uint32_t, unsigned pos, int v)
+    __device__ __forceinline__ void ac(uint32_t, uint32_t r_scaled, int v)
     {
-        ac_ring.push((uint32_t(v) & 0xffffu) | (pos << 16) | blk_bits);     // coef_entry
+        ac_ring.push((uint32_t(v) & 0xffffu) | (blk_bits - r_scaled));      // coef_entry: position = 63 - r
     }
     __device__ __forceinline__ void flush_groups()          // wave-uniform call
     {
@@ -177,7 +178,7 @@ struct StreamSink {
     }
     __device__ __forceinline__ void block_done(uint32_t next_blk)
     {
-        blk_bits = (next_blk & 0xffu) << 22;
+        blk_bits += 1u << 22;
         if (next_blk == total_blocks) tile_eoff[ntiles] = ac_ring.off;
     }
     __device__ __forceinline__ void flush()
@@ -189,13 +190,15 @@ struct StreamSink {
     __device__ __forceinline__ void tick() const {}
 };
 
-// Decode tables + per-image constants into LDS (dynamic LDS: HuffImage, then the tables).
+// Decode tables + per-image constants into LDS (dynamic LDS: the tables, then HuffImage).  The dynamic LDS of the
+// entropy kernels is declared with the alignment of a primary table (kLutAlign), which lut_slot relies on.
+constexpr uint32_t kLutAlign = kLutPrimarySize * sizeof(LutEntry);
 __device__ __forceinline__ void stage_tables(const DevImage &im, const LutEntry *lut_pool, unsigned char *smem,
                                              const HuffImage *&himg, const LutEntry *&lut)
 {
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
-    HuffImage *h = reinterpret_cast<HuffImage *>(smem);
-    LutEntry *l = reinterpret_cast<LutEntry *>(smem + sizeof(HuffImage));
+    LutEntry *l = reinterpret_cast<LutEntry *>(smem);
+    HuffImage *h = reinterpret_cast<HuffImage *>(smem + size_t(im.lut_n) * sizeof(LutEntry));
     for (uint32_t i = tid; i < sizeof(HuffImage) / 4; i += nthr)
         reinterpret_cast<uint32_t *>(h)[i] = reinterpret_cast<const uint32_t *>(&im.himg)[i];
     const uint4 *lsrc = reinterpret_cast<const uint4 *>(lut_pool + im.lut_off);
@@ -258,8 +261,11 @@ constexpr int kWinDwords = MJX_WIN_DWORDS;
 constexpr int kWinStride = kWinDwords + 1;      // odd stride: lanes spread over all banks
 struct LdsWindow {
     const unsigned char *lds;    // lane's window
-    uint32_t wbase;              // stream byte offset of the window's first dword
+    uint32_t wbase;              // stream byte offset of the window's first dword (as of the last fill the caller noted)
+    uint32_t rp;                 // read pointer (LDS address): the dword after w1 (stream offset wn - 4)
     __device__ __forceinline__ uint32_t be32(uint32_t byte_off) const { return *reinterpret_cast<const uint32_t *>(lds + (byte_off - wbase)); }
+    __device__ __forceinline__ uint32_t ahead(uint32_t) const { return *(const volatile __attribute__((address_space(3))) uint32_t *)(rp); }   // (volatile: one plain read per step, not folded into the restage branch)
+    __device__ __forceinline__ void advance() { rp += 4; }
 };
 __device__ __forceinline__ void window_fill(uint32_t *lds, const GlobalBits &g, uint32_t wbase)
 {
@@ -288,29 +294,35 @@ __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry,
 {
     LaneState st;
     LaneEvents ev;
+    const unsigned char *win_lds = reinterpret_cast<const unsigned char *>(my_win);
+    const uint32_t win_addr = uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)(my_win)));
+    LdsWindow win;
     {
         const uint32_t first = 4u * ((entry.p + 31u) >> 5);                     // byte offset of the lane's w1
-        LdsWindow win{reinterpret_cast<const unsigned char *>(my_win), first ? first - 4u : 0u};
+        win = LdsWindow{win_lds, first ? first - 4u : 0u, 0u};
         window_fill(my_win, g, win.wbase);
         lane_begin(st, win, h, entry);
+        win.rp = win_addr + (st.wn - 4u - win.wbase);
     }
     events_begin<CP>(ev, sub_start, end_bit);
-    uint32_t wbase = st.wn - 12u;
-    if (st.wn == 8u) wbase = 0;
+    const uint32_t win_end = win_addr + 4u * kWinDwords;
     const uint32_t total_blocks = blk_limit;                               // (write pass: first block the lane must not write)
     bool running = live && entry.p <= end_bit && !(WRITE && blk >= total_blocks);
     const bool started = running;
     uint32_t it = 1;
     while (running) {                                                          // per-lane loop: finished lanes are masked off
-        if (__builtin_amdgcn_ballot_w64(st.wn - 4u >= wbase + 4u * kWinDwords)) {       // uniform over the active lanes
-            wbase = st.wn - 4u;
-            window_fill(my_win, g, wbase);
+        if (__builtin_amdgcn_ballot_w64(win.rp >= win_end)) {                  // uniform over the active lanes: restage
+            window_fill(my_win, g, st.wn - 4u);                                // (w0, w1 are in registers; wn - 4 is read next)
+            win.rp = win_addr;
         }
-        const LdsWindow win{reinterpret_cast<const unsigned char *>(my_win), wbase};
-        const bool crossed = symbol_step<WRITE>(st, win, lut, h, blk, sink);
-        bool done = WRITE && blk >= total_blocks;
-        if (crossed) done = lane_event<CP>(st, ev, h, cps) || done;
-        running = !done;
+        (void)symbol_step<WRITE>(st, win, lut, h, blk, sink);
+        // Events (checkpoints, the end of the subsequence) are due when wn -- it only moves when the lane takes a new
+        // dword -- has reached a boundary.  Both are tested on wn alone, as two flat conditions: these loops are bound
+        // by scalar-instruction issue (one per SIMD turn), and exec-mask bookkeeping for nested "crossed -> event ->
+        // done" conditions cost more than the vector work it guarded.
+        static_assert(CP == 0 || CP == 1, "the kernels record checkpoints or not; merging re-decodes go slice-wise (merge_slice)");
+        if (CP == 1 && st.wn >= ev.next_wn && st.wn < ev.end_wn) checkpoint_record(st, ev, cps);
+        running = st.wn < ev.end_wn && !(WRITE && blk >= total_blocks);
         if (WRITE) {
             if (it % kFlushEvery == 0) sink.flush_groups();
             it++;
@@ -329,7 +341,7 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_spec(const DevImage
                                                                    SubseqState *g_exit, uint32_t *g_cps, uint32_t win_off,
                                                                    const uint32_t *segs)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // HuffImage, tables, [windows]
+    extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, windows
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
     const DevImage &im = images[blockIdx.y];
     if (!im.valid || blockIdx.x * kHuffWg >= im.himg.nsub) return;
@@ -394,11 +406,12 @@ __device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, c
             my_win[4 * q + 2] = __builtin_bswap32(v.z);
             my_win[4 * q + 3] = __builtin_bswap32(v.w);
         }
-        const LdsWindow win{reinterpret_cast<const unsigned char *>(my_win), wbase};
+        LdsWindow win{reinterpret_cast<const unsigned char *>(my_win), wbase, 0u};
         LaneState st;
         lane_begin(st, win, h, x);
+        win.rp = uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)(my_win))) + (st.wn - 4u - wbase);
         st.n = it.n;
-        st.x += it.m;
+        lane_add_m(st, it.m);
         const uint32_t end_wn = wn_after(end_bit);
         uint32_t stop_wn = wn_after(sub_start + (it.k + 1) * kCpBits);
         stop_wn = stop_wn < end_wn ? stop_wn : end_wn;
@@ -444,9 +457,9 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
                                                                 uint32_t win_off, uint32_t *g_items, uint32_t *g_item_count,
                                                                 const uint32_t *segs)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // HuffImage, tables, windows (= item exchange)
-    __shared__ uint32_t s_cnt[kMergeWg / 64];
+    extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, windows (= item exchange), wave counts
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
+    uint32_t *s_cnt = s_win + kMergeWg * kMergeStride;                     // (no static LDS: it would be padded to the dynamic part's alignment)
     const DevImage &im = images[blockIdx.y];
     if (!im.valid || blockIdx.x * kMergeWg + 1 >= im.himg.nsub) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -521,7 +534,7 @@ extern "C" __global__ __launch_bounds__(64) void k_huff_merge_tail(const DevImag
                                                                     const uint32_t *g_items, const uint32_t *g_item_count,
                                                                     const uint32_t *segs)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // HuffImage, tables, 64 windows
+    extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, 64 windows
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
     // Workgroup (image, group): the image is the fast grid dimension, so that the groups that have items -- the first
     // few of every image -- are consecutive workgroup ids and spread over all XCDs and CUs; with the group as the fast
@@ -701,7 +714,7 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
                                                                 int *status, const uint32_t *img_flags, uint32_t win_off,
                                                                 const uint32_t *segs, const SubseqState *g_exit)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // HuffImage, tables, windows, rings
+    extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, windows, rings
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
     const DevImage &im = images[blockIdx.y];
     if (!im.valid || blockIdx.x * kHuffWg >= im.himg.nsub || img_flags[im.status_idx]) return;
@@ -744,7 +757,7 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
         sink.dc_ring.begin(rings + threadIdx.x * LaneRing<kDcGroup>::kRing,
                            reinterpret_cast<uint32_t *>(dcbuf + im.coef_off), first_start);
     }
-    sink.blk_bits = (blk & 0xffu) << 22;
+    sink.blk_bits = StreamSink::block_bits(blk);
     sink.tile_blocks = im.tile_blocks;
     sink.total_blocks = h->total_blocks;
     sink.ntiles = (h->total_blocks + im.tile_blocks - 1) / im.tile_blocks;
@@ -756,7 +769,7 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
     wave_decode<true, 0>(live, e, end_bit, blk, blk_limit, gbits, s_win + threadIdx.x * kWinStride, lut, *h, sink, nocp, 0, e);
     sink.flush_groups();                                                   // (the rings hold one flush period, no more)
     for (uint32_t it = 1; __builtin_amdgcn_ballot_w64(sink.ac_ring.off < pad_to); it++) {
-        if (sink.ac_ring.off < pad_to) sink.ac_ring.push(sink.blk_bits);
+        if (sink.ac_ring.off < pad_to) sink.ac_ring.push(0u);              // null entry
         if (it % kFlushEvery == 0) sink.flush_groups();
     }
     sink.flush();
@@ -1183,7 +1196,7 @@ __device__ __forceinline__ void scatter_entry(uint32_t e, uint32_t first_lo, uin
 {
     const uint32_t b = ((e >> 22) - first_lo) & 0xffu;
     const uint32_t pos = (e >> 16) & 63u;
-    // pos == 0 marks a null entry (the write pass fills holes with them when restart intervals cut a lane short)
+    // pos == 0 marks a null entry (the write pass fills up its runs with them)
     if (b < nblk && pos != 0) tile_f[b * kPixStride + s_nat[pos]] = float(int32_t(int16_t(e & 0xffffu))) * s_qm[s_comp[b] * 64 + pos];
 }
 
@@ -1410,7 +1423,8 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
                                                      uint8_t *__restrict__ rgb, unsigned long long *__restrict__ planes,
                                                      const uint32_t *__restrict__ img_flags)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // (its own symbol: dynamic LDS arrays of one name share their alignment, and the entropy kernels ask for 2 KiB)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_px[];
     __shared__ float s_qm[3 * 64];
     __shared__ uint8_t s_nat[64];
     __shared__ uint8_t s_comp[256];
@@ -1442,13 +1456,13 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
         s_nat[tid] = ZZ[tid];
     }
     if (tid < tile_blocks) s_comp[tid] = im.blk_comp[tid % bpm];
-    float *tile_f = reinterpret_cast<float *>(smem);
+    float *tile_f = reinterpret_cast<float *>(smem_px);
 
     for (uint32_t tile = tile0; tile < tile1; tile++) {
         const uint32_t m0 = tile * T;
         const uint32_t nm = min(T, nmcu - m0), nblk = nm * bpm;
         {   // phase 0
-            float4 *z = reinterpret_cast<float4 *>(smem);
+            float4 *z = reinterpret_cast<float4 *>(smem_px);
             const uint32_t nq = nblk * (kPixStride / 4);
             for (uint32_t i = tid; i < nq; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -1537,7 +1551,7 @@ void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
                        uint32_t *cps, uint32_t *mismatches, uint32_t *items, uint32_t *item_count, const uint32_t *segs)
 {
     (void)hipMemsetAsync(item_count, 0, size_t(nimg) * sizeof(uint32_t), st);
-    const size_t lds = tables_lds + size_t(kMergeWg) * kMergeStride * 4 + pad_lds;
+    const size_t lds = tables_lds + size_t(kMergeWg) * kMergeStride * 4 + (kMergeWg / 64) * 4 + pad_lds;
     hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches, uint32_t(tables_lds), items, item_count, segs);
     const size_t tail_lds = tables_lds + size_t(64) * kMergeStride * 4;
     hipLaunchKernelGGL(k_huff_merge_tail, dim3(nimg, max_wg * (kMergeWg / 64)), dim3(64), tail_lds, st, images, scan_pool, lut_pool, exit_, cps, uint32_t(tables_lds), items, item_count, segs);

@@ -137,16 +137,18 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p)
         if (rc != MJX_OK) return fail(rc);
     }
 
-    // decode tables: each distinct (class, slot) used by the scan is built once
+    // decode tables: each distinct (class, slot) used by the scan is built once.  Layout: the primary tables first, each
+    // on a multiple of its size (lut_slot ORs the index into the base), then the sub-tables; a table's links are
+    // relative to its own primary table.
     int dc_base[4] = {-1, -1, -1, -1}, ac_base[4] = {-1, -1, -1, -1};
     p.lut.clear();
     static thread_local LutEntry tmp[kLutPrimarySize + 4096];
+    std::vector<std::vector<LutEntry>> built;
     auto add_table = [&](const mjx_hufftab &t, bool is_dc) -> int {
         const int n = build_decode_table(t.bits, t.vals, is_dc, tmp, int(sizeof tmp / sizeof tmp[0]));
         if (n < 0) return n;
-        const int base = int(p.lut.size());
-        p.lut.insert(p.lut.end(), tmp, tmp + n);
-        return base;
+        built.emplace_back(tmp, tmp + n);
+        return int(built.size() - 1) * kLutPrimarySize;
     };
     for (uint32_t c = 0; c < p.ncomp; c++) {
         const mjx_comp &k = d.comp[c];
@@ -159,6 +161,21 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p)
             const int b = add_table(d.ac[k.ta], false);
             if (b < 0) return fail(-b);
             ac_base[k.ta] = b;
+        }
+    }
+    {
+        size_t subs = built.size() * kLutPrimarySize;                                // where the next sub-table region goes
+        p.lut.assign(subs, 0);
+        for (size_t k = 0; k < built.size(); k++) {
+            const std::vector<LutEntry> &t = built[k];
+            const size_t own = k * kLutPrimarySize;
+            for (int i = 0; i < kLutPrimarySize; i++) {
+                LutEntry e = t[i];
+                if (lut_is_link(e)) e = lut_link(unsigned(lut_link_offset(e) - kLutPrimarySize + subs - own), e & 15u);
+                p.lut[own + i] = e;
+            }
+            p.lut.insert(p.lut.end(), t.begin() + kLutPrimarySize, t.end());
+            subs += t.size() - kLutPrimarySize;
         }
     }
     // table offsets become 16-bit LDS addresses on the device; four tables of a baseline scan need < 24 KB

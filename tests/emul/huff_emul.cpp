@@ -31,6 +31,8 @@ struct HostBits {
         }
         return w;
     }
+    uint32_t ahead(uint32_t byte_off) const { return be32(byte_off); }
+    void advance() const {}
 };
 // Mirrors the device sink of k_huff_write: AC entries appended to the compact stream, DC differences per block,
 // the stream offset of every tile's first block.
@@ -46,7 +48,7 @@ struct StreamSink {
         dcbuf[b] = int16_t(v);
         if (b % tile_blocks == 0) tile_eoff[b / tile_blocks] = off;
     }
-    void ac(uint32_t b, unsigned pos, int v) { entries[off++] = coef_entry(v, pos, b); }
+    void ac(uint32_t b, uint32_t r_scaled, int v) { entries[off++] = coef_entry(v, 63u - (r_scaled >> kRShift), b); }
     void block_done(uint32_t next_blk)
     {
         if (next_blk == total_blocks) tile_eoff[(total_blocks + tile_blocks - 1) / tile_blocks] = off;
@@ -57,7 +59,7 @@ struct StreamSink {
 struct TickSink {
     mutable long ticks = 0;
     void dc(uint32_t, int) const {}
-    void ac(uint32_t, unsigned, int) const {}
+    void ac(uint32_t, uint32_t, int) const {}
     void block_done(uint32_t) const {}
     void bad_code(uint32_t) const {}
     void tick() const { ticks++; }
