@@ -162,11 +162,11 @@ void fill_dev_image(const ImagePlan &p, DevImage &d)
     d.valid = 1;
     d.nseg = p.nseg;
     d.restart_mcus = p.restart_mcus;
-    uint32_t t = tile_mcus(p.bpm, p.hmax), l2 = 0;
+    d.mode = (p.ncomp == 3 && p.h[0] == 2 && p.v[0] == 2 && p.h[1] == 1 && p.v[1] == 1 && p.h[2] == 1 && p.v[2] == 1) ? 1 : 0;
+    uint32_t t = (d.mode == 1 && p.layout != MJX_LAYOUT_REF_COMPAT) ? tile_mcus_420() : tile_mcus(p.bpm, p.hmax), l2 = 0;
     while ((1u << (l2 + 1)) <= t) l2++;
     d.log2_tile = l2;
     d.tile_blocks = (1u << l2) * p.bpm;
-    d.mode = (p.ncomp == 3 && p.h[0] == 2 && p.v[0] == 2 && p.h[1] == 1 && p.v[1] == 1 && p.h[2] == 1 && p.v[2] == 1) ? 1 : 0;
     if (p.layout == MJX_LAYOUT_REF_COMPAT) {
         d.mode = 2;
         for (uint32_t c = 0; c < 3; c++) { d.ref_xf[c] = uint8_t(p.ref_xf[c]); d.ref_yf[c] = uint8_t(p.ref_yf[c]); }

@@ -61,6 +61,8 @@ inline uint32_t tile_mcus(uint32_t bpm, uint32_t hmax)
 }
 
 
+uint32_t tile_mcus_420();       // MCUs per stage-B tile of the 4:2:0 kernel (mode 1)
+
 // ---- launchers (mjx_kernels.hip); all asynchronous on `st` ---------------------------------------------
 #if defined(__HIPCC__) || defined(MJX_WITH_HIP_RUNTIME)
 size_t huff_lds_bytes(uint32_t lut_cap_entries);

@@ -473,7 +473,13 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
         it.zc = prev.z | (uint32_t(prev.c) << 8);
         if (active) g_entry[im.sub_off + it.s] = make_state(prev.p, prev.z, prev.c);
     }
-    if (!__syncthreads_or(active)) return;                                 // nothing to repair in this workgroup
+    {   // nothing to repair in this workgroup?  (not __syncthreads_or: its static LDS word would be padded to kLutAlign)
+        if (lane == 0) s_cnt[wave] = __builtin_amdgcn_ballot_w64(active) != 0;
+        __syncthreads();
+        uint32_t any = 0;
+        for (uint32_t w = 0; w < kMergeWg / 64; w++) any |= s_cnt[w];
+        if (!any) return;
+    }
     const HuffImage *h;
     const LutEntry *lut;
     stage_tables(im, lut_pool, smem, h, lut);
@@ -1165,6 +1171,11 @@ __device__ __forceinline__ void store4(uint8_t *dst, const Rgb4 &v, bool aligned
 // tile overlap the arithmetic of the previous one instead of sitting on the workgroup's critical path.
 constexpr int kPrefetch = 8;         // stream entries per lane held in registers (2048 per tile; the rest is re-read)
 constexpr int kTilesPerWg = 8;
+#ifndef MJX_TILE420
+#define MJX_TILE420 32
+#endif
+constexpr uint32_t kTile420 = MJX_TILE420;        // MCUs per tile of the 4:2:0 kernel; its workgroup has 8 lanes per MCU
+constexpr uint32_t kLanes420 = kTile420 * 8;
 
 struct TileFetch {
     uint32_t e0, e1;                 // the tile's slice of the compact stream
@@ -1172,16 +1183,17 @@ struct TileFetch {
     int32_t dc;
 };
 
+template <uint32_t LANES>
 __device__ __forceinline__ void tile_fetch(const uint32_t *__restrict__ src, const uint32_t *__restrict__ eoff,
                                            const int32_t *__restrict__ dc, uint32_t tile, uint32_t tile_blocks,
                                            uint32_t total_blocks, TileFetch &f)
 {
     const uint32_t tid = threadIdx.x;
-    f.e0 = eoff[tile];
-    f.e1 = eoff[tile + 1];
+    f.e0 = eoff[0];                  // (eoff: the workgroup's copy of its tiles' offsets in LDS, see k_idct_color)
+    f.e1 = eoff[1];
 #pragma unroll
     for (int k = 0; k < kPrefetch; k++) {
-        const uint32_t i = f.e0 + tid + 256u * k;
+        const uint32_t i = f.e0 + tid + LANES * k;
         f.ent[k] = i < f.e1 ? src[i] : 0u;
     }
     const uint32_t blk = tile * tile_blocks + tid;
@@ -1247,7 +1259,7 @@ __device__ __forceinline__ void pixels_420(uint32_t width, uint32_t height, uint
                                            uint32_t nm, uint8_t *out_img, bool aligned)
 {
     const uint32_t tid = threadIdx.x;
-    const uint32_t q = tid & 127, t = q >> 2, sx = q & 3;
+    const uint32_t q = tid & (kTile420 * 4 - 1), t = q >> 2, sx = q & 3;
     if (!INTERIOR && t >= nm) return;
     const uint32_t m = m0 + t;
     const uint32_t mx = m % mcux, my = m / mcux;
@@ -1259,7 +1271,7 @@ __device__ __forceinline__ void pixels_420(uint32_t width, uint32_t height, uint
     uint8_t *col = out_img + (size_t(my) * 16 * width + px) * 3;
 #pragma unroll
     for (uint32_t j = 0; j < 4; j++) {
-        const uint32_t rp = (tid >> 7) + 2 * j;                           // row pair 0..7 inside the MCU
+        const uint32_t rp = tid / (kTile420 * 4) + 2 * j;                 // row pair 0..7 inside the MCU
         const uint32_t py = my * 16 + rp * 2;
         if (!INTERIOR && py >= height) break;
         const float *yp = ybase + (rp >> 2) * 2 * kPixStride + ((rp * 2) & 7) * 8;
@@ -1428,10 +1440,12 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
     __shared__ float s_qm[3 * 64];
     __shared__ uint8_t s_nat[64];
     __shared__ uint8_t s_comp[256];
+    __shared__ uint32_t s_eoff[kTilesPerWg + 1];
     const DevImage &im = images[blockIdx.y];
     if (!im.valid || im.mode != uint32_t(MODE) || img_flags[im.status_idx]) return;
     // everything the tile loop needs from the descriptor, read once (uniform -> scalar registers)
-    const uint32_t T = MODE == 1 ? 32u : (1u << im.log2_tile);
+    constexpr uint32_t LANES = MODE == 1 ? kLanes420 : 256u;
+    const uint32_t T = MODE == 1 ? kTile420 : (1u << im.log2_tile);
     const uint32_t bpm = MODE == 1 ? 6u : im.bpm;
     const uint32_t nmcu = im.nmcu, width = im.width, height = im.height, mcux = im.mcux;
     const uint32_t total_blocks = im.himg.total_blocks;
@@ -1446,9 +1460,13 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
     const int32_t *__restrict__ dcs = dcbuf + im.coef_off;
     uint8_t *__restrict__ out_img = rgb + im.rgb_off;
     const bool aligned = ((width * 3u) & 3u) == 0 && (im.rgb_off & 3u) == 0;
+    // The stream offsets of all the workgroup's tiles are fetched once: a tile's entries can then be requested without
+    // first waiting for its offsets (two dependent round trips per tile were what paced the tile loop).
+    if (tid <= uint32_t(kTilesPerWg)) s_eoff[tid] = eoff[min(tile0 + tid, ntiles)];
+    __syncthreads();
     TileFetch cur;
-    tile_fetch(src, eoff, dcs, tile0, tile_blocks, total_blocks, cur);
-    if (tid < 192) s_qm[tid] = qmult[im.qm_off + tid];
+    tile_fetch<LANES>(src, s_eoff, dcs, tile0, tile_blocks, total_blocks, cur);
+    for (uint32_t i = tid; i < 192; i += LANES) s_qm[i] = qmult[im.qm_off + i];
     if (tid < 64) {
         constexpr uint8_t ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                                     41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
@@ -1457,6 +1475,11 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
     }
     if (tid < tile_blocks) s_comp[tid] = im.blk_comp[tid % bpm];
     float *tile_f = reinterpret_cast<float *>(smem_px);
+    // (the first tile's words are settled before the loop, so that on no path into a tile iteration a load is pending
+    // on them: see the settle point behind phase 2)
+#pragma unroll
+    for (int k = 0; k < kPrefetch; k++) asm volatile("" : "+v"(cur.ent[k]));
+    asm volatile("" : "+v"(cur.dc), "+v"(cur.e0), "+v"(cur.e1));
 
     for (uint32_t tile = tile0; tile < tile1; tile++) {
         const uint32_t m0 = tile * T;
@@ -1464,15 +1487,15 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
         {   // phase 0
             float4 *z = reinterpret_cast<float4 *>(smem_px);
             const uint32_t nq = nblk * (kPixStride / 4);
-            for (uint32_t i = tid; i < nq; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (uint32_t i = tid; i < nq; i += LANES) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
         {   // phase 1
             const uint32_t first_lo = (tile * tile_blocks) & 0xffu;
 #pragma unroll
             for (int k = 0; k < kPrefetch; k++)
-                if (cur.e0 + tid + 256u * k < cur.e1) scatter_entry(cur.ent[k], first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
-            for (uint32_t i = cur.e0 + tid + 256u * kPrefetch; i < cur.e1; i += 256)
+                if (cur.e0 + tid + LANES * k < cur.e1) scatter_entry(cur.ent[k], first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+            for (uint32_t i = cur.e0 + tid + LANES * kPrefetch; i < cur.e1; i += LANES)
                 scatter_entry(src[i], first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
             // DC; luminance blocks also take the + 128 of decoder.rs:318-330 here (a constant on the DC term of the
             // prescaled transform is the same constant on all 64 samples); REF_COMPAT adds it per pixel in k_ref_color,
@@ -1480,10 +1503,16 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
             if (tid < nblk) tile_f[tid * kPixStride] = float(cur.dc) * s_qm[s_comp[tid] * 64] + ((MODE != 2 && s_comp[tid] == 0) ? 128.0f : 0.0f);
         }
         TileFetch nxt = cur;
-        if (tile + 1 < tile1) tile_fetch(src, eoff, dcs, tile + 1, tile_blocks, total_blocks, nxt);
+        if (tile + 1 < tile1) tile_fetch<LANES>(src, s_eoff + (tile + 1 - tile0), dcs, tile + 1, tile_blocks, total_blocks, nxt);
         __syncthreads();
         if (tid < nblk) idct_row_inplace(tile_f + tid * kPixStride);      // phase 2
         __syncthreads();
+        // The next tile's prefetched words are made to land here, a whole IDCT phase after their loads were issued and
+        // before this tile's pixel stores go out.  Left to the next iteration, the wait for them is a vmcnt(0) that
+        // sits behind those stores -- a full store drain per tile.
+#pragma unroll
+        for (int k = 0; k < kPrefetch; k++) asm volatile("" : "+v"(nxt.ent[k]));
+        asm volatile("" : "+v"(nxt.dc), "+v"(nxt.e0), "+v"(nxt.e1));
         if (MODE == 1) {                                                  // phase 3
             // interior tile: all 32 MCUs in one MCU row, fully inside the image, rows 4-byte aligned
             const uint32_t mx0 = m0 % mcux, my0 = m0 / mcux;
@@ -1507,6 +1536,7 @@ size_t huff_lds_bytes(uint32_t lut_cap_entries) { return (sizeof(HuffImage) + si
 size_t huff_window_bytes() { return size_t(kHuffWg) * kWinStride * 4; }
 size_t huff_stage_bytes() { return size_t(kHuffWg) * (LaneRing<kAcGroup>::kRing + LaneRing<kDcGroup>::kRing) * 4; }    // the write pass's rings
 
+uint32_t tile_mcus_420() { return kTile420; }
 size_t idct_lds_bytes(uint32_t max_tile_blocks) { return size_t(max_tile_blocks) * kPixStride * 4; }
 
 int configure_kernels(size_t huff_lds, size_t idct_lds)
@@ -1595,7 +1625,7 @@ void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t
     if (mode_mask & 1u)
         hipLaunchKernelGGL(k_idct_color<0>, dim3(max_tiles, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags);
     if (mode_mask & 2u)
-        hipLaunchKernelGGL(k_idct_color<1>, dim3(max_tiles, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags);
+        hipLaunchKernelGGL(k_idct_color<1>, dim3(max_tiles, nimg), dim3(kLanes420), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags);
     if (mode_mask & 4u)
         hipLaunchKernelGGL(k_idct_color<2>, dim3(max_tiles, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags);
 }

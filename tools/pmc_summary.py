@@ -17,7 +17,11 @@ for k, c in rows.items():
         print("   lane utilisation (THREAD_CYCLES_VALU / ACTIVE_INST_VALU / 64): %.3f" % (d["SQ_THREAD_CYCLES_VALU"] / d["SQ_ACTIVE_INST_VALU"] / 64))
         print("   VALU busy share of wave cycles: %.3f ; wait_any %.3f ; wait_inst_any %.3f ; valu insts/wave %.0f" % (
             d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"], d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"], d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"], d["SQ_INSTS_VALU"] / d["SQ_WAVES"]))
-        print("   avg waves in flight per SIMD (WAVE_CYCLES / BUSY_CYCLES-ish): %.2f" % (d["SQ_WAVE_CYCLES"] / d["SQ_BUSY_CYCLES"]))
+        # SQ_BUSY_CYCLES is summed over the chip's 32 shader engines; a SIMD-32 issues a wave64 VALU instruction in 2 cycles
+        cyc = d["SQ_BUSY_CYCLES"] / 32.0
+        print("   VALU issue share of SIMD time (INSTS_VALU * 2 / (1024 SIMDs * BUSY_CYCLES / 32)): %.3f" % (d["SQ_INSTS_VALU"] * 2.0 / (1024.0 * cyc)))
+    if d.get("SQ_INSTS_SALU") and d.get("SQ_INSTS_VALU"):
+        print("   scalar instructions per vector instruction: %.2f" % (d["SQ_INSTS_SALU"] / d["SQ_INSTS_VALU"]))
     if "SQ_INSTS_LDS" in d and d.get("SQ_INSTS_LDS"):
         print("   LDS: insts %d, bank conflict cycles / idx active %.3f, wait_inst_lds share of active_any %.3f" % (
             d["SQ_INSTS_LDS"], d["SQ_LDS_BANK_CONFLICT"] / max(d["SQ_LDS_IDX_ACTIVE"], 1), d["SQ_WAIT_INST_LDS"] / max(d["SQ_ACTIVE_INST_ANY"], 1)))
