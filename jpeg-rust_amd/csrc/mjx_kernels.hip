@@ -264,7 +264,7 @@ struct LdsWindow {
     uint32_t wbase;              // stream byte offset of the window's first dword (as of the last fill the caller noted)
     uint32_t rp;                 // read pointer (LDS address): the dword after w1 (stream offset wn - 4)
     __device__ __forceinline__ uint32_t be32(uint32_t byte_off) const { return *reinterpret_cast<const uint32_t *>(lds + (byte_off - wbase)); }
-    __device__ __forceinline__ uint32_t ahead(uint32_t) const { return *(const volatile __attribute__((address_space(3))) uint32_t *)(rp); }   // (volatile: one plain read per step, not folded into the restage branch)
+    __device__ __forceinline__ uint32_t ahead(uint32_t) const { return *(const volatile __attribute__((address_space(3))) uint32_t *)(uintptr_t(rp)); }   // (volatile: one plain read per step, not folded into the restage branch)
     __device__ __forceinline__ void advance() { rp += 4; }
 };
 __device__ __forceinline__ void window_fill(uint32_t *lds, const GlobalBits &g, uint32_t wbase)
@@ -474,7 +474,8 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
         if (active) g_entry[im.sub_off + it.s] = make_state(prev.p, prev.z, prev.c);
     }
     {   // nothing to repair in this workgroup?  (not __syncthreads_or: its static LDS word would be padded to kLutAlign)
-        if (lane == 0) s_cnt[wave] = __builtin_amdgcn_ballot_w64(active) != 0;
+        const bool wave_any = __builtin_amdgcn_ballot_w64(active) != 0;    // (all lanes vote: outside the branch)
+        if (lane == 0) s_cnt[wave] = wave_any;
         __syncthreads();
         uint32_t any = 0;
         for (uint32_t w = 0; w < kMergeWg / 64; w++) any |= s_cnt[w];
@@ -1487,7 +1488,9 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
         {   // phase 0
             float4 *z = reinterpret_cast<float4 *>(smem_px);
             const uint32_t nq = nblk * (kPixStride / 4);
+#ifndef MJX_EXP_NOZERO
             for (uint32_t i = tid; i < nq; i += LANES) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
         }
         __syncthreads();
         {   // phase 1
