@@ -138,6 +138,10 @@ void read_sos(const ByteView &f, size_t pos, ParserState &st, bool strict, bool 
     i += 4;
     if (!st.have_frame) throw ParseError{MJX_ERR_REF_PANIC};                     // mod.rs:388 unwrap
     if (n != 1 && n != 3) throw ParseError{MJX_ERR_UNSUPPORTED_FORMAT};          // decoder.rs:328-330 panic!("asd")
+    // A scan that carries fewer components than the frame is the first of several (non-interleaved baseline, SURVEY
+    // s8(f)-4: not built).  The reference decodes that first scan with the frame's sampling factors and stops
+    // (mod.rs:415-417); strict_ref keeps that, otherwise the file is refused rather than decoded to a wrong picture.
+    if (!strict && n < st.frame.size()) throw ParseError{MJX_ERR_UNSUPPORTED_FORMAT};
 
     d->width = uint16_t(st.width);
     d->height = uint16_t(st.height);

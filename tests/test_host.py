@@ -237,6 +237,20 @@ def test_progressive_and_restart_files_are_rejected(mjx):
     assert _code(mjx, rst, False) == mjx.OK                           # restart intervals are decoded
 
 
+def test_first_scan_of_a_multi_scan_file_is_refused_unless_strict(mjx):
+    """A scan with fewer components than the frame (non-interleaved baseline: not built) is refused in the default mode; in
+    strict_ref mode the first scan goes through as in the reference (jpeg/mod.rs:415-417 returns after the first scan)."""
+    data = bytearray(open(os.path.join(PIL_DIR, "std_420_big.jpg"), "rb").read())
+    sos = data.index(b"\xff\xda")
+    assert data[sos + 4] == 3
+    # rewrite the scan header to a one-component scan of the first component (the entropy data then is not a valid
+    # one-component scan, which the parser does not look at)
+    hdr = bytes([0xff, 0xda, 0x00, 0x08, 0x01]) + bytes(data[sos + 5:sos + 7]) + bytes([0x00, 0x3f, 0x00])
+    one = bytes(data[:sos]) + hdr + bytes(data[sos + 14:])
+    assert _code(mjx, one, False) == mjx.ERR_UNSUPPORTED_FORMAT
+    assert _code(mjx, one, True) == mjx.OK
+
+
 DRI_FIXTURES = ["dri_420_r5", "dri_444_r1", "dri_422_rows", "dri_gray_r7", "dri_420_720p_rows", "dri_420_r300"]
 
 
