@@ -1,0 +1,174 @@
+//! FFI binding of `include/mjx.h` for martinhath/jpeg-rust (Rust 2015, like the crate: no `?`, no `dyn`).
+//!
+//! Replaces the reference's decode path behind its own surface:
+//!   * `JPEGImage::parse(vec)` + `width()` / `height()` / `image_data()`  (src/jpeg/mod.rs:202, 467, 471, 475)
+//!       -> `decode(&[u8])`
+//!   * the marker walk of src/jpeg/mod.rs:206-385 -> `mjx_parse`; `JPEGDecoder::new(..)...decode()`
+//!     (src/jpeg/decoder.rs:55-162) -> `mjx_batch_create` / `mjx_batch_decode` / `mjx_batch_wait`
+//!
+//! Not compiled in the jpeg-rust_amd repository (no Rust toolchain in its image); kept in step with the header by a test.
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_double, c_int, c_uint, c_void};
+
+pub const MJX_OK: c_int = 0;
+pub const MJX_LAYOUT_STANDARD: u8 = 0;
+pub const MJX_LAYOUT_REF_COMPAT: u8 = 1;
+pub const MJX_STAGE_ALL: c_uint = 3;
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct mjx_opts {
+    pub strict_ref: u8,
+    pub layout: u8,
+    pub keep_coefs: u8,
+    pub device_destuff: u8,
+    pub chunk_images: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct mjx_comp {
+    pub id: u8,
+    pub h: u8,
+    pub v: u8,
+    pub tq: u8,
+    pub td: u8,
+    pub ta: u8,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct mjx_hufftab {
+    pub bits: [u8; 16],
+    pub vals: [u8; 256],
+}
+
+#[repr(C)]
+pub struct mjx_scan_desc {
+    pub scan: *const u8,
+    pub scan_len: usize,
+    pub width: u16,
+    pub height: u16,
+    pub ncomp: u8,
+    pub comp: [mjx_comp; 3],
+    pub qt: [[u16; 64]; 4],
+    pub qt_present: u8,
+    pub dc: [mjx_hufftab; 4],
+    pub ac: [mjx_hufftab; 4],
+    pub dc_present: u8,
+    pub ac_present: u8,
+    pub scan_is_stuffed: u8,
+    pub restart_interval: u16,
+    pub n_restart: u32,
+    pub restart_offsets: *const u32,
+    pub owner_: *mut c_void,
+}
+
+#[repr(C)]
+pub struct mjx_image {
+    pub width: u32,
+    pub height: u32,
+    pub rgb: *mut u8,
+}
+
+pub enum mjx_ctx {}
+pub enum mjx_batch {}
+
+extern "C" {
+    pub fn mjx_parse(jpeg: *const u8, len: usize, opts: *const mjx_opts, out: *mut mjx_scan_desc) -> c_int;
+    pub fn mjx_free_scan(desc: *mut mjx_scan_desc);
+    pub fn mjx_validate(desc: *const mjx_scan_desc, opts: *const mjx_opts) -> c_int;
+    pub fn mjx_decode(jpeg: *const u8, len: usize, opts: *const mjx_opts, out: *mut mjx_image) -> c_int;
+    pub fn mjx_free_image(img: *mut mjx_image);
+    pub fn mjx_ctx_create(device: c_int, out: *mut *mut mjx_ctx) -> c_int;
+    pub fn mjx_ctx_destroy(ctx: *mut mjx_ctx);
+    pub fn mjx_ctx_set_profiling(ctx: *mut mjx_ctx, enable: c_int) -> c_int;
+    pub fn mjx_batch_create(ctx: *mut mjx_ctx, descs: *const mjx_scan_desc, n: usize, opts: *const mjx_opts,
+                            out: *mut *mut mjx_batch, status: *mut c_int) -> c_int;
+    pub fn mjx_batch_tile(ctx: *mut mjx_ctx, src: *const mjx_batch, times: usize, out: *mut *mut mjx_batch) -> c_int;
+    pub fn mjx_batch_free(b: *mut mjx_batch);
+    pub fn mjx_batch_decode(b: *mut mjx_batch, stages: c_uint) -> c_int;
+    pub fn mjx_batch_wait(b: *mut mjx_batch) -> c_int;
+    pub fn mjx_batch_size(b: *const mjx_batch) -> usize;
+    pub fn mjx_batch_status(b: *const mjx_batch, i: usize) -> c_int;
+    pub fn mjx_batch_image_info(b: *const mjx_batch, i: usize, width: *mut u32, height: *mut u32,
+                                blocks_per_mcu: *mut u32, mcus: *mut u32) -> c_int;
+    pub fn mjx_batch_rgb_device(b: *const mjx_batch, i: usize, dev_ptr: *mut *mut c_void, bytes: *mut usize) -> c_int;
+    pub fn mjx_batch_copy_rgb(b: *mut mjx_batch, i: usize, host_rgb: *mut u8) -> c_int;
+    pub fn mjx_batch_copy_coefs(b: *mut mjx_batch, i: usize, host_coefs: *mut i16, cap_blocks: usize,
+                                nblocks: *mut usize) -> c_int;
+    pub fn mjx_batch_bytes(b: *const mjx_batch, scan_bytes: *mut u64, rgb_bytes: *mut u64, coef_bytes: *mut u64,
+                           pixels: *mut u64) -> c_int;
+    pub fn mjx_batch_kernel_ms(b: *mut mjx_batch, ms: *mut c_double, launches: *mut u64, reset: c_int) -> c_int;
+    pub fn mjx_decode_scans(ctx: *mut mjx_ctx, descs: *const mjx_scan_desc, n: usize, opts: *const mjx_opts,
+                            rgb_dev: *mut *mut u8, status: *mut c_int, out: *mut *mut mjx_batch) -> c_int;
+    pub fn mjx_strerror(code: c_int) -> *const c_char;
+    pub fn mjx_version() -> *const c_char;
+}
+
+/// Same surface as the crate's decode path: bytes in, (width, height, pixels) out.
+/// `JPEGImage::parse` (src/jpeg/mod.rs:202) becomes
+/// `let (w, h, px) = try!(mjx::decode(&vec).map_err(|rc| format!("mjx error {}", rc)));`
+/// followed by `image.dimensions = (w as u16, h as u16); image.image_data = Some(px);`.
+pub fn decode(bytes: &[u8]) -> Result<(usize, usize, Vec<(u8, u8, u8)>), i32> {
+    let opts = mjx_opts::default(); // strict_ref = 0: APPn segments are skipped
+    let mut img = mjx_image { width: 0, height: 0, rgb: std::ptr::null_mut() };
+    let rc = unsafe { mjx_decode(bytes.as_ptr(), bytes.len(), &opts, &mut img) };
+    if rc != MJX_OK {
+        return Err(rc);
+    }
+    let (w, h) = (img.width as usize, img.height as usize);
+    let px = unsafe { std::slice::from_raw_parts(img.rgb, w * h * 3) }
+        .chunks(3)
+        .map(|c| (c[0], c[1], c[2]))
+        .collect();
+    unsafe { mjx_free_image(&mut img) };
+    Ok((w, h, px))
+}
+
+/// Device-resident batch: one context per GPU, outputs stay on the device (`mjx_batch_rgb_device`).
+pub struct Batch {
+    raw: *mut mjx_batch,
+}
+
+impl Batch {
+    /// `descs` come from `mjx_parse`; per-image parse/plan errors land in `status`.
+    pub fn new(ctx: *mut mjx_ctx, descs: &[mjx_scan_desc], opts: &mjx_opts, status: &mut [c_int]) -> Result<Batch, i32> {
+        assert_eq!(descs.len(), status.len());
+        let mut raw: *mut mjx_batch = std::ptr::null_mut();
+        let rc = unsafe { mjx_batch_create(ctx, descs.as_ptr(), descs.len(), opts, &mut raw, status.as_mut_ptr()) };
+        if rc != MJX_OK { Err(rc) } else { Ok(Batch { raw: raw }) }
+    }
+    /// Enqueue every kernel of the hot path and wait for them.
+    pub fn decode(&mut self) -> Result<(), i32> {
+        let rc = unsafe { mjx_batch_decode(self.raw, MJX_STAGE_ALL) };
+        if rc != MJX_OK {
+            return Err(rc);
+        }
+        let rc = unsafe { mjx_batch_wait(self.raw) };
+        if rc != MJX_OK { Err(rc) } else { Ok(()) }
+    }
+    pub fn status(&self, i: usize) -> i32 {
+        unsafe { mjx_batch_status(self.raw, i) }
+    }
+    /// Copy image `i` to the host as the crate's `Vec<(u8,u8,u8)>`.
+    pub fn image_data(&mut self, i: usize) -> Result<(usize, usize, Vec<(u8, u8, u8)>), i32> {
+        let (mut w, mut h, mut bpm, mut mcus) = (0u32, 0u32, 0u32, 0u32);
+        let rc = unsafe { mjx_batch_image_info(self.raw, i, &mut w, &mut h, &mut bpm, &mut mcus) };
+        if rc != MJX_OK {
+            return Err(rc);
+        }
+        let mut buf = vec![0u8; w as usize * h as usize * 3];
+        let rc = unsafe { mjx_batch_copy_rgb(self.raw, i, buf.as_mut_ptr()) };
+        if rc != MJX_OK {
+            return Err(rc);
+        }
+        Ok((w as usize, h as usize, buf.chunks(3).map(|c| (c[0], c[1], c[2])).collect()))
+    }
+}
+
+impl Drop for Batch {
+    fn drop(&mut self) {
+        unsafe { mjx_batch_free(self.raw) }
+    }
+}

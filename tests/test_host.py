@@ -237,6 +237,40 @@ def test_progressive_and_restart_files_are_rejected(mjx):
     assert _code(mjx, rst, False) == mjx.OK                           # restart intervals are decoded
 
 
+def test_rust_binding_mirrors_the_header():
+    """bindings/rust/src/lib.rs is not compiled here (no Rust toolchain); this keeps it in step with include/mjx.h: every
+    entry point is declared with the same number of parameters, and the #[repr(C)] structs list the header's fields in
+    order."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "mjx.h")).read()
+    rs = open(os.path.join(root, "bindings", "rust", "src", "lib.rs")).read()
+    hdr_nc = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = dict((m.group(1), m.group(2)) for m in re.finditer(r"\b(mjx_[a-z_]+)\(([^;{]*?)\);", hdr_nc))
+    assert len(protos) >= 24
+    for name, params in protos.items():
+        m = re.search(r"pub fn " + name + r"\((.*?)\)\s*(->[^;]*)?;", rs, flags=re.S)
+        assert m, name + " is not declared in lib.rs"
+        n_c = 0 if params.strip() in ("", "void") else params.count(",") + 1
+        n_rs = 0 if not m.group(1).strip() else m.group(1).count(",") + 1
+        assert n_c == n_rs, (name, n_c, n_rs)
+    def c_fields(struct):
+        body = re.search(r"typedef struct " + struct + r"\s*\{(.*?)\}\s*" + struct + ";", hdr_nc, flags=re.S).group(1)
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names = re.sub(r"^(const\s+)?[A-Za-z_0-9]+\s*\**", "", decl)
+            out += [re.sub(r"[\[\]0-9\s\*]", "", n) for n in names.split(",")]
+        return out
+    def rs_fields(struct):
+        body = re.search(r"pub struct " + struct + r"\s*\{(.*?)\n\}", rs, flags=re.S).group(1)
+        return re.findall(r"pub ([a-z_0-9]+):", body)
+    for struct in ("mjx_opts", "mjx_comp", "mjx_hufftab", "mjx_scan_desc", "mjx_image"):
+        assert c_fields(struct) == rs_fields(struct), struct
+
+
 def test_first_scan_of_a_multi_scan_file_is_refused_unless_strict(mjx):
     """A scan with fewer components than the frame (non-interleaved baseline: not built) is refused in the default mode; in
     strict_ref mode the first scan goes through as in the reference (jpeg/mod.rs:415-417 returns after the first scan)."""
