@@ -1,0 +1,77 @@
+"""Randomised parity sweep on a GPU box: python tools/fuzz_parity.py [seed] [images]
+
+Encodes random pictures with Pillow (libjpeg) -- random size 1..900 x 1..700, grey / 4:4:4 / 4:2:2 / 4:2:0, quality 1..100,
+standard or optimised Huffman tables, with or without restart intervals, smooth / noisy / mixed content -- decodes them in
+batches of random chunking through the C ABI and checks every image against the CPU oracle (test infrastructure):
+coefficients bit-exact (T0), RGB within 1 LSB (T2a).  tests/test_gpu_parity.py holds the fixed cases; this is the wide net.
+"""
+import io, os, sys
+import numpy as np
+from PIL import Image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as ge
+import oracle_binding as orc
+
+mjx = ge.load_package()
+orc.lib()
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+total = int(sys.argv[2]) if len(sys.argv) > 2 else 600
+rng = np.random.default_rng(seed)
+ctx = mjx.Context(0)
+
+
+def picture(w, h, kind):
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([127 + 100 * np.sin(xx / rng.uniform(3, 90) + yy / rng.uniform(3, 90) + p) for p in (0.0, 2.0, 4.0)], -1)
+    if kind == 0:
+        img = base
+    elif kind == 1:
+        img = rng.integers(0, 256, (h, w, 3)).astype(np.float64)
+    elif kind == 2:
+        img = base + rng.normal(0, rng.uniform(2, 40), (h, w, 3))
+    else:
+        img = np.full((h, w, 3), float(rng.integers(0, 256)))
+        img[: h // 2, : w // 2] = rng.integers(0, 256, 3)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def encode():
+    w = int(rng.integers(1, 900)) if rng.random() < 0.8 else int(rng.integers(1, 40))
+    h = int(rng.integers(1, 700)) if rng.random() < 0.8 else int(rng.integers(1, 40))
+    arr = picture(w, h, int(rng.integers(0, 4)))
+    grey = rng.random() < 0.15
+    im = Image.fromarray(arr[..., 0] if grey else arr, "L" if grey else "RGB")
+    kw = dict(quality=int(rng.integers(1, 101)), optimize=bool(rng.random() < 0.5))
+    if not grey:
+        kw["subsampling"] = int(rng.integers(0, 3))
+    r = rng.random()
+    if r < 0.2:
+        kw["restart_marker_blocks"] = int(rng.integers(1, 40))
+    elif r < 0.3:
+        kw["restart_marker_rows"] = int(rng.integers(1, 4))
+    buf = io.BytesIO()
+    try:
+        im.save(buf, "JPEG", **kw)
+    except OSError:                       # (Pillow gives up on some option combinations; draw again)
+        return encode()
+    return buf.getvalue(), (w, h, kw)
+
+
+done = differ = 0
+while done < total:
+    items = [encode() for _ in range(int(rng.integers(1, 48)))]
+    scans = [mjx.ParsedScan(d) for d, _ in items]
+    batch = mjx.Batch(ctx, scans, keep_coefs=True, chunk_images=int(rng.integers(1, 64)))
+    batch.decode(); batch.wait()
+    for i, (d, what) in enumerate(items):
+        assert batch.status(i) == mjx.OK, (what, batch.status(i))
+        ref = orc.decode(d, layout=orc.LAYOUT_STD, ext_dri=True, ext_1bit=True)
+        assert np.array_equal(batch.coefs(i), orc.interleave(ref)), ("T0", what, seed)
+        diff = np.abs(batch.rgb(i).astype(np.int16) - ref.rgb.astype(np.int16))
+        assert diff.max() <= 1, ("T2a", what, int(diff.max()), seed)
+        differ += int((diff > 0).sum())
+    batch.close()
+    done += len(items)
+print("fuzz ok: seed %d, %d images, %d samples off by one" % (seed, done, differ))
