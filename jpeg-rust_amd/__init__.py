@@ -16,6 +16,7 @@ GPU is present.  The directory name contains a hyphen (it is the name the projec
 ``__graft_entry__.load_package()`` or ``importlib``.
 """
 import ctypes
+import sys
 import os
 from concurrent.futures import ThreadPoolExecutor
 
@@ -143,9 +144,9 @@ class ParsedScan:
     def scan_bytes(self):
         return ctypes.string_at(self.desc.scan, self.desc.scan_len)
 
-    def validate(self, layout=LAYOUT_STANDARD):
+    def validate(self, layout=LAYOUT_STANDARD, strict_ref=False):
         """Status mjx_batch_create would give this image (host only)."""
-        o = _opts(layout=layout)
+        o = _opts(layout=layout, strict_ref=strict_ref)
         return int(lib().mjx_validate(ctypes.byref(self.desc), ctypes.byref(o)))
 
     def close(self):
@@ -177,6 +178,10 @@ class Context:
             self.h = _vp()
 
     def __del__(self):
+        # not during interpreter shutdown: the HIP runtime may already be gone (its teardown aborts the process when a
+        # device handle is released after it); the driver reclaims everything at exit anyway
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -262,6 +267,10 @@ class Batch:
             self.h = _vp()
 
     def __del__(self):
+        # not during interpreter shutdown: the HIP runtime may already be gone (its teardown aborts the process when a
+        # device handle is released after it); the driver reclaims everything at exit anyway
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

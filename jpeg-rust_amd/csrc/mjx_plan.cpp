@@ -86,7 +86,10 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p)
     if (!d.scan) return fail(MJX_ERR_INVALID_ARG);
     if (d.ncomp != 1 && d.ncomp != 3) return fail(MJX_ERR_UNSUPPORTED_FORMAT);     // decoder.rs:328-330
     if (d.width == 0 || d.height == 0) return fail(MJX_ERR_REF_PANIC);             // x_factor division by zero
-    if (d.scan_len < 4) return fail(MJX_ERR_TRUNCATED);                            // huffman.rs:127-128 data[0..4]
+    // huffman.rs:127-128 preloads data[0..4] and panics on a shorter scan; the bug-compatible modes keep that.  Otherwise a
+    // short scan (a flat 8x8 grey picture has one byte of entropy data) is decoded: past its end the lanes read the 0xAA
+    // padding the reference itself reads there (huffman.rs:236-246).
+    if (d.scan_len < ((opts.strict_ref || opts.layout == MJX_LAYOUT_REF_COMPAT) ? 4u : 1u)) return fail(MJX_ERR_TRUNCATED);
     if (d.scan_len >= (size_t(1) << 28)) return fail(MJX_ERR_UNSUPPORTED_FORMAT);  // bit positions are 32 bit
     p.width = d.width;
     p.height = d.height;

@@ -122,12 +122,16 @@ typedef struct {
 } orc_hdec;
 
 /* huffman.rs:124-135 */
-static void orc_hdec_new(orc_env *env, orc_hdec *d, const uint8_t *data, size_t len)
+static void orc_hdec_new(orc_env *env, orc_hdec *d, const uint8_t *data, size_t len, int allow_short)
 {
-    PANIC_IF(len < 4, "HuffmanDecoder::new: data[0..4] out of bounds");
+    /* NOT reference behaviour (allow_short: STANDARD layout, not strict_ref): a scan shorter than the four bytes the
+       reference preloads -- a flat 8x8 grey picture has one byte of entropy data -- is read with the 0xAA padding the
+       reference itself uses past the end of the data (:236-246) */
+    PANIC_IF(len < 4 && !(allow_short && len >= 1), "HuffmanDecoder::new: data[0..4] out of bounds");
     d->data = data;
     d->len = len;
-    d->current = ((uint32_t)data[0] << 24) | ((uint32_t)data[1] << 16) | ((uint32_t)data[2] << 8) | data[3];
+    d->current = 0;
+    for (size_t k = 0; k < 4; k++) d->current = (d->current << 8) | (k < len ? data[k] : 0xaau);
     d->next_index = 4;
     d->bits_read = 0;
     d->total_bits = 0;
@@ -432,7 +436,7 @@ static void orc_jpeg_decode(orc_env *env, const orc_opts *opts, const orc_parse 
     out->mcus_read = num_read;
 
     orc_hdec hd;
-    orc_hdec_new(env, &hd, data, data_len);                        /* :189 */
+    orc_hdec_new(env, &hd, data, data_len, opts->layout == ORC_LAYOUT_STD && !opts->strict_ref);   /* :189 */
 
     /* Step 1 :195-215 */
     float prev_dc[3] = {0, 0, 0};

@@ -278,7 +278,8 @@ def test_two_streams_give_the_same_bytes(mjx, orc, data_dir, tmp_path):
 
 
 PIL_FIXTURES = {"opt_420_q85.jpg": True, "opt_444_q40.jpg": True, "opt_422_q95.jpg": False, "std_420_q100.jpg": False,
-                "opt_gray_q70.jpg": False, "opt_420_q10.jpg": True, "std_420_big.jpg": False}
+                "opt_gray_q70.jpg": False, "opt_420_q10.jpg": True, "std_420_big.jpg": False,
+                "tiny_gray_3x7_q7.jpg": False}      # one byte of entropy data: found by tools/fuzz_parity.py
 
 
 @pytest.mark.parametrize("name", sorted(PIL_FIXTURES))

@@ -214,7 +214,8 @@ def test_ref_compat_panic_detection_matches_the_oracle(mjx, orc):
 PIL_DIR = os.path.join(ROOT, "tests", "golden", "pil")
 # files written by libjpeg (tests/golden/pil): name -> (needs the 1-bit-code extension of the oracle)
 PIL_FIXTURES = {"opt_420_q85.jpg": True, "opt_444_q40.jpg": True, "opt_422_q95.jpg": False, "std_420_q100.jpg": False,
-                "opt_gray_q70.jpg": False, "opt_420_q10.jpg": True, "std_420_big.jpg": False}
+                "opt_gray_q70.jpg": False, "opt_420_q10.jpg": True, "std_420_big.jpg": False,
+                "tiny_gray_3x7_q7.jpg": False}      # one byte of entropy data: found by tools/fuzz_parity.py
 
 
 @pytest.mark.parametrize("name", sorted(PIL_FIXTURES))
@@ -227,6 +228,21 @@ def test_libjpeg_written_files_on_the_emulation(mjx, orc, emul, name):
     ref = orc.decode(data, layout=orc.LAYOUT_STD, ext_1bit=needs_ext)
     rc, coefs, st = emul(data, 0)
     assert rc == 0 and np.array_equal(coefs, orc.interleave(ref))
+
+
+def test_scan_shorter_than_the_reference_preload(mjx, orc):
+    """huffman.rs:127-128 preloads four bytes and panics on a shorter scan; the bug-compatible modes report that, the
+    default mode decodes the picture (the bytes past the end read as 0xAA, as the reference reads them further on)."""
+    data = open(os.path.join(PIL_DIR, "tiny_gray_3x7_q7.jpg"), "rb").read()
+    scan = mjx.ParsedScan(data)
+    assert scan.desc.scan_len == 3
+    assert scan.validate(layout=mjx.LAYOUT_STANDARD) == mjx.OK
+    assert scan.validate(layout=mjx.LAYOUT_REF_COMPAT) == mjx.ERR_TRUNCATED
+    assert scan.validate(strict_ref=True) == mjx.ERR_TRUNCATED
+    with pytest.raises(orc.OracleError):
+        orc.decode(data, layout=orc.LAYOUT_REF)
+    ref = orc.decode(data, layout=orc.LAYOUT_STD)
+    assert ref.rgb.shape == (7, 3, 3) and int(ref.rgb.max()) - int(ref.rgb.min()) <= 2      # a flat grey picture
 
 
 def test_progressive_and_restart_files_are_rejected(mjx):
