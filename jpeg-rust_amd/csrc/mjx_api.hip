@@ -321,6 +321,28 @@ int allocate_work_buffers(mjx_batch *b)
             HIPOK(hipMalloc(&a.d_dc, size_t(coef_blocks) * sizeof(int32_t) + 64));
         }
     }
+    if (const char *e = std::getenv("MJX_POISON")) {
+        // debugging aid: scratch that the kernels must write before they read it is filled with a byte pattern, so that a
+        // read of stale memory (fresh allocations are usually zero, recycled ones hold the previous batch) shows at once
+        const int v = std::atoi(e) & 0xff;
+        const char *only = std::getenv("MJX_POISON_ONLY");               // one buffer (index below) instead of all
+        const int sel = only ? std::atoi(only) : -1;
+        const size_t cps_bytes = (size_t(max_nsub) + 256) / 256 * 256 * kMaxCp * 2 * sizeof(uint32_t);
+        struct { void *p; size_t n; } bufs[] = {
+            {b->d_entry, size_t(max_nsub) * sizeof(SubseqState)},                 // 0
+            {b->d_exit, size_t(max_nsub) * sizeof(SubseqState)},                  // 1
+            {b->d_blkbase, size_t(max_nsub) * sizeof(uint32_t)},                  // 2
+            {b->d_ebase, size_t(max_nsub) * sizeof(uint32_t)},                    // 3
+            {b->d_cps, cps_bytes},                                                // 4
+            {b->d_items, size_t(max_nsub) * 6 * sizeof(uint32_t)},                // 5
+            {b->d_segsum, max_segsum * 3 * sizeof(int32_t)},                      // 6
+            {b->d_entries, size_t(b->opts.keep_coefs ? std::max<uint64_t>(total_entries, 4) : max_entries) * 4 + 64},      // 7
+            {b->d_tile_eoff, size_t(b->opts.keep_coefs ? std::max<uint32_t>(total_tiles_arr, 1) : max_tiles_arr) * 4 + 16},   // 8
+            {b->d_dc, size_t(coef_blocks) * sizeof(int32_t) + 64},                // 9
+        };
+        for (int k = 0; k < int(sizeof bufs / sizeof bufs[0]); k++)
+            if (sel < 0 || sel == k) HIPOK(hipMemset(bufs[k].p, v, bufs[k].n));
+    }
     b->huff_lds = huff_lds_bytes(lut_cap);
     b->idct_lds = idct_lds_bytes(max_tile_blocks);
     if (b->huff_lds + huff_window_bytes() + huff_stage_bytes() > 160 * 1024 || b->idct_lds > 160 * 1024) return MJX_ERR_UNSUPPORTED_FORMAT;
@@ -382,7 +404,14 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     }
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_TAIL)) {
         prof_begin(b, MJX_K_HUFF_SCAN, st);
-        launch_huff_scan(st, nimg, imgs, SCR(d_exit), SCR(d_blkbase), SCR(d_ebase), b->d_img_entries, b->d_img_flags, b->d_segs);
+        // the round whose count decides whether the synchronisation has converged: the last one enqueued above, or --
+        // tail-only call of the repair path -- the last of a full set of rounds
+        const uint32_t *verdict = nullptr;
+        if (c.merge_wgs > 0) {
+            const int last = (phases & PH_FIX) ? fix_passes - 1 : kMaxFix - 1;
+            if (last >= 0) verdict = b->d_mismatch + ci * kMaxFix + last;
+        }
+        launch_huff_scan(st, nimg, imgs, SCR(d_exit), SCR(d_blkbase), SCR(d_ebase), b->d_img_entries, b->d_img_flags, b->d_segs, verdict);
         prof_end(b, st);
         prof_begin(b, MJX_K_HUFF_WRITE, st);
         launch_huff_write(st, c.max_wg, nimg, b->huff_lds, b->ctx->write_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_blkbase), SCR(d_ebase),

@@ -670,11 +670,23 @@ extern "C" __global__ __launch_bounds__(256) void k_destuff_scatter(const Destuf
 extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *images, const SubseqState *g_exit,
                                                                uint32_t *g_blkbase, uint32_t *g_ebase,
                                                                uint32_t *img_entries, uint32_t *img_flags,
-                                                               const uint32_t *segs)
+                                                               const uint32_t *segs, const uint32_t *verdict)
 {
     __shared__ uint32_t s_tmp[4];
     const DevImage &im = images[blockIdx.x];
     if (!im.valid) return;
+    // `verdict` = what the last enqueued synchronisation round of this chunk re-decoded.  Non-zero: the entries are not
+    // yet the fixed point (the host finds out at mjx_batch_wait and runs more rounds), block and entry counts of
+    // neighbouring subsequences do not fit together, and the kernels behind this one would write a stream with holes
+    // -- tile offsets nobody wrote -- and read it.  The chunk's images are flagged instead; every later kernel skips
+    // flagged images, and the repair run clears the flag.
+    if (verdict && *verdict != 0) {
+        if (threadIdx.x == 0) {
+            img_entries[im.status_idx] = 0;
+            img_flags[im.status_idx] = 2u;
+        }
+        return;
+    }
     const uint32_t nsub = im.himg.nsub, tid = threadIdx.x;
     const uint32_t per = (nsub + kWgLanes - 1) / kWgLanes;
     const uint32_t a = min(nsub, tid * per), b = min(nsub, a + per);
@@ -1591,9 +1603,9 @@ void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
 }
 
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,
-                      uint32_t *ebase, uint32_t *img_entries, uint32_t *img_flags, const uint32_t *segs)
+                      uint32_t *ebase, uint32_t *img_entries, uint32_t *img_flags, const uint32_t *segs, const uint32_t *verdict)
 {
-    hipLaunchKernelGGL(k_huff_scan, dim3(nimg), dim3(kWgLanes), 0, st, images, exit_, blkbase, ebase, img_entries, img_flags, segs);
+    hipLaunchKernelGGL(k_huff_scan, dim3(nimg), dim3(kWgLanes), 0, st, images, exit_, blkbase, ebase, img_entries, img_flags, segs, verdict);
 }
 
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,

@@ -277,6 +277,39 @@ def test_two_streams_give_the_same_bytes(mjx, orc, data_dir, tmp_path):
     assert out.returncode == 0 and "streams ok" in out.stdout, out.stdout + out.stderr
 
 
+def test_slowly_synchronising_stream_with_stale_scratch(mjx, orc, data_dir, tmp_path):
+    """A 27x546 4:4:4 quality-99 picture of noise needs twelve synchronisation rounds where four are enqueued (found by
+    tools/fuzz_parity.py).  Until the host has seen that at mjx_batch_wait, nothing behind the synchronisation may run on
+    the unconverged state: with scratch that holds stale bytes (MJX_POISON fills it) stage B used to read tile offsets
+    nobody had written and fault.  The picture shares a chunk with ordinary ones, all of which must come out right."""
+    import subprocess, sys
+    root = os.path.dirname(data_dir.rstrip('/')).rsplit('/tests', 1)[0]
+    script = tmp_path / "slow.py"
+    script.write_text(
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "import __graft_entry__ as ge, oracle_binding as orc\n"
+        "mjx = ge.load_package()\n"
+        "ctx = mjx.Context(0)\n"
+        "slow = open(os.path.join(%r, 'tests', 'golden', 'pil', 'slow_sync_444_q99.jpg'), 'rb').read()\n"
+        "datas = [mjx.synth_jpeg(640, 480, '420', 75, seed=1), slow, mjx.synth_jpeg(333, 217, '444', 85, seed=5), slow,\n"
+        "         mjx.synth_jpeg(1920, 1080, '420', 75, seed=2)]\n"
+        "for chunk in (0, 2):\n"
+        "    b = mjx.Batch(ctx, [mjx.ParsedScan(d) for d in datas], keep_coefs=True, chunk_images=chunk)\n"
+        "    b.decode(); b.wait()\n"
+        "    for i, d in enumerate(datas):\n"
+        "        ref = orc.decode(d, layout=orc.LAYOUT_STD)\n"
+        "        assert b.status(i) == 0, (chunk, i, b.status(i))\n"
+        "        assert np.array_equal(b.coefs(i), orc.interleave(ref)), (chunk, i)\n"
+        "        assert np.abs(b.rgb(i).astype(int) - ref.rgb.astype(int)).max() <= 1, (chunk, i)\n"
+        "    b.close()\n"
+        "print('slow ok')\n" % (root, root, root))
+    for poison in ("255", "165", "1"):
+        env = dict(os.environ, MJX_POISON=poison)
+        out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "slow ok" in out.stdout, poison + ": " + out.stdout[-2000:] + out.stderr[-2000:]
+
+
 PIL_FIXTURES = {"opt_420_q85.jpg": True, "opt_444_q40.jpg": True, "opt_422_q95.jpg": False, "std_420_q100.jpg": False,
                 "opt_gray_q70.jpg": False, "opt_420_q10.jpg": True, "std_420_big.jpg": False,
                 "tiny_gray_3x7_q7.jpg": False}      # one byte of entropy data: found by tools/fuzz_parity.py

@@ -1,4 +1,4 @@
-"""Randomised parity sweep on a GPU box: python tools/fuzz_parity.py [seed] [images]
+"""Randomised parity sweep on a GPU box: python tools/fuzz_parity.py [seed] [images] [dump-dir]
 
 Encodes random pictures with Pillow (libjpeg) -- random size 1..900 x 1..700, grey / 4:4:4 / 4:2:2 / 4:2:0, quality 1..100,
 standard or optimised Huffman tables, with or without restart intervals, smooth / noisy / mixed content -- decodes them in
@@ -18,6 +18,7 @@ mjx = ge.load_package()
 orc.lib()
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 total = int(sys.argv[2]) if len(sys.argv) > 2 else 600
+dump = sys.argv[3] if len(sys.argv) > 3 else None          # directory that receives every batch before it runs
 rng = np.random.default_rng(seed)
 ctx = mjx.Context(0)
 
@@ -63,7 +64,15 @@ done = differ = 0
 while done < total:
     items = [encode() for _ in range(int(rng.integers(1, 48)))]
     scans = [mjx.ParsedScan(d) for d, _ in items]
-    batch = mjx.Batch(ctx, scans, keep_coefs=True, chunk_images=int(rng.integers(1, 64)))
+    chunk = int(rng.integers(1, 64))
+    if dump:                                       # the batch that is about to run, for a post-mortem
+        os.makedirs(dump, exist_ok=True)
+        for f in os.listdir(dump):
+            os.remove(os.path.join(dump, f))
+        for k, (d, what) in enumerate(items):
+            open(os.path.join(dump, "%03d.jpg" % k), "wb").write(d)
+        open(os.path.join(dump, "batch.txt"), "w").write("seed %d chunk_images %d\n" % (seed, chunk) + "\n".join(str(w) for _, w in items))
+    batch = mjx.Batch(ctx, scans, keep_coefs=True, chunk_images=chunk)
     batch.decode(); batch.wait()
     for i, (d, what) in enumerate(items):
         assert batch.status(i) == mjx.OK, (what, batch.status(i))
