@@ -32,7 +32,8 @@ struct mjx_ctx {
     hipStream_t stream2 = nullptr;  // odd chunks run here (MJX_STREAMS=2): one chunk's stage B overlaps the next one's stage A
     int nstreams = 1;
     bool profiling = false;
-    int fix_passes = 4;            // synchronisation rounds enqueued up front (the last one must re-decode nothing)
+    int fix_passes = 6;            // synchronisation rounds enqueued up front (the last one must re-decode nothing; rounds
+                                   // behind an empty one leave at once)
     // Extra dynamic LDS per entropy kernel = occupancy caps for experiments (MJX_SPEC/MERGE/WRITE_LDS_PAD); 0 in production.
     size_t spec_lds_pad = 0, merge_lds_pad = 0, write_lds_pad = 0;
 };
@@ -395,7 +396,8 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
             for (int k = 0; k < fix_passes; k++) {
                 prof_begin(b, MJX_K_HUFF_FIX, st);
                 launch_huff_merge(st, c.merge_wgs, nimg, b->huff_lds, b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps),
-                                  b->d_mismatch + ci * kMaxFix + k, SCR(d_items), SCR(d_pull), b->d_segs);
+                                  b->d_mismatch + ci * kMaxFix + k, SCR(d_items), SCR(d_pull), b->d_segs,
+                                  k > 0 ? b->d_mismatch + ci * kMaxFix + k - 1 : nullptr);
                 prof_end(b, st);
             }
             HIPOK(hipMemcpyAsync(b->h_mismatch + ci * kMaxFix, b->d_mismatch + ci * kMaxFix, kMaxFix * sizeof(uint32_t),

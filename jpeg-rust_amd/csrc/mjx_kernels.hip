@@ -455,8 +455,12 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
                                                                 const LutEntry *lut_pool, SubseqState *g_entry,
                                                                 SubseqState *g_exit, uint32_t *g_cps, uint32_t *mismatches,
                                                                 uint32_t win_off, uint32_t *g_items, uint32_t *g_item_count,
-                                                                const uint32_t *segs)
+                                                                const uint32_t *segs, const uint32_t *prev_mismatches)
 {
+    // A round behind one that re-decoded nothing has nothing to do either (the fixed point is reached): it leaves at
+    // once, its own count stays zero, and so does every later round's.  That makes spare rounds nearly free (a launch),
+    // so enough of them are enqueued for streams that synchronise slowly (noisy pictures at quality >= 95 need 5..15).
+    if (prev_mismatches && *prev_mismatches == 0) return;
     extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, windows (= item exchange), wave counts
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
     uint32_t *s_cnt = s_win + kMergeWg * kMergeStride;                     // (no static LDS: it would be padded to the dynamic part's alignment)
@@ -1593,11 +1597,12 @@ void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tab
 
 void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                        const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
-                       uint32_t *cps, uint32_t *mismatches, uint32_t *items, uint32_t *item_count, const uint32_t *segs)
+                       uint32_t *cps, uint32_t *mismatches, uint32_t *items, uint32_t *item_count, const uint32_t *segs,
+                       const uint32_t *prev_mismatches)
 {
     (void)hipMemsetAsync(item_count, 0, size_t(nimg) * sizeof(uint32_t), st);
     const size_t lds = tables_lds + size_t(kMergeWg) * kMergeStride * 4 + (kMergeWg / 64) * 4 + pad_lds;
-    hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches, uint32_t(tables_lds), items, item_count, segs);
+    hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches, uint32_t(tables_lds), items, item_count, segs, prev_mismatches);
     const size_t tail_lds = tables_lds + size_t(64) * kMergeStride * 4;
     hipLaunchKernelGGL(k_huff_merge_tail, dim3(nimg, max_wg * (kMergeWg / 64)), dim3(64), tail_lds, st, images, scan_pool, lut_pool, exit_, cps, uint32_t(tables_lds), items, item_count, segs);
 }
