@@ -2,7 +2,7 @@
 
 Encodes random pictures with Pillow (libjpeg) -- random size 1..900 x 1..700, grey / 4:4:4 / 4:2:2 / 4:2:0, quality 1..100,
 standard or optimised Huffman tables, with or without restart intervals, smooth / noisy / mixed content -- decodes them in
-batches of random chunking through the C ABI and checks every image against the CPU oracle (test infrastructure):
+batches of random chunking (host- or device-side de-stuffing) through the C ABI and checks every image against the CPU oracle (test infrastructure):
 coefficients bit-exact (T0), RGB within 1 LSB (T2a).  tests/test_gpu_parity.py holds the fixed cases; this is the wide net.
 """
 import io, os, sys
@@ -63,7 +63,8 @@ def encode():
 done = differ = 0
 while done < total:
     items = [encode() for _ in range(int(rng.integers(1, 48)))]
-    scans = [mjx.ParsedScan(d) for d, _ in items]
+    stuffed = bool(rng.random() < 0.3)             # FF00 pairs left in: the upload compacts the scans on the GPU
+    scans = [mjx.ParsedScan(d, device_destuff=stuffed) for d, _ in items]
     chunk = int(rng.integers(1, 64))
     if dump:                                       # the batch that is about to run, for a post-mortem
         os.makedirs(dump, exist_ok=True)
