@@ -44,6 +44,10 @@ def picture(w, h, kind):
 def encode():
     w = int(rng.integers(1, 900)) if rng.random() < 0.8 else int(rng.integers(1, 40))
     h = int(rng.integers(1, 700)) if rng.random() < 0.8 else int(rng.integers(1, 40))
+    if rng.random() < 0.25:                # the package's own generator: also 4:4:0, Annex-K tables
+        sub = ["444", "422", "420", "440", "gray"][int(rng.integers(0, 5))]
+        q = int(rng.integers(1, 101))
+        return mjx.synth_jpeg(w, h, sub, q, seed=int(rng.integers(0, 1 << 30))), (w, h, {"synth": sub, "quality": q})
     arr = picture(w, h, int(rng.integers(0, 4)))
     grey = rng.random() < 0.15
     im = Image.fromarray(arr[..., 0] if grey else arr, "L" if grey else "RGB")
