@@ -1504,9 +1504,7 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
         {   // phase 0
             float4 *z = reinterpret_cast<float4 *>(smem_px);
             const uint32_t nq = nblk * (kPixStride / 4);
-#ifndef MJX_EXP_NOZERO
             for (uint32_t i = tid; i < nq; i += LANES) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
         }
         __syncthreads();
         {   // phase 1
