@@ -44,6 +44,18 @@ pub struct mjx_hufftab {
 }
 
 #[repr(C)]
+pub struct mjx_scan_part {
+    pub scan: *const u8,
+    pub scan_len: usize,
+    pub comp: u8,
+    pub restart_interval: u16,
+    pub n_restart: u32,
+    pub restart_offsets: *const u32,
+    pub dc: mjx_hufftab,
+    pub ac: mjx_hufftab,
+}
+
+#[repr(C)]
 pub struct mjx_scan_desc {
     pub scan: *const u8,
     pub scan_len: usize,
@@ -61,6 +73,8 @@ pub struct mjx_scan_desc {
     pub restart_interval: u16,
     pub n_restart: u32,
     pub restart_offsets: *const u32,
+    pub n_parts: u8,
+    pub parts: *const mjx_scan_part,
     pub owner_: *mut c_void,
 }
 

@@ -60,6 +60,18 @@ typedef struct mjx_hufftab {       /* the two slices given to HuffmanTable::from
     uint8_t vals[256];
 } mjx_hufftab;
 
+/* One scan of a multi-scan baseline file in which every scan carries a single component (non-interleaved order, T.81
+ * A.2.2) -- beyond the reference, which stops after the first SOS (jpeg/mod.rs:415-417).  SURVEY s8(f)-4. */
+typedef struct mjx_scan_part {
+    const uint8_t *scan;           /* this scan's entropy-coded segment, de-stuffed, RSTn taken out */
+    size_t scan_len;
+    uint8_t comp;                  /* index into mjx_scan_desc.comp of the component this scan carries */
+    uint16_t restart_interval;     /* blocks per restart interval as defined when the SOS was read, 0 = none */
+    uint32_t n_restart;
+    const uint32_t *restart_offsets;
+    mjx_hufftab dc, ac;            /* the two tables the scan uses, as defined when its SOS was read */
+} mjx_scan_part;
+
 typedef struct mjx_scan_desc {
     const uint8_t *scan;           /* bytes after the SOS header to end of file, de-stuffed (jpeg/mod.rs:371-385) unless
                                       scan_is_stuffed */
@@ -77,7 +89,11 @@ typedef struct mjx_scan_desc {
     uint16_t restart_interval;     /* MCUs per interval, 0 = none */
     uint32_t n_restart;            /* entries of restart_offsets */
     const uint32_t *restart_offsets; /* byte offset in `scan` of the first byte of interval 1, 2, ... (interval 0 starts at 0) */
-    void *owner_;                  /* internal: storage behind `scan` when filled by mjx_parse */
+    /* Multi-scan files: n_parts > 0 means `scan` is NULL, `comp` lists the frame's components in frame order and every
+       component has exactly one entry in `parts`; the dc / ac slots above are not used. */
+    uint8_t n_parts;
+    const mjx_scan_part *parts;
+    void *owner_;                  /* internal: storage behind `scan` / `parts` when filled by mjx_parse */
 } mjx_scan_desc;
 
 /* ---- outer surface ------------------------------------------------------------------------ */

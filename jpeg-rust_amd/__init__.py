@@ -54,13 +54,20 @@ class HuffTab(ctypes.Structure):
     _fields_ = [("bits", ctypes.c_uint8 * 16), ("vals", ctypes.c_uint8 * 256)]
 
 
+class ScanPart(ctypes.Structure):
+    _fields_ = [("scan", ctypes.POINTER(ctypes.c_uint8)), ("scan_len", ctypes.c_size_t), ("comp", ctypes.c_uint8),
+                ("restart_interval", ctypes.c_uint16), ("n_restart", ctypes.c_uint32),
+                ("restart_offsets", ctypes.POINTER(ctypes.c_uint32)), ("dc", HuffTab), ("ac", HuffTab)]
+
+
 class ScanDesc(ctypes.Structure):
     _fields_ = [("scan", ctypes.POINTER(ctypes.c_uint8)), ("scan_len", ctypes.c_size_t),
                 ("width", ctypes.c_uint16), ("height", ctypes.c_uint16), ("ncomp", ctypes.c_uint8),
                 ("comp", Comp * 3), ("qt", (ctypes.c_uint16 * 64) * 4), ("qt_present", ctypes.c_uint8),
                 ("dc", HuffTab * 4), ("ac", HuffTab * 4), ("dc_present", ctypes.c_uint8),
                 ("ac_present", ctypes.c_uint8), ("scan_is_stuffed", ctypes.c_uint8), ("restart_interval", ctypes.c_uint16),
-                ("n_restart", ctypes.c_uint32), ("restart_offsets", ctypes.POINTER(ctypes.c_uint32)), ("owner_", ctypes.c_void_p)]
+                ("n_restart", ctypes.c_uint32), ("restart_offsets", ctypes.POINTER(ctypes.c_uint32)),
+                ("n_parts", ctypes.c_uint8), ("parts", ctypes.POINTER(ScanPart)), ("owner_", ctypes.c_void_p)]
 
 
 class Image(ctypes.Structure):

@@ -50,6 +50,7 @@ struct ImageInfo {
     uint32_t tile_off = 0, ntiles = 0, tile_blocks = 0;
     uint64_t scan_len = 0;
     uint32_t chunk = 0;
+    uint32_t role = 0;             // 0 ordinary picture; multi-scan files: 1 = one scan (internal), 2 = the picture
 };
 
 struct Chunk {
@@ -62,6 +63,7 @@ struct Chunk {
     uint32_t max_wg = 0, merge_wgs = 0, max_tiles = 0, lut_cap = 0, max_tile_blocks = 0, mode_mask = 0, max_segs = 0, bpm_mask = 0, max_restart_segs = 0;
     uint64_t plane_words = 0;      // REF_COMPAT scratch of the chunk
     uint32_t max_pixel_wgs = 0;
+    bool has_gather = false;       // holds multi-scan pictures (k_planar_gather runs)
 };
 
 struct EventPair {
@@ -74,7 +76,9 @@ struct EventPair {
 struct mjx_batch {
     mjx_ctx *ctx = nullptr;
     mjx_opts opts{};
-    std::vector<ImageInfo> info;
+    std::vector<ImageInfo> info;        // every image the kernels see: the caller's pictures, and the scans of multi-scan
+                                        // files as internal one-component pictures in front of theirs
+    std::vector<size_t> visible;        // caller's picture i -> index into info / himages
     std::vector<DevImage> himages;
     std::vector<Chunk> chunks;
     DevImage *d_images = nullptr;
@@ -174,6 +178,14 @@ void fill_dev_image(const ImagePlan &p, DevImage &d)
         d.nbx = p.nbx;
         d.nby = p.nby;
     }
+    d.role = p.role;
+    if (p.role == 1) {                 // a scan of a multi-scan file: no stage B; one tile offset per block for the gather
+        d.mode = 7;
+        d.log2_tile = 0;
+        d.tile_blocks = 1;
+    } else if (p.role == 2) {
+        for (uint32_t c = 0; c < 3; c++) { d.src_back[c] = 3 - c; d.cbw[c] = p.cbw[c]; d.cbh[c] = p.cbh[c]; }
+    }
     std::memcpy(d.blk_comp, p.blk_comp, sizeof d.blk_comp);
     std::memcpy(d.blk_bx, p.blk_bx, sizeof d.blk_bx);
     std::memcpy(d.blk_by, p.blk_by, sizeof d.blk_by);
@@ -206,9 +218,13 @@ void plan_chunks(mjx_batch *b)
         c.coef_base = keep ? coef_running : 0;
         c.ent_base = keep ? ent_running : 0;
         c.tile_base = keep ? tile_running : 0;
-        while (i < n && c.count < per_chunk) {
+        for (;;) {
+            if (i >= n) break;
             const ImageInfo &inf = b->info[i];
-            if (c.count > 0 && (c.entries + inf.ent_cap > kMaxChunkEntries || c.nsub >= sub_target)) break;
+            // (the scans of a multi-scan file and their picture stay in one chunk: only a group's first image may open one)
+            const bool head = inf.role == 0 || (inf.role == 1 && (i == 0 || b->info[i - 1].role != 1));
+            if (head && c.count >= per_chunk) break;
+            if (head && c.count > 0 && (c.entries + inf.ent_cap > kMaxChunkEntries || c.nsub >= sub_target)) break;
             DevImage &d = b->himages[i];
             if (inf.status == MJX_OK) {
                 d.sub_off = c.nsub;
@@ -225,8 +241,11 @@ void plan_chunks(mjx_batch *b)
                 c.max_wg = std::max<uint32_t>(c.max_wg, (d.himg.nsub + kHuffWg - 1) / kHuffWg);
                 if (d.himg.nsub > 1) c.merge_wgs = std::max<uint32_t>(c.merge_wgs, (d.himg.nsub - 1 + kMergeWg - 1) / kMergeWg);
                 const uint32_t T = 1u << d.log2_tile;
-                c.max_tiles = std::max<uint32_t>(c.max_tiles, (d.nmcu + T - 1) / T);
-                c.max_tile_blocks = std::max<uint32_t>(c.max_tile_blocks, T * d.bpm);
+                if (d.role != 1) {
+                    c.max_tiles = std::max<uint32_t>(c.max_tiles, (d.nmcu + T - 1) / T);
+                    c.max_tile_blocks = std::max<uint32_t>(c.max_tile_blocks, T * d.bpm);
+                }
+                if (d.role == 2) c.has_gather = true;
                 c.lut_cap = std::max<uint32_t>(c.lut_cap, d.lut_n);
                 c.mode_mask |= 1u << d.mode;
                 c.bpm_mask |= 1u << d.bpm;
@@ -421,6 +440,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         prof_end(b, st);
         prof_begin(b, MJX_K_DC_SCAN, st);
         launch_dc_scan(st, c.max_segs, nimg, imgs, dcb, SCR(d_segsum), b->d_img_flags, c.bpm_mask, c.max_restart_segs);
+        if (c.has_gather) launch_planar_gather(st, nimg, imgs, SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_img_flags);
         prof_end(b, st);
     }
     if (stages & MJX_STAGE_PIXELS) {
@@ -525,17 +545,26 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
         // with restart intervals the lanes also fill what the synchronisation passes counted after a segment's last block
         // (garbage, up to one entry per two bits of scan)
         if (p.restart_mcus) inf.ent_cap = (uint64_t(p.scan_len) * 4 + 64 + group_pad) / 8 * 8;
+        inf.role = p.role;
+        if (p.role == 2) {                     // gathered from the three scans in front of it
+            if (i < 3) return MJX_ERR_INVALID_ARG;
+            inf.ent_cap = b->info[i - 1].ent_cap + b->info[i - 2].ent_cap + b->info[i - 3].ent_cap + 8;
+        }
         d.ent_cap = uint32_t(std::min<uint64_t>(inf.ent_cap, 0xffffffffu));
         inf.scan_len = p.scan_len;
         inf.rgb_off = rgb_pool;
-        inf.rgb_bytes = uint64_t(p.width) * p.height * 3;
+        inf.rgb_bytes = p.role == 1 ? 0 : uint64_t(p.width) * p.height * 3;     // (a scan of a multi-scan file has no picture)
         d.rgb_off = rgb_pool;
         rgb_pool += align_up(inf.rgb_bytes, 256);
         b->scan_bytes += p.scan_len;
         b->rgb_bytes += inf.rgb_bytes;
-        b->coef_bytes += inf.nblocks * 128;
-        b->pixels += uint64_t(p.width) * p.height;
+        if (p.role != 1) {
+            b->coef_bytes += inf.nblocks * 128;
+            b->pixels += uint64_t(p.width) * p.height;
+        }
     }
+    for (size_t i = 0; i < n; i++)
+        if (b->info[i].role != 1) b->visible.push_back(i);
     b->rgb_pool_bytes = rgb_pool;
     plan_chunks(b);
 
@@ -597,7 +626,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
     };
     rc = dev();
     if (rc != MJX_OK) { release(b); return rc; }
-    if (status) for (size_t i = 0; i < n; i++) status[i] = b->info[i].status;
+    if (status) for (size_t i = 0; i < b->visible.size(); i++) status[i] = b->info[b->visible[i]].status;
     *out = b;
     return MJX_OK;
 }
@@ -715,8 +744,14 @@ extern "C" int mjx_batch_create(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t
         (void)hipFree(d_cnt);
         if (rc != MJX_OK) { (void)hipGetLastError(); return rc; }
     }
-    std::vector<ImagePlan> plans(n);
-    for (size_t i = 0; i < n; i++) plan_image(dd[i], o, plans[i]);
+    std::vector<ImagePlan> plans;
+    std::vector<size_t> plan_of(n);                    // input i -> its picture's plan (multi-scan files add plans in front)
+    plans.reserve(n);
+    for (size_t i = 0; i < n; i++) {
+        plan_input(dd[i], o, plans);
+        plan_of[i] = plans.size() - 1;
+    }
+    for (size_t &pi : ds.plan_index) pi = plan_of[pi];
     return build_batch(ctx, plans, o, nullptr, 1, out, status, any_stuffed ? &ds : nullptr);
 }
 
@@ -757,6 +792,8 @@ extern "C" int mjx_batch_tile(mjx_ctx *ctx, const mjx_batch *src, size_t times, 
         p.lut.assign(d.lut_n, 0);                         // sizes only: the pool is copied device-to-device
         p.nseg = d.nseg;
         p.restart_mcus = d.restart_mcus;
+        p.role = d.role;
+        for (uint32_t c = 0; c < 3; c++) { p.cbw[c] = d.cbw[c]; p.cbh[c] = d.cbh[c]; }
         p.seg.assign(src->h_segs.begin() + size_t(d.seg_off) * 2, src->h_segs.begin() + size_t(d.seg_off) * 2 + 2 * (size_t(d.nseg) + 1));
         p.scan = nullptr;
         p.scan_len = src->info[k].scan_len;
@@ -836,21 +873,38 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
         if (flags[i]) b->info[i].status = MJX_ERR_TRUNCATED;           // scan ended before the last MCU
         else if (dev[i]) b->info[i].status = MJX_ERR_BAD_HUFFMAN;       // no code matched (huffman.rs:156/162)
     }
+    for (size_t i = 3; i < dev.size(); i++) {                           // a multi-scan picture takes its scans' failures
+        if (b->info[i].role != 2 || (b->info[i].status != MJX_OK && b->info[i].status != MJX_ERR_TRUNCATED)) continue;
+        for (size_t k = 1; k <= 3; k++)
+            if (b->info[i - k].status != MJX_OK) b->info[i].status = b->info[i - k].status;
+    }
     return MJX_OK;
 }
 
-extern "C" size_t mjx_batch_size(const mjx_batch *b) { return b ? b->info.size() : 0; }
-
-extern "C" int mjx_batch_status(const mjx_batch *b, size_t i)
+namespace {
+// caller's picture index -> internal image (multi-scan files keep their scans as internal images)
+inline bool visible_index(const mjx_batch *b, size_t i, size_t &ii)
 {
-    if (!b || i >= b->info.size()) return MJX_ERR_INVALID_ARG;
+    if (!b || i >= b->visible.size()) return false;
+    ii = b->visible[i];
+    return true;
+}
+}   // namespace
+
+extern "C" size_t mjx_batch_size(const mjx_batch *b) { return b ? b->visible.size() : 0; }
+
+extern "C" int mjx_batch_status(const mjx_batch *b, size_t iu)
+{
+    size_t i;
+    if (!visible_index(b, iu, i)) return MJX_ERR_INVALID_ARG;
     return b->info[i].status;
 }
 
-extern "C" int mjx_batch_image_info(const mjx_batch *b, size_t i, uint32_t *width, uint32_t *height,
+extern "C" int mjx_batch_image_info(const mjx_batch *b, size_t iu, uint32_t *width, uint32_t *height,
                                     uint32_t *blocks_per_mcu, uint32_t *mcus)
 {
-    if (!b || i >= b->info.size()) return MJX_ERR_INVALID_ARG;
+    size_t i;
+    if (!visible_index(b, iu, i)) return MJX_ERR_INVALID_ARG;
     const ImageInfo &inf = b->info[i];
     if (width) *width = inf.width;
     if (height) *height = inf.height;
@@ -859,9 +913,10 @@ extern "C" int mjx_batch_image_info(const mjx_batch *b, size_t i, uint32_t *widt
     return inf.status;
 }
 
-extern "C" int mjx_batch_rgb_device(const mjx_batch *b, size_t i, void **dev_ptr, size_t *bytes)
+extern "C" int mjx_batch_rgb_device(const mjx_batch *b, size_t iu, void **dev_ptr, size_t *bytes)
 {
-    if (!b || i >= b->info.size() || !dev_ptr) return MJX_ERR_INVALID_ARG;
+    size_t i;
+    if (!visible_index(b, iu, i) || !dev_ptr) return MJX_ERR_INVALID_ARG;
     const ImageInfo &inf = b->info[i];
     if (inf.status != MJX_OK) { *dev_ptr = nullptr; if (bytes) *bytes = 0; return inf.status; }
     *dev_ptr = b->d_rgb + inf.rgb_off;
@@ -869,9 +924,10 @@ extern "C" int mjx_batch_rgb_device(const mjx_batch *b, size_t i, void **dev_ptr
     return MJX_OK;
 }
 
-extern "C" int mjx_batch_copy_rgb(mjx_batch *b, size_t i, uint8_t *host_rgb)
+extern "C" int mjx_batch_copy_rgb(mjx_batch *b, size_t iu, uint8_t *host_rgb)
 {
-    if (!b || i >= b->info.size() || !host_rgb) return MJX_ERR_INVALID_ARG;
+    size_t i;
+    if (!visible_index(b, iu, i) || !host_rgb) return MJX_ERR_INVALID_ARG;
     const ImageInfo &inf = b->info[i];
     if (inf.status != MJX_OK) return inf.status;
     HIPOK(hipSetDevice(b->ctx->device));
@@ -880,9 +936,10 @@ extern "C" int mjx_batch_copy_rgb(mjx_batch *b, size_t i, uint8_t *host_rgb)
     return MJX_OK;
 }
 
-extern "C" int mjx_batch_copy_coefs(mjx_batch *b, size_t i, int16_t *host_coefs, size_t cap_blocks, size_t *nblocks)
+extern "C" int mjx_batch_copy_coefs(mjx_batch *b, size_t iu, int16_t *host_coefs, size_t cap_blocks, size_t *nblocks)
 {
-    if (!b || i >= b->info.size() || !host_coefs) return MJX_ERR_INVALID_ARG;
+    size_t i;
+    if (!visible_index(b, iu, i) || !host_coefs) return MJX_ERR_INVALID_ARG;
     const ImageInfo &inf = b->info[i];
     if (inf.status != MJX_OK) return inf.status;
     if (nblocks) *nblocks = size_t(inf.nblocks);
@@ -963,7 +1020,7 @@ extern "C" int mjx_decode_scans(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t
     if (rc == MJX_OK) rc = mjx_batch_wait(*out);
     if (rc != MJX_OK) { mjx_batch_free(*out); *out = nullptr; return rc; }
     for (size_t i = 0; i < n; i++) {
-        if (status) status[i] = (*out)->info[i].status;
+        if (status) status[i] = mjx_batch_status(*out, i);
         if (rgb_dev) {
             void *p = nullptr;
             (void)mjx_batch_rgb_device(*out, i, &p, nullptr);

@@ -41,6 +41,12 @@ struct DevImage {
     uint32_t nseg;          // 1 = no restart interval
     uint32_t restart_mcus;
     uint32_t ent_cap;       // entries the image's stream region holds
+    // multi-scan files: role 1 = one scan as a one-component picture (entropy stage only, tile = one
+    // block, so tile_eoff holds an offset per block), role 2 = the picture (no scan; k_planar_gather builds its stream
+    // from the role-1 images, which sit src_back[c] places before it in the image array)
+    uint32_t role;
+    uint32_t src_back[3];
+    uint32_t cbw[3], cbh[3];    // role 2: block grid of each component's own scan
 };
 
 // Device-side de-stuffing (jpeg/mod.rs:371-385 on the GPU): one image of an upload.
@@ -93,6 +99,9 @@ void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevI
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint32_t *entries, const uint32_t *tile_eoff, const int32_t *dcbuf, const float *qmult,
                        uint8_t *rgb, uint32_t mode_mask, unsigned long long *planes, const uint32_t *img_flags);
+// multi-scan pictures: component streams (raster order) -> the picture's stream in MCU order, tile offsets, DC values
+void launch_planar_gather(hipStream_t st, uint32_t nimg, const DevImage *images, uint32_t *entries, uint32_t *tile_eoff,
+                          int32_t *dcbuf, uint32_t *img_flags);
 void launch_ref_color(hipStream_t st, uint32_t max_pixel_wgs, uint32_t nimg, const DevImage *images,
                       const unsigned long long *planes, uint8_t *rgb, const uint32_t *img_flags);
 #endif

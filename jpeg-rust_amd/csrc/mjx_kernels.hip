@@ -678,7 +678,7 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *im
 {
     __shared__ uint32_t s_tmp[4];
     const DevImage &im = images[blockIdx.x];
-    if (!im.valid) return;
+    if (!im.valid || im.role == 2) return;          // (role 2: a multi-scan picture, flagged by k_planar_gather)
     // `verdict` = what the last enqueued synchronisation round of this chunk re-decoded.  Non-zero: the entries are not
     // yet the fixed point (the host finds out at mjx_batch_wait and runs more rounds), block and entry counts of
     // neighbouring subsequences do not fit together, and the kernels behind this one would write a stream with holes
@@ -796,6 +796,66 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
         if (it % kFlushEvery == 0) sink.flush_groups();
     }
     sink.flush();
+}
+
+// Multi-scan pictures (beyond the reference, which stops after the first scan).  Every scan went through
+// the entropy stage as a one-component picture of its own: stream entries and DC values in the component's raster
+// order over its own block grid, one tile offset per block.  One workgroup per picture walks the picture's tiles in
+// MCU order: a lane per block slot looks up its block's run in the component stream (blocks that exist only as MCU
+// padding have none), a workgroup scan places the runs, and the entries are copied with the block field rewritten.
+// The result is what k_huff_write + DC prediction leave behind for an interleaved picture, so stage B runs unchanged.
+// Serial over the tiles of a picture -- a rare format; pictures of a chunk run side by side.
+extern "C" __global__ __launch_bounds__(256) void k_planar_gather(const DevImage *images, uint32_t *entries,
+                                                                   uint32_t *tile_eoff, int32_t *dcbuf, uint32_t *img_flags)
+{
+    __shared__ uint32_t s_tmp[4];
+    const DevImage &im = images[blockIdx.x];
+    if (!im.valid || im.role != 2) return;
+    const uint32_t tid = threadIdx.x;
+    const DevImage *src[3] = {&images[blockIdx.x - im.src_back[0]], &images[blockIdx.x - im.src_back[1]],
+                              &images[blockIdx.x - im.src_back[2]]};
+    const uint32_t bad = img_flags[src[0]->status_idx] | img_flags[src[1]->status_idx] | img_flags[src[2]->status_idx];
+    if (bad) {                                       // a scan is short (or its chunk unconverged): no picture
+        if (tid == 0) img_flags[im.status_idx] = bad;
+        return;
+    }
+    const uint32_t T = 1u << im.log2_tile, bpm = im.bpm, tile_blocks = im.tile_blocks;
+    const uint32_t ntiles = (im.nmcu + T - 1) / T;
+    uint32_t *dst = entries + im.ent_off;
+    uint32_t *eoff = tile_eoff + im.tile_off;
+    int32_t *dc_dst = dcbuf + im.coef_off;
+    uint32_t run = 0;
+    for (uint32_t tile = 0; tile < ntiles; tile++) {
+        const uint32_t m = tile * T + tid / bpm, k = tid % bpm;
+        uint32_t s0 = 0, cnt = 0, c = 0, rb = 0;
+        bool real = false;
+        if (tid < tile_blocks && m < im.nmcu) {
+            c = im.blk_comp[k];
+            const uint32_t bx = (m % im.mcux) * im.ch[c] + im.blk_bx[k], by = (m / im.mcux) * im.cv[c] + im.blk_by[k];
+            real = bx < im.cbw[c] && by < im.cbh[c];
+            if (real) {
+                rb = by * im.cbw[c] + bx;
+                const uint32_t *se = tile_eoff + src[c]->tile_off;      // one offset per block (+ sentinel)
+                s0 = se[rb];
+                cnt = se[rb + 1] - s0;
+            }
+        }
+        uint32_t total;
+        const uint32_t at = run + wg_exclusive_scan(cnt, s_tmp, &total);
+        if (tid == 0) eoff[tile] = run;
+        if (tid < tile_blocks && m < im.nmcu) {
+            const uint32_t blk = tile * tile_blocks + tid;
+            dc_dst[blk] = real ? (dcbuf + src[c]->coef_off)[rb] : 0;
+            const uint32_t *sp = entries + src[c]->ent_off + s0;
+            const uint32_t field = (blk & 0xffu) << 22;
+            for (uint32_t j = 0; j < cnt; j++) dst[at + j] = (sp[j] & 0x003fffffu) | field;
+        }
+        run += total;
+    }
+    if (tid == 0) {
+        eoff[ntiles] = run;
+        img_flags[im.status_idx] = 0;
+    }
 }
 
 // DC prediction (decoder.rs:173, 208-210: running sum per component, never reset) as a two-level prefix sum over
@@ -1646,6 +1706,12 @@ void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t
         hipLaunchKernelGGL(k_idct_color<1>, dim3(max_tiles, nimg), dim3(kLanes420), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags);
     if (mode_mask & 4u)
         hipLaunchKernelGGL(k_idct_color<2>, dim3(max_tiles, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags);
+}
+
+void launch_planar_gather(hipStream_t st, uint32_t nimg, const DevImage *images, uint32_t *entries, uint32_t *tile_eoff,
+                          int32_t *dcbuf, uint32_t *img_flags)
+{
+    hipLaunchKernelGGL(k_planar_gather, dim3(nimg), dim3(256), 0, st, images, entries, tile_eoff, dcbuf, img_flags);
 }
 
 void launch_ref_color(hipStream_t st, uint32_t max_pixel_wgs, uint32_t nimg, const DevImage *images,

@@ -43,6 +43,15 @@ struct ParserState {
     unsigned width = 0, height = 0;
     std::vector<FrameComp> frame;
     unsigned restart_interval = 0;     // DRI (accepted unless strict_ref)
+    // multi-scan files (one component per scan): what each scan contributed, assembled into one block at the end
+    struct Part {
+        std::vector<uint8_t> scan;
+        std::vector<uint32_t> rst;
+        uint8_t comp = 0, td = 0, ta = 0;
+        unsigned restart_interval = 0;
+        mjx_hufftab dc, ac;
+    };
+    std::vector<Part> parts;
     mjx_scan_desc *d;
 };
 
@@ -126,7 +135,89 @@ void read_dht(const ByteView &f, size_t pos, size_t len, mjx_scan_desc *d)      
 }
 
 // SOS header (mod.rs:337-362) + component re-ordering (decoder.rs:83-152) + de-stuffing (mod.rs:371-385).
-void read_sos(const ByteView &f, size_t pos, ParserState &st, bool strict, bool keep_stuffed)
+// One scan of a multi-scan file (single component): its entropy-coded segment runs up to the next marker that is not
+// RSTn.  Returns the offset of that marker.
+size_t read_part(const ByteView &f, size_t i, uint8_t cid, uint8_t td, uint8_t ta, ParserState &st)
+{
+    const mjx_scan_desc *d = st.d;
+    ParserState::Part part;
+    int ci = -1;
+    for (size_t c = 0; c < st.frame.size(); c++) if (st.frame[c].id == cid) ci = int(c);
+    if (ci < 0 || td > 3 || ta > 3) throw ParseError{MJX_ERR_UNSUPPORTED_FORMAT};
+    for (const ParserState::Part &p : st.parts) if (p.comp == ci) throw ParseError{MJX_ERR_UNSUPPORTED_FORMAT};   // twice
+    if (!((d->dc_present >> td) & 1) || !((d->ac_present >> ta) & 1)) throw ParseError{MJX_ERR_MISSING_TABLE};
+    part.comp = uint8_t(ci);
+    part.td = td;
+    part.ta = ta;
+    part.dc = d->dc[td];
+    part.ac = d->ac[ta];
+    part.restart_interval = st.restart_interval;
+    const size_t total = f.size();
+    size_t k = i;
+    while (k < total) {
+        const uint8_t b = f.at(k);
+        if (b != 0xff) { part.scan.push_back(b); k++; continue; }
+        if (k + 1 >= total) { part.scan.push_back(b); k++; break; }
+        const uint8_t m = f.at(k + 1);
+        if (m == 0x00) { part.scan.push_back(0xff); k += 2; continue; }
+        if (m == 0xff) { k++; continue; }                                         // fill byte (T.81 B.1.1.2)
+        if ((m & 0xf8) == 0xd0 && part.restart_interval) {                        // RSTn: the next interval starts here
+            part.rst.push_back(uint32_t(part.scan.size()));
+            k += 2;
+            continue;
+        }
+        break;                                                                    // the next marker segment
+    }
+    st.parts.push_back(std::move(part));
+    return k;
+}
+
+// All scans of a multi-scan file are read: one block holds the parts array, the scans and the restart offsets.
+void finish_parts(ParserState &st)
+{
+    mjx_scan_desc *d = st.d;
+    const size_t n = st.parts.size();
+    if (n != st.frame.size() || n > 3) throw ParseError{MJX_ERR_UNSUPPORTED_FORMAT};                  // a component without a scan
+    size_t bytes = (n * sizeof(mjx_scan_part) + 15) & ~size_t(15);
+    for (const ParserState::Part &p : st.parts) bytes += ((p.scan.size() + 32 + 15) & ~size_t(15)) + ((p.rst.size() * 4 + 15) & ~size_t(15));
+    uint8_t *buf = static_cast<uint8_t *>(std::malloc(bytes));
+    if (!buf) throw ParseError{MJX_ERR_NOMEM};
+    mjx_scan_part *parts = reinterpret_cast<mjx_scan_part *>(buf);
+    size_t off = (n * sizeof(mjx_scan_part) + 15) & ~size_t(15);
+    d->width = uint16_t(st.width);
+    d->height = uint16_t(st.height);
+    d->ncomp = uint8_t(n);
+    for (size_t k = 0; k < n; k++) {
+        const ParserState::Part &p = st.parts[k];
+        const FrameComp &fc = st.frame[p.comp];
+        d->comp[p.comp] = mjx_comp{fc.id, fc.h, fc.v, fc.tq, p.td, p.ta};
+        mjx_scan_part &o = parts[k];
+        std::memset(&o, 0, sizeof o);
+        uint8_t *sc = buf + off;
+        if (!p.scan.empty()) std::memcpy(sc, p.scan.data(), p.scan.size());
+        std::memset(sc + p.scan.size(), 0xaa, 32);                                // huffman.rs:236-246
+        off += (p.scan.size() + 32 + 15) & ~size_t(15);
+        uint32_t *rst = reinterpret_cast<uint32_t *>(buf + off);
+        if (!p.rst.empty()) std::memcpy(rst, p.rst.data(), p.rst.size() * 4);
+        off += (p.rst.size() * 4 + 15) & ~size_t(15);
+        o.scan = sc;
+        o.scan_len = p.scan.size();
+        o.comp = p.comp;
+        o.restart_interval = uint16_t(p.restart_interval);
+        o.n_restart = uint32_t(p.rst.size());
+        o.restart_offsets = p.rst.empty() ? nullptr : rst;
+        o.dc = p.dc;
+        o.ac = p.ac;
+    }
+    d->scan = nullptr;
+    d->scan_len = 0;
+    d->n_parts = uint8_t(n);
+    d->parts = parts;
+    d->owner_ = buf;
+}
+
+// Returns 0 when the file's only scan has been read, else (multi-scan file) the offset of the marker behind this scan.
+size_t read_sos(const ByteView &f, size_t pos, ParserState &st, bool strict, bool keep_stuffed)
 {
     mjx_scan_desc *d = st.d;
     const unsigned n = f.at(pos);
@@ -138,10 +229,13 @@ void read_sos(const ByteView &f, size_t pos, ParserState &st, bool strict, bool 
     i += 4;
     if (!st.have_frame) throw ParseError{MJX_ERR_REF_PANIC};                     // mod.rs:388 unwrap
     if (n != 1 && n != 3) throw ParseError{MJX_ERR_UNSUPPORTED_FORMAT};          // decoder.rs:328-330 panic!("asd")
-    // A scan that carries fewer components than the frame is the first of several (non-interleaved baseline, SURVEY
-    // s8(f)-4: not built).  The reference decodes that first scan with the frame's sampling factors and stops
-    // (mod.rs:415-417); strict_ref keeps that, otherwise the file is refused rather than decoded to a wrong picture.
-    if (!strict && n < st.frame.size()) throw ParseError{MJX_ERR_UNSUPPORTED_FORMAT};
+    // A scan that carries fewer components than the frame is one of several (non-interleaved baseline).
+    // The reference decodes the first one with the frame's sampling factors and stops (mod.rs:415-417); strict_ref keeps
+    // that.  Otherwise single-component scans are collected (read_part); scans that interleave a subset are not built.
+    if (!strict && (n < st.frame.size() || !st.parts.empty())) {
+        if (n != 1) throw ParseError{MJX_ERR_UNSUPPORTED_FORMAT};
+        return read_part(f, i, sc[0].id, sc[0].td, sc[0].ta, st);
+    }
 
     d->width = uint16_t(st.width);
     d->height = uint16_t(st.height);
@@ -195,6 +289,7 @@ void read_sos(const ByteView &f, size_t pos, ParserState &st, bool strict, bool 
     d->n_restart = nrst;
     d->restart_offsets = nrst ? rst : nullptr;
     d->owner_ = buf;
+    return 0;
 }
 
 void walk(const uint8_t *jpeg, size_t len, const mjx_opts &opts, mjx_scan_desc *out)
@@ -210,7 +305,11 @@ void walk(const uint8_t *jpeg, size_t len, const mjx_opts &opts, mjx_scan_desc *
         uint8_t m = f.at(i + 1);
         if (m == 0) m = f.at(i + 2);
         const Seg seg = classify(m);
-        if (seg == Seg::SOI_EOI) { i += 2; continue; }                            // :209-215
+        if (seg == Seg::SOI_EOI) {                                                // :209-215
+            if (m == 0xd9 && !st.parts.empty()) { finish_parts(st); return; }      // EOI behind the last scan of several
+            i += 2;
+            continue;
+        }
         if (seg == Seg::OTHER_SKIPPABLE || seg == Seg::OTHER_STANDALONE || seg == Seg::OTHER_SOF) {
             if (strict) throw ParseError{MJX_ERR_UNSUPPORTED_MARKER};             // :456-462
             if (seg == Seg::OTHER_SOF) throw ParseError{MJX_ERR_UNSUPPORTED_FORMAT};
@@ -224,7 +323,12 @@ void walk(const uint8_t *jpeg, size_t len, const mjx_opts &opts, mjx_scan_desc *
         case Seg::DQT: read_dqt(f, i, body, out, strict); break;
         case Seg::SOF0: read_sof0(f, i, st, strict); break;
         case Seg::DHT: read_dht(f, i, body, out); break;
-        case Seg::SOS: read_sos(f, i, st, strict, opts.device_destuff != 0); return;                        // :415-417 returns after the first scan
+        case Seg::SOS: {
+            const size_t next = read_sos(f, i, st, strict, opts.device_destuff != 0);
+            if (!next) return;                                                    // :415-417 returns after the first scan
+            i = next;
+            continue;
+        }
         case Seg::DRI:                                                             // :424-428 panics; T.81 B.2.4.4 otherwise
             if (strict) throw ParseError{MJX_ERR_DRI_UNSUPPORTED};
             if (body < 2) throw ParseError{MJX_ERR_TRUNCATED};
@@ -242,6 +346,7 @@ void walk(const uint8_t *jpeg, size_t len, const mjx_opts &opts, mjx_scan_desc *
         }
         i += body;                                                                // :454
     }
+    if (!st.parts.empty()) { finish_parts(st); return; }
     throw ParseError{MJX_ERR_NO_SCAN};
 }
 

@@ -83,13 +83,19 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p)
 {
     p = ImagePlan{};
     auto fail = [&](int code) { p.status = code; return code; };
-    if (!d.scan) return fail(MJX_ERR_INVALID_ARG);
+    const bool gather = d.n_parts != 0;            // the picture of a multi-scan file: geometry only, no scan of its own
+    if (gather) {
+        if (!d.parts || d.n_parts != d.ncomp || d.ncomp != 3) return fail(MJX_ERR_UNSUPPORTED_FORMAT);
+        if (opts.layout == MJX_LAYOUT_REF_COMPAT || opts.strict_ref) return fail(MJX_ERR_UNSUPPORTED_FORMAT);   // the reference stops after scan 1
+    } else if (!d.scan) {
+        return fail(MJX_ERR_INVALID_ARG);
+    }
     if (d.ncomp != 1 && d.ncomp != 3) return fail(MJX_ERR_UNSUPPORTED_FORMAT);     // decoder.rs:328-330
     if (d.width == 0 || d.height == 0) return fail(MJX_ERR_REF_PANIC);             // x_factor division by zero
     // huffman.rs:127-128 preloads data[0..4] and panics on a shorter scan; the bug-compatible modes keep that.  Otherwise a
     // short scan (a flat 8x8 grey picture has one byte of entropy data) is decoded: past its end the lanes read the 0xAA
     // padding the reference itself reads there (huffman.rs:236-246).
-    if (d.scan_len < ((opts.strict_ref || opts.layout == MJX_LAYOUT_REF_COMPAT) ? 4u : 1u)) return fail(MJX_ERR_TRUNCATED);
+    if (!gather && d.scan_len < ((opts.strict_ref || opts.layout == MJX_LAYOUT_REF_COMPAT) ? 4u : 1u)) return fail(MJX_ERR_TRUNCATED);
     if (d.scan_len >= (size_t(1) << 28)) return fail(MJX_ERR_UNSUPPORTED_FORMAT);  // bit positions are 32 bit
     p.width = d.width;
     p.height = d.height;
@@ -101,8 +107,8 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p)
         const mjx_comp &k = d.comp[c];
         if (k.h < 1 || k.h > 2 || k.v < 1 || k.v > 2) return fail(MJX_ERR_UNSUPPORTED_FORMAT);   // mod.rs:275-277
         if (k.tq > 3 || !(d.qt_present & (1u << k.tq))) return fail(MJX_ERR_MISSING_TABLE);      // decoder.rs:222-225
-        if (k.td > 3 || !(d.dc_present & (1u << k.td))) return fail(MJX_ERR_MISSING_TABLE);      // decoder.rs:158-160
-        if (k.ta > 3 || !(d.ac_present & (1u << k.ta))) return fail(MJX_ERR_MISSING_TABLE);      // decoder.rs:154-156
+        if (!gather && (k.td > 3 || !(d.dc_present & (1u << k.td)))) return fail(MJX_ERR_MISSING_TABLE);      // decoder.rs:158-160
+        if (!gather && (k.ta > 3 || !(d.ac_present & (1u << k.ta)))) return fail(MJX_ERR_MISSING_TABLE);      // decoder.rs:154-156
         p.h[c] = k.h;
         p.v[c] = k.v;
         p.tq[c] = k.tq;
@@ -140,10 +146,26 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p)
         if (rc != MJX_OK) return fail(rc);
     }
 
+    if (gather) {
+        // no scan of its own: the kernels of the entropy stage find no subsequences here; stage B needs the geometry above,
+        // the dequantisation multipliers below and the components' own block grids (what the scans actually carry)
+        p.role = 2;
+        std::memset(&p.himg, 0, sizeof p.himg);
+        p.himg.bpm = p.bpm;
+        p.himg.total_blocks = p.nmcu * p.bpm;
+        p.himg.sub_bits = kSubseqBits;
+        p.nseg = 1;
+        p.seg = {0u, 0u, 0u, 0u};
+        for (uint32_t c = 0; c < p.ncomp; c++) {
+            p.cbw[c] = ((p.width * p.h[c] + p.hmax - 1) / p.hmax + 7) / 8;
+            p.cbh[c] = ((p.height * p.v[c] + p.vmax - 1) / p.vmax + 7) / 8;
+        }
+    }
+    int dc_base[4] = {-1, -1, -1, -1}, ac_base[4] = {-1, -1, -1, -1};
+    if (!gather) {
     // decode tables: each distinct (class, slot) used by the scan is built once.  Layout: the primary tables first, each
     // on a multiple of its size (lut_slot ORs the index into the base), then the sub-tables; a table's links are
     // relative to its own primary table.
-    int dc_base[4] = {-1, -1, -1, -1}, ac_base[4] = {-1, -1, -1, -1};
     p.lut.clear();
     static thread_local LutEntry tmp[kLutPrimarySize + 4096];
     std::vector<std::vector<LutEntry>> built;
@@ -240,6 +262,8 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p)
         p.himg.nsub = sub;
     }
 
+    }   // !gather
+
     // dequantisation x IDCT prescale, zig-zag order (reference: decoder.rs:230-232 multiplies by the raw table;
     // the AAN row/column factors and the 1/8 are folded in here so the kernel does one multiply per coefficient)
     double aan[8];
@@ -250,6 +274,52 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p)
             p.qmult[c][k] = float(double(d.qt[p.tq[c]][k]) * aan[nat >> 3] * aan[nat & 7] / 8.0);
         }
     return p.status;
+}
+
+void plan_input(const mjx_scan_desc &d, const mjx_opts &opts, std::vector<ImagePlan> &out)
+{
+    if (d.n_parts == 0) {
+        out.emplace_back();
+        plan_image(d, opts, out.back());
+        return;
+    }
+    ImagePlan pic;
+    plan_image(d, opts, pic);
+    const size_t first = out.size();
+    int bad = pic.status;
+    for (uint32_t c = 0; c < 3 && bad == MJX_OK; c++) {
+        const mjx_scan_part *part = nullptr;
+        for (uint32_t k = 0; k < d.n_parts; k++) if (d.parts[k].comp == c) part = &d.parts[k];
+        if (!part) { bad = MJX_ERR_UNSUPPORTED_FORMAT; break; }
+        // the scan as a one-component picture over the component's own block grid
+        mjx_scan_desc sub;
+        std::memset(&sub, 0, sizeof sub);
+        sub.scan = part->scan;
+        sub.scan_len = part->scan_len;
+        sub.width = uint16_t((uint32_t(d.width) * pic.h[c] + pic.hmax - 1) / pic.hmax);
+        sub.height = uint16_t((uint32_t(d.height) * pic.v[c] + pic.vmax - 1) / pic.vmax);
+        sub.ncomp = 1;
+        sub.comp[0] = mjx_comp{d.comp[c].id, 1, 1, d.comp[c].tq, 0, 0};
+        std::memcpy(sub.qt, d.qt, sizeof sub.qt);
+        sub.qt_present = d.qt_present;
+        sub.dc[0] = part->dc;
+        sub.ac[0] = part->ac;
+        sub.dc_present = sub.ac_present = 1;
+        sub.restart_interval = part->restart_interval;
+        sub.n_restart = part->n_restart;
+        sub.restart_offsets = part->restart_offsets;
+        out.emplace_back();
+        ImagePlan &pp = out.back();
+        plan_image(sub, opts, pp);
+        pp.role = 1;
+        if (pp.status != MJX_OK) bad = pp.status;
+    }
+    if (bad != MJX_OK) {                       // one status for the whole picture
+        out.resize(first);
+        pic = ImagePlan{};
+        pic.status = bad;
+    }
+    out.push_back(pic);
 }
 
 }   // namespace mjx

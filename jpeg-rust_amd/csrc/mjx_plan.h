@@ -39,6 +39,11 @@ struct ImagePlan {
     uint32_t restart_mcus = 0;
     std::vector<uint32_t> seg;                     // 2 * (nseg + 1) words
     uint32_t nseg = 1;
+    // Multi-scan files (one component per scan): every scan is planned as a one-component picture of
+    // its own (role 1: entropy decode and DC prediction only, blocks in the component's raster order), the picture
+    // itself as role 2 (no scan: its coefficient stream is gathered from the role-1 streams, then stage B as usual).
+    uint32_t role = 0;
+    uint32_t cbw[3] = {0, 0, 0}, cbh[3] = {0, 0, 0};   // role 2: the components' own block grids (T.81 A.2.2)
 };
 
 // decoder.rs:259-288 get_indices: raster counter (x, y) of a component's blocks -> block position (bug-for-bug, Q3).
@@ -48,6 +53,10 @@ bool ref_get_indices(long x, long y, long max_x, long x_factor, long y_factor, l
 
 // Validates `d` and fills `plan`.  Returns plan.status.
 int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &plan);
+
+// The plans of one input: `plan_image` for an ordinary file; for a multi-scan file one role-1 plan per component (in
+// component order) followed by the role-2 plan of the picture.  The last plan appended is the picture's.
+void plan_input(const mjx_scan_desc &d, const mjx_opts &opts, std::vector<ImagePlan> &out);
 
 extern const uint8_t kZigZag[64];                  // decoder.rs:404-407 ZIGZAG_INDICES
 

@@ -332,6 +332,60 @@ def test_libjpeg_written_files(mjx, orc, gpu_ctx, name):
     batch.close()
 
 
+# ---- multi-scan (non-interleaved) baseline files -- beyond the reference, which stops after scan 1 ------
+MULTISCAN = {"ms_420_big": "std_420_big", "ms_444_q40": "opt_444_q40", "ms_422_q95": "opt_422_q95",
+             "ms_420_q85_rst": "opt_420_q85", "ms_420_odd": "dri_420_r5_plain"}
+
+
+@pytest.mark.parametrize("name", sorted(MULTISCAN))
+def test_multi_scan_files_decode_like_their_interleaved_twins(mjx, orc, gpu_ctx, name):
+    """tests/golden/make_multiscan.py re-encodes the coefficients of an interleaved file as one scan per component (blocks in
+    the component's raster order, MCU padding blocks dropped, one twin with restart intervals).  Same coefficients, same
+    picture: the RGB must be bit-identical to the twin's, which in turn is checked against the oracle."""
+    pil = os.path.join(os.path.dirname(__file__), "golden", "pil")
+    ms = open(os.path.join(pil, name + ".jpg"), "rb").read()
+    src = open(os.path.join(pil, MULTISCAN[name] + ".jpg"), "rb").read()
+    scans = [mjx.ParsedScan(src), mjx.ParsedScan(ms), mjx.ParsedScan(ms), mjx.ParsedScan(src)]
+    assert scans[1].desc.n_parts == 3 and scans[0].desc.n_parts == 0
+    for chunk in (0, 1, 2):
+        batch = mjx.Batch(gpu_ctx, scans, keep_coefs=True, chunk_images=chunk)
+        assert len(batch) == 4
+        batch.decode()
+        batch.wait()
+        assert [batch.status(i) for i in range(4)] == [mjx.OK] * 4
+        ref = orc.decode(src, layout=orc.LAYOUT_STD, ext_1bit=True)
+        _check(ref, batch.coefs(0), batch.rgb(0), name)
+        for i in (1, 2, 3):
+            assert np.array_equal(batch.rgb(i), batch.rgb(0)), (name, chunk, i)
+        # the same coefficients wherever the scans carried the block (MCU padding blocks of the twin are zero)
+        a, b = batch.coefs(0), batch.coefs(1)
+        assert a.shape == b.shape
+        real = np.abs(b).sum(axis=1) != 0
+        assert np.array_equal(a[real], b[real]) and real.mean() > 0.5
+        batch.close()
+
+
+def test_multi_scan_errors_stay_with_their_picture(mjx, orc, gpu_ctx, data_dir):
+    """A multi-scan file with a truncated chroma scan fails as a whole; its neighbours in the batch are not affected, and
+    the bug-compatible modes refuse the format (the reference decodes the first scan only)."""
+    pil = os.path.join(os.path.dirname(__file__), "golden", "pil")
+    ms = open(os.path.join(pil, "ms_420_big.jpg"), "rb").read()
+    sos = [i for i in range(len(ms) - 1) if ms[i] == 0xff and ms[i + 1] == 0xda]
+    assert len(sos) == 3
+    cut = ms[:sos[2] + 10 + 40] + b"\xff\xd9"                      # third scan: header + 40 bytes of data
+    lena = open(os.path.join(data_dir, "lena.jpeg"), "rb").read()
+    scans = [mjx.ParsedScan(lena), mjx.ParsedScan(cut), mjx.ParsedScan(ms), mjx.ParsedScan(lena)]
+    batch = mjx.Batch(gpu_ctx, scans)
+    batch.decode()
+    batch.wait()
+    st = [batch.status(i) for i in range(4)]
+    assert st[0] == st[2] == st[3] == mjx.OK and st[1] == mjx.ERR_TRUNCATED, st
+    ref = orc.decode(lena, layout=orc.LAYOUT_STD)
+    assert np.abs(batch.rgb(3).astype(int) - ref.rgb.astype(int)).max() <= TOL
+    batch.close()
+    assert mjx.ParsedScan(ms).validate(layout=mjx.LAYOUT_REF_COMPAT) == mjx.ERR_UNSUPPORTED_FORMAT
+
+
 # ---- SURVEY s8(f) row 3: restart intervals (beyond the reference, which panics on DRI) -------------------------------
 DRI_FIXTURES = ["dri_420_r5", "dri_444_r1", "dri_422_rows", "dri_gray_r7", "dri_420_720p_rows", "dri_420_r300"]
 

@@ -283,8 +283,32 @@ def test_rust_binding_mirrors_the_header():
     def rs_fields(struct):
         body = re.search(r"pub struct " + struct + r"\s*\{(.*?)\n\}", rs, flags=re.S).group(1)
         return re.findall(r"pub ([a-z_0-9]+):", body)
-    for struct in ("mjx_opts", "mjx_comp", "mjx_hufftab", "mjx_scan_desc", "mjx_image"):
+    for struct in ("mjx_opts", "mjx_comp", "mjx_hufftab", "mjx_scan_part", "mjx_scan_desc", "mjx_image"):
         assert c_fields(struct) == rs_fields(struct), struct
+
+
+def test_multi_scan_files_are_parsed_into_parts(mjx):
+    """One scan per component (tests/golden/make_multiscan.py): mjx_parse lists every scan as a part with its own
+    de-stuffed data, tables and restart offsets; the bug-compatible modes keep the reference's view (first scan only /
+    refused)."""
+    for name, rst in (("ms_420_big", 0), ("ms_422_q95", 0), ("ms_420_q85_rst", 7)):
+        data = open(os.path.join(PIL_DIR, name + ".jpg"), "rb").read()
+        scan = mjx.ParsedScan(data)
+        d = scan.desc
+        assert d.n_parts == 3 and d.ncomp == 3 and not d.scan
+        assert sorted(d.parts[k].comp for k in range(3)) == [0, 1, 2]
+        assert [d.comp[c].id for c in range(3)] == [1, 2, 3]
+        total = sum(d.parts[k].scan_len for k in range(3))
+        assert 0 < total < len(data)
+        for k in range(3):
+            p = d.parts[k]
+            assert p.restart_interval == rst and (p.n_restart > 0) == (rst > 0)
+            assert sum(p.dc.bits) > 0 and sum(p.ac.bits) > 0
+        assert scan.validate() == mjx.OK
+        assert scan.validate(layout=mjx.LAYOUT_REF_COMPAT) == mjx.ERR_UNSUPPORTED_FORMAT
+        strict = mjx.ParsedScan(data, strict_ref=True) if rst == 0 else None     # (strict: DRI is a reference panic)
+        if strict is not None:
+            assert strict.desc.n_parts == 0 and strict.desc.ncomp == 1           # jpeg/mod.rs:415-417: the first scan only
 
 
 def test_first_scan_of_a_multi_scan_file_is_refused_unless_strict(mjx):
