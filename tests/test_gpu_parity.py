@@ -363,6 +363,17 @@ def test_multi_scan_files_decode_like_their_interleaved_twins(mjx, orc, gpu_ctx,
         real = np.abs(b).sum(axis=1) != 0
         assert np.array_equal(a[real], b[real]) and real.mean() > 0.5
         batch.close()
+    # replicated on the device, without kept coefficients, in small chunks: still the twin's picture
+    small = mjx.Batch(gpu_ctx, scans[:2], chunk_images=1)
+    tiled = small.tile(3)
+    assert len(tiled) == 6
+    tiled.decode()
+    tiled.wait()
+    first = tiled.rgb(0)
+    for i in range(6):
+        assert tiled.status(i) == mjx.OK and np.array_equal(tiled.rgb(i), first), (name, i)
+    tiled.close()
+    small.close()
 
 
 def test_multi_scan_errors_stay_with_their_picture(mjx, orc, gpu_ctx, data_dir):

@@ -1,6 +1,6 @@
 """Hostile-input stress run for the device path (GPU box only): python tools/stress_hostile.py [seed]
 
-Mutates the scan data of the restart-interval and plain fixtures (byte flips that favour 0xFF / RSTn, truncation,
+Mutates the scan data of the restart-interval, multi-scan and plain fixtures (byte flips that favour 0xFF / RSTn, truncation,
 64-byte random overwrites, deletions), decodes everything in randomly sized chunks and only requires that the
 process survives and every image reports a status.  tests/test_gpu_parity.py holds the bounded version of this.
 """
@@ -11,7 +11,8 @@ import __graft_entry__ as ge
 mjx = ge.load_package()
 ctx = mjx.Context(0)
 d = os.path.join(ROOT, "tests", "golden", "pil")
-names = ["dri_420_r5", "dri_420_720p_rows", "dri_444_r1", "dri_422_rows", "dri_gray_r7", "dri_420_r300", "opt_420_q85", "std_420_big"]
+names = ["dri_420_r5", "dri_420_720p_rows", "dri_444_r1", "dri_422_rows", "dri_gray_r7", "dri_420_r300", "opt_420_q85", "std_420_big",
+         "ms_420_big", "ms_420_q85_rst", "ms_422_q95"]
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 tot = 0
 for rnd in range(12):
