@@ -92,9 +92,12 @@ def test_parse_never_crashes_on_mutations(mjx):
         for data in (bytes(b), bytes(b[:cut])):
             for strict in (True, False):
                 assert 0 <= _code(mjx, data, strict) <= mjx.ERR_MISSING_TABLE
-    # a file with restart intervals: mutations anywhere (markers inside the scan included), parse + plan must stay in bounds
-    base = open(os.path.join(os.path.dirname(__file__), "golden", "pil", "dri_420_r5.jpg"), "rb").read()
-    for k in range(200):
+    # files with restart intervals: mutations anywhere (markers inside the scan included), parse + plan must stay in bounds
+    # ... and multi-scan files (markers between the scans, with and without restart intervals)
+    bases = [open(os.path.join(os.path.dirname(__file__), "golden", "pil", n + ".jpg"), "rb").read()
+             for n in ("dri_420_r5", "ms_420_q85_rst", "ms_422_q95", "ms_444_q40")]
+    for k in range(400):
+        base = bases[k % len(bases)]
         b = bytearray(base)
         for _ in range(int(rng.integers(1, 8))):
             b[int(rng.integers(0, len(b)))] = int(rng.choice([0xff, 0xd0, 0xd7, 0x00, int(rng.integers(0, 256))]))
