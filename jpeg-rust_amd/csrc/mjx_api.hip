@@ -440,7 +440,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         prof_end(b, st);
         prof_begin(b, MJX_K_DC_SCAN, st);
         launch_dc_scan(st, c.max_segs, nimg, imgs, dcb, SCR(d_segsum), b->d_img_flags, c.bpm_mask, c.max_restart_segs);
-        if (c.has_gather) launch_planar_gather(st, nimg, imgs, SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_img_flags);
+        if (c.has_gather) launch_planar_gather(st, c.max_tiles, nimg, imgs, SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_img_flags);
         prof_end(b, st);
     }
     if (stages & MJX_STAGE_PIXELS) {

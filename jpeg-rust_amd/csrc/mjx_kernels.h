@@ -100,8 +100,8 @@ void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t
                        const uint32_t *entries, const uint32_t *tile_eoff, const int32_t *dcbuf, const float *qmult,
                        uint8_t *rgb, uint32_t mode_mask, unsigned long long *planes, const uint32_t *img_flags);
 // multi-scan pictures: component streams (raster order) -> the picture's stream in MCU order, tile offsets, DC values
-void launch_planar_gather(hipStream_t st, uint32_t nimg, const DevImage *images, uint32_t *entries, uint32_t *tile_eoff,
-                          int32_t *dcbuf, uint32_t *img_flags);
+void launch_planar_gather(hipStream_t st, uint32_t max_tiles, uint32_t nimg, const DevImage *images, uint32_t *entries,
+                          uint32_t *tile_eoff, int32_t *dcbuf, uint32_t *img_flags);
 void launch_ref_color(hipStream_t st, uint32_t max_pixel_wgs, uint32_t nimg, const DevImage *images,
                       const unsigned long long *planes, uint8_t *rgb, const uint32_t *img_flags);
 #endif

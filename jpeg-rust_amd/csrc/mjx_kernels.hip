@@ -800,61 +800,119 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
 
 // Multi-scan pictures (beyond the reference, which stops after the first scan).  Every scan went through
 // the entropy stage as a one-component picture of its own: stream entries and DC values in the component's raster
-// order over its own block grid, one tile offset per block.  One workgroup per picture walks the picture's tiles in
-// MCU order: a lane per block slot looks up its block's run in the component stream (blocks that exist only as MCU
-// padding have none), a workgroup scan places the runs, and the entries are copied with the block field rewritten.
+// order over its own block grid, one tile offset per block.  The picture's stream in MCU order is gathered from them:
+//   k_planar_count    one workgroup per tile of the picture: a lane per block slot looks up its block's run in the
+//                     component stream (blocks that exist only as MCU padding have none); the tile's total
+//   k_planar_offsets  one workgroup per picture: exclusive scan of the totals -> tile offsets
+//   k_planar_copy     one workgroup per tile: a workgroup scan places the runs; entries are copied with the block field
+//                     rewritten, DC values land in MCU order
 // The result is what k_huff_write + DC prediction leave behind for an interleaved picture, so stage B runs unchanged.
-// Serial over the tiles of a picture -- a rare format; pictures of a chunk run side by side.
-extern "C" __global__ __launch_bounds__(256) void k_planar_gather(const DevImage *images, uint32_t *entries,
-                                                                   uint32_t *tile_eoff, int32_t *dcbuf, uint32_t *img_flags)
+struct PlanarSlot { uint32_t s0, cnt, c, rb; bool inside, real; };
+__device__ __forceinline__ PlanarSlot planar_slot(const DevImage *images, const DevImage &im, uint32_t img, uint32_t tile,
+                                                  const uint32_t *tile_eoff)
+{
+    const uint32_t T = 1u << im.log2_tile, bpm = im.bpm, tid = threadIdx.x;
+    const uint32_t m = tile * T + tid / bpm, k = tid % bpm;
+    PlanarSlot p{0, 0, 0, 0, false, false};
+    p.inside = tid < im.tile_blocks && m < im.nmcu;
+    if (p.inside) {
+        p.c = im.blk_comp[k];
+        const uint32_t bx = (m % im.mcux) * im.ch[p.c] + im.blk_bx[k], by = (m / im.mcux) * im.cv[p.c] + im.blk_by[k];
+        p.real = bx < im.cbw[p.c] && by < im.cbh[p.c];
+        if (p.real) {
+            p.rb = by * im.cbw[p.c] + bx;
+            const uint32_t *se = tile_eoff + images[img - im.src_back[p.c]].tile_off;     // one offset per block (+ sentinel)
+            p.s0 = se[p.rb];
+            p.cnt = se[p.rb + 1] - p.s0;
+        }
+    }
+    return p;
+}
+__device__ __forceinline__ bool planar_flags(const DevImage *images, const DevImage &im, uint32_t img, const uint32_t *img_flags,
+                                             uint32_t &bad)
+{
+    bad = img_flags[images[img - im.src_back[0]].status_idx] | img_flags[images[img - im.src_back[1]].status_idx] |
+          img_flags[images[img - im.src_back[2]].status_idx];
+    return bad != 0;
+}
+
+extern "C" __global__ __launch_bounds__(256) void k_planar_count(const DevImage *images, uint32_t *tile_eoff,
+                                                                  const uint32_t *img_flags)
 {
     __shared__ uint32_t s_tmp[4];
-    const DevImage &im = images[blockIdx.x];
+    const uint32_t img = blockIdx.y, tile = blockIdx.x;
+    const DevImage &im = images[img];
+    const uint32_t T = 1u << im.log2_tile;
+    uint32_t bad;
+    if (!im.valid || im.role != 2 || tile >= (im.nmcu + T - 1) / T || planar_flags(images, im, img, img_flags, bad)) return;
+    const PlanarSlot p = planar_slot(images, im, img, tile, tile_eoff);
+    uint32_t total;
+    (void)wg_exclusive_scan(p.cnt, s_tmp, &total);
+    if (threadIdx.x == 0) (tile_eoff + im.tile_off)[tile + 1] = total;
+}
+
+extern "C" __global__ __launch_bounds__(256) void k_planar_offsets(const DevImage *images, uint32_t *tile_eoff,
+                                                                    uint32_t *img_flags)
+{
+    __shared__ uint32_t s_tmp[4];
+    const uint32_t img = blockIdx.x, tid = threadIdx.x;
+    const DevImage &im = images[img];
     if (!im.valid || im.role != 2) return;
-    const uint32_t tid = threadIdx.x;
-    const DevImage *src[3] = {&images[blockIdx.x - im.src_back[0]], &images[blockIdx.x - im.src_back[1]],
-                              &images[blockIdx.x - im.src_back[2]]};
-    const uint32_t bad = img_flags[src[0]->status_idx] | img_flags[src[1]->status_idx] | img_flags[src[2]->status_idx];
-    if (bad) {                                       // a scan is short (or its chunk unconverged): no picture
+    uint32_t bad;
+    if (planar_flags(images, im, img, img_flags, bad)) {          // a scan is short (or its chunk unconverged): no picture
         if (tid == 0) img_flags[im.status_idx] = bad;
         return;
     }
-    const uint32_t T = 1u << im.log2_tile, bpm = im.bpm, tile_blocks = im.tile_blocks;
-    const uint32_t ntiles = (im.nmcu + T - 1) / T;
-    uint32_t *dst = entries + im.ent_off;
+    const uint32_t T = 1u << im.log2_tile, ntiles = (im.nmcu + T - 1) / T;
     uint32_t *eoff = tile_eoff + im.tile_off;
-    int32_t *dc_dst = dcbuf + im.coef_off;
     uint32_t run = 0;
-    for (uint32_t tile = 0; tile < ntiles; tile++) {
-        const uint32_t m = tile * T + tid / bpm, k = tid % bpm;
-        uint32_t s0 = 0, cnt = 0, c = 0, rb = 0;
-        bool real = false;
-        if (tid < tile_blocks && m < im.nmcu) {
-            c = im.blk_comp[k];
-            const uint32_t bx = (m % im.mcux) * im.ch[c] + im.blk_bx[k], by = (m / im.mcux) * im.cv[c] + im.blk_by[k];
-            real = bx < im.cbw[c] && by < im.cbh[c];
-            if (real) {
-                rb = by * im.cbw[c] + bx;
-                const uint32_t *se = tile_eoff + src[c]->tile_off;      // one offset per block (+ sentinel)
-                s0 = se[rb];
-                cnt = se[rb + 1] - s0;
-            }
-        }
+    for (uint32_t t0 = 0; t0 < ntiles; t0 += kWgLanes) {           // eoff[t + 1] holds tile t's count -> the offset behind it
+        const uint32_t t = t0 + tid;
+        const uint32_t v = t < ntiles ? eoff[t + 1] : 0u;
         uint32_t total;
-        const uint32_t at = run + wg_exclusive_scan(cnt, s_tmp, &total);
-        if (tid == 0) eoff[tile] = run;
-        if (tid < tile_blocks && m < im.nmcu) {
-            const uint32_t blk = tile * tile_blocks + tid;
-            dc_dst[blk] = real ? (dcbuf + src[c]->coef_off)[rb] : 0;
-            const uint32_t *sp = entries + src[c]->ent_off + s0;
-            const uint32_t field = (blk & 0xffu) << 22;
-            for (uint32_t j = 0; j < cnt; j++) dst[at + j] = (sp[j] & 0x003fffffu) | field;
-        }
+        const uint32_t ex = wg_exclusive_scan(v, s_tmp, &total);
+        if (t < ntiles) eoff[t + 1] = run + ex + v;
         run += total;
     }
     if (tid == 0) {
-        eoff[ntiles] = run;
+        eoff[0] = 0;
         img_flags[im.status_idx] = 0;
+    }
+}
+
+extern "C" __global__ __launch_bounds__(256) void k_planar_copy(const DevImage *images, uint32_t *entries,
+                                                                 const uint32_t *tile_eoff, int32_t *dcbuf,
+                                                                 const uint32_t *img_flags)
+{
+    __shared__ uint32_t s_tmp[4];
+    __shared__ uint32_t s_at[257];          // where each block slot's run starts inside the tile's output (+ total)
+    __shared__ uint32_t s_src[256];         // ... and where it comes from (index into the entry pool)
+    const uint32_t img = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const DevImage &im = images[img];
+    const uint32_t T = 1u << im.log2_tile;
+    if (!im.valid || im.role != 2 || tile >= (im.nmcu + T - 1) / T || img_flags[im.status_idx]) return;
+    const PlanarSlot p = planar_slot(images, im, img, tile, tile_eoff);
+    uint32_t total;
+    const uint32_t at = wg_exclusive_scan(p.cnt, s_tmp, &total);
+    s_at[tid] = at;
+    if (tid == 0) s_at[256] = total;
+    if (p.inside) {
+        const DevImage &sim = images[img - im.src_back[p.c]];
+        (dcbuf + im.coef_off)[tile * im.tile_blocks + tid] = p.real ? (dcbuf + sim.coef_off)[p.rb] : 0;
+        s_src[tid] = uint32_t(sim.ent_off) + p.s0;
+    }
+    __syncthreads();
+    // the tile's entries, consecutive lanes on consecutive outputs: entry i belongs to the last slot that starts at or
+    // before i (binary search over the 256 starts; empty slots share their successor's start and are never chosen)
+    uint32_t *dst = entries + im.ent_off + (tile_eoff + im.tile_off)[tile];
+    for (uint32_t i = tid; i < total; i += 256) {
+        uint32_t lo = 0, hi = 256;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_at[mid] <= i) lo = mid; else hi = mid;
+        }
+        const uint32_t e = entries[s_src[lo] + (i - s_at[lo])];
+        dst[i] = (e & 0x003fffffu) | (((tile * im.tile_blocks + lo) & 0xffu) << 22);
     }
 }
 
@@ -1708,10 +1766,12 @@ void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t
         hipLaunchKernelGGL(k_idct_color<2>, dim3(max_tiles, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags);
 }
 
-void launch_planar_gather(hipStream_t st, uint32_t nimg, const DevImage *images, uint32_t *entries, uint32_t *tile_eoff,
-                          int32_t *dcbuf, uint32_t *img_flags)
+void launch_planar_gather(hipStream_t st, uint32_t max_tiles, uint32_t nimg, const DevImage *images, uint32_t *entries,
+                          uint32_t *tile_eoff, int32_t *dcbuf, uint32_t *img_flags)
 {
-    hipLaunchKernelGGL(k_planar_gather, dim3(nimg), dim3(256), 0, st, images, entries, tile_eoff, dcbuf, img_flags);
+    hipLaunchKernelGGL(k_planar_count, dim3(max_tiles, nimg), dim3(256), 0, st, images, tile_eoff, img_flags);
+    hipLaunchKernelGGL(k_planar_offsets, dim3(nimg), dim3(256), 0, st, images, tile_eoff, img_flags);
+    hipLaunchKernelGGL(k_planar_copy, dim3(max_tiles, nimg), dim3(256), 0, st, images, entries, tile_eoff, dcbuf, img_flags);
 }
 
 void launch_ref_color(hipStream_t st, uint32_t max_pixel_wgs, uint32_t nimg, const DevImage *images,
