@@ -353,6 +353,15 @@ typedef struct {
     orc_framecomp fcomp[256];
     int width, height;
     int restart_interval;      /* MCUs per restart interval (ext_dri), 0 = none */
+    /* ext_multiscan: one entry per scan read so far (single-component scans) */
+    struct {
+        int comp;                      /* index into fcomp */
+        orc_htable dc, ac;             /* the tables the scan selected, as they were when its SOS was read */
+        const uint8_t *data;           /* its entropy-coded segment, FF00 compacted, RSTn left in */
+        size_t len;
+        int restart_interval;
+    } parts[3];
+    int nparts;
 } orc_parse;
 
 /* decoder.rs:259-288 get_indices.  usize arithmetic: underflow panics. */
@@ -436,7 +445,8 @@ static void orc_jpeg_decode(orc_env *env, const orc_opts *opts, const orc_parse 
     out->mcus_read = num_read;
 
     orc_hdec hd;
-    orc_hdec_new(env, &hd, data, data_len, opts->layout == ORC_LAYOUT_STD && !opts->strict_ref);   /* :189 */
+    memset(&hd, 0, sizeof hd);
+    if (!ps->nparts) orc_hdec_new(env, &hd, data, data_len, opts->layout == ORC_LAYOUT_STD && !opts->strict_ref);   /* :189 */
 
     /* Step 1 :195-215 */
     float prev_dc[3] = {0, 0, 0};
@@ -449,7 +459,40 @@ static void orc_jpeg_decode(orc_env *env, const orc_opts *opts, const orc_parse 
         out->hs[c] = hs[c];
         out->vs[c] = vs[c];
     }
-    for (size_t m = 0; m < num_read; m++) {
+    if (ps->nparts) {
+        /* ext_multiscan: every scan carries the blocks of one component in raster order over the component's own block
+           grid; each is put where the interleaved order would have it (MCU padding blocks stay zero) */
+        for (int q = 0; q < ps->nparts; q++) {
+            const int c = ps->parts[q].comp;
+            const size_t cbw = ((W * (size_t)hs[c] + hmax - 1) / hmax + 7) / 8, cbh = ((H * (size_t)vs[c] + vmax - 1) / vmax + 7) / 8;
+            orc_hdec pd;
+            orc_hdec_new(env, &pd, ps->parts[q].data, ps->parts[q].len, 1);
+            float pred = 0;
+            const size_t ri = (size_t)ps->parts[q].restart_interval;
+            size_t done = 0;
+            for (size_t by = 0; by < cbh; by++)
+                for (size_t bx = 0; bx < cbw; bx++) {
+                    int16_t blk[64];
+                    orc_next_block(env, &pd, &ps->parts[q].ac, &ps->parts[q].dc, (opts->faithful_huff ? 1 : 0) | (opts->ext_1bit ? 2 : 0), blk);
+                    pred += (float)blk[0];
+                    const size_t m = (by / (size_t)vs[c]) * mcux + bx / (size_t)hs[c];
+                    const size_t k = (by % (size_t)vs[c]) * (size_t)hs[c] + bx % (size_t)hs[c];
+                    int16_t *dst = out->coef[c] + (m * per_mcu[c] + k) * 64;
+                    memcpy(dst, blk, sizeof blk);
+                    dst[0] = (int16_t)pred;
+                    done++;
+                    if (ri > 0 && done % ri == 0 && done < cbw * cbh) {
+                        orc_shift_and_fix(&pd, (size_t)((8 - pd.total_bits % 8) % 8));
+                        const uint32_t mk = pd.current >> 16;
+                        if ((mk & 0xfff8u) != 0xffd0u) orc_panic(env, ORC_ERR_UNSUPPORTED, "restart marker expected");
+                        orc_shift_and_fix(&pd, 16);
+                        pred = 0;
+                    }
+                }
+            hd.total_bits += pd.total_bits;
+        }
+    }
+    for (size_t m = 0; m < (ps->nparts ? 0 : num_read); m++) {
         for (int c = 0; c < ncomp; c++) {
             PANIC_IF(cf[c].ac_table_id > 3 || !ps->ac[cf[c].ac_table_id].present, "ac_table unwrap on None"); /* :154-156 */
             PANIC_IF(cf[c].dc_table_id > 3 || !ps->dc[cf[c].dc_table_id].present, "dc_table unwrap on None"); /* :158-160 */
@@ -558,6 +601,22 @@ static void orc_jpeg_decode(orc_env *env, const orc_opts *opts, const orc_parse 
  * ------------------------------------------------------------------------------------------ */
 #define VEC(i) (((size_t)(i) < len) ? vec[(size_t)(i)] : (orc_panic(env, ORC_ERR_REF_PANIC, "index out of bounds in parse"), (uint8_t)0))
 
+/* ext_multiscan: every component has its scan -> decode the picture (components in frame order) */
+static void orc_decode_parts(orc_env *env, const orc_opts *opts, orc_parse *ps, orc_image *out)
+{
+    if (ps->nparts != ps->ncomp_frame || ps->nparts != 3) orc_panic(env, ORC_ERR_UNSUPPORTED, "multi-scan file: a component without a scan");
+    orc_compfields ordered[3];
+    for (int c = 0; c < 3; c++) {
+        ordered[c].component = ps->fcomp[c].id;
+        ordered[c].h = ps->fcomp[c].h;
+        ordered[c].v = ps->fcomp[c].v;
+        ordered[c].quantization_id = ps->fcomp[c].tq;
+        ordered[c].dc_table_id = ordered[c].ac_table_id = 0;
+    }
+    out->width = ps->width; out->height = ps->height; out->ncomp = 3;
+    orc_jpeg_decode(env, opts, ps, ordered, 3, NULL, 0, out);
+}
+
 static void orc_parse_and_decode(orc_env *env, const uint8_t *vec, size_t len, const orc_opts *opts,
                                  orc_image *out)
 {
@@ -591,6 +650,7 @@ static void orc_parse_and_decode(orc_env *env, const uint8_t *vec, size_t len, c
             i += 2 + l;
             continue;
         }
+        if (n == 0xd9 && ps->nparts) { orc_decode_parts(env, opts, ps, out); return; }   /* ext_multiscan: EOI behind the last scan */
         if (n == 0xd8 || n == 0xd9) { i += 2; continue; }                         /* :209-215 */
 
         size_t seglen = ((size_t)VEC(i + 2) << 8) + VEC(i + 3);                   /* :219 */
@@ -675,6 +735,36 @@ static void orc_parse_and_decode(orc_env *env, const uint8_t *vec, size_t len, c
             (void)VEC(i + 3);                                    /* :356-359 reads vec[i+1..i+3] */
             i += 4;                                              /* :362 */
 
+            if (opts->ext_multiscan && opts->layout == ORC_LAYOUT_STD && !opts->strict_ref && ps->have_frame &&
+                (num_components < ps->ncomp_frame || ps->nparts)) {
+                /* NOT reference behaviour: one scan of several.  Its data runs up to the next marker that is not RSTn. */
+                if (num_components != 1 || ps->nparts >= 3) orc_panic(env, ORC_ERR_UNSUPPORTED, "multi-scan file: scans must carry one component each");
+                int ci = -1;
+                for (int c = 0; c < ps->ncomp_frame; c++) if (ps->fcomp[c].id == sc[0].id) ci = c;
+                if (ci < 0 || sc[0].dc_sel > 3 || sc[0].ac_sel > 3) orc_panic(env, ORC_ERR_UNSUPPORTED, "multi-scan file: unknown component or table");
+                for (int q = 0; q < ps->nparts; q++) if (ps->parts[q].comp == ci) orc_panic(env, ORC_ERR_UNSUPPORTED, "multi-scan file: component coded twice");
+                PANIC_IF(!ps->dc[sc[0].dc_sel].present || !ps->ac[sc[0].ac_sel].present, "table unwrap on None");
+                uint8_t *pd = (uint8_t *)orc_alloc(env, len - (i < len ? i : len) + 8);
+                size_t np = 0, k = i;
+                while (k < len) {
+                    if (vec[k] != 0xff) { pd[np++] = vec[k++]; continue; }
+                    if (k + 1 >= len) { pd[np++] = vec[k++]; break; }
+                    if (vec[k + 1] == 0x00) { pd[np++] = 0xff; k += 2; continue; }
+                    if (vec[k + 1] == 0xff) { k += 1; continue; }                                  /* fill byte */
+                    if ((vec[k + 1] & 0xf8) == 0xd0) { pd[np++] = 0xff; pd[np++] = vec[k + 1]; k += 2; continue; }   /* RSTn stays */
+                    break;
+                }
+                const int q = ps->nparts++;
+                ps->parts[q].comp = ci;
+                ps->parts[q].dc = ps->dc[sc[0].dc_sel];
+                ps->parts[q].ac = ps->ac[sc[0].ac_sel];
+                ps->parts[q].data = pd;
+                ps->parts[q].len = np;
+                ps->parts[q].restart_interval = ps->restart_interval;
+                i = k;
+                continue;
+            }
+
             /* :371-385 copy data, replace ff00 with ff, to end of file */
             uint8_t *enc = (uint8_t *)orc_alloc(env, len - (i < len ? i : len) + 8);
             size_t nenc = 0;
@@ -737,12 +827,13 @@ static void orc_parse_and_decode(orc_env *env, const uint8_t *vec, size_t len, c
         }
         i += data_length;                                         /* :454 */
     }
+    if (ps->nparts) { orc_decode_parts(env, opts, ps, out); return; }
     orc_panic(env, ORC_ERR_NO_SCAN, "no SOS segment: image_data() is None");
 }
 
 int orc_decode(const uint8_t *jpeg, size_t len, const orc_opts *opts, orc_image *out)
 {
-    static const orc_opts defaults = {0, ORC_LAYOUT_REF, 0, 0, 0, 0};
+    static const orc_opts defaults = {0, ORC_LAYOUT_REF, 0, 0, 0, 0, 0};
     const orc_opts *volatile o = opts ? opts : &defaults;
     memset(out, 0, sizeof *out);
     orc_env *env = (orc_env *)calloc(1, sizeof(orc_env));

@@ -50,6 +50,10 @@ typedef struct {
     int ext_dri;      /* NOT reference behaviour: accept DRI / RSTn restart intervals (T.81 B.2.4.4, E.2.4) instead of panicking
                          like jpeg/mod.rs:424-428: after every Ri MCUs the bit reader moves to the next byte boundary, skips the
                          RSTn marker and the DC predictors start again from 0.  Used to check the GPU path's SURVEY s8(f)-3 row. */
+    int ext_multiscan;/* NOT reference behaviour: decode baseline files whose scans carry one component each (non-interleaved
+                         order, T.81 A.2.2) instead of stopping after the first scan like jpeg/mod.rs:415-417.  STANDARD
+                         layout only.  Used to check the GPU path's SURVEY s8(f)-4 row; pinned by twins of interleaved files
+                         (tests/golden/make_multiscan.py). */
 } orc_opts;
 
 typedef struct {

@@ -13,7 +13,8 @@ OK, ERR_REF_PANIC, ERR_UNSUPPORTED, ERR_NO_SCAN, ERR_NOMEM = range(5)
 
 class Opts(ctypes.Structure):
     _fields_ = [("strict_ref", ctypes.c_int), ("layout", ctypes.c_int), ("faithful_cos", ctypes.c_int),
-                ("faithful_huff", ctypes.c_int), ("ext_1bit", ctypes.c_int), ("ext_dri", ctypes.c_int)]
+                ("faithful_huff", ctypes.c_int), ("ext_1bit", ctypes.c_int), ("ext_dri", ctypes.c_int),
+                ("ext_multiscan", ctypes.c_int)]
 
 
 class Img(ctypes.Structure):
@@ -55,9 +56,10 @@ class Decoded:
     pass
 
 
-def decode(data, layout=LAYOUT_REF, strict_ref=False, faithful_cos=False, faithful_huff=False, ext_1bit=False, ext_dri=False):
+def decode(data, layout=LAYOUT_REF, strict_ref=False, faithful_cos=False, faithful_huff=False, ext_1bit=False, ext_dri=False,
+           ext_multiscan=False):
     """-> object with rgb [H,W,3] u8, coefs (list per component of int16 [blocks,64]), hv (blocks per MCU per comp)."""
-    o = Opts(int(strict_ref), int(layout), int(faithful_cos), int(faithful_huff), int(ext_1bit), int(ext_dri))
+    o = Opts(int(strict_ref), int(layout), int(faithful_cos), int(faithful_huff), int(ext_1bit), int(ext_dri), int(ext_multiscan))
     im = Img()
     rc = lib().orc_decode(bytes(data), len(data), ctypes.byref(o), ctypes.byref(im))
     if rc != OK:
@@ -101,7 +103,7 @@ def decode_many(datas, nthreads, layout=LAYOUT_REF, faithful=True):
     arr = (ctypes.c_char_p * n)(*datas)
     lens = (ctypes.c_size_t * n)(*[len(d) for d in datas])
     st = (ctypes.c_int * n)()
-    o = Opts(0, layout, int(faithful), int(faithful), 0)
+    o = Opts(0, layout, int(faithful), int(faithful), 0, 0, 0)
     px = lib().orc_decode_many(arr, lens, n, ctypes.byref(o), nthreads, st)
     return int(px), list(st)
 

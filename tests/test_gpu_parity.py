@@ -357,11 +357,13 @@ def test_multi_scan_files_decode_like_their_interleaved_twins(mjx, orc, gpu_ctx,
         _check(ref, batch.coefs(0), batch.rgb(0), name)
         for i in (1, 2, 3):
             assert np.array_equal(batch.rgb(i), batch.rgb(0)), (name, chunk, i)
-        # the same coefficients wherever the scans carried the block (MCU padding blocks of the twin are zero)
+        # ... and against the oracle's own multi-scan extension (pinned to the twins in tests/test_host.py): the same
+        # coefficients block for block, zeros where the interleaved order has MCU padding blocks
+        ref_ms = orc.decode(ms, layout=orc.LAYOUT_STD, ext_1bit=True, ext_dri=True, ext_multiscan=True)
+        _check(ref_ms, batch.coefs(1), batch.rgb(1), name + " (multi-scan)")
         a, b = batch.coefs(0), batch.coefs(1)
-        assert a.shape == b.shape
         real = np.abs(b).sum(axis=1) != 0
-        assert np.array_equal(a[real], b[real]) and real.mean() > 0.5
+        assert a.shape == b.shape and np.array_equal(a[real], b[real]) and real.mean() > 0.5
         batch.close()
     # replicated on the device, without kept coefficients, in small chunks: still the twin's picture
     small = mjx.Batch(gpu_ctx, scans[:2], chunk_images=1)

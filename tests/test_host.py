@@ -290,6 +290,24 @@ def test_rust_binding_mirrors_the_header():
         assert c_fields(struct) == rs_fields(struct), struct
 
 
+def test_oracle_multi_scan_extension_is_pinned_by_twins(orc):
+    """The oracle's ext_multiscan (not reference behaviour) must decode every non-interleaved twin to the picture of the
+    interleaved file it was made from (tests/golden/make_multiscan.py; Pillow confirmed each twin when it was written),
+    coefficients included wherever the scans carry the block; without the extension the oracle keeps to the reference."""
+    pairs = {"ms_420_big": "std_420_big", "ms_444_q40": "opt_444_q40", "ms_422_q95": "opt_422_q95",
+             "ms_420_q85_rst": "opt_420_q85", "ms_420_odd": "dri_420_r5_plain"}
+    for ms, src in pairs.items():
+        a = orc.decode(open(os.path.join(PIL_DIR, ms + ".jpg"), "rb").read(), layout=orc.LAYOUT_STD, ext_1bit=True, ext_dri=True,
+                       ext_multiscan=True)
+        b = orc.decode(open(os.path.join(PIL_DIR, src + ".jpg"), "rb").read(), layout=orc.LAYOUT_STD, ext_1bit=True)
+        assert np.array_equal(a.rgb, b.rgb) and a.mcus == b.mcus, ms
+        for c in range(3):
+            real = np.abs(a.coefs[c]).sum(axis=1) != 0
+            assert np.array_equal(a.coefs[c][real], b.coefs[c][real]), (ms, c)
+    one = orc.decode(open(os.path.join(PIL_DIR, "ms_420_big.jpg"), "rb").read(), layout=orc.LAYOUT_STD)
+    assert one.ncomp == 1                                   # jpeg/mod.rs:415-417: the first scan only
+
+
 def test_multi_scan_files_are_parsed_into_parts(mjx):
     """One scan per component (tests/golden/make_multiscan.py): mjx_parse lists every scan as a part with its own
     de-stuffed data, tables and restart offsets; the bug-compatible modes keep the reference's view (first scan only /
