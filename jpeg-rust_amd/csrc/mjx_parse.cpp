@@ -267,19 +267,26 @@ size_t read_sos(const ByteView &f, size_t pos, ParserState &st, bool strict, boo
         w = remain;
         d->scan_is_stuffed = 1;
     }
-    for (size_t k = 0; !keep_stuffed && k < remain; k++) {
-        const uint8_t b = src[k];
-        buf[w++] = b;
-        if (b == 0xff) {
-            if (k + 1 >= remain) {                      // mod.rs:377 reads vec[i + 1] unguarded
-                if (strict) { std::free(buf); throw ParseError{MJX_ERR_TRUNCATED}; }
-            } else if (src[k + 1] == 0x00) {
-                k++;
-            } else if (restarts && (src[k + 1] & 0xf8) == 0xd0) {
-                w--;                                    // drop FF Dn; the next interval starts at the following byte
-                k++;
-                rst[nrst++] = uint32_t(w);
-            }
+    for (size_t k = 0; !keep_stuffed && k < remain;) {
+        // runs without 0xFF are copied whole (memchr / memcpy: the byte-wise loop was the slowest part of the host side)
+        const uint8_t *ff = static_cast<const uint8_t *>(std::memchr(src + k, 0xff, remain - k));
+        const size_t run = ff ? size_t(ff - (src + k)) : remain - k;
+        if (run) std::memcpy(buf + w, src + k, run);
+        w += run;
+        k += run;
+        if (!ff) break;
+        buf[w++] = 0xff;
+        if (k + 1 >= remain) {                          // mod.rs:377 reads vec[i + 1] unguarded
+            if (strict) { std::free(buf); throw ParseError{MJX_ERR_TRUNCATED}; }
+            k += 1;
+        } else if (src[k + 1] == 0x00) {
+            k += 2;
+        } else if (restarts && (src[k + 1] & 0xf8) == 0xd0) {
+            w--;                                        // drop FF Dn; the next interval starts at the following byte
+            k += 2;
+            rst[nrst++] = uint32_t(w);
+        } else {
+            k += 1;
         }
     }
     std::memset(buf + w, 0xaa, 32);                     // huffman.rs:236-246: bytes past the end read as 0xaa
