@@ -1059,9 +1059,10 @@ extern "C" int mjx_decode(const uint8_t *jpeg, size_t len, const mjx_opts *opts,
     if (rc == MJX_OK) rc = mjx_batch_wait(b);
     if (rc == MJX_OK) rc = mjx_batch_status(b, 0);
     if (rc == MJX_OK) {
-        out->width = b->info[0].width;
-        out->height = b->info[0].height;
-        out->rgb = static_cast<uint8_t *>(std::malloc(size_t(b->info[0].rgb_bytes) + 1));
+        const ImageInfo &inf = b->info[b->visible[0]];          // (a multi-scan file keeps its scans in front of the picture)
+        out->width = inf.width;
+        out->height = inf.height;
+        out->rgb = static_cast<uint8_t *>(std::malloc(size_t(inf.rgb_bytes) + 1));
         if (!out->rgb) rc = MJX_ERR_NOMEM;
         else rc = mjx_batch_copy_rgb(b, 0, out->rgb);
         if (rc != MJX_OK) { std::free(out->rgb); out->rgb = nullptr; }

@@ -397,6 +397,12 @@ def test_multi_scan_errors_stay_with_their_picture(mjx, orc, gpu_ctx, data_dir):
     assert np.abs(batch.rgb(3).astype(int) - ref.rgb.astype(int)).max() <= TOL
     batch.close()
     assert mjx.ParsedScan(ms).validate(layout=mjx.LAYOUT_REF_COMPAT) == mjx.ERR_UNSUPPORTED_FORMAT
+    # the one-shot surface (mjx_decode, what the CLI and the Rust binding's decode() call)
+    one = mjx.decode(ms)
+    twin = mjx.decode(open(os.path.join(pil, "std_420_big.jpg"), "rb").read())
+    assert one.shape == (480, 640, 3) and np.array_equal(one, twin)
+    img = mjx.JPEGImage.parse(ms)                            # ... and the mirror of the reference's JPEGImage
+    assert (img.width(), img.height()) == (640, 480) and np.array_equal(img.image_data(), twin)
 
 
 # ---- restart intervals (beyond the reference, which panics on DRI) -------------------------------
