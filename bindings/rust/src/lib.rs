@@ -47,12 +47,13 @@ pub struct mjx_hufftab {
 pub struct mjx_scan_part {
     pub scan: *const u8,
     pub scan_len: usize,
-    pub comp: u8,
+    pub ncomp: u8,
+    pub comp: [u8; 3],
     pub restart_interval: u16,
     pub n_restart: u32,
     pub restart_offsets: *const u32,
-    pub dc: mjx_hufftab,
-    pub ac: mjx_hufftab,
+    pub dc: [mjx_hufftab; 3],
+    pub ac: [mjx_hufftab; 3],
 }
 
 #[repr(C)]

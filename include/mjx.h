@@ -60,16 +60,18 @@ typedef struct mjx_hufftab {       /* the two slices given to HuffmanTable::from
     uint8_t vals[256];
 } mjx_hufftab;
 
-/* One scan of a multi-scan baseline file in which every scan carries a single component (non-interleaved order, T.81
- * A.2.2) -- beyond the reference, which stops after the first SOS (jpeg/mod.rs:415-417).  SURVEY s8(f)-4. */
+/* One scan of a multi-scan baseline file: a single component (non-interleaved order, T.81 A.2.2) or an interleaved
+ * subset of the frame's components ("0; 1 2;", the separate-luma-and-chroma script of libjpeg's wizard.txt) -- beyond the
+ * reference, which stops after the first SOS (jpeg/mod.rs:415-417).  SURVEY s8(f)-4. */
 typedef struct mjx_scan_part {
     const uint8_t *scan;           /* this scan's entropy-coded segment, de-stuffed, RSTn taken out */
     size_t scan_len;
-    uint8_t comp;                  /* index into mjx_scan_desc.comp of the component this scan carries */
-    uint16_t restart_interval;     /* blocks per restart interval as defined when the SOS was read, 0 = none */
+    uint8_t ncomp;                 /* components in this scan: 1 or 2 */
+    uint8_t comp[3];               /* their indices into mjx_scan_desc.comp, scan order */
+    uint16_t restart_interval;     /* MCUs (single component: blocks) per restart interval as defined when the SOS was read */
     uint32_t n_restart;
     const uint32_t *restart_offsets;
-    mjx_hufftab dc, ac;            /* the two tables the scan uses, as defined when its SOS was read */
+    mjx_hufftab dc[3], ac[3];      /* per component of the scan: the tables it selects, as defined when the SOS was read */
 } mjx_scan_part;
 
 typedef struct mjx_scan_desc {
@@ -90,7 +92,7 @@ typedef struct mjx_scan_desc {
     uint32_t n_restart;            /* entries of restart_offsets */
     const uint32_t *restart_offsets; /* byte offset in `scan` of the first byte of interval 1, 2, ... (interval 0 starts at 0) */
     /* Multi-scan files: n_parts > 0 means `scan` is NULL, `comp` lists the frame's components in frame order and every
-       component has exactly one entry in `parts`; the dc / ac slots above are not used. */
+       component is carried by exactly one of `parts`; the dc / ac slots above are not used. */
     uint8_t n_parts;
     const mjx_scan_part *parts;
     void *owner_;                  /* internal: storage behind `scan` / `parts` when filled by mjx_parse */

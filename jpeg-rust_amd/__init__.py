@@ -55,9 +55,9 @@ class HuffTab(ctypes.Structure):
 
 
 class ScanPart(ctypes.Structure):
-    _fields_ = [("scan", ctypes.POINTER(ctypes.c_uint8)), ("scan_len", ctypes.c_size_t), ("comp", ctypes.c_uint8),
-                ("restart_interval", ctypes.c_uint16), ("n_restart", ctypes.c_uint32),
-                ("restart_offsets", ctypes.POINTER(ctypes.c_uint32)), ("dc", HuffTab), ("ac", HuffTab)]
+    _fields_ = [("scan", ctypes.POINTER(ctypes.c_uint8)), ("scan_len", ctypes.c_size_t), ("ncomp", ctypes.c_uint8),
+                ("comp", ctypes.c_uint8 * 3), ("restart_interval", ctypes.c_uint16), ("n_restart", ctypes.c_uint32),
+                ("restart_offsets", ctypes.POINTER(ctypes.c_uint32)), ("dc", HuffTab * 3), ("ac", HuffTab * 3)]
 
 
 class ScanDesc(ctypes.Structure):

@@ -51,6 +51,7 @@ struct ImageInfo {
     uint64_t scan_len = 0;
     uint32_t chunk = 0;
     uint32_t role = 0;             // 0 ordinary picture; multi-scan files: 1 = one scan (internal), 2 = the picture
+    uint32_t nparts = 0;           // role 2: scans in front of it
 };
 
 struct Chunk {
@@ -184,7 +185,13 @@ void fill_dev_image(const ImagePlan &p, DevImage &d)
         d.log2_tile = 0;
         d.tile_blocks = 1;
     } else if (p.role == 2) {
-        for (uint32_t c = 0; c < 3; c++) { d.src_back[c] = 3 - c; d.cbw[c] = p.cbw[c]; d.cbh[c] = p.cbh[c]; }
+        d.nparts = p.nparts;
+        for (uint32_t c = 0; c < 3; c++) {
+            d.src_back[c] = p.nparts - p.src_part[c];
+            d.src_comp[c] = p.src_comp[c];
+            d.cbw[c] = p.cbw[c];
+            d.cbh[c] = p.cbh[c];
+        }
     }
     std::memcpy(d.blk_comp, p.blk_comp, sizeof d.blk_comp);
     std::memcpy(d.blk_bx, p.blk_bx, sizeof d.blk_bx);
@@ -547,8 +554,10 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
         if (p.restart_mcus) inf.ent_cap = (uint64_t(p.scan_len) * 4 + 64 + group_pad) / 8 * 8;
         inf.role = p.role;
         if (p.role == 2) {                     // gathered from the three scans in front of it
-            if (i < 3) return MJX_ERR_INVALID_ARG;
-            inf.ent_cap = b->info[i - 1].ent_cap + b->info[i - 2].ent_cap + b->info[i - 3].ent_cap + 8;
+            if (i < p.nparts) return MJX_ERR_INVALID_ARG;
+            inf.nparts = p.nparts;
+            inf.ent_cap = 8;
+            for (uint32_t k = 1; k <= p.nparts; k++) inf.ent_cap += b->info[i - k].ent_cap;
         }
         d.ent_cap = uint32_t(std::min<uint64_t>(inf.ent_cap, 0xffffffffu));
         inf.scan_len = p.scan_len;
@@ -793,7 +802,13 @@ extern "C" int mjx_batch_tile(mjx_ctx *ctx, const mjx_batch *src, size_t times, 
         p.nseg = d.nseg;
         p.restart_mcus = d.restart_mcus;
         p.role = d.role;
-        for (uint32_t c = 0; c < 3; c++) { p.cbw[c] = d.cbw[c]; p.cbh[c] = d.cbh[c]; }
+        p.nparts = d.nparts;
+        for (uint32_t c = 0; c < 3; c++) {
+            p.cbw[c] = d.cbw[c];
+            p.cbh[c] = d.cbh[c];
+            p.src_comp[c] = d.src_comp[c];
+            p.src_part[c] = d.nparts - d.src_back[c];
+        }
         p.seg.assign(src->h_segs.begin() + size_t(d.seg_off) * 2, src->h_segs.begin() + size_t(d.seg_off) * 2 + 2 * (size_t(d.nseg) + 1));
         p.scan = nullptr;
         p.scan_len = src->info[k].scan_len;
@@ -873,9 +888,9 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
         if (flags[i]) b->info[i].status = MJX_ERR_TRUNCATED;           // scan ended before the last MCU
         else if (dev[i]) b->info[i].status = MJX_ERR_BAD_HUFFMAN;       // no code matched (huffman.rs:156/162)
     }
-    for (size_t i = 3; i < dev.size(); i++) {                           // a multi-scan picture takes its scans' failures
+    for (size_t i = 0; i < dev.size(); i++) {                           // a multi-scan picture takes its scans' failures
         if (b->info[i].role != 2 || (b->info[i].status != MJX_OK && b->info[i].status != MJX_ERR_TRUNCATED)) continue;
-        for (size_t k = 1; k <= 3; k++)
+        for (size_t k = 1; k <= b->info[i].nparts && k <= i; k++)
             if (b->info[i - k].status != MJX_OK) b->info[i].status = b->info[i - k].status;
     }
     return MJX_OK;

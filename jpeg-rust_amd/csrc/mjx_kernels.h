@@ -41,11 +41,13 @@ struct DevImage {
     uint32_t nseg;          // 1 = no restart interval
     uint32_t restart_mcus;
     uint32_t ent_cap;       // entries the image's stream region holds
-    // multi-scan files: role 1 = one scan as a one-component picture (entropy stage only, tile = one
-    // block, so tile_eoff holds an offset per block), role 2 = the picture (no scan; k_planar_gather builds its stream
-    // from the role-1 images, which sit src_back[c] places before it in the image array)
+    // multi-scan files: role 1 = one scan as a picture of its own (one component in raster order, or two
+    // interleaved; entropy stage only; tile = one block, so tile_eoff holds an offset per block), role 2 = the picture
+    // (no scan; the k_planar_* kernels build its stream from the role-1 images: component c comes from the image
+    // src_back[c] places before it in the image array, as that image's src_comp[c]-th component)
     uint32_t role;
-    uint32_t src_back[3];
+    uint32_t src_back[3], src_comp[3];
+    uint32_t nparts;
     uint32_t cbw[3], cbh[3];    // role 2: block grid of each component's own scan
 };
 

@@ -818,10 +818,17 @@ __device__ __forceinline__ PlanarSlot planar_slot(const DevImage *images, const 
     if (p.inside) {
         p.c = im.blk_comp[k];
         const uint32_t bx = (m % im.mcux) * im.ch[p.c] + im.blk_bx[k], by = (m / im.mcux) * im.cv[p.c] + im.blk_by[k];
-        p.real = bx < im.cbw[p.c] && by < im.cbh[p.c];
-        if (p.real) {
+        const DevImage &sim = images[img - im.src_back[p.c]];
+        if (sim.ncomp == 1) {                           // non-interleaved scan: raster order over the component's own grid
+            p.real = bx < im.cbw[p.c] && by < im.cbh[p.c];
             p.rb = by * im.cbw[p.c] + bx;
-            const uint32_t *se = tile_eoff + images[img - im.src_back[p.c]].tile_off;     // one offset per block (+ sentinel)
+        } else {                                        // interleaved subset: that scan's own MCU order
+            const uint32_t h = im.ch[p.c], v = im.cv[p.c], sm = (by / v) * sim.mcux + bx / h;
+            p.real = bx / h < sim.mcux && sm < sim.nmcu;
+            p.rb = sm * sim.bpm + sim.cfirst[im.src_comp[p.c]] + (by % v) * h + bx % h;
+        }
+        if (p.real) {
+            const uint32_t *se = tile_eoff + sim.tile_off;                               // one offset per block (+ sentinel)
             p.s0 = se[p.rb];
             p.cnt = se[p.rb + 1] - p.s0;
         }

@@ -47,9 +47,9 @@ struct ParserState {
     struct Part {
         std::vector<uint8_t> scan;
         std::vector<uint32_t> rst;
-        uint8_t comp = 0, td = 0, ta = 0;
+        uint8_t ncomp = 0, comp[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
         unsigned restart_interval = 0;
-        mjx_hufftab dc, ac;
+        mjx_hufftab dc[3], ac[3];
     };
     std::vector<Part> parts;
     mjx_scan_desc *d;
@@ -135,22 +135,28 @@ void read_dht(const ByteView &f, size_t pos, size_t len, mjx_scan_desc *d)      
 }
 
 // SOS header (mod.rs:337-362) + component re-ordering (decoder.rs:83-152) + de-stuffing (mod.rs:371-385).
-// One scan of a multi-scan file (single component): its entropy-coded segment runs up to the next marker that is not
-// RSTn.  Returns the offset of that marker.
-size_t read_part(const ByteView &f, size_t i, uint8_t cid, uint8_t td, uint8_t ta, ParserState &st)
+// One scan of a multi-scan file (one component, or two interleaved): its entropy-coded segment runs up to the next marker
+// that is not RSTn.  Returns the offset of that marker.
+struct ScanCompSel { uint8_t id, td, ta; };
+size_t read_part(const ByteView &f, size_t i, const ScanCompSel *sel, unsigned n, ParserState &st)
 {
     const mjx_scan_desc *d = st.d;
     ParserState::Part part;
-    int ci = -1;
-    for (size_t c = 0; c < st.frame.size(); c++) if (st.frame[c].id == cid) ci = int(c);
-    if (ci < 0 || td > 3 || ta > 3) throw ParseError{MJX_ERR_UNSUPPORTED_FORMAT};
-    for (const ParserState::Part &p : st.parts) if (p.comp == ci) throw ParseError{MJX_ERR_UNSUPPORTED_FORMAT};   // twice
-    if (!((d->dc_present >> td) & 1) || !((d->ac_present >> ta) & 1)) throw ParseError{MJX_ERR_MISSING_TABLE};
-    part.comp = uint8_t(ci);
-    part.td = td;
-    part.ta = ta;
-    part.dc = d->dc[td];
-    part.ac = d->ac[ta];
+    part.ncomp = uint8_t(n);
+    for (unsigned q = 0; q < n; q++) {
+        int ci = -1;
+        for (size_t c = 0; c < st.frame.size(); c++) if (st.frame[c].id == sel[q].id) ci = int(c);
+        if (ci < 0 || sel[q].td > 3 || sel[q].ta > 3) throw ParseError{MJX_ERR_UNSUPPORTED_FORMAT};
+        for (const ParserState::Part &p : st.parts)
+            for (unsigned k = 0; k < p.ncomp; k++) if (p.comp[k] == ci) throw ParseError{MJX_ERR_UNSUPPORTED_FORMAT};   // twice
+        for (unsigned k = 0; k < q; k++) if (part.comp[k] == ci) throw ParseError{MJX_ERR_UNSUPPORTED_FORMAT};
+        if (!((d->dc_present >> sel[q].td) & 1) || !((d->ac_present >> sel[q].ta) & 1)) throw ParseError{MJX_ERR_MISSING_TABLE};
+        part.comp[q] = uint8_t(ci);
+        part.td[q] = sel[q].td;
+        part.ta[q] = sel[q].ta;
+        part.dc[q] = d->dc[sel[q].td];
+        part.ac[q] = d->ac[sel[q].ta];
+    }
     part.restart_interval = st.restart_interval;
     const size_t total = f.size();
     size_t k = i;
@@ -177,7 +183,9 @@ void finish_parts(ParserState &st)
 {
     mjx_scan_desc *d = st.d;
     const size_t n = st.parts.size();
-    if (n != st.frame.size() || n > 3) throw ParseError{MJX_ERR_UNSUPPORTED_FORMAT};                  // a component without a scan
+    size_t covered = 0;
+    for (const ParserState::Part &p : st.parts) covered += p.ncomp;
+    if (covered != st.frame.size() || st.frame.size() != 3) throw ParseError{MJX_ERR_UNSUPPORTED_FORMAT};   // a component without a scan
     size_t bytes = (n * sizeof(mjx_scan_part) + 15) & ~size_t(15);
     for (const ParserState::Part &p : st.parts) bytes += ((p.scan.size() + 32 + 15) & ~size_t(15)) + ((p.rst.size() * 4 + 15) & ~size_t(15));
     uint8_t *buf = static_cast<uint8_t *>(std::malloc(bytes));
@@ -186,11 +194,13 @@ void finish_parts(ParserState &st)
     size_t off = (n * sizeof(mjx_scan_part) + 15) & ~size_t(15);
     d->width = uint16_t(st.width);
     d->height = uint16_t(st.height);
-    d->ncomp = uint8_t(n);
+    d->ncomp = uint8_t(st.frame.size());
     for (size_t k = 0; k < n; k++) {
         const ParserState::Part &p = st.parts[k];
-        const FrameComp &fc = st.frame[p.comp];
-        d->comp[p.comp] = mjx_comp{fc.id, fc.h, fc.v, fc.tq, p.td, p.ta};
+        for (unsigned q = 0; q < p.ncomp; q++) {
+            const FrameComp &fc = st.frame[p.comp[q]];
+            d->comp[p.comp[q]] = mjx_comp{fc.id, fc.h, fc.v, fc.tq, p.td[q], p.ta[q]};
+        }
         mjx_scan_part &o = parts[k];
         std::memset(&o, 0, sizeof o);
         uint8_t *sc = buf + off;
@@ -202,12 +212,11 @@ void finish_parts(ParserState &st)
         off += (p.rst.size() * 4 + 15) & ~size_t(15);
         o.scan = sc;
         o.scan_len = p.scan.size();
-        o.comp = p.comp;
+        o.ncomp = p.ncomp;
+        for (unsigned q = 0; q < p.ncomp; q++) { o.comp[q] = p.comp[q]; o.dc[q] = p.dc[q]; o.ac[q] = p.ac[q]; }
         o.restart_interval = uint16_t(p.restart_interval);
         o.n_restart = uint32_t(p.rst.size());
         o.restart_offsets = p.rst.empty() ? nullptr : rst;
-        o.dc = p.dc;
-        o.ac = p.ac;
     }
     d->scan = nullptr;
     d->scan_len = 0;
@@ -228,14 +237,16 @@ size_t read_sos(const ByteView &f, size_t pos, ParserState &st, bool strict, boo
     (void)f.at(i + 3);                                  // Ss, Se, AhAl are read (mod.rs:356-359) and ignored
     i += 4;
     if (!st.have_frame) throw ParseError{MJX_ERR_REF_PANIC};                     // mod.rs:388 unwrap
-    if (n != 1 && n != 3) throw ParseError{MJX_ERR_UNSUPPORTED_FORMAT};          // decoder.rs:328-330 panic!("asd")
-    // A scan that carries fewer components than the frame is one of several (non-interleaved baseline).
-    // The reference decodes the first one with the frame's sampling factors and stops (mod.rs:415-417); strict_ref keeps
-    // that.  Otherwise single-component scans are collected (read_part); scans that interleave a subset are not built.
+    // A scan that carries fewer components than the frame is one of several.  The reference decodes the
+    // first one with the frame's sampling factors and stops (mod.rs:415-417); strict_ref keeps that.  Otherwise scans of
+    // one component, or of two interleaved ones, are collected (read_part) until every component has been seen.
     if (!strict && (n < st.frame.size() || !st.parts.empty())) {
-        if (n != 1) throw ParseError{MJX_ERR_UNSUPPORTED_FORMAT};
-        return read_part(f, i, sc[0].id, sc[0].td, sc[0].ta, st);
+        if (n < 1 || n > 2 || st.frame.size() != 3) throw ParseError{MJX_ERR_UNSUPPORTED_FORMAT};
+        ScanCompSel sel[2];
+        for (unsigned q = 0; q < n; q++) sel[q] = ScanCompSel{sc[q].id, sc[q].td, sc[q].ta};
+        return read_part(f, i, sel, n, st);
     }
+    if (n != 1 && n != 3) throw ParseError{MJX_ERR_UNSUPPORTED_FORMAT};          // decoder.rs:328-330 panic!("asd")
 
     d->width = uint16_t(st.width);
     d->height = uint16_t(st.height);

@@ -79,18 +79,18 @@ static int plan_ref_layout(ImagePlan &p)
     return MJX_OK;
 }
 
-int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p)
+int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p, bool scan_part)
 {
     p = ImagePlan{};
     auto fail = [&](int code) { p.status = code; return code; };
     const bool gather = d.n_parts != 0;            // the picture of a multi-scan file: geometry only, no scan of its own
     if (gather) {
-        if (!d.parts || d.n_parts != d.ncomp || d.ncomp != 3) return fail(MJX_ERR_UNSUPPORTED_FORMAT);
+        if (!d.parts || d.n_parts < 2 || d.n_parts > 3 || d.ncomp != 3) return fail(MJX_ERR_UNSUPPORTED_FORMAT);
         if (opts.layout == MJX_LAYOUT_REF_COMPAT || opts.strict_ref) return fail(MJX_ERR_UNSUPPORTED_FORMAT);   // the reference stops after scan 1
     } else if (!d.scan) {
         return fail(MJX_ERR_INVALID_ARG);
     }
-    if (d.ncomp != 1 && d.ncomp != 3) return fail(MJX_ERR_UNSUPPORTED_FORMAT);     // decoder.rs:328-330
+    if (d.ncomp != 1 && d.ncomp != 3 && !(scan_part && d.ncomp == 2)) return fail(MJX_ERR_UNSUPPORTED_FORMAT);     // decoder.rs:328-330
     if (d.width == 0 || d.height == 0) return fail(MJX_ERR_REF_PANIC);             // x_factor division by zero
     // huffman.rs:127-128 preloads data[0..4] and panics on a shorter scan; the bug-compatible modes keep that.  Otherwise a
     // short scan (a flat 8x8 grey picture has one byte of entropy data) is decoded: past its end the lanes read the 0xAA
@@ -287,33 +287,48 @@ void plan_input(const mjx_scan_desc &d, const mjx_opts &opts, std::vector<ImageP
     plan_image(d, opts, pic);
     const size_t first = out.size();
     int bad = pic.status;
-    for (uint32_t c = 0; c < 3 && bad == MJX_OK; c++) {
-        const mjx_scan_part *part = nullptr;
-        for (uint32_t k = 0; k < d.n_parts; k++) if (d.parts[k].comp == c) part = &d.parts[k];
-        if (!part) { bad = MJX_ERR_UNSUPPORTED_FORMAT; break; }
-        // the scan as a one-component picture over the component's own block grid
+    uint32_t seen = 0;
+    for (uint32_t k = 0; k < d.n_parts && bad == MJX_OK; k++) {
+        const mjx_scan_part &part = d.parts[k];
+        if (part.ncomp < 1 || part.ncomp > 2) { bad = MJX_ERR_UNSUPPORTED_FORMAT; break; }
+        // the scan as a picture of its own: one component over the component's own block grid (non-interleaved order), or
+        // two interleaved components on the MCU grid their sampling factors give
         mjx_scan_desc sub;
         std::memset(&sub, 0, sizeof sub);
-        sub.scan = part->scan;
-        sub.scan_len = part->scan_len;
-        sub.width = uint16_t((uint32_t(d.width) * pic.h[c] + pic.hmax - 1) / pic.hmax);
-        sub.height = uint16_t((uint32_t(d.height) * pic.v[c] + pic.vmax - 1) / pic.vmax);
-        sub.ncomp = 1;
-        sub.comp[0] = mjx_comp{d.comp[c].id, 1, 1, d.comp[c].tq, 0, 0};
+        sub.scan = part.scan;
+        sub.scan_len = part.scan_len;
+        sub.ncomp = part.ncomp;
+        uint32_t hm = 1, vm = 1;
+        for (uint32_t q = 0; q < part.ncomp; q++) {
+            const uint32_t c = part.comp[q];
+            if (c > 2 || ((seen >> c) & 1)) { bad = MJX_ERR_UNSUPPORTED_FORMAT; break; }
+            seen |= 1u << c;
+            pic.src_part[c] = k;
+            pic.src_comp[c] = q;
+            hm = std::max(hm, pic.h[c]);
+            vm = std::max(vm, pic.v[c]);
+            sub.comp[q] = mjx_comp{d.comp[c].id, uint8_t(part.ncomp == 1 ? 1 : pic.h[c]), uint8_t(part.ncomp == 1 ? 1 : pic.v[c]),
+                                   d.comp[c].tq, uint8_t(q), uint8_t(q)};
+            sub.dc[q] = part.dc[q];
+            sub.ac[q] = part.ac[q];
+        }
+        if (bad != MJX_OK) break;
+        sub.width = uint16_t((uint32_t(d.width) * hm + pic.hmax - 1) / pic.hmax);
+        sub.height = uint16_t((uint32_t(d.height) * vm + pic.vmax - 1) / pic.vmax);
         std::memcpy(sub.qt, d.qt, sizeof sub.qt);
         sub.qt_present = d.qt_present;
-        sub.dc[0] = part->dc;
-        sub.ac[0] = part->ac;
-        sub.dc_present = sub.ac_present = 1;
-        sub.restart_interval = part->restart_interval;
-        sub.n_restart = part->n_restart;
-        sub.restart_offsets = part->restart_offsets;
+        sub.dc_present = sub.ac_present = uint8_t((1u << part.ncomp) - 1);
+        sub.restart_interval = part.restart_interval;
+        sub.n_restart = part.n_restart;
+        sub.restart_offsets = part.restart_offsets;
         out.emplace_back();
         ImagePlan &pp = out.back();
-        plan_image(sub, opts, pp);
+        plan_image(sub, opts, pp, true);
         pp.role = 1;
         if (pp.status != MJX_OK) bad = pp.status;
     }
+    if (bad == MJX_OK && seen != 7u) bad = MJX_ERR_UNSUPPORTED_FORMAT;
+    pic.nparts = d.n_parts;
     if (bad != MJX_OK) {                       // one status for the whole picture
         out.resize(first);
         pic = ImagePlan{};

@@ -44,6 +44,8 @@ struct ImagePlan {
     // itself as role 2 (no scan: its coefficient stream is gathered from the role-1 streams, then stage B as usual).
     uint32_t role = 0;
     uint32_t cbw[3] = {0, 0, 0}, cbh[3] = {0, 0, 0};   // role 2: the components' own block grids (T.81 A.2.2)
+    uint32_t nparts = 0;                               // role 2: scans in front of the picture
+    uint32_t src_part[3] = {0, 0, 0}, src_comp[3] = {0, 0, 0};   // ... which of them carries component c, as its n-th component
 };
 
 // decoder.rs:259-288 get_indices: raster counter (x, y) of a component's blocks -> block position (bug-for-bug, Q3).
@@ -51,11 +53,12 @@ struct ImagePlan {
 bool ref_get_indices(long x, long y, long max_x, long x_factor, long y_factor, long max_x_factor, long max_y_factor,
                      long *ox, long *oy);
 
-// Validates `d` and fills `plan`.  Returns plan.status.
-int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &plan);
+// Validates `d` and fills `plan`.  Returns plan.status.  `scan_part`: d is one scan of a multi-scan file (two interleaved
+// components are then allowed).
+int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &plan, bool scan_part = false);
 
-// The plans of one input: `plan_image` for an ordinary file; for a multi-scan file one role-1 plan per component (in
-// component order) followed by the role-2 plan of the picture.  The last plan appended is the picture's.
+// The plans of one input: `plan_image` for an ordinary file; for a multi-scan file one role-1 plan per scan (in file
+// order) followed by the role-2 plan of the picture.  The last plan appended is the picture's.
 void plan_input(const mjx_scan_desc &d, const mjx_opts &opts, std::vector<ImagePlan> &out);
 
 extern const uint8_t kZigZag[64];                  // decoder.rs:404-407 ZIGZAG_INDICES

@@ -353,10 +353,11 @@ typedef struct {
     orc_framecomp fcomp[256];
     int width, height;
     int restart_interval;      /* MCUs per restart interval (ext_dri), 0 = none */
-    /* ext_multiscan: one entry per scan read so far (single-component scans) */
+    /* ext_multiscan: one entry per scan read so far (one component, or two interleaved) */
     struct {
-        int comp;                      /* index into fcomp */
-        orc_htable dc, ac;             /* the tables the scan selected, as they were when its SOS was read */
+        int ncomp;
+        int comp[2];                   /* indices into fcomp, scan order */
+        orc_htable dc[2], ac[2];       /* the tables the scan selected, as they were when its SOS was read */
         const uint8_t *data;           /* its entropy-coded segment, FF00 compacted, RSTn left in */
         size_t len;
         int restart_interval;
@@ -463,32 +464,53 @@ static void orc_jpeg_decode(orc_env *env, const orc_opts *opts, const orc_parse 
         /* ext_multiscan: every scan carries the blocks of one component in raster order over the component's own block
            grid; each is put where the interleaved order would have it (MCU padding blocks stay zero) */
         for (int q = 0; q < ps->nparts; q++) {
-            const int c = ps->parts[q].comp;
-            const size_t cbw = ((W * (size_t)hs[c] + hmax - 1) / hmax + 7) / 8, cbh = ((H * (size_t)vs[c] + vmax - 1) / vmax + 7) / 8;
+            const int pn = ps->parts[q].ncomp;
             orc_hdec pd;
             orc_hdec_new(env, &pd, ps->parts[q].data, ps->parts[q].len, 1);
-            float pred = 0;
             const size_t ri = (size_t)ps->parts[q].restart_interval;
-            size_t done = 0;
-            for (size_t by = 0; by < cbh; by++)
-                for (size_t bx = 0; bx < cbw; bx++) {
-                    int16_t blk[64];
-                    orc_next_block(env, &pd, &ps->parts[q].ac, &ps->parts[q].dc, (opts->faithful_huff ? 1 : 0) | (opts->ext_1bit ? 2 : 0), blk);
-                    pred += (float)blk[0];
-                    const size_t m = (by / (size_t)vs[c]) * mcux + bx / (size_t)hs[c];
-                    const size_t k = (by % (size_t)vs[c]) * (size_t)hs[c] + bx % (size_t)hs[c];
-                    int16_t *dst = out->coef[c] + (m * per_mcu[c] + k) * 64;
-                    memcpy(dst, blk, sizeof blk);
-                    dst[0] = (int16_t)pred;
-                    done++;
-                    if (ri > 0 && done % ri == 0 && done < cbw * cbh) {
-                        orc_shift_and_fix(&pd, (size_t)((8 - pd.total_bits % 8) % 8));
-                        const uint32_t mk = pd.current >> 16;
-                        if ((mk & 0xfff8u) != 0xffd0u) orc_panic(env, ORC_ERR_UNSUPPORTED, "restart marker expected");
-                        orc_shift_and_fix(&pd, 16);
-                        pred = 0;
-                    }
+            float pred[2] = {0, 0};
+            size_t units, gw;                  /* restart units (blocks / MCUs) of the scan; width of its grid */
+            if (pn == 1) {                     /* non-interleaved: raster order over the component's own block grid */
+                const int c = ps->parts[q].comp[0];
+                gw = ((W * (size_t)hs[c] + hmax - 1) / hmax + 7) / 8;
+                units = gw * (((H * (size_t)vs[c] + vmax - 1) / vmax + 7) / 8);
+            } else {                           /* interleaved subset: MCUs of the scan's own components */
+                size_t hm = 1, vm = 1;
+                for (int k = 0; k < pn; k++) {
+                    if ((size_t)hs[ps->parts[q].comp[k]] > hm) hm = (size_t)hs[ps->parts[q].comp[k]];
+                    if ((size_t)vs[ps->parts[q].comp[k]] > vm) vm = (size_t)vs[ps->parts[q].comp[k]];
                 }
+                const size_t sw = (W * hm + hmax - 1) / hmax, sh = (H * vm + vmax - 1) / vmax;
+                gw = (sw + 8 * hm - 1) / (8 * hm);
+                units = gw * ((sh + 8 * vm - 1) / (8 * vm));
+            }
+            for (size_t u = 0; u < units; u++) {
+                for (int k = 0; k < pn; k++) {
+                    const int c = ps->parts[q].comp[k];
+                    const size_t nh = pn == 1 ? 1 : (size_t)hs[c], nv = pn == 1 ? 1 : (size_t)vs[c];
+                    for (size_t yy = 0; yy < nv; yy++)
+                        for (size_t xx = 0; xx < nh; xx++) {
+                            int16_t blk[64];
+                            orc_next_block(env, &pd, &ps->parts[q].ac[k], &ps->parts[q].dc[k], (opts->faithful_huff ? 1 : 0) | (opts->ext_1bit ? 2 : 0), blk);
+                            pred[k] += (float)blk[0];
+                            const size_t bx = (u % gw) * nh + xx, by = (u / gw) * nv + yy;   /* block position in the component */
+                            const size_t m = (by / (size_t)vs[c]) * mcux + bx / (size_t)hs[c];
+                            const size_t kk = (by % (size_t)vs[c]) * (size_t)hs[c] + bx % (size_t)hs[c];
+                            if (bx / (size_t)hs[c] < mcux && m < num_read) {
+                                int16_t *dst = out->coef[c] + (m * per_mcu[c] + kk) * 64;
+                                memcpy(dst, blk, sizeof blk);
+                                dst[0] = (int16_t)pred[k];
+                            }
+                        }
+                }
+                if (ri > 0 && (u + 1) % ri == 0 && u + 1 < units) {
+                    orc_shift_and_fix(&pd, (size_t)((8 - pd.total_bits % 8) % 8));
+                    const uint32_t mk = pd.current >> 16;
+                    if ((mk & 0xfff8u) != 0xffd0u) orc_panic(env, ORC_ERR_UNSUPPORTED, "restart marker expected");
+                    orc_shift_and_fix(&pd, 16);
+                    pred[0] = pred[1] = 0;
+                }
+            }
             hd.total_bits += pd.total_bits;
         }
     }
@@ -604,7 +626,9 @@ static void orc_jpeg_decode(orc_env *env, const orc_opts *opts, const orc_parse 
 /* ext_multiscan: every component has its scan -> decode the picture (components in frame order) */
 static void orc_decode_parts(orc_env *env, const orc_opts *opts, orc_parse *ps, orc_image *out)
 {
-    if (ps->nparts != ps->ncomp_frame || ps->nparts != 3) orc_panic(env, ORC_ERR_UNSUPPORTED, "multi-scan file: a component without a scan");
+    int covered = 0;
+    for (int q = 0; q < ps->nparts; q++) covered += ps->parts[q].ncomp;
+    if (covered != ps->ncomp_frame || covered != 3) orc_panic(env, ORC_ERR_UNSUPPORTED, "multi-scan file: a component without a scan");
     orc_compfields ordered[3];
     for (int c = 0; c < 3; c++) {
         ordered[c].component = ps->fcomp[c].id;
@@ -738,12 +762,20 @@ static void orc_parse_and_decode(orc_env *env, const uint8_t *vec, size_t len, c
             if (opts->ext_multiscan && opts->layout == ORC_LAYOUT_STD && !opts->strict_ref && ps->have_frame &&
                 (num_components < ps->ncomp_frame || ps->nparts)) {
                 /* NOT reference behaviour: one scan of several.  Its data runs up to the next marker that is not RSTn. */
-                if (num_components != 1 || ps->nparts >= 3) orc_panic(env, ORC_ERR_UNSUPPORTED, "multi-scan file: scans must carry one component each");
-                int ci = -1;
-                for (int c = 0; c < ps->ncomp_frame; c++) if (ps->fcomp[c].id == sc[0].id) ci = c;
-                if (ci < 0 || sc[0].dc_sel > 3 || sc[0].ac_sel > 3) orc_panic(env, ORC_ERR_UNSUPPORTED, "multi-scan file: unknown component or table");
-                for (int q = 0; q < ps->nparts; q++) if (ps->parts[q].comp == ci) orc_panic(env, ORC_ERR_UNSUPPORTED, "multi-scan file: component coded twice");
-                PANIC_IF(!ps->dc[sc[0].dc_sel].present || !ps->ac[sc[0].ac_sel].present, "table unwrap on None");
+                if (num_components < 1 || num_components > 2 || ps->nparts >= 3) orc_panic(env, ORC_ERR_UNSUPPORTED, "multi-scan file: scans of one or two components");
+                const int q = ps->nparts;
+                ps->parts[q].ncomp = num_components;
+                for (int k = 0; k < num_components; k++) {
+                    int ci = -1;
+                    for (int c = 0; c < ps->ncomp_frame; c++) if (ps->fcomp[c].id == sc[k].id) ci = c;
+                    if (ci < 0 || sc[k].dc_sel > 3 || sc[k].ac_sel > 3) orc_panic(env, ORC_ERR_UNSUPPORTED, "multi-scan file: unknown component or table");
+                    for (int p = 0; p < ps->nparts; p++)
+                        for (int j = 0; j < ps->parts[p].ncomp; j++) if (ps->parts[p].comp[j] == ci) orc_panic(env, ORC_ERR_UNSUPPORTED, "multi-scan file: component coded twice");
+                    PANIC_IF(!ps->dc[sc[k].dc_sel].present || !ps->ac[sc[k].ac_sel].present, "table unwrap on None");
+                    ps->parts[q].comp[k] = ci;
+                    ps->parts[q].dc[k] = ps->dc[sc[k].dc_sel];
+                    ps->parts[q].ac[k] = ps->ac[sc[k].ac_sel];
+                }
                 uint8_t *pd = (uint8_t *)orc_alloc(env, len - (i < len ? i : len) + 8);
                 size_t np = 0, k = i;
                 while (k < len) {
@@ -754,10 +786,7 @@ static void orc_parse_and_decode(orc_env *env, const uint8_t *vec, size_t len, c
                     if ((vec[k + 1] & 0xf8) == 0xd0) { pd[np++] = 0xff; pd[np++] = vec[k + 1]; k += 2; continue; }   /* RSTn stays */
                     break;
                 }
-                const int q = ps->nparts++;
-                ps->parts[q].comp = ci;
-                ps->parts[q].dc = ps->dc[sc[0].dc_sel];
-                ps->parts[q].ac = ps->ac[sc[0].ac_sel];
+                ps->nparts++;
                 ps->parts[q].data = pd;
                 ps->parts[q].len = np;
                 ps->parts[q].restart_interval = ps->restart_interval;

@@ -69,18 +69,22 @@ def magnitude(v):
     return s, (int(v) if v >= 0 else int(v) + (1 << s) - 1)
 
 
-def encode_scan(blocks, dc, ac, restart=0):
-    """blocks: int16 [n, 64] zig-zag order, DC absolute."""
-    w, pred = BitWriter(), 0
+def encode_scan(blocks, dc, ac, restart=0, ncomp=1):
+    """blocks: int16 [n, 64] zig-zag order, DC absolute; with ncomp > 1 the blocks of an MCU follow each other (one per
+    component), dc / ac are lists of tables per component and restart counts MCUs."""
+    if ncomp == 1:
+        dc, ac = [dc], [ac]
+    w, pred = BitWriter(), [0] * ncomp
     chunks, rst = [], 0
     for k, blk in enumerate(blocks):
-        if restart and k and k % restart == 0:
+        c = k % ncomp
+        if restart and k and k % (restart * ncomp) == 0:
             chunks.append(w.flush() + bytes([0xff, 0xd0 + (rst & 7)]))
             rst += 1
-            w, pred = BitWriter(), 0
-        s, bits = magnitude(int(blk[0]) - pred)
-        pred = int(blk[0])
-        w.put(*dc[s])
+            w, pred = BitWriter(), [0] * ncomp
+        s, bits = magnitude(int(blk[0]) - pred[c])
+        pred[c] = int(blk[0])
+        w.put(*dc[c][s])
         if s:
             w.put(bits, s)
         run = 0
@@ -90,19 +94,20 @@ def encode_scan(blocks, dc, ac, restart=0):
                 run += 1
                 continue
             while run > 15:
-                w.put(*ac[0xf0])
+                w.put(*ac[c][0xf0])
                 run -= 16
             s, bits = magnitude(blk[i])
-            w.put(*ac[(run << 4) | s])
+            w.put(*ac[c][(run << 4) | s])
             w.put(bits, s)
             run = 0
         if last < 63:
-            w.put(*ac[0x00])
+            w.put(*ac[c][0x00])
     chunks.append(w.flush())
     return b"".join(chunks)
 
 
-def twin(data, restart=0):
+def twin(data, restart=0, chroma_together=False):
+    """chroma_together: two scans, "0; 1 2;" (libjpeg wizard.txt: separate scans for luma and chroma) instead of three."""
     ref = orc.decode(data, layout=orc.LAYOUT_STD, ext_1bit=True)
     segs = segments(data)
     comps, dht_dc, dht_ac, sos_comp = [], {}, {}, []
@@ -128,6 +133,7 @@ def twin(data, restart=0):
     out = bytearray(data[:sos_at])
     if restart:
         out += bytes([0xff, 0xdd, 0, 4]) + struct.pack(">H", restart)
+    rasters = []
     for c, (cid, h, v) in enumerate(comps):
         bw = ((W * h + hmax - 1) // hmax + 7) // 8          # the component's own block grid
         bh = ((H * v + vmax - 1) // vmax + 7) // 8
@@ -136,9 +142,19 @@ def twin(data, restart=0):
         for y in range(bh):
             for x in range(bw):
                 raster[y, x] = mc[(y // v) * mcux + (x // h), y % v, x % h]
+        rasters.append(raster)
+    for c, (cid, h, v) in enumerate(comps):
         _, td, ta = sos_comp[c]
+        if chroma_together and c == 1:
+            # Cb and Cr interleaved: both 1x1 here, so the scan's MCU is one block of each, over their common block grid
+            assert comps[1][1:] == comps[2][1:] == (1, 1) and rasters[1].shape == rasters[2].shape
+            _, td2, ta2 = sos_comp[2]
+            out += bytes([0xff, 0xda, 0, 10, 2, cid, (td << 4) | ta, comps[2][0], (td2 << 4) | ta2, 0, 63, 0])
+            both = np.stack([rasters[1].reshape(-1, 64), rasters[2].reshape(-1, 64)], 1).reshape(-1, 64)
+            out += encode_scan(both, [dht_dc[td], dht_dc[td2]], [dht_ac[ta], dht_ac[ta2]], restart, ncomp=2)
+            break
         out += bytes([0xff, 0xda, 0, 8, 1, cid, (td << 4) | ta, 0, 63, 0])
-        out += encode_scan(raster.reshape(-1, 64), dht_dc[td], dht_ac[ta], restart)
+        out += encode_scan(rasters[c].reshape(-1, 64), dht_dc[td], dht_ac[ta], restart)
     out += b"\xff\xd9"
     out = bytes(out)
     a = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
@@ -149,10 +165,11 @@ def twin(data, restart=0):
 
 if __name__ == "__main__":
     jobs = [("std_420_big.jpg", "ms_420_big.jpg", 0), ("opt_444_q40.jpg", "ms_444_q40.jpg", 0), ("opt_422_q95.jpg", "ms_422_q95.jpg", 0),
-            ("opt_420_q85.jpg", "ms_420_q85_rst.jpg", 7), ("dri_420_r5_plain.jpg", "ms_420_odd.jpg", 0)]
+            ("opt_420_q85.jpg", "ms_420_q85_rst.jpg", 7), ("dri_420_r5_plain.jpg", "ms_420_odd.jpg", 0),
+            ("std_420_big.jpg", "ms2_420_big.jpg", 0), ("opt_420_q85.jpg", "ms2_420_q85_rst.jpg", 5), ("opt_444_q40.jpg", "ms2_444_q40.jpg", 0)]
     for src, dst, rst in jobs:
         data = open(os.path.join(PIL_DIR, src), "rb").read()
-        t = twin(data, rst)
+        t = twin(data, rst, chroma_together=dst.startswith("ms2_"))
         open(os.path.join(PIL_DIR, dst), "wb").write(t)
         im = Image.open(io.BytesIO(t))
         print(dst, im.size, len(data), "->", len(t), "bytes")

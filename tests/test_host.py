@@ -95,7 +95,7 @@ def test_parse_never_crashes_on_mutations(mjx):
     # files with restart intervals: mutations anywhere (markers inside the scan included), parse + plan must stay in bounds
     # ... and multi-scan files (markers between the scans, with and without restart intervals)
     bases = [open(os.path.join(os.path.dirname(__file__), "golden", "pil", n + ".jpg"), "rb").read()
-             for n in ("dri_420_r5", "ms_420_q85_rst", "ms_422_q95", "ms_444_q40")]
+             for n in ("dri_420_r5", "ms_420_q85_rst", "ms_422_q95", "ms_444_q40", "ms2_420_q85_rst", "ms2_444_q40")]
     for k in range(400):
         base = bases[k % len(bases)]
         b = bytearray(base)
@@ -295,7 +295,8 @@ def test_oracle_multi_scan_extension_is_pinned_by_twins(orc):
     interleaved file it was made from (tests/golden/make_multiscan.py; Pillow confirmed each twin when it was written),
     coefficients included wherever the scans carry the block; without the extension the oracle keeps to the reference."""
     pairs = {"ms_420_big": "std_420_big", "ms_444_q40": "opt_444_q40", "ms_422_q95": "opt_422_q95",
-             "ms_420_q85_rst": "opt_420_q85", "ms_420_odd": "dri_420_r5_plain"}
+             "ms_420_q85_rst": "opt_420_q85", "ms_420_odd": "dri_420_r5_plain",
+             "ms2_420_big": "std_420_big", "ms2_420_q85_rst": "opt_420_q85", "ms2_444_q40": "opt_444_q40"}    # ms2: "0; 1 2;"
     for ms, src in pairs.items():
         a = orc.decode(open(os.path.join(PIL_DIR, ms + ".jpg"), "rb").read(), layout=orc.LAYOUT_STD, ext_1bit=True, ext_dri=True,
                        ext_multiscan=True)
@@ -312,19 +313,21 @@ def test_multi_scan_files_are_parsed_into_parts(mjx):
     """One scan per component (tests/golden/make_multiscan.py): mjx_parse lists every scan as a part with its own
     de-stuffed data, tables and restart offsets; the bug-compatible modes keep the reference's view (first scan only /
     refused)."""
-    for name, rst in (("ms_420_big", 0), ("ms_422_q95", 0), ("ms_420_q85_rst", 7)):
+    for name, rst, shape in (("ms_420_big", 0, [[0], [1], [2]]), ("ms_422_q95", 0, [[0], [1], [2]]), ("ms_420_q85_rst", 7, [[0], [1], [2]]),
+                             ("ms2_420_big", 0, [[0], [1, 2]]), ("ms2_420_q85_rst", 5, [[0], [1, 2]])):
         data = open(os.path.join(PIL_DIR, name + ".jpg"), "rb").read()
         scan = mjx.ParsedScan(data)
         d = scan.desc
-        assert d.n_parts == 3 and d.ncomp == 3 and not d.scan
-        assert sorted(d.parts[k].comp for k in range(3)) == [0, 1, 2]
+        assert d.n_parts == len(shape) and d.ncomp == 3 and not d.scan
+        assert [[d.parts[k].comp[q] for q in range(d.parts[k].ncomp)] for k in range(d.n_parts)] == shape
         assert [d.comp[c].id for c in range(3)] == [1, 2, 3]
-        total = sum(d.parts[k].scan_len for k in range(3))
+        total = sum(d.parts[k].scan_len for k in range(d.n_parts))
         assert 0 < total < len(data)
-        for k in range(3):
+        for k in range(d.n_parts):
             p = d.parts[k]
             assert p.restart_interval == rst and (p.n_restart > 0) == (rst > 0)
-            assert sum(p.dc.bits) > 0 and sum(p.ac.bits) > 0
+            for q in range(p.ncomp):
+                assert sum(p.dc[q].bits) > 0 and sum(p.ac[q].bits) > 0
         assert scan.validate() == mjx.OK
         assert scan.validate(layout=mjx.LAYOUT_REF_COMPAT) == mjx.ERR_UNSUPPORTED_FORMAT
         strict = mjx.ParsedScan(data, strict_ref=True) if rst == 0 else None     # (strict: DRI is a reference panic)

@@ -73,7 +73,8 @@ def encode():
         # decode of the interleaved file
         try:
             rst = int(rng.integers(1, 30)) if rng.random() < 0.4 else 0
-            return make_multiscan.twin(data, rst), (w, h, dict(kw, multiscan=True, rst=rst), data)
+            together = bool(rng.random() < 0.5)         # "0; 1 2;": the two chroma components (1x1 each) interleaved
+            return make_multiscan.twin(data, rst, chroma_together=together), (w, h, dict(kw, multiscan=True, rst=rst, cbcr=together), data)
         except KeyError:                  # an optimised table lacks a symbol the per-scan DC prediction needs
             pass
     return data, (w, h, kw)
