@@ -12,7 +12,7 @@ mjx = ge.load_package()
 ctx = mjx.Context(0)
 d = os.path.join(ROOT, "tests", "golden", "pil")
 names = ["dri_420_r5", "dri_420_720p_rows", "dri_444_r1", "dri_422_rows", "dri_gray_r7", "dri_420_r300", "opt_420_q85", "std_420_big",
-         "ms_420_big", "ms_420_q85_rst", "ms_422_q95"]
+         "ms_420_big", "ms_420_q85_rst", "ms_422_q95", "ms2_420_big", "ms2_420_q85_rst"]
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 tot = 0
 for rnd in range(12):
