@@ -3,16 +3,21 @@
 //   stage A (entropy, replaces HuffmanDecoder::next_block + the MCU loop, reference
 //            src/jpeg/huffman.rs:146-254 and src/jpeg/decoder.rs:195-215):
 //     k_huff_spec   speculative decode of every 512-byte subsequence, recording exit states and checkpoints
-//     k_huff_merge  one synchronisation round: re-decode the subsequences whose entry changed until they merge
-//     k_huff_scan   per-image exclusive scan of completed-block / stream-entry counts
+//     k_huff_merge (+ k_huff_merge_tail)  one synchronisation round: re-decode the subsequences whose entry changed
+//                   until they merge with their previous decode
+//     k_huff_scan   per-image exclusive scan of completed-block / stream-entry counts; fences unconverged chunks
 //     k_huff_write  final decode from the synchronised entry states into the compact coefficient stream
-//     k_dc_sums / k_dc_apply   DC prediction (decoder.rs:208-210) as a per-component prefix sum
+//     k_dc_sums / k_dc_apply (+ _t<BPM>, k_dc_restart)   DC prediction (decoder.rs:208-210) as a per-component prefix sum
+//     k_planar_count / _offsets / _copy   multi-scan files only: component streams -> the picture's stream in MCU order
+//     k_destuff_count / _scatter          optional: the FF00 -> FF compaction of jpeg/mod.rs:371-385 at upload
 //   stage B (pixels, replaces decoder.rs:227-235, 239-331 and src/transform.rs:55-87):
 //     k_idct_color  dequant + un-zigzag + 8x8 float IDCT + chroma replication + YCbCr->RGB + packed store
+//     k_ref_color   REF_COMPAT layout only: the reference's plane-wise colour step
 //
-// The bitstream has no restart markers (the reference panics on DRI, jpeg/mod.rs:424-428), so intra-image
-// parallelism comes from the self-synchronisation of Huffman codes: a lane that starts decoding at an arbitrary bit
-// with a guessed state converges to the true symbol boundaries; entry states are iterated to a fixed point.
+// Without restart markers (the reference panics on DRI, jpeg/mod.rs:424-428; files that have them are cut at the markers
+// as well) intra-image parallelism comes from the self-synchronisation of Huffman codes: a lane that starts decoding
+// at an arbitrary bit with a guessed state converges to the true symbol boundaries; entry states are iterated to a
+// fixed point.
 #include <hip/hip_runtime.h>
 
 #include "mjx_kernels.h"
