@@ -771,8 +771,9 @@ extern "C" int mjx_validate(const mjx_scan_desc *desc, const mjx_opts *opts)
     if (!desc) return MJX_ERR_INVALID_ARG;
     mjx_opts o{};
     if (opts) o = *opts;
-    ImagePlan p;
-    return plan_image(*desc, o, p);
+    std::vector<ImagePlan> plans;                      // (a multi-scan file: every scan is checked, the picture's plan is last)
+    plan_input(*desc, o, plans);
+    return plans.back().status;
 }
 
 extern "C" int mjx_batch_tile(mjx_ctx *ctx, const mjx_batch *src, size_t times, mjx_batch **out)

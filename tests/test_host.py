@@ -330,6 +330,9 @@ def test_multi_scan_files_are_parsed_into_parts(mjx):
                 assert sum(p.dc[q].bits) > 0 and sum(p.ac[q].bits) > 0
         assert scan.validate() == mjx.OK
         assert scan.validate(layout=mjx.LAYOUT_REF_COMPAT) == mjx.ERR_UNSUPPORTED_FORMAT
+        # validate looks into every scan: an emptied one is refused
+        d.parts[d.n_parts - 1].scan_len = 0
+        assert scan.validate() == mjx.ERR_TRUNCATED
         strict = mjx.ParsedScan(data, strict_ref=True) if rst == 0 else None     # (strict: DRI is a reference panic)
         if strict is not None:
             assert strict.desc.n_parts == 0 and strict.desc.ncomp == 1           # jpeg/mod.rs:415-417: the first scan only
