@@ -10,6 +10,8 @@
 #include "mjx_plan.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -594,7 +596,10 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
             HIPOK(hipMemcpy(b->d_lut, src->d_lut, std::max<size_t>(lut_pool, 8) * sizeof(LutEntry), hipMemcpyDeviceToDevice));
             HIPOK(hipMemcpy(b->d_qm, src->d_qm, std::max<size_t>(nu, 1) * 192 * sizeof(float), hipMemcpyDeviceToDevice));
         } else {
-            std::vector<uint8_t> hs(scan_pool, 0xaa);
+            const bool timing = std::getenv("MJX_TIMING") != nullptr;
+            auto now = [] { return std::chrono::steady_clock::now(); };
+            auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) { return std::chrono::duration<double, std::milli>(b2 - a).count(); };
+            const auto t0 = now();
             std::vector<LutEntry> hl(std::max<size_t>(lut_pool, 8), 0);
             std::vector<float> hq(std::max<size_t>(nu, 1) * 192, 0.f);
             std::vector<char> on_device(nu, 0);
@@ -602,11 +607,22 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
             for (size_t k = 0; k < nu; k++) {
                 const ImagePlan &p = plans[k];
                 if (p.status != MJX_OK) continue;
-                if (!on_device[k]) std::memcpy(hs.data() + scan_off[k], p.scan, p.scan_len);
                 std::memcpy(hl.data() + lut_off[k], p.lut.data(), p.lut.size() * sizeof(LutEntry));
                 std::memcpy(hq.data() + k * 192, p.qmult, sizeof p.qmult);
             }
-            HIPOK(hipMemcpy(b->d_scan, hs.data(), scan_pool, hipMemcpyHostToDevice));
+            const auto t1 = now();
+            // the pool is filled with the 0xAA the reference reads past the end of a scan (huffman.rs:236-246) on the
+            // device, then every scan goes up straight from the caller's buffer: a host-side staging copy of the whole
+            // pool (first-touch page faults included) cost six times the transfer itself
+            HIPOK(hipMemsetAsync(b->d_scan, 0xaa, scan_pool, ctx->stream));
+            for (size_t k = 0; k < nu; k++) {
+                const ImagePlan &p = plans[k];
+                if (p.status != MJX_OK || on_device[k] || p.scan_len == 0) continue;
+                HIPOK(hipMemcpyAsync(b->d_scan + scan_off[k], p.scan, p.scan_len, hipMemcpyHostToDevice, ctx->stream));
+            }
+            HIPOK(hipStreamSynchronize(ctx->stream));
+            const auto t2 = now();
+            if (timing) std::fprintf(stderr, "[mjx] staging %.2f ms, H2D of %.1f MB %.2f ms\n", ms(t0, t1), scan_pool / 1e6, ms(t1, t2));
             if (ds && !ds->imgs.empty()) {                 // compact the stuffed scans straight into the pool
                 std::vector<DestuffImg> di;
                 for (size_t j = 0; j < ds->imgs.size(); j++) {
@@ -631,7 +647,11 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
             HIPOK(hipMemcpy(b->d_lut, hl.data(), hl.size() * sizeof(LutEntry), hipMemcpyHostToDevice));
             HIPOK(hipMemcpy(b->d_qm, hq.data(), hq.size() * sizeof(float), hipMemcpyHostToDevice));
         }
-        return allocate_work_buffers(b);
+        const auto ta = std::chrono::steady_clock::now();
+        const int rca = allocate_work_buffers(b);
+        if (std::getenv("MJX_TIMING"))
+            std::fprintf(stderr, "[mjx] work buffers %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta).count());
+        return rca;
     };
     rc = dev();
     if (rc != MJX_OK) { release(b); return rc; }
@@ -756,10 +776,13 @@ extern "C" int mjx_batch_create(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t
     std::vector<ImagePlan> plans;
     std::vector<size_t> plan_of(n);                    // input i -> its picture's plan (multi-scan files add plans in front)
     plans.reserve(n);
+    const auto tp0 = std::chrono::steady_clock::now();
     for (size_t i = 0; i < n; i++) {
         plan_input(dd[i], o, plans);
         plan_of[i] = plans.size() - 1;
     }
+    if (std::getenv("MJX_TIMING"))
+        std::fprintf(stderr, "[mjx] planning %zu inputs %.2f ms\n", n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
     for (size_t &pi : ds.plan_index) pi = plan_of[pi];
     return build_batch(ctx, plans, o, nullptr, 1, out, status, any_stuffed ? &ds : nullptr);
 }
