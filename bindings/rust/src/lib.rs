@@ -117,6 +117,8 @@ extern "C" {
     pub fn mjx_batch_kernel_ms(b: *mut mjx_batch, ms: *mut c_double, launches: *mut u64, reset: c_int) -> c_int;
     pub fn mjx_decode_scans(ctx: *mut mjx_ctx, descs: *const mjx_scan_desc, n: usize, opts: *const mjx_opts,
                             rgb_dev: *mut *mut u8, status: *mut c_int, out: *mut *mut mjx_batch) -> c_int;
+    pub fn mjx_decode_batch(ctx: *mut mjx_ctx, jpegs: *const *const u8, lens: *const usize, n: usize, opts: *const mjx_opts,
+                            threads: c_uint, rgb_dev: *mut *mut u8, status: *mut c_int, out: *mut *mut mjx_batch) -> c_int;
     pub fn mjx_strerror(code: c_int) -> *const c_char;
     pub fn mjx_version() -> *const c_char;
 }

@@ -82,6 +82,7 @@ SYMBOLS = {
     "mjx_free_scan": (None, [_P(ScanDesc)]),
     "mjx_validate": (_int, [_P(ScanDesc), _P(Opts)]),
     "mjx_decode": (_int, [ctypes.c_char_p, _sz, _P(Opts), _P(Image)]),
+    "mjx_decode_batch": (_int, [_vp, _P(ctypes.c_char_p), _P(_sz), _sz, _P(Opts), ctypes.c_uint, _P(_P(ctypes.c_uint8)), _P(_int), _P(_vp)]),
     "mjx_free_image": (None, [_P(Image)]),
     "mjx_ctx_create": (_int, [_int, _P(_vp)]),
     "mjx_ctx_destroy": (None, [_vp]),
@@ -452,6 +453,19 @@ class JPEGImage:
     def image_data(self):
         """ndarray [H, W, 3] uint8 (the reference returns Option<&Vec<(u8,u8,u8)>> of length W*H, row-major)."""
         return self._rgb
+
+
+def decode_batch(ctx, datas, strict_ref=False, layout=LAYOUT_STANDARD, threads=0):
+    """mjx_decode_batch: parse (host threads) + GPU decode of a list of files -> (Batch, [status per file])."""
+    n = len(datas)
+    arr = (ctypes.c_char_p * max(n, 1))(*[bytes(d) for d in datas])
+    lens = (_sz * max(n, 1))(*[len(d) for d in datas])
+    st = (_int * max(n, 1))()
+    ptrs = (_P(ctypes.c_uint8) * max(n, 1))()
+    h = _vp()
+    o = _opts(strict_ref, layout)
+    _check(lib().mjx_decode_batch(ctx.h, arr, lens, n, ctypes.byref(o), int(threads), ptrs, st, ctypes.byref(h)), "mjx_decode_batch")
+    return Batch(ctx, _handle=h), list(st)[:n]
 
 
 def decode(data, strict_ref=False, layout=LAYOUT_STANDARD):

@@ -10,12 +10,14 @@
 #include "mjx_plan.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 using namespace mjx;
@@ -1063,6 +1065,49 @@ extern "C" int mjx_decode_scans(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t
         if (rgb_dev) {
             void *p = nullptr;
             (void)mjx_batch_rgb_device(*out, i, &p, nullptr);
+            rgb_dev[i] = static_cast<uint8_t *>(p);
+        }
+    }
+    return MJX_OK;
+}
+
+extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const size_t *lens, size_t n, const mjx_opts *opts,
+                                unsigned threads, uint8_t **rgb_dev, int *status, mjx_batch **out)
+{
+    if (!ctx || !out || ((!jpegs || !lens) && n)) return MJX_ERR_INVALID_ARG;
+    *out = nullptr;
+    std::vector<mjx_scan_desc> descs(n);
+    std::vector<int> prc(n, MJX_OK);
+    // host side: every file is parsed on its own; a file that does not parse keeps an empty descriptor and its status
+    unsigned nt = threads ? threads : std::thread::hardware_concurrency();
+    nt = std::max(1u, std::min(nt, 32u));
+    nt = unsigned(std::min<size_t>(nt, std::max<size_t>(n, 1)));
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+            prc[i] = mjx_parse(jpegs[i], lens[i], opts, &descs[i]);
+            if (prc[i] != MJX_OK) std::memset(&descs[i], 0, sizeof descs[i]);
+        }
+    };
+    {
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool) t.join();
+    }
+    std::vector<int> st(n, MJX_OK);
+    int rc = mjx_batch_create(ctx, descs.data(), n, opts, out, st.data());
+    for (size_t i = 0; i < n; i++) mjx_free_scan(&descs[i]);
+    if (rc != MJX_OK) return rc;
+    rc = mjx_batch_decode(*out, MJX_STAGE_ALL);
+    if (rc == MJX_OK) rc = mjx_batch_wait(*out);
+    if (rc != MJX_OK) { mjx_batch_free(*out); *out = nullptr; return rc; }
+    for (size_t i = 0; i < n; i++) {
+        const int si = prc[i] != MJX_OK ? prc[i] : mjx_batch_status(*out, i);
+        if (status) status[i] = si;
+        if (rgb_dev) {
+            void *p = nullptr;
+            if (si == MJX_OK) (void)mjx_batch_rgb_device(*out, i, &p, nullptr);
             rgb_dev[i] = static_cast<uint8_t *>(p);
         }
     }

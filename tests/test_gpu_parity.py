@@ -117,6 +117,29 @@ def test_one_shot_and_mirror_api(mjx, orc, gpu_ctx, data_dir):
     assert e.value.code == mjx.ERR_UNSUPPORTED_MARKER
 
 
+def test_decode_batch_from_files(mjx, orc, gpu_ctx, data_dir):
+    """mjx_decode_batch: the outer surface for a list of files (parse on host threads, decode on the GPU).  A file that does
+    not parse keeps its parse status and does not disturb the others."""
+    pil = os.path.join(os.path.dirname(__file__), "golden", "pil")
+    names = ["lena.jpeg", "2x2-chroma.jpeg", "huff_simple0.jpg"]
+    datas = [open(os.path.join(data_dir, n), "rb").read() for n in names]
+    datas += [open(os.path.join(pil, n), "rb").read() for n in ("ms2_420_big.jpg", "dri_420_r5.jpg", "progressive.jpg")]
+    datas += [b"not a jpeg", datas[0][:300], mjx.synth_jpeg(333, 217, "444", 85, seed=5)] * 3
+    for threads in (0, 1, 5):
+        batch, st = mjx.decode_batch(gpu_ctx, datas, threads=threads)
+        assert len(batch) == len(datas)
+        for i, d in enumerate(datas):
+            try:
+                ref = orc.decode(d, layout=orc.LAYOUT_STD, ext_dri=True, ext_multiscan=True)
+            except orc.OracleError:
+                assert st[i] != mjx.OK, i
+                continue
+            assert st[i] == mjx.OK and batch.status(i) == mjx.OK, (i, st[i])
+            assert np.abs(batch.rgb(i).astype(int) - ref.rgb.astype(int)).max() <= TOL, i
+        assert st[5] == mjx.ERR_UNSUPPORTED_FORMAT and st[6] != mjx.OK and st[7] != mjx.OK
+        batch.close()
+
+
 def test_tiled_batch_round_trip(mjx, orc, gpu_ctx):
     datas = [mjx.synth_jpeg(320, 240, "420", 75, seed=s) for s in range(3)]
     scans = [mjx.ParsedScan(d) for d in datas]
