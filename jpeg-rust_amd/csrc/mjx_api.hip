@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <memory>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,6 +37,10 @@ struct mjx_ctx {
     hipStream_t stream2 = nullptr;  // odd chunks run here (MJX_STREAMS=2): one chunk's stage B overlaps the next one's stage A
     int nstreams = 1;
     bool profiling = false;
+    // mjx_decode_batch: pinned arena the files of a call are de-stuffed into; kept between calls (fresh pages cost ~0.35 us
+    // per KB to fault in and unmap again -- four times the parsing itself), released with the context
+    uint8_t *parse_arena = nullptr;
+    size_t parse_arena_cap = 0;
     int fix_passes = 6;            // synchronisation rounds enqueued up front (the last one must re-decode nothing; rounds
                                    // behind an empty one leave at once)
     // Extra dynamic LDS per entropy kernel = occupancy caps for experiments (MJX_SPEC/MERGE/WRITE_LDS_PAD); 0 in production.
@@ -700,6 +705,7 @@ extern "C" void mjx_ctx_destroy(mjx_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->parse_arena) (void)hipHostFree(ctx->parse_arena);
     delete ctx;
 }
 
@@ -1082,10 +1088,29 @@ extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const
     unsigned nt = threads ? threads : std::thread::hardware_concurrency();
     nt = std::max(1u, std::min(nt, 32u));
     nt = unsigned(std::min<size_t>(nt, std::max<size_t>(n, 1)));
+    const bool timing = std::getenv("MJX_TIMING") != nullptr;
+    const auto tb0 = std::chrono::steady_clock::now();
+    // one arena for all the de-stuffed scans (a slice of len + 64 bytes per file; what does not fit -- files with many
+    // restart markers, multi-scan files -- is allocated by the parser): hundreds of megabyte-sized malloc / free pairs cost
+    // several times the parsing, and more with few threads
+    std::vector<size_t> slice(n + 1, 0);
+    for (size_t i = 0; i < n; i++) slice[i + 1] = slice[i] + ((lens[i] + 64 + 63) & ~size_t(63));
+    if (ctx->parse_arena_cap < slice[n]) {
+        // (pinned: the scans are uploaded straight from it by DMA)
+        HIPOK(hipSetDevice(ctx->device));
+        if (ctx->parse_arena) (void)hipHostFree(ctx->parse_arena);
+        ctx->parse_arena = nullptr;
+        ctx->parse_arena_cap = 0;
+        void *pa = nullptr;
+        if (hipHostMalloc(&pa, slice[n] + slice[n] / 4 + 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return MJX_ERR_NOMEM; }
+        ctx->parse_arena = static_cast<uint8_t *>(pa);
+        ctx->parse_arena_cap = slice[n] + slice[n] / 4 + 64;
+    }
+    uint8_t *const arena = ctx->parse_arena;
     std::atomic<size_t> next{0};
     auto work = [&] {
         for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
-            prc[i] = mjx_parse(jpegs[i], lens[i], opts, &descs[i]);
+            prc[i] = mjx::parse_into(jpegs[i], lens[i], opts, &descs[i], arena + slice[i], slice[i + 1] - slice[i]);
             if (prc[i] != MJX_OK) std::memset(&descs[i], 0, sizeof descs[i]);
         }
     };
@@ -1095,12 +1120,23 @@ extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const
         work();
         for (std::thread &t : pool) t.join();
     }
+    const auto tb1 = std::chrono::steady_clock::now();
     std::vector<int> st(n, MJX_OK);
     int rc = mjx_batch_create(ctx, descs.data(), n, opts, out, st.data());
+    const auto tb2 = std::chrono::steady_clock::now();
     for (size_t i = 0; i < n; i++) mjx_free_scan(&descs[i]);
+    const auto tb2b = std::chrono::steady_clock::now();
     if (rc != MJX_OK) return rc;
     rc = mjx_batch_decode(*out, MJX_STAGE_ALL);
+    const auto tb2c = std::chrono::steady_clock::now();
     if (rc == MJX_OK) rc = mjx_batch_wait(*out);
+    if (timing) {
+        const auto tb3 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[mjx]   free %.2f ms, enqueue %.2f ms, wait %.2f ms\n", std::chrono::duration<double, std::milli>(tb2b - tb2).count(),
+                     std::chrono::duration<double, std::milli>(tb2c - tb2b).count(), std::chrono::duration<double, std::milli>(tb3 - tb2c).count());
+        auto msf = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) { return std::chrono::duration<double, std::milli>(b2 - a).count(); };
+        std::fprintf(stderr, "[mjx] decode_batch: parse (%u threads) %.2f ms, create %.2f ms, free + decode + wait %.2f ms\n", nt, msf(tb0, tb1), msf(tb1, tb2), msf(tb2, tb3));
+    }
     if (rc != MJX_OK) { mjx_batch_free(*out); *out = nullptr; return rc; }
     for (size_t i = 0; i < n; i++) {
         const int si = prc[i] != MJX_OK ? prc[i] : mjx_batch_status(*out, i);

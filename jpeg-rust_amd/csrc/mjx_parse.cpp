@@ -52,6 +52,9 @@ struct ParserState {
         mjx_hufftab dc[3], ac[3];
     };
     std::vector<Part> parts;
+    // storage lent by the caller for the de-stuffed scan (mjx_parse_into); null: the parser allocates
+    uint8_t *lent = nullptr;
+    size_t lent_cap = 0;
     mjx_scan_desc *d;
 };
 
@@ -268,7 +271,9 @@ size_t read_sos(const ByteView &f, size_t pos, ParserState &st, bool strict, boo
     size_t max_rst = 0;
     for (size_t k = 0; restarts && k + 1 < remain; k++) max_rst += (src[k] == 0xff && (src[k + 1] & 0xf8) == 0xd0);
     const size_t scan_room = (remain + 32 + 3) & ~size_t(3);
-    uint8_t *buf = static_cast<uint8_t *>(std::malloc(scan_room + max_rst * sizeof(uint32_t) + 4));
+    const size_t need = scan_room + max_rst * sizeof(uint32_t) + 4;
+    const bool lent = st.lent && need <= st.lent_cap;
+    uint8_t *buf = lent ? st.lent : static_cast<uint8_t *>(std::malloc(need));
     if (!buf) throw ParseError{MJX_ERR_NOMEM};
     uint32_t *rst = reinterpret_cast<uint32_t *>(buf + scan_room);
     uint32_t nrst = 0;
@@ -288,7 +293,7 @@ size_t read_sos(const ByteView &f, size_t pos, ParserState &st, bool strict, boo
         if (!ff) break;
         buf[w++] = 0xff;
         if (k + 1 >= remain) {                          // mod.rs:377 reads vec[i + 1] unguarded
-            if (strict) { std::free(buf); throw ParseError{MJX_ERR_TRUNCATED}; }
+            if (strict) { if (!lent) std::free(buf); throw ParseError{MJX_ERR_TRUNCATED}; }
             k += 1;
         } else if (src[k + 1] == 0x00) {
             k += 2;
@@ -306,16 +311,18 @@ size_t read_sos(const ByteView &f, size_t pos, ParserState &st, bool strict, boo
     d->restart_interval = uint16_t(st.restart_interval);
     d->n_restart = nrst;
     d->restart_offsets = nrst ? rst : nullptr;
-    d->owner_ = buf;
+    d->owner_ = lent ? nullptr : buf;
     return 0;
 }
 
-void walk(const uint8_t *jpeg, size_t len, const mjx_opts &opts, mjx_scan_desc *out)
+void walk(const uint8_t *jpeg, size_t len, const mjx_opts &opts, mjx_scan_desc *out, uint8_t *lent, size_t lent_cap)
 {
     const ByteView f(jpeg, len);
     const bool strict = opts.strict_ref != 0;
     ParserState st;
     st.d = out;
+    st.lent = lent;
+    st.lent_cap = lent_cap;
     size_t i = 0;
     while (i < len) {
         // bytes_to_marker, mod.rs:157-181 (including its "FF 00 xx" quirk, :161-164)
@@ -370,14 +377,26 @@ void walk(const uint8_t *jpeg, size_t len, const mjx_opts &opts, mjx_scan_desc *
 
 }   // namespace
 
+namespace mjx {
+// mjx_parse with storage for the de-stuffed scan lent by the caller (len + 64 bytes are always enough for a file without
+// restart markers; when `cap` is too small the parser allocates as usual).  Used by mjx_decode_batch, which parses many
+// files into one arena: hundreds of megabyte-sized malloc / free pairs cost more than the parsing.
+int parse_into(const uint8_t *jpeg, size_t len, const mjx_opts *opts, mjx_scan_desc *out, uint8_t *storage, size_t cap);
+}
+
 extern "C" int mjx_parse(const uint8_t *jpeg, size_t len, const mjx_opts *opts, mjx_scan_desc *out)
+{
+    return mjx::parse_into(jpeg, len, opts, out, nullptr, 0);
+}
+
+int mjx::parse_into(const uint8_t *jpeg, size_t len, const mjx_opts *opts, mjx_scan_desc *out, uint8_t *storage, size_t cap)
 {
     if (!out || (!jpeg && len)) return MJX_ERR_INVALID_ARG;
     mjx_opts o{};
     if (opts) o = *opts;
     std::memset(out, 0, sizeof *out);
     try {
-        walk(jpeg, len, o, out);
+        walk(jpeg, len, o, out, storage, cap);
     } catch (const ParseError &e) {
         std::free(out->owner_);
         std::memset(out, 0, sizeof *out);

@@ -61,6 +61,9 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &plan, bo
 // order) followed by the role-2 plan of the picture.  The last plan appended is the picture's.
 void plan_input(const mjx_scan_desc &d, const mjx_opts &opts, std::vector<ImagePlan> &out);
 
+// mjx_parse.cpp: mjx_parse with caller-lent storage for the de-stuffed scan (see there)
+int parse_into(const uint8_t *jpeg, size_t len, const mjx_opts *opts, mjx_scan_desc *out, uint8_t *storage, size_t cap);
+
 extern const uint8_t kZigZag[64];                  // decoder.rs:404-407 ZIGZAG_INDICES
 
 }   // namespace mjx
