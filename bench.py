@@ -58,7 +58,7 @@ def algorithmic_bytes(kind, by, nsub_total, nblk):
     state = 32 * nsub_total                       # entry + exit state per subsequence
     cps = 8 * 15 * nsub_total                     # two checkpoint words every 256 bits
     return {
-        "clear": 0,
+        "gather": 2 * coef,                       # multi-scan pictures only: component streams in, picture stream out
         "huff_sync": S + state + cps,             # k_huff_spec: scan in, states + checkpoints out
         "huff_fix": S // 5 + state + cps // 5,    # k_huff_merge rounds: ~1/5 of the scan is re-read (median merge distance)
         "huff_scan": 24 * nsub_total,             # exit state in, block base + entry base out

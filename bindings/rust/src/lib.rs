@@ -112,6 +112,8 @@ extern "C" {
     pub fn mjx_batch_copy_rgb(b: *mut mjx_batch, i: usize, host_rgb: *mut u8) -> c_int;
     pub fn mjx_batch_copy_coefs(b: *mut mjx_batch, i: usize, host_coefs: *mut i16, cap_blocks: usize,
                                 nblocks: *mut usize) -> c_int;
+    pub fn mjx_batch_compare_rgb(a: *mut mjx_batch, ia: *const usize, b: *mut mjx_batch, ib: *const usize, n: usize,
+                                 max_abs_diff: *mut u32, n_diff: *mut u64) -> c_int;
     pub fn mjx_batch_bytes(b: *const mjx_batch, scan_bytes: *mut u64, rgb_bytes: *mut u64, coef_bytes: *mut u64,
                            pixels: *mut u64) -> c_int;
     pub fn mjx_batch_kernel_ms(b: *mut mjx_batch, ms: *mut c_double, launches: *mut u64, reset: c_int) -> c_int;

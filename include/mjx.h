@@ -160,13 +160,20 @@ int mjx_batch_copy_rgb(mjx_batch *b, size_t i, uint8_t *host_rgb);
  * order, 64 x i16 zig-zag, DC prediction applied, before dequantisation.  `cap_blocks` = capacity of host buffer. */
 int mjx_batch_copy_coefs(mjx_batch *b, size_t i, int16_t *host_coefs, size_t cap_blocks, size_t *nblocks);
 
+/* Verification helper (bench.py's parity gate, batch-scale tests): compares the decoded RGB of n pairs of pictures on the
+ * device -- picture ia[k] of batch a with picture ib[k] of batch b (same device; a == b is fine) -- without copying them
+ * to the host.  Per pair: the largest absolute difference of a byte and the number of differing bytes; a pair whose
+ * pictures differ in size, or either of which failed to decode, reports max_abs_diff = 0xffffffff. */
+int mjx_batch_compare_rgb(mjx_batch *a, const size_t *ia, mjx_batch *b, const size_t *ib, size_t n,
+                          uint32_t *max_abs_diff, uint64_t *n_diff);
+
 /* bytes used to compute roofline figures: sum of de-stuffed entropy bytes and of RGB bytes over valid images */
 int mjx_batch_bytes(const mjx_batch *b, uint64_t *scan_bytes, uint64_t *rgb_bytes, uint64_t *coef_bytes,
                     uint64_t *pixels);
 
 /* accumulated kernel time (ms) and launch count per kernel class since the last reset (profiling enabled) */
 enum {
-    MJX_K_CLEAR = 0,      /* zero-fill of the coefficient chunk */
+    MJX_K_GATHER = 0,     /* multi-scan pictures only: component streams -> the picture's stream (k_planar_*) */
     MJX_K_HUFF_SYNC = 1,  /* speculative decode + intra-workgroup synchronisation */
     MJX_K_HUFF_FIX = 2,   /* inter-workgroup synchronisation passes */
     MJX_K_HUFF_SCAN = 3,  /* block-count prefix sums */

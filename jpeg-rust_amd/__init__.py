@@ -30,7 +30,7 @@ OK, ERR_TRUNCATED, ERR_UNSUPPORTED_MARKER, ERR_DRI_UNSUPPORTED, ERR_BAD_HUFFMAN,
     ERR_UNSUPPORTED_FORMAT, ERR_NO_SCAN, ERR_INVALID_ARG, ERR_NOMEM, ERR_MISSING_TABLE = range(12)
 LAYOUT_STANDARD, LAYOUT_REF_COMPAT = 0, 1
 STAGE_ENTROPY, STAGE_PIXELS, STAGE_ALL = 1, 2, 3
-KERNEL_NAMES = ["clear", "huff_sync", "huff_fix", "huff_scan", "huff_write", "dc_scan", "idct_color"]
+KERNEL_NAMES = ["gather", "huff_sync", "huff_fix", "huff_scan", "huff_write", "dc_scan", "idct_color"]
 SUBSAMPLING = {"444": 0, "422": 1, "420": 2, "gray": 3, "440": 4}
 
 
@@ -98,6 +98,7 @@ SYMBOLS = {
     "mjx_batch_rgb_device": (_int, [_vp, _sz, _P(_vp), _P(_sz)]),
     "mjx_batch_copy_rgb": (_int, [_vp, _sz, _vp]),
     "mjx_batch_copy_coefs": (_int, [_vp, _sz, _vp, _sz, _P(_sz)]),
+    "mjx_batch_compare_rgb": (_int, [_vp, _P(_sz), _vp, _P(_sz), _sz, _P(ctypes.c_uint32), _P(ctypes.c_uint64)]),
     "mjx_batch_bytes": (_int, [_vp] + [_P(ctypes.c_uint64)] * 4),
     "mjx_batch_kernel_ms": (_int, [_vp, _P(ctypes.c_double), _P(ctypes.c_uint64), _int]),
     "mjx_decode_scans": (_int, [_vp, _P(ScanDesc), _sz, _P(Opts), _P(_P(ctypes.c_uint8)), _P(_int), _P(_vp)]),
@@ -257,6 +258,19 @@ class Batch:
         got = _sz()
         _check(lib().mjx_batch_copy_coefs(self.h, i, out.ctypes.data_as(_vp), nb, ctypes.byref(got)), "copy_coefs")
         return out
+
+    def compare_rgb(self, mine, other, theirs):
+        """On-device comparison of picture mine[k] with picture theirs[k] of batch `other` (may be self):
+        -> (max |difference| per pair as uint32 array, 0xffffffff = sizes differ / a picture failed; differing bytes per pair)."""
+        n = len(mine)
+        assert n == len(theirs)
+        ia = (_sz * max(n, 1))(*[int(x) for x in mine])
+        ib = (_sz * max(n, 1))(*[int(x) for x in theirs])
+        mx = np.zeros(max(n, 1), np.uint32)
+        cnt = np.zeros(max(n, 1), np.uint64)
+        _check(lib().mjx_batch_compare_rgb(self.h, ia, other.h, ib, n, mx.ctypes.data_as(_P(ctypes.c_uint32)),
+                                           cnt.ctypes.data_as(_P(ctypes.c_uint64))), "mjx_batch_compare_rgb")
+        return mx[:n], cnt[:n]
 
     def bytes(self):
         v = [ctypes.c_uint64() for _ in range(4)]
@@ -492,6 +506,10 @@ def synth_lib():
         s = ctypes.CDLL(path)
         s.mjxs_synth_jpeg.restype = _sz
         s.mjxs_synth_jpeg.argtypes = [_int] * 4 + [ctypes.c_uint64, ctypes.c_float, ctypes.c_char_p, _sz]
+        s.mjxs_synth_jpeg_ex.restype = _sz
+        s.mjxs_synth_jpeg_ex.argtypes = [_int] * 5 + [ctypes.c_uint64, ctypes.c_float, ctypes.c_char_p, _sz]
+        s.mjxs_encode_ex.restype = _sz
+        s.mjxs_encode_ex.argtypes = [_vp, _int, _int, _int, _int, _int, ctypes.c_char_p, _sz]
         s.mjxs_encode.restype = _sz
         s.mjxs_encode.argtypes = [_vp, _int, _int, _int, _int, ctypes.c_char_p, _sz]
         s.mjxs_fill_rgb.restype = None
@@ -500,22 +518,23 @@ def synth_lib():
     return _synth
 
 
-def synth_jpeg(width, height, subsampling="420", quality=75, seed=0, noise_sigma=6.0):
-    """Deterministic baseline JPEG: plane waves + noise content, Annex-K tables, only markers the reference parses."""
+def synth_jpeg(width, height, subsampling="420", quality=75, seed=0, noise_sigma=6.0, dqt16=False):
+    """Deterministic baseline JPEG: plane waves + noise content, Annex-K tables, only markers the reference parses.
+    dqt16: 16-bit quantisation tables (Pq = 1, src/jpeg/mod.rs:245-256), values not clamped at 255."""
     cap = width * height * 3 + 65536
     buf = ctypes.create_string_buffer(cap)
-    n = synth_lib().mjxs_synth_jpeg(width, height, SUBSAMPLING[subsampling], quality, seed, noise_sigma, buf, cap)
+    n = synth_lib().mjxs_synth_jpeg_ex(width, height, SUBSAMPLING[subsampling], quality, 1 if dqt16 else 0, seed, noise_sigma, buf, cap)
     if n == 0:
         raise RuntimeError("synthetic encode failed")
     return buf.raw[:n]
 
 
-def encode_rgb(rgb, subsampling="420", quality=75):
+def encode_rgb(rgb, subsampling="420", quality=75, dqt16=False):
     rgb = np.ascontiguousarray(rgb, np.uint8)
     h, w = rgb.shape[:2]
     cap = w * h * 3 + 65536
     buf = ctypes.create_string_buffer(cap)
-    n = synth_lib().mjxs_encode(rgb.ctypes.data_as(_vp), w, h, SUBSAMPLING[subsampling], quality, buf, cap)
+    n = synth_lib().mjxs_encode_ex(rgb.ctypes.data_as(_vp), w, h, SUBSAMPLING[subsampling], quality, 1 if dqt16 else 0, buf, cap)
     if n == 0:
         raise RuntimeError("encode failed")
     return buf.raw[:n]

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 
@@ -30,6 +31,22 @@ using namespace mjx;
             return MJX_ERR_DEVICE;                    \
         }                                             \
     } while (0)
+
+// Nothing may unwind through the C ABI (include/mjx.h: the reference's panics become status codes; so do ours): every
+// entry point that allocates runs its body inside guarded().
+template <class F>
+static int guarded(F &&body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return MJX_ERR_NOMEM;
+    } catch (const std::length_error &) {
+        return MJX_ERR_NOMEM;
+    } catch (...) {
+        return MJX_ERR_DEVICE;
+    }
+}
 
 struct mjx_ctx {
     int device = 0;
@@ -456,8 +473,12 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         prof_end(b, st);
         prof_begin(b, MJX_K_DC_SCAN, st);
         launch_dc_scan(st, c.max_segs, nimg, imgs, dcb, SCR(d_segsum), b->d_img_flags, c.bpm_mask, c.max_restart_segs);
-        if (c.has_gather) launch_planar_gather(st, c.max_tiles, nimg, imgs, SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_img_flags);
         prof_end(b, st);
+        if (c.has_gather) {
+            prof_begin(b, MJX_K_GATHER, st);
+            launch_planar_gather(st, c.max_tiles, nimg, imgs, SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_img_flags);
+            prof_end(b, st);
+        }
     }
     if (stages & MJX_STAGE_PIXELS) {
         prof_begin(b, MJX_K_IDCT_COLOR, st);
@@ -509,6 +530,10 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
 {
     mjx_batch *b = new (std::nothrow) mjx_batch;
     if (!b) return MJX_ERR_NOMEM;
+    struct Owner {                      // releases the half-built batch on every early exit, exceptions included
+        mjx_batch *b;
+        ~Owner() { if (b) release(b); }
+    } owner{b};
     b->ctx = ctx;
     b->opts = opts;
     const size_t nu = plans.size(), n = nu * times;
@@ -661,8 +686,9 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
         return rca;
     };
     rc = dev();
-    if (rc != MJX_OK) { release(b); return rc; }
+    if (rc != MJX_OK) return rc;
     if (status) for (size_t i = 0; i < b->visible.size(); i++) status[i] = b->info[b->visible[i]].status;
+    owner.b = nullptr;
     *out = b;
     return MJX_OK;
 }
@@ -675,6 +701,7 @@ mjx_ctx *g_default_ctx = nullptr;
 // ---- context -------------------------------------------------------------------------------------
 extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
 {
+    return guarded([&]() -> int {
     if (!out) return MJX_ERR_INVALID_ARG;
     *out = nullptr;
     int ndev = 0;
@@ -696,6 +723,7 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     }
     *out = c;
     return MJX_OK;
+    });
 }
 
 extern "C" void mjx_ctx_destroy(mjx_ctx *ctx)
@@ -720,6 +748,7 @@ extern "C" int mjx_ctx_set_profiling(mjx_ctx *ctx, int enable)
 extern "C" int mjx_batch_create(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t n, const mjx_opts *opts,
                                 mjx_batch **out, int *status)
 {
+    return guarded([&]() -> int {
     if (!ctx || !out || (!descs && n)) return MJX_ERR_INVALID_ARG;
     *out = nullptr;
     mjx_opts o{};
@@ -740,7 +769,7 @@ extern "C" int mjx_batch_create(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t
             x.raw_len = dd[i].scan_len;
             x.seg0 = nseg_total;
             x.nseg = uint32_t((dd[i].scan_len + kDestuffSeg - 1) / kDestuffSeg);
-            raw_bytes += align_up(dd[i].scan_len, 16) + 16;
+            raw_bytes += align_up(dd[i].scan_len, 64) + 64;      // destuff_keep_mask loads whole 64-byte pieces
             nseg_total += x.nseg;
             ds.max_seg = std::max(ds.max_seg, x.nseg);
             ds.imgs.push_back(x);
@@ -793,22 +822,26 @@ extern "C" int mjx_batch_create(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t
         std::fprintf(stderr, "[mjx] planning %zu inputs %.2f ms\n", n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
     for (size_t &pi : ds.plan_index) pi = plan_of[pi];
     return build_batch(ctx, plans, o, nullptr, 1, out, status, any_stuffed ? &ds : nullptr);
+    });
 }
 
 // Host-only: would this scan decode?  Runs the same planning step as mjx_batch_create (tables, geometry, and for
 // MJX_LAYOUT_REF_COMPAT the inputs on which the reference panics) without touching the GPU.
 extern "C" int mjx_validate(const mjx_scan_desc *desc, const mjx_opts *opts)
 {
+    return guarded([&]() -> int {
     if (!desc) return MJX_ERR_INVALID_ARG;
     mjx_opts o{};
     if (opts) o = *opts;
     std::vector<ImagePlan> plans;                      // (a multi-scan file: every scan is checked, the picture's plan is last)
     plan_input(*desc, o, plans);
     return plans.back().status;
+    });
 }
 
 extern "C" int mjx_batch_tile(mjx_ctx *ctx, const mjx_batch *src, size_t times, mjx_batch **out)
 {
+    return guarded([&]() -> int {
     if (!ctx || !src || !out || times == 0) return MJX_ERR_INVALID_ARG;
     *out = nullptr;
     // rebuild light-weight plans from the source batch's device images (geometry only; tables stay on the device)
@@ -846,6 +879,7 @@ extern "C" int mjx_batch_tile(mjx_ctx *ctx, const mjx_batch *src, size_t times, 
         p.scan_len = src->info[k].scan_len;
     }
     return build_batch(ctx, plans, src->opts, src, times, out, nullptr);
+    });
 }
 
 extern "C" void mjx_batch_free(mjx_batch *b)
@@ -858,6 +892,7 @@ extern "C" void mjx_batch_free(mjx_batch *b)
 
 extern "C" int mjx_batch_decode(mjx_batch *b, unsigned stages)
 {
+    return guarded([&]() -> int {
     if (!b) return MJX_ERR_INVALID_ARG;
     if (stages == 0) stages = MJX_STAGE_ALL;
     HIPOK(hipSetDevice(b->ctx->device));
@@ -875,10 +910,12 @@ extern "C" int mjx_batch_decode(mjx_batch *b, unsigned stages)
         b->resident_second = b->dual && ((b->chunks.size() - 1) & 1);
     }
     return MJX_OK;
+    });
 }
 
 extern "C" int mjx_batch_wait(mjx_batch *b)
 {
+    return guarded([&]() -> int {
     if (!b) return MJX_ERR_INVALID_ARG;
     HIPOK(hipSetDevice(b->ctx->device));
     { const int rc0 = sync_streams(b); if (rc0 != MJX_OK) return rc0; }
@@ -926,6 +963,7 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
             if (b->info[i - k].status != MJX_OK) b->info[i].status = b->info[i - k].status;
     }
     return MJX_OK;
+    });
 }
 
 namespace {
@@ -973,6 +1011,7 @@ extern "C" int mjx_batch_rgb_device(const mjx_batch *b, size_t iu, void **dev_pt
 
 extern "C" int mjx_batch_copy_rgb(mjx_batch *b, size_t iu, uint8_t *host_rgb)
 {
+    return guarded([&]() -> int {
     size_t i;
     if (!visible_index(b, iu, i) || !host_rgb) return MJX_ERR_INVALID_ARG;
     const ImageInfo &inf = b->info[i];
@@ -981,10 +1020,12 @@ extern "C" int mjx_batch_copy_rgb(mjx_batch *b, size_t iu, uint8_t *host_rgb)
     { const int rcs = sync_streams(b); if (rcs != MJX_OK) return rcs; }
     HIPOK(hipMemcpy(host_rgb, b->d_rgb + inf.rgb_off, size_t(inf.rgb_bytes), hipMemcpyDeviceToHost));
     return MJX_OK;
+    });
 }
 
 extern "C" int mjx_batch_copy_coefs(mjx_batch *b, size_t iu, int16_t *host_coefs, size_t cap_blocks, size_t *nblocks)
 {
+    return guarded([&]() -> int {
     size_t i;
     if (!visible_index(b, iu, i) || !host_coefs) return MJX_ERR_INVALID_ARG;
     const ImageInfo &inf = b->info[i];
@@ -1018,11 +1059,66 @@ extern "C" int mjx_batch_copy_coefs(mjx_batch *b, size_t iu, int16_t *host_coefs
     }
     for (size_t k = 0; k < dc.size(); k++) host_coefs[k * 64] = int16_t(dc[k]);
     return MJX_OK;
+    });
+}
+
+extern "C" int mjx_batch_compare_rgb(mjx_batch *a, const size_t *ia, mjx_batch *b, const size_t *ib, size_t n,
+                                     uint32_t *max_abs_diff, uint64_t *n_diff)
+{
+    return guarded([&]() -> int {
+        if (!a || !b || (n && (!ia || !ib || !max_abs_diff))) return MJX_ERR_INVALID_ARG;
+        if (a->ctx->device != b->ctx->device) return MJX_ERR_INVALID_ARG;
+        if (n == 0) return MJX_OK;
+        if (n > 0x7fffffffu / 64) return MJX_ERR_INVALID_ARG;
+        HIPOK(hipSetDevice(a->ctx->device));
+        { const int rcs = sync_streams(a); if (rcs != MJX_OK) return rcs; }
+        { const int rcs = sync_streams(b); if (rcs != MJX_OK) return rcs; }
+        std::vector<RgbPair> pairs(n);
+        std::vector<char> bad(n, 0);
+        uint64_t max_bytes = 0;
+        for (size_t k = 0; k < n; k++) {
+            size_t xa, xb;
+            if (!visible_index(a, ia[k], xa) || !visible_index(b, ib[k], xb)) return MJX_ERR_INVALID_ARG;
+            const ImageInfo &fa = a->info[xa], &fb = b->info[xb];
+            pairs[k] = RgbPair{fa.rgb_off, fb.rgb_off, fa.rgb_bytes};
+            if (fa.status != MJX_OK || fb.status != MJX_OK || fa.width != fb.width || fa.height != fb.height) {
+                bad[k] = 1;
+                pairs[k].bytes = 0;
+            }
+            max_bytes = std::max<uint64_t>(max_bytes, pairs[k].bytes);
+        }
+        RgbPair *d_pairs = nullptr;
+        uint32_t *d_max = nullptr;
+        unsigned long long *d_cnt = nullptr;
+        std::vector<uint32_t> hmax(n, 0);
+        std::vector<unsigned long long> hcnt(n, 0);
+        int rc = MJX_OK;
+        if (hipMalloc(&d_pairs, n * sizeof(RgbPair)) != hipSuccess || hipMalloc(&d_max, n * 4) != hipSuccess || hipMalloc(&d_cnt, n * 8) != hipSuccess)
+            rc = MJX_ERR_DEVICE;
+        if (rc == MJX_OK && (hipMemcpy(d_pairs, pairs.data(), n * sizeof(RgbPair), hipMemcpyHostToDevice) != hipSuccess ||
+                             hipMemset(d_max, 0, n * 4) != hipSuccess || hipMemset(d_cnt, 0, n * 8) != hipSuccess))
+            rc = MJX_ERR_DEVICE;
+        if (rc == MJX_OK) {
+            launch_rgb_compare(a->ctx->stream, uint32_t(n), max_bytes, d_pairs, a->d_rgb, b->d_rgb, d_max, d_cnt);
+            if (hipStreamSynchronize(a->ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess ||
+                hipMemcpy(hmax.data(), d_max, n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(hcnt.data(), d_cnt, n * 8, hipMemcpyDeviceToHost) != hipSuccess)
+                rc = MJX_ERR_DEVICE;
+        }
+        (void)hipFree(d_pairs); (void)hipFree(d_max); (void)hipFree(d_cnt);
+        if (rc != MJX_OK) { (void)hipGetLastError(); return rc; }
+        for (size_t k = 0; k < n; k++) {
+            max_abs_diff[k] = bad[k] ? 0xffffffffu : hmax[k];
+            if (n_diff) n_diff[k] = bad[k] ? 0 : uint64_t(hcnt[k]);
+        }
+        return MJX_OK;
+    });
 }
 
 extern "C" int mjx_batch_bytes(const mjx_batch *b, uint64_t *scan_bytes, uint64_t *rgb_bytes, uint64_t *coef_bytes,
                                uint64_t *pixels)
 {
+    return guarded([&]() -> int {
     if (!b) return MJX_ERR_INVALID_ARG;
     if (scan_bytes) *scan_bytes = b->scan_bytes;
     if (rgb_bytes) *rgb_bytes = b->rgb_bytes;
@@ -1041,10 +1137,12 @@ extern "C" int mjx_batch_bytes(const mjx_batch *b, uint64_t *scan_bytes, uint64_
         *coef_bytes = total;
     }
     return MJX_OK;
+    });
 }
 
 extern "C" int mjx_batch_kernel_ms(mjx_batch *b, double ms[MJX_K_COUNT], uint64_t launches[MJX_K_COUNT], int reset)
 {
+    return guarded([&]() -> int {
     if (!b) return MJX_ERR_INVALID_ARG;
     HIPOK(hipSetDevice(b->ctx->device));
     { const int rcs = sync_streams(b); if (rcs != MJX_OK) return rcs; }
@@ -1055,11 +1153,13 @@ extern "C" int mjx_batch_kernel_ms(mjx_batch *b, double ms[MJX_K_COUNT], uint64_
         if (reset) { b->ms[k] = 0; b->launches[k] = 0; }
     }
     return MJX_OK;
+    });
 }
 
 extern "C" int mjx_decode_scans(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t n, const mjx_opts *opts,
                                 uint8_t **rgb_dev, int *status, mjx_batch **out)
 {
+    return guarded([&]() -> int {
     if (!out) return MJX_ERR_INVALID_ARG;
     int rc = mjx_batch_create(ctx, descs, n, opts, out, nullptr);
     if (rc != MJX_OK) return rc;
@@ -1075,11 +1175,13 @@ extern "C" int mjx_decode_scans(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t
         }
     }
     return MJX_OK;
+    });
 }
 
 extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const size_t *lens, size_t n, const mjx_opts *opts,
                                 unsigned threads, uint8_t **rgb_dev, int *status, mjx_batch **out)
 {
+    return guarded([&]() -> int {
     if (!ctx || !out || ((!jpegs || !lens) && n)) return MJX_ERR_INVALID_ARG;
     *out = nullptr;
     std::vector<mjx_scan_desc> descs(n);
@@ -1148,11 +1250,13 @@ extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const
         }
     }
     return MJX_OK;
+    });
 }
 
 // ---- one-shot surface ------------------------------------------------------------------------------
 extern "C" int mjx_decode(const uint8_t *jpeg, size_t len, const mjx_opts *opts, mjx_image *out)
 {
+    return guarded([&]() -> int {
     if (!out) return MJX_ERR_INVALID_ARG;
     out->width = out->height = 0;
     out->rgb = nullptr;
@@ -1189,6 +1293,7 @@ extern "C" int mjx_decode(const uint8_t *jpeg, size_t len, const mjx_opts *opts,
     }
     mjx_batch_free(b);
     return rc;
+    });
 }
 
 extern "C" void mjx_free_image(mjx_image *img)
@@ -1200,5 +1305,11 @@ extern "C" void mjx_free_image(mjx_image *img)
 
 extern "C" const char *mjx_version(void)
 {
-    return "mjx 0.1 gfx950 subseq_bits=1024 lut_primary_bits=9 wg_lanes=256";
+    static char v[160];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        std::snprintf(v, sizeof v, "mjx 0.2 gfx950 subseq_bits=%d..%d checkpoint_bits=%d lut_primary_bits=%d huff_wg_lanes=%d merge_wg_lanes=%d",
+                      kSubseqBits, kSubseqBits * 5 / 4, kCpBits, kLutPrimaryBits, kHuffWg, kMergeWg);
+    });
+    return v;
 }

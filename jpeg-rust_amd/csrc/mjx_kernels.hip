@@ -607,7 +607,8 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t *s_tm
 // the counts per image (host, a few dozen numbers per image), then every lane writes the kept bytes of its 64-byte
 // piece at segment base + workgroup-scan offset.  Runs once per upload, before any decode.
 // keep flags of the 64 bytes [i0, i0+64) of `raw` as a bit mask (+ the bytes themselves in q[0..3]); returns the
-// number of kept bytes.  The raw staging buffer is 16-byte aligned per image and padded, so 16-byte loads are safe.
+// number of kept bytes.  The raw staging buffer is 64-byte aligned per image and padded by 64 bytes (mjx_batch_create),
+// so the four 16-byte loads of a piece stay inside the image's own region.
 __device__ __forceinline__ uint32_t destuff_keep_mask(const uint8_t *raw, uint64_t i0, uint64_t raw_len, uint4 q[4],
                                                       uint64_t *mask_out)
 {
@@ -898,7 +899,8 @@ extern "C" __global__ __launch_bounds__(256) void k_planar_copy(const DevImage *
 {
     __shared__ uint32_t s_tmp[4];
     __shared__ uint32_t s_at[257];          // where each block slot's run starts inside the tile's output (+ total)
-    __shared__ uint32_t s_src[256];         // ... and where it comes from (index into the entry pool)
+    __shared__ uint64_t s_src[256];         // ... and where it comes from (index into the entry pool: 64-bit, a chunk's
+                                            // stream regions pass 2^32 entries after a few hundred multi-scan 4K pictures)
     const uint32_t img = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     const DevImage &im = images[img];
     const uint32_t T = 1u << im.log2_tile;
@@ -911,7 +913,7 @@ extern "C" __global__ __launch_bounds__(256) void k_planar_copy(const DevImage *
     if (p.inside) {
         const DevImage &sim = images[img - im.src_back[p.c]];
         (dcbuf + im.coef_off)[tile * im.tile_blocks + tid] = p.real ? (dcbuf + sim.coef_off)[p.rb] : 0;
-        s_src[tid] = uint32_t(sim.ent_off) + p.s0;
+        s_src[tid] = sim.ent_off + p.s0;
     }
     __syncthreads();
     // the tile's entries, consecutive lanes on consecutive outputs: entry i belongs to the last slot that starts at or
@@ -1676,6 +1678,55 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
     }
 }
 
+// ---- verification helper: byte-wise comparison of decoded pictures on the device ------------------------------
+// (mjx_batch_compare_rgb: the parity gate of bench.py and the batch-scale tests compare tens of gigabytes of output
+// without copying them to the host.)  One workgroup per 16 KiB of a pair; per pair the largest absolute byte
+// difference and the number of differing bytes.
+extern "C" __global__ __launch_bounds__(256) void k_rgb_compare(const RgbPair *pairs, const uint8_t *rgb_a,
+                                                                 const uint8_t *rgb_b, uint32_t *maxdiff,
+                                                                 unsigned long long *ndiff)
+{
+    const RgbPair p = pairs[blockIdx.y];
+    const uint64_t base = uint64_t(blockIdx.x) * 16384u;
+    if (base >= p.bytes) return;
+    const uint8_t *a = rgb_a + p.off_a, *b = rgb_b + p.off_b;
+    uint32_t mx = 0, cnt = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint64_t i = base + (uint64_t(k) * 256u + threadIdx.x) * 16u;
+        if (i + 16 <= p.bytes) {
+            const uint4 va = *reinterpret_cast<const uint4 *>(a + i), vb = *reinterpret_cast<const uint4 *>(b + i);
+            const uint32_t wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int d = int((wa[w] >> (8 * j)) & 0xffu) - int((wb[w] >> (8 * j)) & 0xffu);
+                    const uint32_t ad = uint32_t(d < 0 ? -d : d);
+                    mx = ad > mx ? ad : mx;
+                    cnt += ad != 0;
+                }
+        } else {
+            for (uint64_t j = i; j < p.bytes && j < i + 16; j++) {
+                const int d = int(a[j]) - int(b[j]);
+                const uint32_t ad = uint32_t(d < 0 ? -d : d);
+                mx = ad > mx ? ad : mx;
+                cnt += ad != 0;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = __shfl_xor(mx, d);
+        mx = o > mx ? o : mx;
+        cnt += __shfl_xor(cnt, d);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) {
+        atomicMax(maxdiff + blockIdx.y, mx);
+        atomicAdd(ndiff + blockIdx.y, (unsigned long long)cnt);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host launchers (declared in mjx_kernels.h)
 // ------------------------------------------------------------------------------------------------
@@ -1784,6 +1835,14 @@ void launch_planar_gather(hipStream_t st, uint32_t max_tiles, uint32_t nimg, con
     hipLaunchKernelGGL(k_planar_count, dim3(max_tiles, nimg), dim3(256), 0, st, images, tile_eoff, img_flags);
     hipLaunchKernelGGL(k_planar_offsets, dim3(nimg), dim3(256), 0, st, images, tile_eoff, img_flags);
     hipLaunchKernelGGL(k_planar_copy, dim3(max_tiles, nimg), dim3(256), 0, st, images, entries, tile_eoff, dcbuf, img_flags);
+}
+
+void launch_rgb_compare(hipStream_t st, uint32_t npairs, uint64_t max_bytes, const RgbPair *pairs, const uint8_t *rgb_a,
+                        const uint8_t *rgb_b, uint32_t *maxdiff, unsigned long long *ndiff)
+{
+    const uint32_t gx = uint32_t((max_bytes + 16383) / 16384);
+    if (gx == 0 || npairs == 0) return;
+    hipLaunchKernelGGL(k_rgb_compare, dim3(gx, npairs), dim3(256), 0, st, pairs, rgb_a, rgb_b, maxdiff, ndiff);
 }
 
 void launch_ref_color(hipStream_t st, uint32_t max_pixel_wgs, uint32_t nimg, const DevImage *images,

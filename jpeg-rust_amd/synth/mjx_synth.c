@@ -211,8 +211,11 @@ static void encode_block(bitw *b, const int16_t zz[64], int *pred, const henc *d
 static void put16(uint8_t **p, unsigned v) { *(*p)++ = (uint8_t)(v >> 8); *(*p)++ = (uint8_t)v; }
 
 /* subsampling: 0 = 4:4:4, 1 = 4:2:2 (Y 2x1), 2 = 4:2:0 (Y 2x2), 3 = greyscale, 4 = 4:4:0 (Y 1x2).
+ * flags: MJXS_DQT16 = write the quantisation tables with 16-bit precision (Pq = 1, jpeg/mod.rs:245-256) and do not
+ *        clamp their values at 255 (low qualities then give values up to 99 * 50 = 4950, like libjpeg without force_baseline).
  * Returns bytes written, or 0 if `cap` is too small. */
-size_t mjxs_encode(const uint8_t *rgb, int w, int h, int subsampling, int quality, uint8_t *out, size_t cap)
+enum { MJXS_DQT16 = 1 };
+size_t mjxs_encode_ex(const uint8_t *rgb, int w, int h, int subsampling, int quality, int flags, uint8_t *out, size_t cap)
 {
     if (!dct_ready) dct_init();
     if (w < 1 || h < 1 || w > 65535 || h > 65535 || cap < 1024) return 0;
@@ -225,8 +228,9 @@ size_t mjxs_encode(const uint8_t *rgb, int w, int h, int subsampling, int qualit
     uint16_t qt[2][64];
     for (int k = 0; k < 64; k++) {
         int a = (K_QT_LUMA[k] * scale + 50) / 100, c = (K_QT_CHROMA[k] * scale + 50) / 100;
-        qt[0][k] = (uint16_t)(a < 1 ? 1 : (a > 255 ? 255 : a));
-        qt[1][k] = (uint16_t)(c < 1 ? 1 : (c > 255 ? 255 : c));
+        const int top = (flags & MJXS_DQT16) ? 65535 : 255;
+        qt[0][k] = (uint16_t)(a < 1 ? 1 : (a > top ? top : a));
+        qt[1][k] = (uint16_t)(c < 1 ? 1 : (c > top ? top : c));
     }
     henc hdc[2], hac[2];
     henc_build(&hdc[0], K_DC_LUMA_BITS, K_DC_VALS);
@@ -240,9 +244,14 @@ size_t mjxs_encode(const uint8_t *rgb, int w, int h, int subsampling, int qualit
     *p++ = 0xff; *p++ = 0xe0; put16(&p, 16);
     memcpy(p, "JFIF\0", 5); p += 5;
     *p++ = 1; *p++ = 1; *p++ = 0; put16(&p, 1); put16(&p, 1); *p++ = 0; *p++ = 0;
-    /* DQT (zig-zag order, 8 bit) */
-    *p++ = 0xff; *p++ = 0xdb; put16(&p, 2 + 65 * (ncomp == 1 ? 1 : 2));
-    for (int t = 0; t < (ncomp == 1 ? 1 : 2); t++) { *p++ = (uint8_t)t; for (int k = 0; k < 64; k++) *p++ = (uint8_t)qt[t][ZZ[k]]; }
+    /* DQT (zig-zag order; 8 bit, or 16 bit big-endian with Pq = 1 in the high nibble) */
+    if (flags & MJXS_DQT16) {
+        *p++ = 0xff; *p++ = 0xdb; put16(&p, 2 + 129 * (ncomp == 1 ? 1 : 2));
+        for (int t = 0; t < (ncomp == 1 ? 1 : 2); t++) { *p++ = (uint8_t)(0x10 | t); for (int k = 0; k < 64; k++) put16(&p, qt[t][ZZ[k]]); }
+    } else {
+        *p++ = 0xff; *p++ = 0xdb; put16(&p, 2 + 65 * (ncomp == 1 ? 1 : 2));
+        for (int t = 0; t < (ncomp == 1 ? 1 : 2); t++) { *p++ = (uint8_t)t; for (int k = 0; k < 64; k++) *p++ = (uint8_t)qt[t][ZZ[k]]; }
+    }
     /* SOF0 */
     *p++ = 0xff; *p++ = 0xc0; put16(&p, 8 + 3 * ncomp); *p++ = 8; put16(&p, (unsigned)h); put16(&p, (unsigned)w); *p++ = (uint8_t)ncomp;
     *p++ = 1; *p++ = (uint8_t)((ncomp == 1 ? 0x11 : (hy << 4) | vy)); *p++ = 0;
@@ -320,16 +329,27 @@ size_t mjxs_encode(const uint8_t *rgb, int w, int h, int subsampling, int qualit
     return (size_t)(p - out);
 }
 
+size_t mjxs_encode(const uint8_t *rgb, int w, int h, int subsampling, int quality, uint8_t *out, size_t cap)
+{
+    return mjxs_encode_ex(rgb, w, h, subsampling, quality, 0, out, cap);
+}
+
 /* generate content for `seed` and encode it; returns bytes written (0 = cap too small) */
-size_t mjxs_synth_jpeg(int w, int h, int subsampling, int quality, uint64_t seed, float noise_sigma,
-                       uint8_t *out, size_t cap)
+size_t mjxs_synth_jpeg_ex(int w, int h, int subsampling, int quality, int flags, uint64_t seed, float noise_sigma,
+                          uint8_t *out, size_t cap)
 {
     uint8_t *rgb = (uint8_t *)malloc((size_t)w * h * 3);
     if (!rgb) return 0;
     mjxs_fill_rgb(rgb, w, h, seed, noise_sigma);
-    size_t n = mjxs_encode(rgb, w, h, subsampling, quality, out, cap);
+    size_t n = mjxs_encode_ex(rgb, w, h, subsampling, quality, flags, out, cap);
     free(rgb);
     return n;
+}
+
+size_t mjxs_synth_jpeg(int w, int h, int subsampling, int quality, uint64_t seed, float noise_sigma,
+                       uint8_t *out, size_t cap)
+{
+    return mjxs_synth_jpeg_ex(w, h, subsampling, quality, 0, seed, noise_sigma, out, cap);
 }
 
 #ifdef __cplusplus

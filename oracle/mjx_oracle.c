@@ -896,6 +896,7 @@ void orc_free_image(orc_image *img)
 typedef struct {
     const uint8_t *const *jpegs; const size_t *lens; size_t n; const orc_opts *opts; int *status;
     size_t next; uint64_t pixels; pthread_mutex_t mu;
+    uint8_t *const *rgb_out; const size_t *rgb_cap;
 } orc_many;
 
 static void *orc_many_worker(void *arg)
@@ -910,6 +911,8 @@ static void *orc_many_worker(void *arg)
         int rc = orc_decode(job->jpegs[i], job->lens[i], job->opts, &img);
         if (job->status) job->status[i] = rc;
         if (rc == ORC_OK) {
+            const size_t bytes = (size_t)img.width * (size_t)img.height * 3;
+            if (job->rgb_out && job->rgb_out[i] && job->rgb_cap && job->rgb_cap[i] >= bytes) memcpy(job->rgb_out[i], img.rgb, bytes);
             pthread_mutex_lock(&job->mu);
             job->pixels += (uint64_t)img.width * (uint64_t)img.height;
             pthread_mutex_unlock(&job->mu);
@@ -919,14 +922,25 @@ static void *orc_many_worker(void *arg)
     return NULL;
 }
 
+uint64_t orc_decode_many_rgb(const uint8_t *const *jpegs, const size_t *lens, size_t n, const orc_opts *opts, int nthreads,
+                             int *status, uint8_t *const *rgb_out, const size_t *rgb_cap)
+{
+    orc_many job = {jpegs, lens, n, opts, status, 0, 0, PTHREAD_MUTEX_INITIALIZER, rgb_out, rgb_cap};
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 1024) nthreads = 1024;
+    pthread_t th[1024];
+    int started = 0;
+    for (int t = 0; t < nthreads; t++) {
+        if (pthread_create(&th[started], NULL, orc_many_worker, &job) != 0) break;
+        started++;
+    }
+    if (started == 0) orc_many_worker(&job);
+    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+    return job.pixels;
+}
+
 uint64_t orc_decode_many(const uint8_t *const *jpegs, const size_t *lens, size_t n,
                          const orc_opts *opts, int nthreads, int *status)
 {
-    orc_many job = {jpegs, lens, n, opts, status, 0, 0, PTHREAD_MUTEX_INITIALIZER};
-    if (nthreads < 1) nthreads = 1;
-    if (nthreads > 256) nthreads = 256;
-    pthread_t th[256];
-    for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, orc_many_worker, &job);
-    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
-    return job.pixels;
+    return orc_decode_many_rgb(jpegs, lens, n, opts, nthreads, status, NULL, NULL);
 }

@@ -84,6 +84,11 @@ uint8_t orc_f32_to_u8(float n);
 uint64_t orc_decode_many(const uint8_t *const *jpegs, const size_t *lens, size_t n,
                          const orc_opts *opts, int nthreads, int *status);
 
+/* The same, and image i's RGB (width*height*3 bytes) is copied to rgb_out[i] when that pointer is non-NULL and rgb_cap[i]
+ * holds it: bench.py's parity gate compares the pictures the CPU baseline decodes anyway with the GPU's. */
+uint64_t orc_decode_many_rgb(const uint8_t *const *jpegs, const size_t *lens, size_t n, const orc_opts *opts, int nthreads,
+                             int *status, uint8_t *const *rgb_out, const size_t *rgb_cap);
+
 #ifdef __cplusplus
 }
 #endif

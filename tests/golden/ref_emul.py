@@ -1,0 +1,524 @@
+"""ref_emul.py -- a SECOND, independent restatement of martinhath/jpeg-rust's decoder, in Python / numpy float32.
+
+TEST INFRASTRUCTURE.  Written from the Rust sources (src/jpeg/mod.rs, huffman.rs, decoder.rs, src/transform.rs -- every
+function cites the lines it follows), not from oracle/mjx_oracle.c: its only purpose is to check the C oracle.  The
+reference cannot be compiled in this image (Rust 2015, no rustc / cargo) and ships no golden vectors, so by the project's
+rules the oracle's parity stays "unpinned"; two restatements written independently in different languages that agree
+byte for byte on the reference's four sample files -- coefficient stream, bits consumed, every RGB byte of the reference's
+(bug-compatible) output -- is the strongest pin available without the Rust toolchain.
+
+    python tests/golden/ref_emul.py            # decodes the four sample files, prints SHA-256s, writes ref_emul_golden.json
+
+All arithmetic the reference does in f32 is done in numpy float32 element-wise operations (IEEE single, no fused
+multiply-add, same operation order as the Rust expressions); `f32::cos` / `f32::sqrt` are the platform libm's cosf / sqrtf,
+called through ctypes exactly like Rust's std does on linux-gnu.
+"""
+import ctypes
+import ctypes.util
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+F = np.float32
+_libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+_libm.cosf.restype = ctypes.c_float
+_libm.cosf.argtypes = [ctypes.c_float]
+_libm.sqrtf.restype = ctypes.c_float
+_libm.sqrtf.argtypes = [ctypes.c_float]
+
+
+class RefPanic(Exception):
+    """The Rust code would panic here (unwrap / expect / assert / slice index / explicit panic!)."""
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# src/jpeg/huffman.rs
+# ---------------------------------------------------------------------------------------------------------------
+class HuffmanTable:
+    """huffman.rs:24-98"""
+
+    def __init__(self, size_data, data_table):                     # from_size_data_tables, :37-58
+        code_lengths = []
+        for i in range(16):
+            code_lengths += [i + 1] * size_data[i]
+        code_table = self.make_code_table(code_lengths)
+        # zip of three iterators stops at the shortest (:46-56)
+        self.codes = [(l, c, v) for v, l, c in zip(data_table, code_lengths, code_table)]     # (length, code, value)
+
+    @staticmethod
+    def make_code_table(sizes):                                    # :80-98
+        vec = []
+        if not sizes:
+            raise RefPanic("sizes[0] on an empty size list")      # :85
+        code = 0
+        current_size = sizes[0]
+        for size in sizes:
+            while size > current_size:
+                code = (code << 1) & 0xffff                       # u16 `<<=` drops the high bits
+                current_size += 1
+            vec.append(code)
+            if current_size > 16 or code == 0xffff:
+                break
+            code += 1
+        return vec
+
+    def codes_of_length(self, length):                            # :60-76
+        assert 2 <= length < 17
+        a = None
+        for i, (l, _, _) in enumerate(self.codes):                # skip_while(length != len)
+            if l == length:
+                a = i
+                break
+        if a is None:
+            return []
+        b = a
+        while b < len(self.codes) and self.codes[b][0] == length:  # take_while(length == len)
+            b += 1
+        return self.codes[a:b]
+
+
+BIT_MASKS = [0x0, 0x8000, 0xC000, 0xE000, 0xF000, 0xF800, 0xFC00, 0xFE00, 0xFF00, 0xFF80, 0xFFC0, 0xFFE0, 0xFFF0, 0xFFF8,
+             0xFFFC, 0xFFFE, 0xFFFF]                               # :5-6
+
+
+class HuffmanDecoder:
+    """huffman.rs:109-268"""
+
+    def __init__(self, data):                                      # new, :124-135
+        if len(data) < 4:
+            raise RefPanic("data[0..4] preload on a %d-byte scan" % len(data))
+        self.data = data
+        self.current = (data[0] << 24) | (data[1] << 16) | (data[2] << 8) | data[3]
+        self.next_index = 4
+        self.bits_read = 0
+        self.total_bits = 0                                        # bookkeeping of this restatement (SURVEY s4 "bits used")
+        self._by_len = {}
+
+    def _lookup(self, table):
+        # the per-length slices the reference searches linearly (:218-220), as dictionaries code -> value; the first
+        # match in slice order wins, as with `find`
+        t = self._by_len.get(id(table))
+        if t is None:
+            t = {}
+            for length in range(2, 17):
+                d = {}
+                for (_, c, v) in table.codes_of_length(length):
+                    d.setdefault(c, v)
+                t[length] = d
+            self._by_len[id(table)] = t
+        return t
+
+    def shift_and_fix_current(self, length):                       # :231-254
+        if length == 0:
+            return
+        self.current = (self.current << length) & 0xffffffff
+        self.bits_read += length
+        self.total_bits += length
+        while self.bits_read >= 8:
+            self.bits_read -= 8
+            nxt = 0xaa if self.next_index >= len(self.data) else self.data[self.next_index]
+            self.current |= nxt << self.bits_read
+            self.next_index += 1
+
+    def read_n_bits(self, n):                                      # :198-208
+        if n == 0:
+            return 0
+        if n > 16:
+            raise RefPanic("Should not read more than 16 bits at a time!")
+        current_16 = (self.current >> 16) & 0xffff
+        number = (current_16 & BIT_MASKS[n]) >> (16 - n)
+        self.shift_and_fix_current(n)
+        return number
+
+    def next_code(self, table):                                    # :211-227 (lengths 2..=16 only: SURVEY Q8)
+        by_len = self._lookup(table)
+        current_16 = (self.current >> 16) & 0xffff
+        for length in range(2, 17):
+            bits = (current_16 & BIT_MASKS[length]) >> (16 - length)
+            v = by_len[length].get(bits)
+            if v is not None:
+                self.shift_and_fix_current(length)
+                return v
+        return None
+
+    @staticmethod
+    def value_correction(val, length):                             # :256-268 (i16 arithmetic)
+        if length == 0:
+            return 0
+        if length > 15:
+            raise RefPanic("1 << 15 overflows i16")
+        base = 1 << (length - 1)
+        return (-2 * base + 1 + val) if val < base else val
+
+    def next_block(self, ac_table, dc_table):                      # :146-195
+        num_bits = self.next_code(dc_table)
+        if num_bits is None:
+            raise RefPanic("DC lookup fail")                      # :152-156 unwrap
+        block = [self.value_correction(self.read_n_bits(num_bits), num_bits)]
+        while len(block) < 64:
+            code = self.next_code(ac_table)
+            if code is None:
+                raise RefPanic("ILLEGAL STATE!")                  # :162
+            if code == 0x00:
+                block += [0] * (64 - len(block))
+                break
+            if code == 0xf0:
+                block += [0] * min(16, 64 - len(block))
+                continue
+            zeroes = (code & 0xf0) >> 4
+            nbits = code & 0xf
+            number = self.value_correction(self.read_n_bits(nbits), nbits)
+            block += [0] * min(zeroes, 64 - len(block) - 1)
+            block.append(number)
+        assert len(block) == 64
+        return block
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# src/transform.rs:55-87
+# ---------------------------------------------------------------------------------------------------------------
+_PI = F(np.pi)                                                     # `PI as f32`
+
+
+def _alpha(u):
+    return F(1) / F(_libm.sqrtf(F(2))) if u == 0 else F(1)
+
+
+def _cos_table():
+    # ((2f32 * xf + 1f32) * uf * Pi / 16f32).cos(): the products and the quotient in f32, left to right
+    t = np.empty((8, 8), np.float32)
+    for x in range(8):
+        for u in range(8):
+            arg = F(F(F(F(2) * F(x) + F(1)) * F(u)) * _PI) / F(16)
+            t[x, u] = _libm.cosf(ctypes.c_float(arg))
+    return t
+
+
+def idct_blocks(blocks):
+    """discrete_cosine_transform_inverse on every row of `blocks` (float32 [n, 64], natural order v*8+u) at once: the
+    same f32 operations in the same order per output sample, vectorised over the blocks only."""
+    blocks = np.ascontiguousarray(blocks, np.float32)
+    n = blocks.shape[0]
+    cos = _cos_table()
+    aa = [[F(_alpha(u) * _alpha(v)) for u in range(8)] for v in range(8)]      # alpha(u) * alpha(v), f32
+    out = np.empty((n, 64), np.float32)
+    for y in range(8):
+        for x in range(8):
+            s = np.zeros(n, np.float32)
+            for v in range(8):
+                for u in range(8):
+                    # sum += alpha(u) * alpha(v) * f_uv * cos(x,u) * cos(y,v)      (left-associative products)
+                    s = s + ((aa[v][u] * blocks[:, v * 8 + u]) * cos[x, u]) * cos[y, v]
+            out[:, y * 8 + x] = s / F(4)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# src/jpeg/decoder.rs
+# ---------------------------------------------------------------------------------------------------------------
+ZIGZAG_INDICES = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7,
+                  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39,
+                  46, 53, 60, 61, 54, 47, 55, 62, 63]              # :404-407
+
+
+def f32_to_u8(n):                                                  # :382-390, element-wise
+    n = np.asarray(n, np.float32)
+    out = np.where(n < 0, F(0), np.where(n > 255, F(255), n))
+    return np.trunc(out).astype(np.uint8)                          # `n as u8` truncates toward zero
+
+
+def y_cb_cr_to_rgb(y, cb, cr):                                     # :392-402
+    c_red, c_green, c_blue = F(0.299), F(0.587), F(0.114)
+    r = cr * (F(2.0) - F(2.0) * c_red) + y
+    b = cb * (F(2.0) - F(2.0) * c_blue) + y
+    g = (y - c_blue * b - c_red * r) / c_green
+    return f32_to_u8(r + F(128.0)), f32_to_u8(g + F(128.0)), f32_to_u8(b + F(128.0))
+
+
+def get_indices(x, y, max_x, max_y, x_factor, y_factor, max_x_factor, max_y_factor):     # :259-288 (usize arithmetic)
+    def usub(a, b):
+        if a < b:
+            raise RefPanic("usize underflow in get_indices")
+        return a - b
+    if max_y_factor > 1 and y_factor == 1:
+        if max_x_factor > 1 and x_factor == 1:
+            if y & 1 == 0:
+                if (x // 2) & 1 == 1:
+                    return usub(x // 2, 1) + (x & 1), y + 1
+                return x // 2 + (x & 1), y
+            if y > 0 and (x // 2) & 1 == 0:
+                return usub(max_x // 2 + x // 2, 1) + (x & 1), y
+            return max_x // 2 + x // 2 + (x & 1), usub(y, 1)
+        if y & 1 == 0:
+            return x // 2, y + (x & 1)
+        return x // 2 + max_x // 2, usub(y, x & 1)
+    return x, y
+
+
+def fill_block_in_array(block, target, x_scale, y_scale, x, y, stride):                 # :347-379
+    rep = np.repeat(block, x_scale)                                # flat_map(repeat(n).take(x_scale))
+    width = 8 * x_scale                                            # chunks_lazy(8 * x_scale)
+    length = target.shape[0]
+    start_x = x * 8 * x_scale
+    if stride < start_x:                                           # :360 (every line returns)
+        return
+    for line_number in range(8):
+        line = rep[line_number * width:(line_number + 1) * width]
+        start_i = y * 8 * y_scale * stride + line_number * stride + start_x
+        i = start_i + np.arange(width)
+        for j in range(y_scale):
+            ok = i + j * stride < length                           # :370 guard ...
+            idx = i[ok] + j * stride * 8                           # ... :371 index (they disagree: SURVEY Q5)
+            if idx.size and idx.max() >= length:
+                raise RefPanic("index out of bounds in fill_block_in_array")
+            target[idx] = line[ok]
+
+
+class ComponentFields:                                             # :39-52
+    def __init__(self, component):
+        self.component = component
+        self.dc_table_id = self.ac_table_id = self.quantization_id = 0xff
+        self.horizontal_sampling_factor = self.vertical_sampling_factor = 0xff
+
+
+class JPEGDecoder:                                                 # :19-343
+    def __init__(self, data):
+        self.data = data
+        self.huffman_ac_tables = [None] * 4
+        self.huffman_dc_tables = [None] * 4
+        self.quantization_tables = [None] * 4
+        self.component_fields = []
+        self.dimensions = (0, 0)
+
+    def frame_header(self, frame_components):                      # :83-111
+        for (cid, h, v, tq) in frame_components:
+            cf = next((c for c in self.component_fields if c.component == cid), None)
+            if cf is None:
+                cf = ComponentFields(cid)
+                self.component_fields.append(cf)
+            cf.horizontal_sampling_factor, cf.vertical_sampling_factor, cf.quantization_id = h, v, tq
+        return self
+
+    def scan_header(self, scan_components):                        # :113-152
+        for (cid, td, ta) in scan_components:
+            cf = next((c for c in self.component_fields if c.component == cid), None)
+            if cf is not None:
+                cf.ac_table_id, cf.dc_table_id = ta, td
+            else:
+                cf = ComponentFields(cid)
+                cf.dc_table_id, cf.ac_table_id = ta, td             # :134-135 (swapped in the reference)
+                self.component_fields.append(cf)
+        ordered = []
+        for (cid, _, _) in scan_components:                        # :141-150
+            cf = next((c for c in self.component_fields if c.component == cid), None)
+            if cf is None:
+                raise RefPanic("unwrap on None in scan_header")
+            ordered.append(cf)
+        self.component_fields = ordered
+        return self
+
+    def decode(self):                                              # :162-343
+        W, H = self.dimensions
+        num_blocks_x, num_blocks_y = (W + 7) // 8, (H + 7) // 8
+        num_blocks = num_blocks_x * num_blocks_y
+        ncomp = len(self.component_fields)
+        blocks = [[] for _ in range(ncomp)]
+        previous_dc = [F(0.0)] * ncomp
+        max_h = max([c.horizontal_sampling_factor for c in self.component_fields] or [1])
+        max_v = max([c.vertical_sampling_factor for c in self.component_fields] or [1])
+        hd = HuffmanDecoder(self.data)
+        skip_factor = max_v * max_h
+        num_read_blocks = (num_blocks + skip_factor - 1) // skip_factor               # :191-192
+        for _ in range(num_read_blocks):                           # Step 1, :195-215
+            for ci, comp in enumerate(self.component_fields):
+                if comp.ac_table_id > 3 or self.huffman_ac_tables[comp.ac_table_id] is None:
+                    raise RefPanic("ac table unwrap")
+                if comp.dc_table_id > 3 or self.huffman_dc_tables[comp.dc_table_id] is None:
+                    raise RefPanic("dc table unwrap")
+                ac, dc = self.huffman_ac_tables[comp.ac_table_id], self.huffman_dc_tables[comp.dc_table_id]
+                for _ in range((comp.horizontal_sampling_factor * comp.vertical_sampling_factor) & 0xff):
+                    decoded = np.array(hd.next_block(ac, dc), dtype=np.float32)       # i16 -> f32
+                    decoded[0] = F(decoded[0] + previous_dc[ci])
+                    previous_dc[ci] = decoded[0]
+                    blocks[ci].append(decoded)
+        self.coef_stream = [np.array(b, np.float32).reshape(-1, 64) for b in blocks]
+        self.mcus_read, self.bits_used = num_read_blocks, hd.total_bits
+        image_data = []
+        for ci, comp in enumerate(self.component_fields):          # Step 2, :221-314
+            if comp.quantization_id > 3 or self.quantization_tables[comp.quantization_id] is None:
+                raise RefPanic("Did not find quantization table for %d" % comp.quantization_id)
+            q = np.array(self.quantization_tables[comp.quantization_id], dtype=np.float32)   # `q as f32`
+            zz = self.coef_stream[ci] * q[None, :]                  # n * q as f32
+            nat = np.zeros_like(zz)
+            nat[:, ZIGZAG_INDICES] = zz                            # zigzag_inverse, :425-437
+            component_blocks = idct_blocks(nat)
+            x_i = np.ceil(F(W) * (F(comp.horizontal_sampling_factor) / F(max_h)))     # :239-246, f32
+            y_i = np.ceil(F(H) * (F(comp.vertical_sampling_factor) / F(max_v)))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                xf, yf = np.ceil(F(W) / F(x_i)), np.ceil(F(H) / F(y_i))
+            if not (np.isfinite(xf) and np.isfinite(yf) and xf >= 1 and yf >= 1):
+                raise RefPanic("division by zero at decoder.rs:290")
+            x_factor, y_factor = int(xf), int(yf)
+            stride = W
+            data = np.zeros(W * H, np.float32)
+            block_i = 0
+            for y in range(num_blocks_y // y_factor):              # :290-312
+                for x in range(num_blocks_x // x_factor):
+                    bx, by = get_indices(x, y, num_blocks_x, num_blocks_y, x_factor, y_factor, max_h, max_v)
+                    if block_i >= component_blocks.shape[0]:
+                        raise RefPanic("component_blocks[block_i] out of range")
+                    fill_block_in_array(component_blocks[block_i], data, x_factor, y_factor, bx, by, stride)
+                    block_i += 1
+            image_data.append(data)
+        if ncomp == 1:                                             # :317-331
+            u = f32_to_u8(image_data[0] + F(128.0))
+            rgb = np.stack([u, u, u], 1)
+        elif ncomp == 3:
+            rgb = np.stack(y_cb_cr_to_rgb(image_data[0], image_data[1], image_data[2]), 1)
+        else:
+            raise RefPanic("asd")
+        return rgb.reshape(H, W, 3)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# src/jpeg/mod.rs:157-465
+# ---------------------------------------------------------------------------------------------------------------
+MARKERS = {0xc0: "BaselineDCT", 0xc4: "DefineHuffmanTable", 0xd8: "StartOfImage", 0xd9: "EndOfImage", 0xda: "StartOfScan",
+           0xdb: "QuantizationTable", 0xdd: "RestartIntervalDefinition", 0xe0: "ApplicationSegment0",
+           0xec: "ApplicationSegment12", 0xee: "ApplicationSegment14", 0xfe: "Comment"}     # :166-179
+
+
+def parse(vec, skip_unknown_app=False):
+    """JPEGImage::parse (mod.rs:202-465) -> the decoder after decode(): .rgb [H,W,3], .coef_stream, .mcus_read, .bits_used.
+    skip_unknown_app: APP12 / APP14 segments are skipped instead of panicking (without this the reference itself
+    cannot open working-jpegs/huff_simple0.jpg); nothing else differs from the reference."""
+    def at(k):
+        if k >= len(vec):
+            raise RefPanic("index %d out of range" % k)
+        return vec[k]
+    ac_tabs, dc_tabs, q_tabs = [None] * 4, [None] * 4, [None] * 4
+    frame, dims = None, (0, 0)
+    i = 0
+    while i < len(vec):
+        if at(i) != 0xff:
+            raise RefPanic("Unhandled byte marker at %d" % i)
+        n = at(i + 1)
+        if n == 0:
+            n = at(i + 2)                                          # :161-164
+        marker = MARKERS.get(n)
+        if marker is None:
+            raise RefPanic("Unhandled byte marker: ff %02x" % n)
+        if marker in ("EndOfImage", "StartOfImage"):
+            i += 2
+            continue
+        data_length = ((at(i + 2) << 8) | at(i + 3)) - 2
+        if data_length < 0:
+            raise RefPanic("u16 underflow in the segment length")
+        i += 4
+        if marker == "QuantizationTable":                          # :228-261
+            index = i
+            while index < i + data_length:
+                precision, ident = (at(index) & 0xf0) >> 4, at(index) & 0x0f
+                if ident > 3:
+                    raise RefPanic("quantization table id")
+                if precision == 0:
+                    at(index + 64)
+                    q_tabs[ident] = list(vec[index + 1:index + 65])
+                    index += 65
+                elif precision == 1:
+                    at(index + 128)
+                    b = vec[index + 1:index + 129]
+                    q_tabs[ident] = [(b[k] << 8) | b[k + 1] for k in range(0, 128, 2)]
+                    index += 129
+                else:
+                    raise RefPanic("Unknown precision of quantization table")
+        elif marker == "BaselineDCT":                              # :262-298
+            num_lines = (at(i + 1) << 8) | at(i + 2)
+            samples_per_line = (at(i + 3) << 8) | at(i + 4)
+            comps, index = [], i + 6
+            for _ in range(at(i + 5)):
+                h, v = (at(index + 1) & 0xf0) >> 4, at(index + 1) & 0x0f
+                if not (0 < h < 3 and 0 < v < 3):
+                    raise RefPanic("sampling factor assert")
+                comps.append((at(index), h, v, at(index + 2)))
+                index += 3
+            dims, frame = (samples_per_line, num_lines), comps
+        elif marker == "DefineHuffmanTable":                       # :299-336
+            hi, end = i, i + data_length
+            while hi < end:
+                tclass, dest = (at(hi) & 0xf0) >> 4, at(hi) & 0x0f
+                hi += 1
+                at(hi + 15)
+                size_area = list(vec[hi:hi + 16])
+                hi += 16
+                ncodes = sum(size_area)
+                if hi + ncodes > len(vec):
+                    raise RefPanic("DHT data slice")
+                data_area = list(vec[hi:hi + ncodes])
+                hi += ncodes
+                if dest > 3:
+                    raise RefPanic("huffman table id")
+                (dc_tabs if tclass == 0 else ac_tabs)[dest] = HuffmanTable(size_area, data_area)
+        elif marker == "StartOfScan":                              # :337-417
+            ncomp, scan_components = at(i), []
+            for _ in range(ncomp):
+                scan_components.append((at(i + 1), (at(i + 2) & 0xf0) >> 4, at(i + 2) & 0x0f))
+                i += 2
+            at(i + 3)
+            i += 4
+            encoded, k = bytearray(), i                            # :371-385 de-stuffing, to the end of the file
+            while k < len(vec):
+                encoded.append(vec[k])
+                if vec[k] == 0xff and at(k + 1) == 0x00:
+                    k += 1
+                k += 1
+            if frame is None:
+                raise RefPanic("frame_header unwrap")
+            dec = JPEGDecoder(bytes(encoded)).frame_header(frame).scan_header(scan_components)
+            dec.dimensions = dims
+            dec.huffman_ac_tables, dec.huffman_dc_tables, dec.quantization_tables = ac_tabs, dc_tabs, q_tabs
+            dec.rgb = dec.decode()
+            return dec                                             # :415-417: returns after the first scan
+        elif marker == "RestartIntervalDefinition":
+            raise RefPanic("got to restart interval def")          # :424-428
+        elif marker in ("ApplicationSegment12", "ApplicationSegment14"):
+            if not skip_unknown_app:
+                raise RefPanic("got " + marker)                    # :445-450
+        elif marker == "ApplicationSegment0":
+            at(15)                                                 # :436-443 reads absolute offsets up to 15
+        i += data_length
+    return None                                                    # no scan: image_data() == None
+
+
+def coef_stream_sha256(dec):
+    """SURVEY s4 serialisation: components in scan order, blocks in decode order, 64 x int16 little-endian, zig-zag order,
+    after DC prediction, before dequantisation."""
+    h = hashlib.sha256()
+    for c in dec.coef_stream:
+        h.update(np.asarray(c, np.float32).astype("<i2").tobytes())
+    return h.hexdigest()
+
+
+SAMPLES = ["huff_simple0.jpg", "lena-bw.jpeg", "lena.jpeg", "2x2-chroma.jpeg"]
+
+
+def decode_sample(path):
+    data = open(path, "rb").read()
+    dec = parse(data, skip_unknown_app=True)
+    return {"width": dec.dimensions[0], "height": dec.dimensions[1], "mcus": int(dec.mcus_read), "bits_used": int(dec.bits_used),
+            "blocks": [int(c.shape[0]) for c in dec.coef_stream], "coef_sha256": coef_stream_sha256(dec),
+            "rgb_sha256": hashlib.sha256(np.ascontiguousarray(dec.rgb).tobytes()).hexdigest()}, dec
+
+
+if __name__ == "__main__":
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = {}
+    for name in SAMPLES:
+        rec, _ = decode_sample(os.path.join(root, "tests", "data", name))
+        out[name] = rec
+        print(name, json.dumps(rec))
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_emul_golden.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)

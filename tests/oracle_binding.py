@@ -42,6 +42,10 @@ def lib():
         l.orc_decode_many.restype = ctypes.c_uint64
         l.orc_decode_many.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_size_t,
                                       ctypes.POINTER(Opts), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        l.orc_decode_many_rgb.restype = ctypes.c_uint64
+        l.orc_decode_many_rgb.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_size_t,
+                                          ctypes.POINTER(Opts), ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                          ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
         _lib = l
     return _lib
 
@@ -98,14 +102,22 @@ def ycbcr_to_rgb(y, cb, cr):
     return out
 
 
-def decode_many(datas, nthreads, layout=LAYOUT_REF, faithful=True):
+def decode_many(datas, nthreads, layout=LAYOUT_REF, faithful=True, rgb_shapes=None):
+    """Decodes the files on `nthreads` threads -> (pixels decoded, [status]) or, with rgb_shapes = [(height, width)] per
+    file, (pixels, [status], [rgb array [H,W,3] u8])."""
     n = len(datas)
     arr = (ctypes.c_char_p * n)(*datas)
     lens = (ctypes.c_size_t * n)(*[len(d) for d in datas])
     st = (ctypes.c_int * n)()
     o = Opts(0, layout, int(faithful), int(faithful), 0, 0, 0)
-    px = lib().orc_decode_many(arr, lens, n, ctypes.byref(o), nthreads, st)
-    return int(px), list(st)
+    if rgb_shapes is None:
+        px = lib().orc_decode_many(arr, lens, n, ctypes.byref(o), nthreads, st)
+        return int(px), list(st)
+    outs = [np.zeros((h, w, 3), np.uint8) for h, w in rgb_shapes]
+    ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in outs])
+    caps = (ctypes.c_size_t * n)(*[a.nbytes for a in outs])
+    px = lib().orc_decode_many_rgb(arr, lens, n, ctypes.byref(o), nthreads, st, ptrs, caps)
+    return int(px), list(st), outs
 
 
 def f32_trunc(x):

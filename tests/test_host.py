@@ -148,7 +148,7 @@ def test_emulated_decode_synthetic(mjx, orc, emul, w, h, sub, q):
         assert rc == 0 and np.array_equal(coefs, orc.interleave(ref)), (wg, st)
 
 
-def test_emulated_decode_with_optimised_tables_and_16bit_dqt(mjx, orc, emul):
+def test_emulated_decode_with_optimised_tables(mjx, orc, emul):
     PIL = pytest.importorskip("PIL.Image")
     rng = np.random.default_rng(3)
     img = PIL.fromarray(rng.integers(0, 256, (72, 88, 3), dtype=np.uint8))
@@ -384,3 +384,61 @@ def test_restart_markers_are_parsed_out_of_the_scan(mjx, orc, name):
     assert np.array_equal(orc.interleave(ref), orc.interleave(twin)) and np.array_equal(ref.rgb, twin.rgb)
     with pytest.raises(orc.OracleError):
         orc.decode(data, layout=orc.LAYOUT_STD)                       # the reference itself panics on DRI
+
+
+# ---- 16-bit quantisation tables (Pq = 1, src/jpeg/mod.rs:245-256) ------------------------------------
+@pytest.mark.parametrize("sub,q", [("420", 1), ("444", 3), ("422", 8), ("gray", 2), ("420", 20)])
+def test_16bit_dqt_is_parsed_like_the_reference_parses_it(mjx, orc, emul, sub, q):
+    """Files whose DQT segments carry 16-bit entries with values above 255 (what libjpeg writes at low quality without
+    force_baseline): the host parse must deliver the table values of the file, the plan must accept them, the oracle (which
+    restates mod.rs:245-256) must decode the file, and the emulated entropy path must give the oracle's coefficients."""
+    import struct
+    data = mjx.synth_jpeg(72, 40, sub, q, seed=q, dqt16=True)
+    at = data.index(b"\xff\xdb")
+    ln = struct.unpack(">H", data[at + 2:at + 4])[0]
+    seg = data[at + 4:at + 2 + ln]
+    ntab = 1 if sub == "gray" else 2
+    assert ln == 2 + 129 * ntab and seg[0] >> 4 == 1                       # Pq = 1
+    scan = mjx.ParsedScan(data)
+    for t in range(ntab):
+        want = struct.unpack(">64H", seg[129 * t + 1:129 * t + 129])
+        assert [scan.desc.qt[t][k] for k in range(64)] == list(want)
+    assert max(scan.desc.qt[0][k] for k in range(64)) > 255 or q >= 20     # really beyond 8 bits at the low qualities
+    assert scan.validate() == mjx.OK and scan.validate(layout=mjx.LAYOUT_REF_COMPAT) in (mjx.OK, mjx.ERR_REF_PANIC)
+    ref = orc.decode(data, layout=orc.LAYOUT_STD, strict_ref=True)
+    rc, coefs, st = emul(data, 0)
+    assert rc == 0 and np.array_equal(coefs, orc.interleave(ref))
+    PIL = pytest.importorskip("PIL.Image")                                  # sanity bound only (libjpeg is not an oracle)
+    pil = np.array(PIL.open(io.BytesIO(data)).convert("RGB")).astype(float)
+    assert np.abs(pil - ref.rgb.astype(float)).mean() < 6
+
+
+# ---- corrupt but decodable streams: the clamps of src/jpeg/huffman.rs:170-189 (SURVEY Q9) ------------------------------
+@pytest.mark.parametrize("w,h,comps", [(48, 32, "420"), (64, 64, "444"), (40, 24, "gray"), (256, 128, "420")])
+def test_emulated_decode_of_semantically_corrupt_streams_equals_the_oracle(mjx, orc, emul, w, h, comps):
+    """Random sequences of valid codes from a table with all 256 run/size symbols, written with no regard to the 64
+    coefficients of a block: the reference does not panic on them, it clamps runs onto coefficient 63, cuts ZRL short and
+    decodes `0x?0` as r zeros and a 0.  The entropy path must reproduce the oracle's coefficients bit for bit."""
+    import jpegwriter as jw
+    data, _ = _corrupt_stream_file(jw, w, h, comps, seed=w + h)
+    ref = orc.decode(data, layout=orc.LAYOUT_STD, strict_ref=True)
+    assert ref.bits_used < 8 * (len(data) - 200)                           # the oracle stayed inside the scan
+    flat = orc.interleave(ref)
+    assert (np.abs(flat[:, 63]) > 0).mean() > 0.2                           # runs really were clamped onto coefficient 63
+    for mode in (0, 1):
+        rc, coefs, st = emul(data, 0, mode)
+        assert rc == 0 and np.array_equal(coefs, flat), (mode, st)
+
+
+def _corrupt_stream_file(jw, w, h, comps, seed):
+    rng = np.random.default_rng(seed)
+    dc_tab, ac_tab = jw.small_dc_table(8), jw.full_ac_table()
+    frame = {"420": [(1, 2, 2, 0, 0, 0), (2, 1, 1, 0, 0, 0), (3, 1, 1, 0, 0, 0)],
+             "444": [(1, 1, 1, 0, 0, 0), (2, 1, 1, 0, 0, 0), (3, 1, 1, 0, 0, 0)], "gray": [(1, 1, 1, 0, 0, 0)]}[comps]
+    hmax, vmax = max(c[1] for c in frame), max(c[2] for c in frame)
+    nmcu = -(-w // (8 * hmax)) * -(-h // (8 * vmax))
+    need = nmcu * sum(c[1] * c[2] for c in frame) if len(frame) > 1 else -(-w // 8) * -(-h // 8)
+    ent, blocks = jw.random_symbol_stream(rng, need * 40, dc_tab, ac_tab)
+    assert blocks > need + 8
+    qt = [int(v) for v in rng.integers(1, 40, 64)]
+    return jw.write_jpeg(w, h, frame, {0: qt}, {(0, 0): dc_tab, (1, 0): ac_tab}, ent), need

@@ -143,3 +143,61 @@ def test_sanity_bounds_against_pil(orc, data_dir):
     le = orc.decode(_read(data_dir, "lena.jpeg")).rgb.astype(float)
     pil = np.array(PIL.open(io.BytesIO(_read(data_dir, "lena.jpeg"))).convert("RGB")).astype(float)
     assert 10 * np.log10(255 ** 2 / np.mean((le - pil) ** 2)) > 40
+
+
+# ---- second pin: an independent Python / numpy-f32 restatement of the reference (tests/golden/ref_emul.py) ---------------
+def _ref_emul():
+    import importlib.util
+    p = os.path.join(os.path.dirname(__file__), "golden", "ref_emul.py")
+    spec = importlib.util.spec_from_file_location("ref_emul", p)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("name", sorted(KNOWN))
+def test_two_independent_restatements_agree_byte_for_byte(orc, data_dir, name):
+    """tests/golden/ref_emul.py was written from the Rust sources, not from the C oracle.  On the reference's own sample
+    files the two must agree on everything the reference computes: the coefficient stream (= SURVEY s4's known answers),
+    the bits consumed, the MCU count and every byte of the RGB picture in the reference's own (bug-compatible) layout with
+    the faithful cosf-per-term IDCT.  The committed ref_emul_golden.json holds the same answers for boxes where running
+    the Python restatement is too slow."""
+    import json
+    re_ = _ref_emul()
+    rec, dec = re_.decode_sample(os.path.join(data_dir, name))
+    d = orc.decode(_read(data_dir, name), layout=orc.LAYOUT_REF, faithful_cos=True, faithful_huff=True)
+    assert rec["coef_sha256"] == KNOWN[name][0] == _coef_sha(d)
+    assert (rec["bits_used"], rec["mcus"], rec["blocks"]) == (d.bits_used, d.mcus, [len(c) for c in d.coefs])
+    assert dec.rgb.shape == d.rgb.shape and np.array_equal(dec.rgb, d.rgb)          # every byte, REF layout
+    fast = orc.decode(_read(data_dir, name), layout=orc.LAYOUT_REF)                 # tabulated cosines: bit-identical
+    assert np.array_equal(fast.rgb, d.rgb)
+    golden = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_emul_golden.json")))
+    assert golden[name] == rec
+
+
+def test_two_restatements_agree_on_synthetic_files_and_on_panics(mjx, orc):
+    """The same comparison on files the samples do not cover: 4:2:0 / 4:4:0 / 4:2:2 geometries whose placement is wrong in
+    the reference, geometries on which it panics, 16-bit quantisation tables, and semantically corrupt
+    streams (the clamps of huffman.rs:170-189)."""
+    import jpegwriter as jw
+    import test_host
+    re_ = _ref_emul()
+    files = [mjx.synth_jpeg(w, h, sub, q, seed=w + h, dqt16=d16) for w, h, sub, q, d16 in [
+        (64, 36, "420", 75, False), (94 * 8, 24, "420", 60, False), (64, 48, "422", 50, False), (48, 64, "440", 75, False),
+        (33, 17, "422", 90, False), (64, 32, "420", 3, True), (40, 24, "gray", 2, True), (100, 60, "444", 8, True),
+        (64, 44, "420", 75, False), (60, 48, "420", 75, False), (64, 90, "420", 75, False)]]
+    files += [test_host._corrupt_stream_file(jw, w, h, c, seed=7)[0] for w, h, c in [(48, 32, "420"), (64, 64, "444"), (40, 24, "gray")]]
+    agreed = panics = 0
+    for k, data in enumerate(files):
+        try:
+            dec = re_.parse(data)
+        except re_.RefPanic:
+            with pytest.raises(orc.OracleError):
+                orc.decode(data, layout=orc.LAYOUT_REF, strict_ref=True, faithful_cos=True, faithful_huff=True)
+            panics += 1
+            continue
+        d = orc.decode(data, layout=orc.LAYOUT_REF, strict_ref=True, faithful_cos=True, faithful_huff=True)
+        assert re_.coef_stream_sha256(dec) == _coef_sha(d), k
+        assert dec.bits_used == d.bits_used and np.array_equal(dec.rgb, d.rgb), k
+        agreed += 1
+    assert agreed >= 10 and panics == 3
