@@ -7,14 +7,23 @@ A *step* = one pass of the whole hot path (entropy decode -> dequant -> IDCT -> 
 `--images-per-gpu` synthetic 3840x2160 4:2:0 q75 baseline JPEGs (BASELINE.json configs[4] is 16384 images over 8 GPUs
 = 2048 per GPU; per-GPU work is fixed as N grows -> weak scaling).  Inputs (de-stuffed scans, tables) are resident in
 HBM before the timed region; outputs stay in HBM.  Images are independent, so ranks never exchange data: image i of the
-global batch goes to rank i mod N; the only collective is the reporting barrier / max-reduce of the elapsed time.
+global batch goes to rank i mod N.  The harness needs one barrier and one MAX-reduce of the elapsed time; both go over
+gloo (host TCP) -- the north star says "no RCCL", and that holds for the harness as well as for the data path.
 
 The JSON line carries, besides the contract fields:
   roofline      dominant kernel (by summed HIP-event time over the timed region): algorithmic bytes per launch / average
-                launch duration vs the 8 TB/s HBM3E peak
+                launch duration vs the 8 TB/s HBM3E peak; frac_physical = the same with the bytes the kernel really moves
   roofline_e2e  whole path: sum over images of (S + 3*W*H) (SURVEY.md s8(d) B_e2e) / sum of all kernel time
   kernels       per kernel class: launches, total ms
-  cpu_baseline  the oracle (C restatement of the reference's algorithm, kind "port") on the host cores, rank 0, N=1
+  parity        the gate behind `value`: every picture of the timed batch compared on the device with its
+                unique original (bit-equal), pictures of the batch compared with the CPU oracle (coefficients equal, RGB
+                within 1), and the pictures the cpu_baseline leg decodes compared with a REF_COMPAT decode on the GPU.
+                The run fails if any check fails.
+  extra_configs the other measurement rows of SURVEY s8(d): BASELINE config 4 (4096 x 1080p) whole path and stage B alone
+                (the ">= 60 % of HBM on B_idct" sweep), 4K at quality 50 and 90; each with Mpixels/s, Gbit/s of entropy-coded
+                data and the dominant kernel's roofline fraction
+  e2e_from_bytes  mjx_decode_batch from JPEG file bytes in host memory to RGB in HBM (parse + H2D + decode), Mpixels/s
+  cpu_baseline  the oracle (C restatement of the reference's algorithm, kind "port") on all host cores and on one core
 """
 import argparse
 import json
@@ -27,6 +36,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+SUBS = {"420": "4:2:0", "422": "4:2:2", "444": "4:4:4", "440": "4:4:0", "gray": "greyscale"}
 
 
 def parse_args():
@@ -43,9 +53,13 @@ def parse_args():
     ap.add_argument("--chunk-images", type=int, default=0)
     ap.add_argument("--stages", default="all", choices=["all", "pixels"], help="pixels = stage-B-only sweep on resident coefficients")
     ap.add_argument("--device-destuff", action="store_true", help="upload stuffed scans; FF00 compaction on the GPU at upload")
-    ap.add_argument("--streams", type=int, default=1, choices=[1, 2], help="2 = odd chunks on a second HIP stream (stage B of one chunk overlaps stage A of the next; per-kernel times then include the contention)")
+    ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2], help="HIP streams of the context (0 = library default); with 2, "
+                    "stage B of one chunk overlaps stage A of the next and per-kernel times include the contention")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU baseline (0 = every host core)")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra_configs and e2e_from_bytes (main line only)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle legs of the parity gate (the on-device check stays)")
+    ap.add_argument("--parity-images", type=int, default=4, help="pictures of the timed batch checked against the CPU oracle")
     return ap.parse_args()
 
 
@@ -101,32 +115,226 @@ def shard_seeds(rank, world, unique):
     return seeds
 
 
-def reduce_elapsed(elapsed, world, device=None):
-    """MAX over ranks of the timed region (the only collective of the job; the data path has none)."""
+def reduce_elapsed(elapsed, world):
+    """MAX over ranks of the timed region: a host-side reduction over gloo (the data path has no collective at all)."""
     if world <= 1:
         return elapsed
     import torch
     import torch.distributed as dist
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device or "cpu")
+    t = torch.tensor([elapsed], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def cpu_baseline(mjx, datas, width, height, threads):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(datas, width, height, threads, keep_rgb):
+    """The reference's algorithm restated in C (oracle/, kind "port"), bug-compatible layout, cosf per term and linear-search
+    Huffman like the Rust code: one picture per thread on every host core, then one picture on one core.  Returns the JSON
+    object and the first `keep_rgb` pictures (for the REF_COMPAT leg of the parity gate)."""
     import oracle_binding as orc
     cores = os.cpu_count() or 1
-    threads = threads or min(cores, 32)
+    threads = max(1, min(threads or cores, 1024))
     sample = [datas[i % len(datas)] for i in range(threads)]
+    shapes = [(height, width)] * keep_rgb + [(1, 1)] * (len(sample) - keep_rgb)       # (RGB kept for the first few only)
     t = time.perf_counter()
-    px, st = orc.decode_many(sample, threads, layout=orc.LAYOUT_REF, faithful=True)
+    px, st, rgbs = orc.decode_many(sample, threads, layout=orc.LAYOUT_REF, faithful=True, rgb_shapes=shapes)
     dt = time.perf_counter() - t
     ok = sum(1 for s in st if s == 0)
-    return {
+    t = time.perf_counter()
+    px1, st1 = orc.decode_many(sample[:1], 1, layout=orc.LAYOUT_REF, faithful=True)
+    dt1 = time.perf_counter() - t
+    out = {
         "value": round(px / dt / 1e6, 4), "unit": "Mpixels/s", "cores": threads, "kind": "port",
-        "sample": "%d images of the same %dx%d batch, one per thread, reference algorithm restated in C "
-                  "(oracle/: O(n^4) float IDCT with cosf per term, linear-search Huffman; gcc -O2 -ffp-contract=off); "
-                  "%d decoded ok in %.1f s; host has %d cores" % (len(sample), width, height, ok, dt, cores),
+        "one_core": {"value": round(px1 / dt1 / 1e6, 4), "unit": "Mpixels/s", "cores": 1, "seconds": round(dt1, 2)},
+        "host": {"nproc": cores, "cpu_model": cpu_model()},
+        "sample": "%d pictures of the same %dx%d batch, one per thread on %d threads (host: %d cores), reference algorithm restated "
+                  "in C (oracle/: O(n^4) float IDCT with cosf per term, linear-search Huffman, the reference's own layout; "
+                  "gcc -O2 -ffp-contract=off) -- not the Rust binary, which cannot be built here; %d decoded ok in %.1f s; "
+                  "then 1 picture on 1 thread in %.1f s" % (len(sample), width, height, threads, cores, ok, dt, dt1),
     }
+    return out, [rgbs[i] for i in range(min(keep_rgb, len(rgbs))) if st[i] == 0], sample[:keep_rgb]
+
+
+def make_inputs(mjx, width, height, subsampling, quality, seeds):
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
+        return list(ex.map(lambda s: mjx.synth_jpeg(width, height, subsampling, quality, s), seeds))
+
+
+def run_config(mjx, ctx, datas, per_gpu, stages, steps, warmup, chunk_images=0, device_destuff=False, sync_all=None,
+               parity_images=0, host_side=None):
+    """Builds the device-resident batch (unique pictures uploaded once, tiled on the device), times `steps` passes, and runs
+    the on-device half of the parity gate.  Returns (record, batch, period) -- the caller closes the batch."""
+    from concurrent.futures import ThreadPoolExecutor
+    period = len(datas)
+    reps = max(1, per_gpu // period)
+    per_gpu = reps * period
+    t_h = time.perf_counter()
+    with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
+        scans = list(ex.map(lambda d: mjx.ParsedScan(d, device_destuff=device_destuff), datas))
+    t_parse = time.perf_counter() - t_h
+    keep = stages == "pixels"
+    t_h = time.perf_counter()
+    base = mjx.Batch(ctx, scans, keep_coefs=keep, chunk_images=chunk_images)
+    t_create = time.perf_counter() - t_h
+    assert all(s == mjx.OK for s in base.create_status), base.create_status
+    if host_side is not None:
+        host_side.update({"files": len(datas), "parse_ms_per_file": round(1e3 * t_parse / len(datas), 3),
+                          "parse_threads": min(32, os.cpu_count() or 1),
+                          "create_ms_per_file": round(1e3 * t_create / len(datas), 3),
+                          "compressed_MB_per_file": round(sum(len(d) for d in datas) / len(datas) / 1e6, 3),
+                          "note": "host marker walk + de-stuffing (threads), then planning + decode tables + H2D of the compressed "
+                                  "scans and first-use allocations (mjx_batch_create) for the unique files; not part of `value`"})
+    batch = base.tile(reps) if reps > 1 else base
+    if batch is not base:
+        base.close()
+    for s in scans:
+        s.close()
+    geo = batch.geometry()
+    nsub_total, nblk = geo["subsequences"], geo["blocks"]
+    st = mjx.STAGE_ALL if stages == "all" else mjx.STAGE_PIXELS
+    if stages == "pixels":
+        batch.decode(mjx.STAGE_ALL)
+        batch.wait()
+    for _ in range(warmup):
+        batch.decode(st)
+        batch.wait()
+    batch.kernel_ms(reset=True)
+    if sync_all:
+        sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.decode(st)
+    batch.wait()
+    if sync_all:
+        sync_all()
+    elapsed = time.perf_counter() - t0
+    bad = [i for i in range(len(batch)) if batch.status(i) != mjx.OK]
+    assert not bad, "images failed: %s" % bad[:8]
+    kms = batch.kernel_ms()
+    by = batch.bytes()
+    kernels = {k: {"launches": v[1], "ms": round(v[0], 4)} for k, v in kms.items() if v[1]}
+    rec = {"elapsed": elapsed, "per_gpu": per_gpu, "period": period, "by": by, "kernels": kernels, "nsub": nsub_total, "nblk": nblk,
+           "chunks": geo["chunks"]}
+    # on-device half of the parity gate: every picture of the batch equals its unique original bit for bit
+    n = len(batch)
+    if n > period:
+        mx, cnt = batch.compare_rgb(list(range(period, n)), batch, [i % period for i in range(period, n)])
+        rec["tiled_compared"] = int(n - period)
+        rec["tiled_max_abs_diff"] = int(mx.max())
+        rec["tiled_differing_bytes"] = int(cnt.sum())
+    else:
+        rec["tiled_compared"], rec["tiled_max_abs_diff"], rec["tiled_differing_bytes"] = 0, 0, 0
+    return rec, batch
+
+
+def rooflines(rec, steps, stages, traffic_ok):
+    kernels, by, nsub_total, nblk = rec["kernels"], rec["by"], rec["nsub"], rec["nblk"]
+    out = {}
+    if not kernels:
+        return out
+    dom = max(kernels, key=lambda k: kernels[k]["ms"])
+    n_launch = kernels[dom]["launches"]
+    avg_s = kernels[dom]["ms"] / 1e3 / n_launch
+    per_launch = algorithmic_bytes(dom, by, nsub_total, nblk) * steps / n_launch
+    per_launch_phys = algorithmic_bytes_physical(dom, by, nsub_total, nblk) * steps / n_launch
+    ach = per_launch / avg_s / 1e9
+    ach_phys = per_launch_phys / avg_s / 1e9
+    imgs_per_launch = rec["per_gpu"] * steps / n_launch * (4 if dom == "huff_fix" else 1)
+    tr = measured_traffic(dom, imgs_per_launch) if traffic_ok else None
+    out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": tr[0] if tr else None,
+                       "traffic_source": tr[1] if tr else None,
+                       "bytes_per_launch": int(per_launch), "avg_launch_ms": round(avg_s * 1e3, 5),
+                       "achieved_physical": round(ach_phys, 2), "frac_physical": round(ach_phys / HBM_PEAK_GBS, 5),
+                       "bytes_basis": "SURVEY s8(d) B_idct = 128*n_blocks + 3*W*H; *_physical: compact stream + DC + RGB, what the kernel moves"
+                       if dom == "idct_color" else "DESIGN.md s5"}
+    out["kernel_rooflines"] = {
+        k: {"GB/s": round(algorithmic_bytes(k, by, nsub_total, nblk) * steps / (v["ms"] / 1e3) / 1e9, 1),
+            "frac": round(algorithmic_bytes(k, by, nsub_total, nblk) * steps / (v["ms"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4)}
+        for k, v in kernels.items() if v["ms"] > 0}
+    tot_ms = sum(v["ms"] for v in kernels.values())
+    e2e_bytes = (by["scan"] + by["rgb"]) if stages == "all" else algorithmic_bytes("idct_color", by, nsub_total, nblk)
+    e2e = e2e_bytes * steps / (tot_ms / 1e3) / 1e9
+    out["roofline_e2e"] = {"bound": "hbm", "achieved": round(e2e, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(e2e / HBM_PEAK_GBS, 5), "bytes_per_step": int(e2e_bytes),
+                           "kernel_ms_per_step": round(tot_ms / steps, 4),
+                           "definition": "sum(S + 3*W*H) / sum of kernel time" if stages == "all" else "B_idct = 128*n_blocks + 3*W*H (SURVEY s8(d)) / kernel time"}
+    return out
+
+
+def oracle_parity(mjx, batch, datas, period, k):
+    """Pictures of the timed batch against the CPU oracle (STANDARD layout = what the batch was decoded in): the
+    coefficient stream must be equal (T0), the RGB within 1 (T2).  The pictures are taken from the batch's last chunk, whose
+    coefficients are still resident after the timed passes."""
+    import numpy as np
+    import oracle_binding as orc
+    n = len(batch)
+    picks = [n - 1 - j * max(1, period // max(k, 1)) for j in range(k)]
+    picks = sorted({i for i in picks if 0 <= i < n})
+    res = {"images": len(picks), "max_abs_diff": 0, "t0_equal": True, "differing_fraction": 0.0}
+    diffs = 0
+    total = 0
+    for i in picks:
+        ref = orc.decode(datas[i % period], layout=orc.LAYOUT_STD)
+        try:
+            t0 = bool(np.array_equal(batch.coefs(i), orc.interleave(ref)))
+        except mjx.MjxError:
+            t0 = None                     # picture not in the resident chunk
+        if t0 is False:
+            res["t0_equal"] = False
+        d = np.abs(batch.rgb(i).astype(np.int16) - ref.rgb.astype(np.int16))
+        res["max_abs_diff"] = max(res["max_abs_diff"], int(d.max()))
+        diffs += int((d > 0).sum())
+        total += d.size
+    res["differing_fraction"] = round(diffs / max(total, 1), 6)
+    return res
+
+
+def ref_compat_parity(mjx, ctx, files, rgbs):
+    """The pictures the cpu_baseline leg decoded (the reference's own layout, cosf per term) against a REF_COMPAT decode of
+    the same files on the GPU: RGB within 1."""
+    import numpy as np
+    if not files:
+        return {"images": 0, "max_abs_diff": 0}
+    scans = [mjx.ParsedScan(d) for d in files]
+    b = mjx.Batch(ctx, scans, layout=mjx.LAYOUT_REF_COMPAT)
+    b.decode()
+    b.wait()
+    mx = 0
+    for i, ref in enumerate(rgbs):
+        assert b.status(i) == mjx.OK, "REF_COMPAT decode failed: %d" % b.status(i)
+        mx = max(mx, int(np.abs(b.rgb(i).astype(np.int16) - ref.astype(np.int16)).max()))
+    b.close()
+    for s in scans:
+        s.close()
+    return {"images": len(rgbs), "max_abs_diff": mx}
+
+
+def e2e_from_bytes(mjx, ctx, datas, n_files, width, height):
+    """mjx_decode_batch: JPEG file bytes in host memory -> RGB in HBM (marker walk + de-stuffing on host threads, planning,
+    H2D of the compressed scans, kernels).  Timed end to end after one warm-up call (the context keeps its pinned arena)."""
+    files = [datas[i % len(datas)] for i in range(n_files)]
+    best = None
+    for _ in range(3):
+        t = time.perf_counter()
+        b, st = mjx.decode_batch(ctx, files)
+        dt = time.perf_counter() - t
+        assert all(s == mjx.OK for s in st)
+        b.close()
+        best = dt if best is None or dt < best else best
+    return {"files": n_files, "ms": round(best * 1e3, 2), "Mpixels/s": round(n_files * width * height / best / 1e6, 1),
+            "files/s": round(n_files / best, 1), "compressed_MB": round(sum(len(f) for f in files) / 1e6, 1),
+            "note": "host bytes -> device RGB through mjx_decode_batch, best of 3 calls; PCIe-inclusive, never part of `value`"}
 
 
 def main():
@@ -143,55 +351,11 @@ def main():
     mjx = ge.load_package()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
-    # one rank per GPU; MJX_BENCH_BACKEND=gloo + a single visible GPU is only for exercising the N>1 code path in tests
-    backend = os.environ.get("MJX_BENCH_BACKEND", "nccl")
     device = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device)
     if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
-        else:
-            dist.init_process_group(backend)
-
-    # ---- this rank's shard of the global batch: global image i -> rank i % world, content seed i % unique ----
-    per_gpu = args.images_per_gpu
-    seeds = shard_seeds(rank, world, args.unique)
-    period = len(seeds)
-    reps = max(1, per_gpu // period)
-    per_gpu = reps * period
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
-        datas = list(ex.map(lambda s: mjx.synth_jpeg(args.width, args.height, args.subsampling, args.quality, s), seeds))
-
-    if args.streams == 2:
-        os.environ["MJX_STREAMS"] = "2"
-    ctx = mjx.Context(device, profiling=True)
-    # host side of the boundary (not part of `value`): marker walk + de-stuffing of the unique files on the
-    # host cores, then planning + table construction + upload of the compressed scans (mjx_batch_create)
-    t_h = time.perf_counter()
-    with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
-        scans = list(ex.map(lambda d: mjx.ParsedScan(d, device_destuff=args.device_destuff), datas))
-    t_parse = time.perf_counter() - t_h
-    keep = args.stages == "pixels"
-    t_h = time.perf_counter()
-    base = mjx.Batch(ctx, scans, keep_coefs=keep, chunk_images=args.chunk_images)
-    t_create = time.perf_counter() - t_h
-    assert all(s == mjx.OK for s in base.create_status), base.create_status
-    host_side = {"files": len(datas), "parse_ms_per_file": round(1e3 * t_parse / len(datas), 3),
-                 "parse_threads": min(32, os.cpu_count() or 1),
-                 "create_ms_per_file": round(1e3 * t_create / len(datas), 3),
-                 "compressed_MB_per_file": round(sum(len(d) for d in datas) / len(datas) / 1e6, 3),
-                 "note": "host marker walk + de-stuffing (threads), then planning + decode tables + H2D of the compressed scans "
-                         "and first-use allocations (mjx_batch_create, one thread) for the unique files; not part of `value`"}
-    batch = base.tile(reps) if reps > 1 else base
-    if batch is not base:
-        base.close()
-    nsub_total = sum((len(mjx.ParsedScan(d).scan_bytes()) + 511) // 512 for d in datas) * reps
-    nblk = sum(batch.info(i)["bpm"] * batch.info(i)["mcus"] for i in range(period)) * reps
-    stages = mjx.STAGE_ALL if args.stages == "all" else mjx.STAGE_PIXELS
-    if args.stages == "pixels":
-        batch.decode(mjx.STAGE_ALL)
-        batch.wait()
+        # host-side rendezvous only: ranks never exchange image data (north star: per-GPU work queues, no RCCL)
+        dist.init_process_group(os.environ.get("MJX_BENCH_BACKEND", "gloo"))
 
     def sync_all():
         torch.cuda.synchronize()
@@ -199,26 +363,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        batch.decode(stages)
-        batch.wait()
-    batch.kernel_ms(reset=True)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        batch.decode(stages)
-    batch.wait()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    elapsed = reduce_elapsed(elapsed, world, "cuda" if backend == "nccl" else None)
-    bad = [i for i in range(len(batch)) if batch.status(i) != mjx.OK]
-    assert not bad, "images failed: %s" % bad[:8]
-
-    kms = batch.kernel_ms()
-    by = batch.bytes()
+    # ---- this rank's shard of the global batch: global image i -> rank i % world, content seed i % unique ----
+    seeds = shard_seeds(rank, world, args.unique)
+    datas = make_inputs(mjx, args.width, args.height, args.subsampling, args.quality, seeds)
+    if args.streams:
+        os.environ["MJX_STREAMS"] = str(args.streams)
+    ctx = mjx.Context(device, profiling=True)
+    host_side = {}
+    rec, batch = run_config(mjx, ctx, datas, args.images_per_gpu, args.stages, args.steps, args.warmup, args.chunk_images,
+                            args.device_destuff, sync_all, host_side=host_side)
+    per_gpu, period, by, kernels = rec["per_gpu"], rec["period"], rec["by"], rec["kernels"]
+    elapsed = reduce_elapsed(rec["elapsed"], world)
     total_px = by["pixels"] * world * args.steps
     value = total_px / elapsed / 1e6
-    kernels = {k: {"launches": v[1], "ms": round(v[0], 4)} for k, v in kms.items() if v[1]}
     out = {
         "metric": "Mpixels/sec decode, 4K 4:2:0 baseline batch", "value": round(value, 2), "unit": "Mpixels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -226,50 +383,80 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%d x %dx%d %s baseline JPEG q%d per GPU (%d unique, tiled on device), de-stuffed scans "
                                "resident in HBM, RGB out in HBM, stages=%s"
-                               % (per_gpu, args.width, args.height,
-                                  {"420": "4:2:0", "422": "4:2:2", "444": "4:4:4", "440": "4:4:0", "gray": "greyscale"}[args.subsampling],
-                                  args.quality, period, args.stages),
+                               % (per_gpu, args.width, args.height, SUBS[args.subsampling], args.quality, period, args.stages),
                    "images_per_gpu": per_gpu, "width": args.width, "height": args.height, "subsampling": args.subsampling,
-                   "quality": args.quality, "layout": "standard", "streams": args.streams, "sharding": "image i -> gpu i %% %d, no collective" % world},
+                   "quality": args.quality, "layout": "standard", "streams": args.streams or "library default",
+                   "chunks_per_step": rec["chunks"],
+                   "sharding": "image i -> gpu i %% %d, no collective (harness barrier over gloo)" % world},
+        "entropy_Gbit_per_s": round(by["scan"] * 8 * world * args.steps / elapsed / 1e9, 2),
+        "bits_per_pixel": round(by["scan"] * 8 / max(by["pixels"], 1), 4),
         "kernels": kernels,
     }
-    if kernels:
-        dom = max(kernels, key=lambda k: kernels[k]["ms"])
-        n_launch = kernels[dom]["launches"]
-        avg_s = kernels[dom]["ms"] / 1e3 / n_launch
-        per_launch = algorithmic_bytes(dom, by, nsub_total, nblk) * args.steps / n_launch
-        per_launch_phys = algorithmic_bytes_physical(dom, by, nsub_total, nblk) * args.steps / n_launch
-        ach = per_launch / avg_s / 1e9
-        imgs_per_launch = per_gpu * args.steps / n_launch * (4 if dom == "huff_fix" else 1)
-        tr = measured_traffic(dom, imgs_per_launch) if args.width == 3840 and args.height == 2160 and args.quality == 75 else None
-        out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": tr[0] if tr else None,
-                           "traffic_source": tr[1] if tr else None,
-                           "bytes_per_launch": int(per_launch), "avg_launch_ms": round(avg_s * 1e3, 5),
-                           "achieved_physical": round(per_launch_phys / avg_s / 1e9, 2),
-                           "bytes_basis": "SURVEY s8(d) B_idct = 128*n_blocks + 3*W*H" if dom == "idct_color" else "DESIGN.md s5"}
-        # every kernel class, same definitions
-        out["kernel_rooflines"] = {
-            k: {"GB/s": round(algorithmic_bytes(k, by, nsub_total, nblk) * args.steps / (v["ms"] / 1e3) / 1e9, 1),
-                "frac": round(algorithmic_bytes(k, by, nsub_total, nblk) * args.steps / (v["ms"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4)}
-            for k, v in kernels.items() if v["ms"] > 0}
-        tot_ms = sum(v["ms"] for v in kernels.values())
-        e2e_bytes = (by["scan"] + by["rgb"]) if args.stages == "all" else algorithmic_bytes("idct_color", by, nsub_total, nblk)
-        e2e = e2e_bytes * args.steps / (tot_ms / 1e3) / 1e9
-        out["roofline_e2e"] = {"bound": "hbm", "achieved": round(e2e, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(e2e / HBM_PEAK_GBS, 5), "bytes_per_step": int(e2e_bytes),
-                               "kernel_ms_per_step": round(tot_ms / args.steps, 4),
-                               "definition": "sum(S + 3*W*H) / sum of kernel time" if args.stages == "all" else "B_idct = 128*n_blocks + 3*W*H (SURVEY s8(d)) / kernel time"}
+    out.update(rooflines(rec, args.steps, args.stages,
+                         args.width == 3840 and args.height == 2160 and args.quality == 75))
     out["host_side"] = host_side
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(mjx, datas, args.width, args.height, args.cpu_threads)
+
+    # ---- parity gate: no number without it ----
+    parity = {"tiled_images_compared_on_device": rec["tiled_compared"], "tiled_max_abs_diff": rec["tiled_max_abs_diff"],
+              "tiled_differing_bytes": rec["tiled_differing_bytes"]}
+    failures = []
+    if rec["tiled_max_abs_diff"] != 0:
+        failures.append("tiled pictures differ from their originals")
+    if not args.no_parity and args.stages == "all":
+        op = oracle_parity(mjx, batch, datas, period, args.parity_images)
+        parity.update({"images": op["images"], "max_abs_diff": op["max_abs_diff"], "t0_equal": op["t0_equal"],
+                       "differing_fraction": op["differing_fraction"],
+                       "oracle": "oracle/ (C restatement of the reference), STANDARD layout, pictures of the timed batch's last chunk"})
+        if op["max_abs_diff"] > 1:
+            failures.append("RGB differs from the oracle by %d" % op["max_abs_diff"])
+        if not op["t0_equal"]:
+            failures.append("coefficient stream differs from the oracle")
     batch.close()
+
+    extra = []
+    if not args.no_extra and world == 1 and args.stages == "all":
+        small_steps = max(2, min(args.steps, 5))
+        for name, w, h, q, n_img, stg in [("config4_1080p_whole_path", 1920, 1080, 75, 4096, "all"),
+                                          ("config4_1080p_stage_B_only", 1920, 1080, 75, 4096, "pixels"),
+                                          ("4K_q50", 3840, 2160, 50, 2048, "all"), ("4K_q90", 3840, 2160, 90, 2048, "all")]:
+            d2 = datas if (w, h, q) == (args.width, args.height, args.quality) else make_inputs(mjx, w, h, "420", q, seeds)
+            r2, b2 = run_config(mjx, ctx, d2, n_img, stg, small_steps, 1, sync_all=sync_all)
+            b2.close()
+            rl = rooflines(r2, small_steps, stg, False)
+            px = r2["by"]["pixels"] * small_steps
+            e = {"name": name, "workload": "%d x %dx%d 4:2:0 q%d, stages=%s" % (r2["per_gpu"], w, h, q, stg),
+                 "Mpixels/s": round(px / r2["elapsed"] / 1e6, 1), "ms_per_step": round(r2["elapsed"] / small_steps * 1e3, 3),
+                 "steps": small_steps,
+                 "entropy_Gbit_per_s": round(r2["by"]["scan"] * 8 * small_steps / r2["elapsed"] / 1e9, 2),
+                 "bits_per_pixel": round(r2["by"]["scan"] * 8 / max(r2["by"]["pixels"], 1), 4),
+                 "roofline": {k: rl["roofline"][k] for k in ("kernel", "achieved", "frac", "achieved_physical", "frac_physical", "avg_launch_ms")},
+                 "roofline_e2e_frac": rl["roofline_e2e"]["frac"],
+                 "tiled_images_compared_on_device": r2["tiled_compared"], "tiled_max_abs_diff": r2["tiled_max_abs_diff"]}
+            if r2["tiled_max_abs_diff"] != 0:
+                failures.append(name + ": tiled pictures differ from their originals")
+            extra.append(e)
+        out["extra_configs"] = extra
+        out["e2e_from_bytes"] = e2e_from_bytes(mjx, ctx, datas, 512, args.width, args.height)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cb, ref_rgbs, ref_files = cpu_baseline(datas, args.width, args.height, args.cpu_threads, 0 if args.no_parity else 2)
+        out["cpu_baseline"] = cb
+        if not args.no_parity:
+            rp = ref_compat_parity(mjx, ctx, ref_files[:len(ref_rgbs)], ref_rgbs)
+            parity["ref_compat_images"] = rp["images"]
+            parity["ref_compat_max_abs_diff"] = rp["max_abs_diff"]
+            if rp["max_abs_diff"] > 1:
+                failures.append("REF_COMPAT RGB differs from the CPU baseline's pictures by %d" % rp["max_abs_diff"])
+    parity["ok"] = not failures
+    out["parity"] = parity
     ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+    if failures:
+        raise SystemExit("PARITY GATE FAILED: " + "; ".join(failures))
 
 
 if __name__ == "__main__":

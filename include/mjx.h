@@ -171,6 +171,10 @@ int mjx_batch_compare_rgb(mjx_batch *a, const size_t *ia, mjx_batch *b, const si
 int mjx_batch_bytes(const mjx_batch *b, uint64_t *scan_bytes, uint64_t *rgb_bytes, uint64_t *coef_bytes,
                     uint64_t *pixels);
 
+/* work units of the batch (valid images): subsequences the entropy stage decodes in parallel (512..640 bytes of scan each,
+ * chosen per image), coefficient blocks, and the kernel chunks the batch is processed in (one launch per kernel class and chunk) */
+int mjx_batch_geometry(const mjx_batch *b, uint64_t *subsequences, uint64_t *blocks, uint64_t *chunks);
+
 /* accumulated kernel time (ms) and launch count per kernel class since the last reset (profiling enabled) */
 enum {
     MJX_K_GATHER = 0,     /* multi-scan pictures only: component streams -> the picture's stream (k_planar_*) */

@@ -100,6 +100,7 @@ SYMBOLS = {
     "mjx_batch_copy_coefs": (_int, [_vp, _sz, _vp, _sz, _P(_sz)]),
     "mjx_batch_compare_rgb": (_int, [_vp, _P(_sz), _vp, _P(_sz), _sz, _P(ctypes.c_uint32), _P(ctypes.c_uint64)]),
     "mjx_batch_bytes": (_int, [_vp] + [_P(ctypes.c_uint64)] * 4),
+    "mjx_batch_geometry": (_int, [_vp] + [_P(ctypes.c_uint64)] * 3),
     "mjx_batch_kernel_ms": (_int, [_vp, _P(ctypes.c_double), _P(ctypes.c_uint64), _int]),
     "mjx_decode_scans": (_int, [_vp, _P(ScanDesc), _sz, _P(Opts), _P(_P(ctypes.c_uint8)), _P(_int), _P(_vp)]),
     "mjx_strerror": (ctypes.c_char_p, [_int]),
@@ -276,6 +277,11 @@ class Batch:
         v = [ctypes.c_uint64() for _ in range(4)]
         _check(lib().mjx_batch_bytes(self.h, *[ctypes.byref(x) for x in v]))
         return dict(scan=v[0].value, rgb=v[1].value, coef=v[2].value, pixels=v[3].value)
+
+    def geometry(self):
+        v = [ctypes.c_uint64() for _ in range(3)]
+        _check(lib().mjx_batch_geometry(self.h, *[ctypes.byref(x) for x in v]))
+        return dict(subsequences=v[0].value, blocks=v[1].value, chunks=v[2].value)
 
     def kernel_ms(self, reset=False):
         ms = (ctypes.c_double * len(KERNEL_NAMES))()

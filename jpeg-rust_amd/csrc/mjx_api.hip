@@ -540,15 +540,18 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
     b->info.resize(n);
     b->himages.resize(n);
     // pools for the unique images
-    std::vector<uint64_t> scan_off(nu, 0);
-    std::vector<uint32_t> scan_padded(nu, 0), lut_off(nu, 0), lut_n(nu, 0), seg_off(nu, 0);
-    size_t scan_pool = 0, lut_pool = 0;
+    // scan_off: the image's lane-interleaved region in the pool (what the kernels read, see LaneBits in mjx_kernels.hip);
+    // lin_off: its linear de-stuffed scan in the staging buffer the region is built from at upload
+    std::vector<uint64_t> scan_off(nu, 0), lin_off(nu, 0);
+    std::vector<uint32_t> lut_off(nu, 0), lut_n(nu, 0), seg_off(nu, 0);
+    size_t scan_pool = 0, lin_pool = 0, lut_pool = 0;
     b->h_segs.clear();
     for (size_t k = 0; k < nu; k++) {
         if (plans[k].status != MJX_OK) continue;
         scan_off[k] = scan_pool;
-        scan_padded[k] = uint32_t(align_up(plans[k].scan_len, 16) + 16);
-        scan_pool += scan_padded[k];
+        scan_pool += align_up(size_t(scan_region_bytes(plans[k].himg.nsub, plans[k].himg.sub_bits)), 256);
+        lin_off[k] = lin_pool;
+        lin_pool += align_up(plans[k].scan_len, 16) + 16;
         lut_off[k] = uint32_t(lut_pool);
         lut_n[k] = uint32_t(plans[k].lut.size());
         lut_pool += plans[k].lut.size();
@@ -570,7 +573,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
         fill_dev_image(p, d);
         d.status_idx = uint32_t(i);
         d.scan_off = rep * scan_pool + scan_off[k];
-        d.scan_padded = scan_padded[k];
+        d.scan_cols = scan_region_cols(p.himg.nsub);
         d.lut_off = lut_off[k];
         d.lut_n = lut_n[k];
         d.qm_off = uint32_t(k * 192);
@@ -616,7 +619,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
         HIPOK(hipSetDevice(ctx->device));
         HIPOK(hipMalloc(&b->d_images, std::max<size_t>(n, 1) * sizeof(DevImage)));
         HIPOK(hipMemcpy(b->d_images, b->himages.data(), n * sizeof(DevImage), hipMemcpyHostToDevice));
-        HIPOK(hipMalloc(&b->d_scan, b->scan_pool_bytes + 256));    // slack: bit windows read up to 96 bytes past a scan
+        HIPOK(hipMalloc(&b->d_scan, b->scan_pool_bytes + 256));
         HIPOK(hipMalloc(&b->d_lut, std::max<size_t>(lut_pool, 8) * sizeof(LutEntry)));
         HIPOK(hipMalloc(&b->d_qm, std::max<size_t>(nu, 1) * 192 * sizeof(float)));
         HIPOK(hipMalloc(&b->d_segs, std::max<size_t>(b->h_segs.size(), 2) * sizeof(uint32_t)));
@@ -643,24 +646,27 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
                 std::memcpy(hq.data() + k * 192, p.qmult, sizeof p.qmult);
             }
             const auto t1 = now();
-            // the pool is filled with the 0xAA the reference reads past the end of a scan (huffman.rs:236-246) on the
-            // device, then every scan goes up straight from the caller's buffer: a host-side staging copy of the whole
-            // pool (first-touch page faults included) cost six times the transfer itself
-            HIPOK(hipMemsetAsync(b->d_scan, 0xaa, scan_pool, ctx->stream));
+            // every scan goes up straight from the caller's buffer into a linear staging buffer (a host-side staging copy of
+            // the whole pool -- first-touch page faults included -- cost six times the transfer itself); k_scan_interleave then
+            // builds the lane-interleaved regions the kernels read, padding with the 0xAA the reference reads past the end of
+            // a scan (huffman.rs:236-246)
+            uint8_t *d_lin = nullptr;
+            HIPOK(hipMalloc(&d_lin, lin_pool + 256));
+            struct LinFree { uint8_t *p; ~LinFree() { (void)hipFree(p); } } lin_free{d_lin};
             for (size_t k = 0; k < nu; k++) {
                 const ImagePlan &p = plans[k];
                 if (p.status != MJX_OK || on_device[k] || p.scan_len == 0) continue;
-                HIPOK(hipMemcpyAsync(b->d_scan + scan_off[k], p.scan, p.scan_len, hipMemcpyHostToDevice, ctx->stream));
+                HIPOK(hipMemcpyAsync(d_lin + lin_off[k], p.scan, p.scan_len, hipMemcpyHostToDevice, ctx->stream));
             }
             HIPOK(hipStreamSynchronize(ctx->stream));
             const auto t2 = now();
-            if (timing) std::fprintf(stderr, "[mjx] staging %.2f ms, H2D of %.1f MB %.2f ms\n", ms(t0, t1), scan_pool / 1e6, ms(t1, t2));
-            if (ds && !ds->imgs.empty()) {                 // compact the stuffed scans straight into the pool
+            if (timing) std::fprintf(stderr, "[mjx] staging %.2f ms, H2D of %.1f MB %.2f ms\n", ms(t0, t1), lin_pool / 1e6, ms(t1, t2));
+            if (ds && !ds->imgs.empty()) {                 // compact the stuffed scans straight into the staging buffer
                 std::vector<DestuffImg> di;
                 for (size_t j = 0; j < ds->imgs.size(); j++) {
                     if (plans[ds->plan_index[j]].status != MJX_OK) continue;
                     DestuffImg x = ds->imgs[j];
-                    x.out_off = scan_off[ds->plan_index[j]];
+                    x.out_off = lin_off[ds->plan_index[j]];
                     di.push_back(x);
                 }
                 if (!di.empty()) {
@@ -669,12 +675,34 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
                     int rc3 = MJX_OK;
                     if (hipMemcpy(d_di, di.data(), di.size() * sizeof(DestuffImg), hipMemcpyHostToDevice) != hipSuccess) rc3 = MJX_ERR_DEVICE;
                     if (rc3 == MJX_OK) {
-                        launch_destuff_scatter(ctx->stream, ds->max_seg, uint32_t(di.size()), d_di, ds->d_raw, ds->d_segbase, b->d_scan);
+                        launch_destuff_scatter(ctx->stream, ds->max_seg, uint32_t(di.size()), d_di, ds->d_raw, ds->d_segbase, d_lin);
                         if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc3 = MJX_ERR_DEVICE;
                     }
                     (void)hipFree(d_di);
                     if (rc3 != MJX_OK) return rc3;
                 }
+            }
+            {   // linear -> lane-interleaved
+                std::vector<InterleaveImg> ii;
+                uint32_t max_pieces = 0;
+                for (size_t k = 0; k < nu; k++) {
+                    const ImagePlan &p = plans[k];
+                    if (p.status != MJX_OK || p.himg.nsub == 0) continue;
+                    ii.push_back(InterleaveImg{lin_off[k], uint32_t(p.scan_len), uint32_t(k)});
+                    max_pieces = std::max<uint32_t>(max_pieces, scan_region_cols(p.himg.nsub) * scan_region_rows(p.himg.sub_bits));
+                }
+                if (!ii.empty()) {
+                    InterleaveImg *d_ii = nullptr;
+                    HIPOK(hipMalloc(&d_ii, ii.size() * sizeof(InterleaveImg)));
+                    int rc3 = MJX_OK;
+                    if (hipMemcpy(d_ii, ii.data(), ii.size() * sizeof(InterleaveImg), hipMemcpyHostToDevice) != hipSuccess) rc3 = MJX_ERR_DEVICE;
+                    for (size_t at = 0; rc3 == MJX_OK && at < ii.size(); at += 32768)
+                        launch_scan_interleave(ctx->stream, max_pieces, uint32_t(std::min<size_t>(32768, ii.size() - at)), d_ii + at, b->d_images, d_lin, b->d_scan, b->d_segs);
+                    if (rc3 == MJX_OK && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)) rc3 = MJX_ERR_DEVICE;
+                    (void)hipFree(d_ii);
+                    if (rc3 != MJX_OK) return rc3;
+                }
+                if (timing) std::fprintf(stderr, "[mjx] interleave %.2f ms\n", ms(t2, now()));
             }
             HIPOK(hipMemcpy(b->d_lut, hl.data(), hl.size() * sizeof(LutEntry), hipMemcpyHostToDevice));
             HIPOK(hipMemcpy(b->d_qm, hq.data(), hq.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1138,6 +1166,21 @@ extern "C" int mjx_batch_bytes(const mjx_batch *b, uint64_t *scan_bytes, uint64_
     }
     return MJX_OK;
     });
+}
+
+extern "C" int mjx_batch_geometry(const mjx_batch *b, uint64_t *subsequences, uint64_t *blocks, uint64_t *chunks)
+{
+    if (!b) return MJX_ERR_INVALID_ARG;
+    uint64_t ns = 0, nb = 0;
+    for (size_t i = 0; i < b->info.size(); i++) {
+        if (b->info[i].status != MJX_OK) continue;
+        ns += b->himages[i].himg.nsub;
+        if (b->info[i].role != 1) nb += b->info[i].nblocks;
+    }
+    if (subsequences) *subsequences = ns;
+    if (blocks) *blocks = nb;
+    if (chunks) *chunks = b->chunks.size();
+    return MJX_OK;
 }
 
 extern "C" int mjx_batch_kernel_ms(mjx_batch *b, double ms[MJX_K_COUNT], uint64_t launches[MJX_K_COUNT], int reset)

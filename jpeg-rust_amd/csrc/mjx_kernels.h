@@ -12,11 +12,12 @@ constexpr int kDcSegMcus = 2048;                                // MCUs per DC-p
 // One image of a chunk, as the kernels see it (HBM, read-only during decode).
 struct DevImage {
     HuffImage himg;
-    uint64_t scan_off;      // bytes into the scan pool, 16-byte aligned
+    uint64_t scan_off;      // bytes into the scan pool (256-byte aligned): the image's lane-interleaved region, see LaneBits
     uint64_t coef_off;      // blocks into the per-block arrays (dcbuf)
     uint64_t ent_off;       // entries into the compact coefficient stream pool (start of the image's region)
     uint64_t rgb_off;       // bytes into the RGB pool
-    uint32_t scan_padded;   // bytes that may be read at scan_off (multiple of 16; tail filled with 0xAA)
+    uint32_t scan_cols;     // columns of the region = subsequences rounded up to 8 (a row = scan_cols 16-byte pieces);
+                            // rows = sub_bits / 128 + kLookPieces
     uint32_t lut_off;       // entries into the decode-table pool (multiple of 4)
     uint32_t lut_n;         // entries (multiple of 4)
     uint32_t sub_off;       // index of subsequence 0 in the per-subsequence arrays
@@ -49,6 +50,18 @@ struct DevImage {
     uint32_t src_back[3], src_comp[3];
     uint32_t nparts;
     uint32_t cbw[3], cbh[3];    // role 2: block grid of each component's own scan
+};
+
+// Lane-interleaved scan pool: pieces of 16 bytes, kLookPieces of look-ahead behind every subsequence (see LaneBits).
+constexpr uint32_t kLookPieces = 4;
+MJX_HD uint32_t scan_region_cols(uint32_t nsub) { return nsub ? (nsub + 7u) & ~7u : 0u; }
+MJX_HD uint32_t scan_region_rows(uint32_t sub_bits) { return sub_bits / 128u + kLookPieces; }
+MJX_HD uint64_t scan_region_bytes(uint32_t nsub, uint32_t sub_bits) { return uint64_t(scan_region_cols(nsub)) * scan_region_rows(sub_bits) * 16u; }
+// One image of an upload for k_scan_interleave: where its linear de-stuffed scan lies in the staging buffer.
+struct InterleaveImg {
+    uint64_t lin_off;       // bytes into the linear staging buffer
+    uint32_t lin_len;       // de-stuffed scan bytes
+    uint32_t image;         // index into the DevImage array
 };
 
 // Device-side de-stuffing (jpeg/mod.rs:371-385 on the GPU): one image of an upload.
@@ -85,6 +98,8 @@ void launch_destuff_count(hipStream_t st, uint32_t max_seg, uint32_t nimg, const
                           uint32_t *segcount);
 void launch_destuff_scatter(hipStream_t st, uint32_t max_seg, uint32_t nimg, const DestuffImg *imgs, const uint8_t *raw,
                             const uint32_t *segbase, uint8_t *pool);
+void launch_scan_interleave(hipStream_t st, uint32_t max_pieces, uint32_t nimg, const InterleaveImg *imgs, const DevImage *images,
+                            const uint8_t *linear, uint8_t *pool, const uint32_t *segs);
 void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                       const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
                       uint32_t *cps, const uint32_t *segs);

@@ -27,12 +27,21 @@ namespace mjx {
 // ------------------------------------------------------------------------------------------------
 // stage A building blocks
 // ------------------------------------------------------------------------------------------------
-// The image's de-stuffed scan in HBM; bytes past the padded end read 0xAA (huffman.rs:236-246).
-struct GlobalBits {
-    const unsigned char *bytes;     // wave-uniform base: loads are `base + 32-bit lane offset`, no 64-bit address math
-    // No bounds test on the loads from it: a window is staged at most 48 bytes past the last scan byte, and every
-    // image's region in the pool ends with >= 16 bytes of 0xAA (mjx_api.hip build_batch; the pool itself has 256
-    // bytes of slack), so the padding *is* the out-of-range value for every dword a lane can decode from.
+// The image's de-stuffed scan in HBM, **lane-interleaved**: the scan is cut into the subsequences the lanes decode, every
+// subsequence into 16-byte pieces, and piece k of subsequence s lies at (k * scan_cols + s) * 16 -- row k holds piece k of
+// all subsequences side by side.  The 64 lanes of a wave advance through their subsequences at nearly the same pace, so
+// their window refills read the same row: 1 KiB of consecutive bytes, eight lines each used by eight lanes.  (With the
+// scan stored linearly a lane's 16-byte reads were 512 bytes apart from its neighbours': every lane pulled its own
+// 128-byte line through L2 four or five times, once per refill -- FETCH_SIZE was 6.3x the scan -- and waited for HBM
+// each time.)  A column carries kLookPieces more pieces than the subsequence has: a copy of the bytes that follow it
+// in the stream (0xAA past the end of the scan, huffman.rs:236-246), because a lane decodes the symbol that straddles
+// its end and stages up to 48 bytes of look-ahead.  Built once per upload by k_scan_interleave.
+// Inside the kernels all bit positions are relative to the lane's subsequence; the states kept in HBM stay relative to the scan.
+struct LaneBits {
+    const unsigned char *base;      // wave-uniform: the image's region of the pool
+    uint32_t col;                   // byte offset of the lane's column inside a row: subsequence index * 16
+    uint32_t row_stride;            // bytes per row: scan_cols * 16
+    __device__ __forceinline__ uint4 piece(uint32_t k) const { return *reinterpret_cast<const uint4 *>(base + (col + k * row_stride)); }
 };
 
 // Checkpoint words live in HBM in blocks of 256 consecutive subsequences; inside a block they are row-major by word
@@ -107,8 +116,12 @@ struct LaneRing {
             const uint4 *src = reinterpret_cast<const uint4 *>(ring + (flushed & (kRing - 1)));
             uint4 *dst = reinterpret_cast<uint4 *>(out + flushed);
             const uint4 v0 = src[0], v1 = src[GROUP / 4 - 1];
+#ifndef MJX_EXP_NOSTORE                 // (measurement builds only: what the write pass costs without its global stores)
             dst[0] = v0;
             if constexpr (GROUP == 8) dst[1] = v1;
+#else
+            asm volatile("" :: "v"(v0.x), "v"(v0.y), "v"(v0.z), "v"(v0.w), "v"(v1.x), "v"(v1.y), "v"(v1.z), "v"(v1.w), "v"(dst));
+#endif
         } else if constexpr (GROUP == 2) {
             *reinterpret_cast<uint2 *>(out + flushed) = *reinterpret_cast<const uint2 *>(ring + (flushed & (kRing - 1)));
         } else {
@@ -272,11 +285,12 @@ struct LdsWindow {
     __device__ __forceinline__ uint32_t ahead(uint32_t) const { return *(const volatile __attribute__((address_space(3))) uint32_t *)(uintptr_t(rp)); }   // (volatile: one plain read per step, not folded into the restage branch)
     __device__ __forceinline__ void advance() { rp += 4; }
 };
-__device__ __forceinline__ void window_fill(uint32_t *lds, const GlobalBits &g, uint32_t wbase)
+// wbase: byte offset inside the lane's subsequence, a multiple of 16
+__device__ __forceinline__ void window_fill(uint32_t *lds, const LaneBits &g, uint32_t wbase)
 {
 #pragma unroll
     for (int q = 0; q < kWinDwords / 4; q++) {
-        uint4 v = *reinterpret_cast<const uint4 *>(g.bytes + wbase + 16 * q);    // 4-byte aligned 16-byte load
+        const uint4 v = g.piece((wbase >> 4) + q);
         lds[4 * q] = __builtin_bswap32(v.x);
         lds[4 * q + 1] = __builtin_bswap32(v.y);
         lds[4 * q + 2] = __builtin_bswap32(v.z);
@@ -293,7 +307,7 @@ __device__ __forceinline__ void window_fill(uint32_t *lds, const GlobalBits &g, 
 //   WRITE  emit coefficients through `sink`      CP  0: none, 1: record checkpoints, 2: record + merge (see mjx_huff.h)
 template <bool WRITE, int CP, class Sink, class CpStore>
 __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry, uint32_t end_bit, uint32_t blk,
-                                                   uint32_t blk_limit, const GlobalBits &g, uint32_t *my_win, const LutEntry *lut,
+                                                   uint32_t blk_limit, const LaneBits &g, uint32_t *my_win, const LutEntry *lut,
                                                    const HuffImage &h, Sink &sink, CpStore &cps, uint32_t sub_start,
                                                    SubseqState old_exit)
 {
@@ -304,7 +318,7 @@ __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry,
     LdsWindow win;
     {
         const uint32_t first = 4u * ((entry.p + 31u) >> 5);                     // byte offset of the lane's w1
-        win = LdsWindow{win_lds, first ? first - 4u : 0u, 0u};
+        win = LdsWindow{win_lds, (first ? first - 4u : 0u) & ~15u, 0u};          // (pieces are 16 bytes)
         window_fill(my_win, g, win.wbase);
         lane_begin(st, win, h, entry);
         win.rp = win_addr + (st.wn - 4u - win.wbase);
@@ -317,8 +331,8 @@ __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry,
     uint32_t it = 1;
     while (running) {                                                          // per-lane loop: finished lanes are masked off
         if (__builtin_amdgcn_ballot_w64(win.rp >= win_end)) {                  // uniform over the active lanes: restage
-            window_fill(my_win, g, st.wn - 4u);                                // (w0, w1 are in registers; wn - 4 is read next)
-            win.rp = win_addr;
+            window_fill(my_win, g, (st.wn - 4u) & ~15u);                       // (w0, w1 are in registers; wn - 4 is read next)
+            win.rp = win_addr + ((st.wn - 4u) & 15u);
         }
         (void)symbol_step<WRITE>(st, win, lut, h, blk, sink);
         // Events (checkpoints, the end of the subsequence) are due when wn -- it only moves when the lane takes a new
@@ -355,14 +369,15 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_spec(const DevImage
     stage_tables(im, lut_pool, smem, h, lut);
     const uint32_t s = blockIdx.x * kHuffWg + threadIdx.x;
     const bool live = s < h->nsub;
-    const GlobalBits bits{scan_pool + im.scan_off};
+    const LaneBits bits{scan_pool + im.scan_off, (live ? s : 0u) * 16u, im.scan_cols * 16u};
     const SubLoc loc = locate_sub(im, *h, segs, live ? s : 0u);
-    const SubseqState e = make_state(live ? loc.start : 0u, 0, 0);
+    const SubseqState e = make_state(0, 0, 0);                              // (positions relative to the subsequence)
     NullSink sink;
     GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + (live ? s : 0u)), 0};
-    const SubseqState x = wave_decode<false, 1>(live, e, live ? loc.end : 0u, 0, 0xffffffffu, bits, s_win + threadIdx.x * kWinStride, lut, *h, sink, cps, loc.start, e);
+    SubseqState x = wave_decode<false, 1>(live, e, live ? loc.end - loc.start : 0u, 0, 0xffffffffu, bits, s_win + threadIdx.x * kWinStride, lut, *h, sink, cps, 0u, e);
     if (!live) return;
-    g_entry[im.sub_off + s] = e;
+    x.p += loc.start;
+    g_entry[im.sub_off + s] = make_state(loc.start, 0, 0);
     g_exit[im.sub_off + s] = x;
 }
 
@@ -382,7 +397,7 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_spec(const DevImage
 // LDS (and with it the CU's occupancy) for a single wave's worth of work.  So k_huff_merge runs kHeadSlices slices and
 // appends what is still unfinished to a per-image list in HBM; k_huff_merge_tail picks the lists up with one-wave
 // workgroups (ten per CU) and runs every item to its end.
-constexpr int kMergeWin = 12, kMergeStride = kMergeWin + 1, kItemDwords = 6;
+constexpr int kMergeWin = 16, kMergeStride = kMergeWin + 1, kItemDwords = 6;    // four pieces: a slice touches < 56 bytes from a 16-byte boundary
 #ifndef MJX_HEAD_SLICES
 #define MJX_HEAD_SLICES 6
 #endif
@@ -392,20 +407,22 @@ struct MergeItem { uint32_t s, p, zc, n, m, k; };
 // One slice of one item: decode from (p, z, c) to the next checkpoint boundary (or the end of the subsequence).
 // Returns true when the item is finished (its exit and checkpoints are final), false when `it` holds the progress.
 __device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, const HuffImage &h, const LutEntry *lut,
-                                            const unsigned char *bytes, uint32_t *my_win, const SubseqState *g_exit,
+                                            const unsigned char *region, uint32_t *my_win, const SubseqState *g_exit,
                                             uint32_t *g_cps, SubseqState &x, const uint32_t *segs)
 {
     const SubLoc loc = locate_sub(im, h, segs, it.s);
-    const uint32_t sub_start = loc.start, end_bit = loc.end;
+    const uint32_t sub_start = loc.start, end_bit = loc.end - loc.start;       // (the lane works relative to its subsequence)
     const GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + it.s), 0};
     bool fin = false;
     x = make_state(it.p, it.zc & 0xffu, it.zc >> 8, it.n, it.m);
-    if (it.p <= end_bit) {                                         // (else nothing starts inside s)
+    const uint32_t pl = it.p - sub_start;
+    if (it.p >= sub_start && pl <= end_bit) {                      // (else nothing starts inside s)
         const uint32_t old_word = it.k < uint32_t(kMaxCp) ? cps.get_plain(it.k) : 0u;   // requested early
-        const uint32_t wi1 = (it.p + 31u) >> 5, wbase = wi1 ? 4u * wi1 - 4u : 0u;
+        const uint32_t wi1 = (pl + 31u) >> 5, wbase = (wi1 ? 4u * wi1 - 4u : 0u) & ~15u;
+        const LaneBits bits{region, it.s * 16u, im.scan_cols * 16u};
 #pragma unroll
         for (int q = 0; q < kMergeWin / 4; q++) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(bytes + wbase + 16 * q);
+            const uint4 v = bits.piece((wbase >> 4) + q);
             my_win[4 * q] = __builtin_bswap32(v.x);
             my_win[4 * q + 1] = __builtin_bswap32(v.y);
             my_win[4 * q + 2] = __builtin_bswap32(v.z);
@@ -413,19 +430,19 @@ __device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, c
         }
         LdsWindow win{reinterpret_cast<const unsigned char *>(my_win), wbase, 0u};
         LaneState st;
-        lane_begin(st, win, h, x);
+        lane_begin(st, win, h, make_state(pl, it.zc & 0xffu, it.zc >> 8));
         win.rp = uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)(my_win))) + (st.wn - 4u - wbase);
         st.n = it.n;
         lane_add_m(st, it.m);
         const uint32_t end_wn = wn_after(end_bit);
-        uint32_t stop_wn = wn_after(sub_start + (it.k + 1) * kCpBits);
+        uint32_t stop_wn = wn_after((it.k + 1) * kCpBits);
         stop_wn = stop_wn < end_wn ? stop_wn : end_wn;
         uint32_t blk = 0;
         NullSink sink;
         while (st.wn < stop_wn) (void)symbol_step<false>(st, win, lut, h, blk, sink);
         if (st.wn >= end_wn) {                                     // left the subsequence without merging
             fin = true;
-            x = make_state(lane_pos(st), lane_z(st), lane_c(st, h), st.n, lane_m(st));
+            x = make_state(lane_pos(st) + sub_start, lane_z(st), lane_c(st, h), st.n, lane_m(st));
         } else {
             const uint32_t state = cp_state_word(st);
             if ((old_word & kCpStateMask) == state) {              // met the previous decode's path
@@ -436,7 +453,7 @@ __device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, c
             } else {
                 cps.set(it.k, state | (st.n << 16), lane_m(st));
                 it.k++;
-                it.p = lane_pos(st);
+                it.p = lane_pos(st) + sub_start;
                 it.zc = lane_z(st) | (lane_c(st, h) << 8);
                 it.n = st.n;
                 it.m = lane_m(st);
@@ -497,7 +514,7 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
         const unsigned long long mm = __ballot(active);
         if (lane == 0 && mm) atomicAdd(mismatches, uint32_t(__popcll(mm)));
     }
-    const unsigned char *bytes = scan_pool + im.scan_off;
+    const unsigned char *bytes = scan_pool + im.scan_off;          // the image's (lane-interleaved) region
     uint32_t *my_win = s_win + tid * kMergeStride;
     for (int slice = 0;; slice++) {
         if (active) {
@@ -675,6 +692,39 @@ extern "C" __global__ __launch_bounds__(256) void k_destuff_scatter(const Destuf
     for (uint32_t i = threadIdx.x; i < total; i += 256) dst[i] = s_out[i];
 }
 
+// ---- lane-interleaved scan pool (see LaneBits) --------------------------------------------------------------------
+// One lane per 16-byte piece of the region: piece (row k, column s) = bytes [start_s + 16 k, + 16) of the linear
+// de-stuffed scan, where start_s is the first byte of subsequence s; 0xAA where the scan has ended (huffman.rs:236-246)
+// and in the padding columns.  Writes are fully coalesced; the reads of a wave are 64 pieces a subsequence apart, each
+// line is read by eight waves of the launch (L2 absorbs that).  Runs once per upload, before any decode.
+extern "C" __global__ __launch_bounds__(256) void k_scan_interleave(const InterleaveImg *imgs, const DevImage *images,
+                                                                     const uint8_t *linear, uint8_t *pool, const uint32_t *segs)
+{
+    const InterleaveImg ii = imgs[blockIdx.y];
+    const DevImage &im = images[ii.image];
+    const uint32_t cols = im.scan_cols, rows = scan_region_rows(im.himg.sub_bits);
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= cols * rows) return;
+    const uint32_t k = q / cols, s = q % cols;
+    uint32_t w[4] = {0xaaaaaaaau, 0xaaaaaaaau, 0xaaaaaaaau, 0xaaaaaaaau};
+    if (s < im.himg.nsub) {
+        const SubLoc loc = locate_sub(im, im.himg, segs, s);
+        const uint64_t at = uint64_t(loc.start >> 3) + 16u * k;              // (subsequences start on byte boundaries)
+        const uint8_t *src = linear + ii.lin_off;
+        if (at + 16 <= ii.lin_len && ((ii.lin_off + at) & 3u) == 0) {
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(src + at);
+            w[0] = p[0]; w[1] = p[1]; w[2] = p[2]; w[3] = p[3];
+        } else if (at < ii.lin_len) {
+#pragma unroll
+            for (uint32_t j = 0; j < 16; j++) {
+                const uint32_t b = at + j < ii.lin_len ? src[at + j] : 0xaau;
+                w[j >> 2] = (w[j >> 2] & ~(0xffu << ((j & 3) * 8))) | (b << ((j & 3) * 8));
+            }
+        }
+    }
+    *reinterpret_cast<uint4 *>(pool + im.scan_off + uint64_t(q) * 16u) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // blkbase[s] / ebase[s] = blocks completed / stream entries produced before subsequence s (one workgroup per image).
 // A subsequence's run of stream entries is rounded up to whole store groups (the write pass fills up with null entries).
 extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *images, const SubseqState *g_exit,
@@ -751,16 +801,19 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
     const LutEntry *lut;
     stage_tables(im, lut_pool, smem, h, lut);
     const uint32_t s = blockIdx.x * kHuffWg + threadIdx.x;
-    const GlobalBits gbits{scan_pool + im.scan_off};
     const bool live = s < h->nsub;
+    const LaneBits gbits{scan_pool + im.scan_off, (live ? s : 0u) * 16u, im.scan_cols * 16u};
     SubseqState e = make_state(0, 0, 0);
     uint32_t blk = 0, end_bit = 0, ebase = 0, blk_limit = h->total_blocks, pad_to = 0;
+    bool live_entry = false;
     if (live) {
         const SubLoc loc = locate_sub(im, *h, segs, s);
         e = g_entry[im.sub_off + s];
+        live_entry = e.p >= loc.start;                                     // (always, once the rounds have converged)
+        e.p -= loc.start;                                                  // the lane works relative to its subsequence
         blk = g_blkbase[im.sub_off + s];
         ebase = g_ebase[im.sub_off + s];
-        end_bit = loc.end;
+        end_bit = loc.end - loc.start;
         if (im.nseg > 1) {
             // blocks are counted from the segment's first one (restart_mcus MCUs per segment); the lane stops at the
             // segment's last block
@@ -795,7 +848,7 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
         sink.next_tile_blk = sink.tile_idx * im.tile_blocks;
     }
     NoCheckpoints nocp;
-    wave_decode<true, 0>(live, e, end_bit, blk, blk_limit, gbits, s_win + threadIdx.x * kWinStride, lut, *h, sink, nocp, 0, e);
+    wave_decode<true, 0>(live && live_entry, e, end_bit, blk, blk_limit, gbits, s_win + threadIdx.x * kWinStride, lut, *h, sink, nocp, 0, e);
     sink.flush_groups();                                                   // (the rings hold one flush period, no more)
     for (uint32_t it = 1; __builtin_amdgcn_ballot_w64(sink.ac_ring.off < pad_to); it++) {
         if (sink.ac_ring.off < pad_to) sink.ac_ring.push(0u);              // null entry
@@ -1764,6 +1817,13 @@ void launch_destuff_scatter(hipStream_t st, uint32_t max_seg, uint32_t nimg, con
                             const uint32_t *segbase, uint8_t *pool)
 {
     hipLaunchKernelGGL(k_destuff_scatter, dim3(max_seg, nimg), dim3(256), 0, st, imgs, raw, segbase, pool);
+}
+
+void launch_scan_interleave(hipStream_t st, uint32_t max_pieces, uint32_t nimg, const InterleaveImg *imgs, const DevImage *images,
+                            const uint8_t *linear, uint8_t *pool, const uint32_t *segs)
+{
+    if (max_pieces == 0 || nimg == 0) return;
+    hipLaunchKernelGGL(k_scan_interleave, dim3((max_pieces + 255) / 256, nimg), dim3(256), 0, st, imgs, images, linear, pool, segs);
 }
 
 void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,

@@ -159,14 +159,14 @@ def small_dc_table(max_size=8):
     return bits, list(range(max_size + 1))
 
 
-def random_symbol_stream(rng, nsymbols, dc_tab, ac_tab, p_dc=0.12):
+def random_symbol_stream(rng, nsymbols, dc_tab, ac_tab, p_dc=0.12, max_size=15):
     """Random *valid codes* with random value bits, written with no regard to block structure: DC-table codes are only
     valid where the decoder expects them, so the stream is produced by simulating the decoder's table choice --
     src/jpeg/huffman.rs:146-195 semantics: first symbol of a block from the DC table, then AC symbols until 64 coefficients
     are produced (EOB fills up; ZRL and runs are clamped, Q9).  Returns the stuffed bytes and the number of whole blocks."""
     dcc, acc = huff_codes(*dc_tab), huff_codes(*ac_tab)
-    dc_syms, ac_syms = list(dcc), list(acc)
-    w, blocks, z = BitWriter(), 0, 0
+    dc_syms, ac_syms = [s for s in dcc if s <= max_size], [s for s in acc if (s & 15) <= max_size]    # (small values: the
+    w, blocks, z = BitWriter(), 0, 0                               # samples stay in range and the RGB comparison means something)
     for _ in range(nsymbols):
         if z == 0:
             s = dc_syms[int(rng.integers(len(dc_syms)))]
@@ -191,3 +191,66 @@ def random_symbol_stream(rng, nsymbols, dc_tab, ac_tab, p_dc=0.12):
             z = 0
             blocks += 1
     return w.flush(), blocks
+
+
+# ---- non-interleaved twins of interleaved files, without Pillow (tests/golden/make_multiscan.py is the checked version) ---
+def _fast_encode_blocks(blocks, dc_codes, ac_codes):
+    """encode_blocks for one component, touching only the non-zero coefficients (a 4K picture has 200 000 blocks)."""
+    w, pred = BitWriter(), 0
+    nzr, nzc = np.nonzero(blocks[:, 1:])
+    starts = np.searchsorted(nzr, np.arange(blocks.shape[0] + 1))
+    for k in range(blocks.shape[0]):
+        blk = blocks[k]
+        s, bits = magnitude(int(blk[0]) - pred)
+        pred = int(blk[0])
+        w.put(*dc_codes[s])
+        w.put(bits, s)
+        prev = 0
+        cols = nzc[starts[k]:starts[k + 1]] + 1
+        for i in cols:
+            run = int(i) - prev - 1
+            while run > 15:
+                w.put(*ac_codes[0xf0])
+                run -= 16
+            s, bits = magnitude(int(blk[i]))
+            w.put(*ac_codes[(run << 4) | s])
+            w.put(bits, s)
+            prev = int(i)
+        if prev < 63:
+            w.put(*ac_codes[0x00])
+    return w.flush()
+
+
+def noninterleaved_twin(data, ref):
+    """One scan per component, blocks in raster order over the component's own block grid (T.81 A.2.2), from the quantised
+    coefficients `ref` (oracle decode of `data`, STANDARD layout).  Same coefficients, same picture."""
+    comps, dht, sos_comp, sos_at, i = [], {}, [], None, 2
+    while True:
+        m = data[i + 1]
+        ln = struct.unpack(">H", data[i + 2:i + 4])[0]
+        p = data[i + 4:i + 2 + ln]
+        if m == 0xc0:
+            H, W, n = struct.unpack(">HH", p[1:5]) + (p[5],)
+            comps = [(p[6 + 3 * c], p[7 + 3 * c] >> 4, p[7 + 3 * c] & 15) for c in range(n)]
+        elif m == 0xda:
+            sos_comp = [(p[1 + 2 * c], p[2 + 2 * c] >> 4, p[2 + 2 * c] & 15) for c in range(p[0])]
+            sos_at = i
+            break
+        i += 2 + ln
+    for key, (bits, vals) in tables_from_jpeg(data).items():
+        dht[key] = huff_codes(bits, vals)
+    assert len(comps) == 3 and [c[0] for c in sos_comp] == [c[0] for c in comps]
+    hmax, vmax = max(c[1] for c in comps), max(c[2] for c in comps)
+    mcux = (W + 8 * hmax - 1) // (8 * hmax)
+    out = bytearray(data[:sos_at])
+    for c, (cid, h, v) in enumerate(comps):
+        bw = ((W * h + hmax - 1) // hmax + 7) // 8
+        bh = ((H * v + vmax - 1) // vmax + 7) // 8
+        mc = ref.coefs[c].reshape(ref.mcus, v, h, 64)
+        yy, xx = np.mgrid[0:bh, 0:bw]
+        raster = mc[(yy // v) * mcux + (xx // h), yy % v, xx % h].reshape(-1, 64)
+        _, td, ta = sos_comp[c]
+        out += bytes([0xff, 0xda, 0, 8, 1, cid, (td << 4) | ta, 0, 63, 0])
+        out += _fast_encode_blocks(raster, dht[(0, td)], dht[(1, ta)])
+    out += b"\xff\xd9"
+    return bytes(out)

@@ -1,0 +1,92 @@
+"""Batch-scale GPU tests (pytest -m gpu): the sizes BASELINE.json quotes, verified byte by byte on the device.
+
+The round-1 numbers rested on status codes; these tests look at every output byte of the full-size batches:
+  * BASELINE config 4 (4096 x 1080p) and config 5's per-GPU share (2048 x 4K): every picture of the tiled batch equals its
+    unique original bit for bit (mjx_batch_compare_rgb, on the device), and originals are checked against the CPU oracle
+    (coefficients equal, RGB within 1)
+  * a multi-scan 4K picture tiled x1024, with and without kept coefficients: the chunk's stream offsets pass 2^32 entries
+    (the 64 -> 32 bit truncation the round-1 review found in k_planar_copy); every copy must equal the first, which must
+    equal the interleaved twin's picture
+  * idempotence at full size: a second decode of the same batch gives the same bytes
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1
+
+
+def _unique_batch(mjx, orc, ctx, datas, n_oracle):
+    scans = [mjx.ParsedScan(d) for d in datas]
+    base = mjx.Batch(ctx, scans, keep_coefs=True)
+    assert all(s == mjx.OK for s in base.create_status)
+    base.decode()
+    base.wait()
+    for i in range(0, len(datas), max(1, len(datas) // n_oracle)):
+        ref = orc.decode(datas[i], layout=orc.LAYOUT_STD)
+        assert base.status(i) == mjx.OK
+        assert np.array_equal(base.coefs(i), orc.interleave(ref)), "T0 differs on unique image %d" % i
+        assert np.abs(base.rgb(i).astype(np.int16) - ref.rgb.astype(np.int16)).max() <= TOL, i
+    return base, scans
+
+
+def _check_tiled_against_base(mjx, big, base, period):
+    n = len(big)
+    assert all(big.status(i) == mjx.OK for i in range(0, n, 37))
+    mx, cnt = big.compare_rgb(list(range(n)), base, [i % period for i in range(n)])
+    assert int(mx.max()) == 0 and int(cnt.sum()) == 0, "pictures %s differ from their originals" % np.nonzero(mx)[0][:8].tolist()
+
+
+@pytest.mark.parametrize("w,h,count,unique", [(1920, 1080, 4096, 64), (3840, 2160, 2048, 64)])
+def test_full_size_batches_equal_their_originals_byte_for_byte(mjx, orc, gpu_ctx, w, h, count, unique):
+    """BASELINE.json configs[3] (4096 x 1080p on one GPU) and configs[4]'s per-GPU share (2048 x 4K)."""
+    datas = mjx.synth_batch(unique, w, h, "420", 75)
+    base, scans = _unique_batch(mjx, orc, gpu_ctx, datas, n_oracle=4)
+    big = base.tile(count // unique)
+    assert len(big) == count
+    big.decode()
+    big.wait()
+    assert big.geometry()["chunks"] >= (2 if w == 3840 else 1)           # (the 4K batch spans several kernel chunks)
+    _check_tiled_against_base(mjx, big, base, unique)
+    big.decode()                                                         # idempotence at full size
+    big.wait()
+    _check_tiled_against_base(mjx, big, base, unique)
+    # the compare helper itself: a picture against a different one must not come out equal
+    mx, cnt = big.compare_rgb([0, 1], base, [1, 1])
+    assert mx[0] > 0 and cnt[0] > 0 and mx[1] == 0
+    big.close()
+    base.close()
+
+
+@pytest.mark.parametrize("keep", [False, True])
+def test_multi_scan_4k_pictures_past_2_to_32_stream_entries(mjx, orc, gpu_ctx, keep):
+    """1024 copies of a non-interleaved 4K picture: three scans + the gathered picture reserve ~7.5 M stream entries per
+    copy, so the offsets inside a chunk (and, with kept coefficients, inside the batch-wide pool) pass 2^32.  Every copy's
+    picture must equal the first copy's, and that one the interleaved twin's."""
+    import jpegwriter as jw
+    src = mjx.synth_jpeg(3840, 2160, "420", 75, seed=5)
+    ref = orc.decode(src, layout=orc.LAYOUT_STD)
+    ms = jw.noninterleaved_twin(src, ref)
+    s_src, s_ms = mjx.ParsedScan(src), mjx.ParsedScan(ms)
+    assert s_ms.desc.n_parts == 3
+    base = mjx.Batch(gpu_ctx, [s_src, s_ms], keep_coefs=True)
+    base.decode()
+    base.wait()
+    assert base.status(0) == mjx.OK and base.status(1) == mjx.OK
+    assert np.abs(base.rgb(0).astype(np.int16) - ref.rgb.astype(np.int16)).max() <= TOL
+    mx, _ = base.compare_rgb([1], base, [0])
+    assert mx[0] == 0                                                    # same coefficients, same picture
+    one = mjx.Batch(gpu_ctx, [s_ms], keep_coefs=keep)
+    big = one.tile(1024)
+    assert len(big) == 1024
+    big.decode()
+    big.wait()
+    assert all(big.status(i) == mjx.OK for i in range(1024))
+    mx, cnt = big.compare_rgb(list(range(1024)), base, [0] * 1024)
+    bad = np.nonzero(mx)[0]
+    assert bad.size == 0, "copies %s (of 1024) differ from the picture: max diff %d" % (bad[:8].tolist(), int(mx.max()))
+    big.close()
+    one.close()
+    base.close()

@@ -430,7 +430,7 @@ def test_emulated_decode_of_semantically_corrupt_streams_equals_the_oracle(mjx, 
         assert rc == 0 and np.array_equal(coefs, flat), (mode, st)
 
 
-def _corrupt_stream_file(jw, w, h, comps, seed):
+def _corrupt_stream_file(jw, w, h, comps, seed, max_size=15, qmax=40):
     rng = np.random.default_rng(seed)
     dc_tab, ac_tab = jw.small_dc_table(8), jw.full_ac_table()
     frame = {"420": [(1, 2, 2, 0, 0, 0), (2, 1, 1, 0, 0, 0), (3, 1, 1, 0, 0, 0)],
@@ -438,7 +438,7 @@ def _corrupt_stream_file(jw, w, h, comps, seed):
     hmax, vmax = max(c[1] for c in frame), max(c[2] for c in frame)
     nmcu = -(-w // (8 * hmax)) * -(-h // (8 * vmax))
     need = nmcu * sum(c[1] * c[2] for c in frame) if len(frame) > 1 else -(-w // 8) * -(-h // 8)
-    ent, blocks = jw.random_symbol_stream(rng, need * 40, dc_tab, ac_tab)
+    ent, blocks = jw.random_symbol_stream(rng, need * 40, dc_tab, ac_tab, max_size=max_size)
     assert blocks > need + 8
-    qt = [int(v) for v in rng.integers(1, 40, 64)]
+    qt = [int(v) for v in rng.integers(1, qmax, 64)]
     return jw.write_jpeg(w, h, frame, {0: qt}, {(0, 0): dc_tab, (1, 0): ac_tab}, ent), need
