@@ -56,7 +56,7 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2], help="HIP streams of the context (0 = library default); with 2, "
                     "stage B of one chunk overlaps stage A of the next and per-kernel times include the contention")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU baseline (0 = every host core)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU baseline (0 = every core the job may use: affinity mask capped by the cgroup quota)")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs and e2e_from_bytes (main line only)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle legs of the parity gate (the on-device check stays)")
     ap.add_argument("--parity-images", type=int, default=4, help="pictures of the timed batch checked against the CPU oracle")
@@ -136,13 +136,36 @@ def cpu_model():
     return "unknown"
 
 
+def usable_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes show 256
+    logical CPUs but run the job under a 16-CPU quota; threads beyond the quota only add contention)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def cpu_baseline(datas, width, height, threads, keep_rgb):
     """The reference's algorithm restated in C (oracle/, kind "port"), bug-compatible layout, cosf per term and linear-search
     Huffman like the Rust code: one picture per thread on every host core, then one picture on one core.  Returns the JSON
     object and the first `keep_rgb` pictures (for the REF_COMPAT leg of the parity gate)."""
     import oracle_binding as orc
     cores = os.cpu_count() or 1
-    threads = max(1, min(threads or cores, 1024))
+    usable, quota = usable_cores()
+    threads = max(1, min(threads or usable, 1024))
     sample = [datas[i % len(datas)] for i in range(threads)]
     shapes = [(height, width)] * keep_rgb + [(1, 1)] * (len(sample) - keep_rgb)       # (RGB kept for the first few only)
     t = time.perf_counter()
@@ -155,11 +178,12 @@ def cpu_baseline(datas, width, height, threads, keep_rgb):
     out = {
         "value": round(px / dt / 1e6, 4), "unit": "Mpixels/s", "cores": threads, "kind": "port",
         "one_core": {"value": round(px1 / dt1 / 1e6, 4), "unit": "Mpixels/s", "cores": 1, "seconds": round(dt1, 2)},
-        "host": {"nproc": cores, "cpu_model": cpu_model()},
-        "sample": "%d pictures of the same %dx%d batch, one per thread on %d threads (host: %d cores), reference algorithm restated "
+        "host": {"nproc": cores, "cpu_model": cpu_model(), "usable_cores": usable, "cgroup_cpu_quota": quota},
+        "sample": "%d pictures of the same %dx%d batch, one per thread on %d threads = every core the job may use (host: %d logical "
+                  "CPUs, cgroup quota %s), reference algorithm restated "
                   "in C (oracle/: O(n^4) float IDCT with cosf per term, linear-search Huffman, the reference's own layout; "
                   "gcc -O2 -ffp-contract=off) -- not the Rust binary, which cannot be built here; %d decoded ok in %.1f s; "
-                  "then 1 picture on 1 thread in %.1f s" % (len(sample), width, height, threads, cores, ok, dt, dt1),
+                  "then 1 picture on 1 thread in %.1f s" % (len(sample), width, height, threads, cores, quota, ok, dt, dt1),
     }
     return out, [rgbs[i] for i in range(min(keep_rgb, len(rgbs))) if st[i] == 0], sample[:keep_rgb]
 

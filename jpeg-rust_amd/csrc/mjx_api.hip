@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <memory>
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +21,7 @@
 #include <new>
 #include <stdexcept>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 using namespace mjx;
@@ -51,8 +53,19 @@ static int guarded(F &&body) noexcept
 struct mjx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;  // odd chunks run here (MJX_STREAMS=2): one chunk's stage B overlaps the next one's stage A
-    int nstreams = 1;
+    hipStream_t stream2 = nullptr;  // stage B runs here, the entropy stage on `stream` (MJX_STREAMS=1: everything on `stream`), see run_chunk
+    hipStream_t upload = nullptr;   // H2D of the compressed scans + the upload-time kernels (de-stuffing, interleaving): a stream of
+                                    // its own, so that the upload of one group of files overlaps the decode of the group before
+    // Device blocks of released batches, kept for the next ones: giving tens of gigabytes back to the driver and asking for
+    // them again cost 2.6 s per mjx_decode_batch call of 2048 4K files (and hipFree synchronises the device).  At most
+    // `cache_limit` bytes are kept (MJX_CACHE_GB, default 96; 0 = off); mjx_ctx_destroy releases them.
+    std::mutex cache_mu;
+    std::vector<std::pair<uint8_t *, size_t>> cache;
+    size_t cache_bytes = 0, cache_limit = size_t(96) << 30;
+    uint8_t *pin_small = nullptr;   // pinned block for the host mirrors of the groups' small pools (mjx_decode_batch)
+    size_t pin_small_cap = 0;
+    std::mutex batch_mu;            // mjx_decode_batch: one call at a time per context (the pinned arena is shared state)
+    int nstreams = 2;
     bool profiling = false;
     // mjx_decode_batch: pinned arena the files of a call are de-stuffed into; kept between calls (fresh pages cost ~0.35 us
     // per KB to fault in and unmap again -- four times the parsing itself), released with the context
@@ -62,6 +75,7 @@ struct mjx_ctx {
                                    // behind an empty one leave at once)
     // Extra dynamic LDS per entropy kernel = occupancy caps for experiments (MJX_SPEC/MERGE/WRITE_LDS_PAD); 0 in production.
     size_t spec_lds_pad = 0, merge_lds_pad = 0, write_lds_pad = 0;
+    size_t configured_huff = 0, configured_idct = 0;   // dynamic-LDS limits the kernels were last configured for
 };
 
 namespace {
@@ -93,6 +107,31 @@ struct Chunk {
     bool has_gather = false;       // holds multi-scan pictures (k_planar_gather runs)
 };
 
+// All device buffers of a batch come out of ONE allocation: the layout code runs twice, first measuring, then handing out
+// slices.  (A batch needs ~30 buffers; 30 hipMalloc calls cost more than planning and enqueuing a group of 48 files.)
+struct DevArena {
+    uint8_t *base = nullptr;
+    size_t off = 0;
+    bool measuring = true;
+    std::vector<void *> *separate = nullptr;     // debugging (MJX_NO_ARENA): one hipMalloc per buffer, as before
+    template <class T>
+    void take(T **p, size_t bytes)
+    {
+        bytes = (std::max<size_t>(bytes, 1) + 255) / 256 * 256;
+        if (!measuring) {
+            if (separate) {
+                void *q = nullptr;
+                (void)hipMalloc(&q, bytes);
+                separate->push_back(q);
+                *p = reinterpret_cast<T *>(q);
+            } else {
+                *p = reinterpret_cast<T *>(base + off);
+            }
+        }
+        off += bytes;
+    }
+};
+
 struct EventPair {
     hipEvent_t a, b;
     int kind;
@@ -111,6 +150,28 @@ struct mjx_batch {
     DevImage *d_images = nullptr;
     uint8_t *d_scan = nullptr;
     size_t scan_pool_bytes = 0;
+    // upload state: the linear staging buffer and the host-side copies of the small pools stay alive until the batch is
+    // released (an asynchronous upload reads them after build_batch has returned; hipFree would synchronise the device)
+    std::vector<void *> separate_allocs;
+    size_t arena_bytes = 0;
+    uint8_t *arena = nullptr;           // the one device allocation every d_* pointer below points into (see DevArena)
+    bool h_mismatch_owned = true;
+    uint8_t *d_lin = nullptr;
+    void *d_ii = nullptr;
+    size_t lut_pool_entries = 0;        // entries of the decode-table pool (identical tables stored once)
+    void *d_meta_end = nullptr;         // [d_images, d_meta_end): the small pools, uploaded in one transfer
+    std::vector<unsigned char> h_meta;  // ... from this host block, unless the caller lent pinned memory
+    std::vector<LutEntry> h_lut;
+    std::vector<float> h_qm;
+    std::vector<unsigned char> h_ii;
+    hipEvent_t ev_entropy[2] = {nullptr, nullptr}, ev_pixels[2] = {nullptr, nullptr};   // per scratch set, see run_chunk
+    bool entropy_recorded[2] = {false, false}, pixels_recorded[2] = {false, false};
+    hipEvent_t uploaded = nullptr;      // recorded on ctx->upload behind the last upload command; the decode streams wait for it
+    bool upload_pending = false;
+    // mjx_decode_batch decodes its files in groups (upload of one group overlaps the decode of the one before): the batch
+    // handed to the caller is then only a directory of the groups' batches
+    std::vector<mjx_batch *> parts;
+    std::vector<std::pair<uint32_t, uint32_t>> part_index;     // caller's picture -> (part, picture inside the part)
     LutEntry *d_lut = nullptr;
     float *d_qm = nullptr;
     uint32_t *d_segs = nullptr;         // restart segments of the unique images: (first subsequence, first bit) pairs
@@ -162,25 +223,68 @@ constexpr uint32_t kTilesPerWgHost = 8;       // must equal kTilesPerWg in mjx_k
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// One device block of at least `bytes`: a cached one of fitting size (at most 1.5x what is asked for), or a new allocation.
+int arena_get(mjx_ctx *ctx, size_t bytes, uint8_t **out, size_t *got)
+{
+    {
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        size_t best = ctx->cache.size();
+        for (size_t k = 0; k < ctx->cache.size(); k++)
+            if (ctx->cache[k].second >= bytes && ctx->cache[k].second <= bytes + bytes / 2 + (size_t(1) << 20) &&
+                (best == ctx->cache.size() || ctx->cache[k].second < ctx->cache[best].second))
+                best = k;
+        if (best != ctx->cache.size()) {
+            *out = ctx->cache[best].first;
+            *got = ctx->cache[best].second;
+            ctx->cache_bytes -= ctx->cache[best].second;
+            ctx->cache.erase(ctx->cache.begin() + long(best));
+            return MJX_OK;
+        }
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        {   // out of memory with blocks in the cache: give them back and try once more
+            std::lock_guard<std::mutex> lk(ctx->cache_mu);
+            for (auto &blk : ctx->cache) (void)hipFree(blk.first);
+            ctx->cache.clear();
+            ctx->cache_bytes = 0;
+        }
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return MJX_ERR_NOMEM; }
+    }
+    *out = static_cast<uint8_t *>(p);
+    *got = bytes;
+    return MJX_OK;
+}
+void arena_put(mjx_ctx *ctx, uint8_t *p, size_t bytes)
+{
+    if (!p) return;
+    if (ctx) {
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        if (ctx->cache_bytes + bytes <= ctx->cache_limit) {
+            ctx->cache.emplace_back(p, bytes);
+            ctx->cache_bytes += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
 void release(mjx_batch *b)
 {
     if (!b) return;
+    for (mjx_batch *part : b->parts) release(part);
     if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    if (b->uploaded) (void)hipEventDestroy(b->uploaded);
+    for (int k = 0; k < 2; k++) {
+        if (b->ev_entropy[k]) (void)hipEventDestroy(b->ev_entropy[k]);
+        if (b->ev_pixels[k]) (void)hipEventDestroy(b->ev_pixels[k]);
+    }
     for (auto &e : b->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : b->event_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    (void)hipFree(b->d_images); (void)hipFree(b->d_scan); (void)hipFree(b->d_lut); (void)hipFree(b->d_qm); (void)hipFree(b->d_segs);
-    (void)hipFree(b->d_entry); (void)hipFree(b->d_exit); (void)hipFree(b->d_blkbase);
-    (void)hipFree(b->d_entries); (void)hipFree(b->d_tile_eoff); (void)hipFree(b->d_ebase); (void)hipFree(b->d_img_entries); (void)hipFree(b->d_img_flags);
-    (void)hipFree(b->d_dc); (void)hipFree(b->d_rgb); (void)hipFree(b->d_status);
-    (void)hipFree(b->d_planes);
-    (void)hipFree(b->d_mismatch); (void)hipFree(b->d_segsum); (void)hipFree(b->d_cps); (void)hipFree(b->d_pull); (void)hipFree(b->d_items);
-    if (b->dual) {
-        (void)hipFree(b->alt.d_entry); (void)hipFree(b->alt.d_exit); (void)hipFree(b->alt.d_blkbase); (void)hipFree(b->alt.d_ebase);
-        (void)hipFree(b->alt.d_cps); (void)hipFree(b->alt.d_pull); (void)hipFree(b->alt.d_items); (void)hipFree(b->alt.d_segsum);
-        (void)hipFree(b->alt.d_planes);
-        if (!b->opts.keep_coefs) { (void)hipFree(b->alt.d_entries); (void)hipFree(b->alt.d_tile_eoff); (void)hipFree(b->alt.d_dc); }
-    }
-    if (b->h_mismatch) (void)hipHostFree(b->h_mismatch);
+    arena_put(b->ctx, b->arena, b->arena_bytes);            // every other device pointer of the batch is a slice of it
+    for (void *q : b->separate_allocs) (void)hipFree(q);
+    if (b->h_mismatch && b->h_mismatch_owned) (void)hipHostFree(b->h_mismatch);
     delete b;
 }
 
@@ -301,7 +405,7 @@ void plan_chunks(mjx_batch *b)
     }
 }
 
-int allocate_work_buffers(mjx_batch *b)
+int allocate_work_buffers(mjx_batch *b, DevArena &ar)
 {
     uint32_t max_nsub = 1;
     uint64_t max_blocks = 1, total_blocks = 0, max_entries = 4, total_entries = 0;
@@ -321,59 +425,62 @@ int allocate_work_buffers(mjx_batch *b)
         max_tile_blocks = std::max(max_tile_blocks, c.max_tile_blocks);
     }
     const uint64_t coef_blocks = b->opts.keep_coefs ? std::max<uint64_t>(total_blocks, 1) : max_blocks;
-    HIPOK(hipMalloc(&b->d_entry, size_t(max_nsub) * sizeof(SubseqState)));
-    HIPOK(hipMalloc(&b->d_exit, size_t(max_nsub) * sizeof(SubseqState)));
-    HIPOK(hipMalloc(&b->d_blkbase, size_t(max_nsub) * sizeof(uint32_t)));
-    HIPOK(hipMalloc(&b->d_cps, (size_t(max_nsub) + 256) / 256 * 256 * kMaxCp * 2 * sizeof(uint32_t)));
+    ar.take(&b->d_entry, size_t(max_nsub) * sizeof(SubseqState));
+    ar.take(&b->d_exit, size_t(max_nsub) * sizeof(SubseqState));
+    ar.take(&b->d_blkbase, size_t(max_nsub) * sizeof(uint32_t));
+    ar.take(&b->d_cps, (size_t(max_nsub) + 256) / 256 * 256 * kMaxCp * 2 * sizeof(uint32_t));
     size_t max_imgs = 1;
     for (const Chunk &c : b->chunks) max_imgs = std::max(max_imgs, c.count);
     b->max_nsub = max_nsub;
     b->max_chunk_images = uint32_t(max_imgs);
-    HIPOK(hipMalloc(&b->d_pull, max_imgs * kMaxFix * sizeof(uint32_t)));
-    HIPOK(hipMalloc(&b->d_items, size_t(max_nsub) * 6 * sizeof(uint32_t)));
-    HIPOK(hipMalloc(&b->d_segsum, max_segsum * 3 * sizeof(int32_t)));
+    ar.take(&b->d_pull, max_imgs * kMaxFix * sizeof(uint32_t));
+    ar.take(&b->d_items, size_t(max_nsub) * 6 * sizeof(uint32_t));
+    ar.take(&b->d_segsum, max_segsum * 3 * sizeof(int32_t));
     {
         uint64_t max_planes = 0;
         for (const Chunk &c : b->chunks) max_planes = std::max(max_planes, c.plane_words);
-        if (max_planes) HIPOK(hipMalloc(&b->d_planes, size_t(max_planes) * 8));
+        if (max_planes) ar.take(&b->d_planes, size_t(max_planes) * 8);
     }
-    HIPOK(hipMalloc(&b->d_entries, size_t(b->opts.keep_coefs ? std::max<uint64_t>(total_entries, 4) : max_entries) * 4 + 64));
-    HIPOK(hipMalloc(&b->d_tile_eoff, size_t(b->opts.keep_coefs ? std::max<uint32_t>(total_tiles_arr, 1) : max_tiles_arr) * 4 + 16));
-    HIPOK(hipMalloc(&b->d_ebase, size_t(max_nsub) * sizeof(uint32_t)));
-    HIPOK(hipMalloc(&b->d_img_entries, std::max<size_t>(b->info.size(), 1) * sizeof(uint32_t)));
-    HIPOK(hipMemset(b->d_img_entries, 0, std::max<size_t>(b->info.size(), 1) * sizeof(uint32_t)));
-    HIPOK(hipMalloc(&b->d_img_flags, std::max<size_t>(b->info.size(), 1) * sizeof(uint32_t)));
-    HIPOK(hipMemset(b->d_img_flags, 0, std::max<size_t>(b->info.size(), 1) * sizeof(uint32_t)));
-    HIPOK(hipMalloc(&b->d_dc, size_t(coef_blocks) * sizeof(int32_t) + 64));
-    HIPOK(hipMalloc(&b->d_rgb, std::max<size_t>(b->rgb_pool_bytes, 16)));
-    HIPOK(hipMalloc(&b->d_status, std::max<size_t>(b->info.size(), 1) * sizeof(int)));
-    HIPOK(hipMemset(b->d_status, 0, std::max<size_t>(b->info.size(), 1) * sizeof(int)));
+    ar.take(&b->d_entries, size_t(b->opts.keep_coefs ? std::max<uint64_t>(total_entries, 4) : max_entries) * 4 + 64);
+    ar.take(&b->d_tile_eoff, size_t(b->opts.keep_coefs ? std::max<uint32_t>(total_tiles_arr, 1) : max_tiles_arr) * 4 + 16);
+    ar.take(&b->d_ebase, size_t(max_nsub) * sizeof(uint32_t));
+    ar.take(&b->d_img_entries, std::max<size_t>(b->info.size(), 1) * sizeof(uint32_t));
+    if (!ar.measuring) HIPOK(hipMemsetAsync(b->d_img_entries, 0, std::max<size_t>(b->info.size(), 1) * sizeof(uint32_t), b->ctx->upload));
+    ar.take(&b->d_img_flags, std::max<size_t>(b->info.size(), 1) * sizeof(uint32_t));
+    if (!ar.measuring) HIPOK(hipMemsetAsync(b->d_img_flags, 0, std::max<size_t>(b->info.size(), 1) * sizeof(uint32_t), b->ctx->upload));
+    ar.take(&b->d_dc, size_t(coef_blocks) * sizeof(int32_t) + 64);
+    ar.take(&b->d_rgb, std::max<size_t>(b->rgb_pool_bytes, 16));
+    ar.take(&b->d_status, std::max<size_t>(b->info.size(), 1) * sizeof(int));
+    if (!ar.measuring) HIPOK(hipMemsetAsync(b->d_status, 0, std::max<size_t>(b->info.size(), 1) * sizeof(int), b->ctx->upload));
     const size_t mm = std::max<size_t>(b->chunks.size(), 1) * kMaxFix * sizeof(uint32_t);
-    HIPOK(hipMalloc(&b->d_mismatch, mm));
-    HIPOK(hipHostMalloc(reinterpret_cast<void **>(&b->h_mismatch), mm, hipHostMallocDefault));
-    std::memset(b->h_mismatch, 0, mm);
+    ar.take(&b->d_mismatch, mm);
+    if (!ar.measuring && !b->h_mismatch) {
+        HIPOK(hipHostMalloc(reinterpret_cast<void **>(&b->h_mismatch), mm, hipHostMallocDefault));
+        std::memset(b->h_mismatch, 0, mm);
+    }
     if (b->ctx->nstreams == 2 && b->chunks.size() > 1) {          // second scratch set for the chunks on stream2
         mjx_batch::Alt &a = b->alt;
         b->dual = true;
-        HIPOK(hipMalloc(&a.d_entry, size_t(max_nsub) * sizeof(SubseqState)));
-        HIPOK(hipMalloc(&a.d_exit, size_t(max_nsub) * sizeof(SubseqState)));
-        HIPOK(hipMalloc(&a.d_blkbase, size_t(max_nsub) * sizeof(uint32_t)));
-        HIPOK(hipMalloc(&a.d_ebase, size_t(max_nsub) * sizeof(uint32_t)));
-        HIPOK(hipMalloc(&a.d_cps, (size_t(max_nsub) + 256) / 256 * 256 * kMaxCp * 2 * sizeof(uint32_t)));
-        HIPOK(hipMalloc(&a.d_pull, max_imgs * kMaxFix * sizeof(uint32_t)));
-        HIPOK(hipMalloc(&a.d_items, size_t(max_nsub) * 6 * sizeof(uint32_t)));
-        HIPOK(hipMalloc(&a.d_segsum, max_segsum * 3 * sizeof(int32_t)));
+        ar.take(&a.d_entry, size_t(max_nsub) * sizeof(SubseqState));
+        ar.take(&a.d_exit, size_t(max_nsub) * sizeof(SubseqState));
+        ar.take(&a.d_blkbase, size_t(max_nsub) * sizeof(uint32_t));
+        ar.take(&a.d_ebase, size_t(max_nsub) * sizeof(uint32_t));
+        ar.take(&a.d_cps, (size_t(max_nsub) + 256) / 256 * 256 * kMaxCp * 2 * sizeof(uint32_t));
+        ar.take(&a.d_pull, max_imgs * kMaxFix * sizeof(uint32_t));
+        ar.take(&a.d_items, size_t(max_nsub) * 6 * sizeof(uint32_t));
+        ar.take(&a.d_segsum, max_segsum * 3 * sizeof(int32_t));
         uint64_t max_planes = 0;
         for (const Chunk &c : b->chunks) max_planes = std::max(max_planes, c.plane_words);
-        if (max_planes) HIPOK(hipMalloc(&a.d_planes, size_t(max_planes) * 8));
+        if (max_planes) ar.take(&a.d_planes, size_t(max_planes) * 8);
         if (b->opts.keep_coefs) {
             a.d_entries = b->d_entries; a.d_tile_eoff = b->d_tile_eoff; a.d_dc = b->d_dc;
         } else {
-            HIPOK(hipMalloc(&a.d_entries, size_t(max_entries) * 4 + 64));
-            HIPOK(hipMalloc(&a.d_tile_eoff, size_t(max_tiles_arr) * 4 + 16));
-            HIPOK(hipMalloc(&a.d_dc, size_t(coef_blocks) * sizeof(int32_t) + 64));
+            ar.take(&a.d_entries, size_t(max_entries) * 4 + 64);
+            ar.take(&a.d_tile_eoff, size_t(max_tiles_arr) * 4 + 16);
+            ar.take(&a.d_dc, size_t(coef_blocks) * sizeof(int32_t) + 64);
         }
     }
+    if (ar.measuring) return MJX_OK;
     if (const char *e = std::getenv("MJX_POISON")) {
         // debugging aid: scratch that the kernels must write before they read it is filled with a byte pattern, so that a
         // read of stale memory (fresh allocations are usually zero, recycled ones hold the previous batch) shows at once
@@ -394,14 +501,19 @@ int allocate_work_buffers(mjx_batch *b)
             {b->d_dc, size_t(coef_blocks) * sizeof(int32_t) + 64},                // 9
         };
         for (int k = 0; k < int(sizeof bufs / sizeof bufs[0]); k++)
-            if (sel < 0 || sel == k) HIPOK(hipMemset(bufs[k].p, v, bufs[k].n));
+            if (sel < 0 || sel == k) HIPOK(hipMemsetAsync(bufs[k].p, v, bufs[k].n, b->ctx->upload));
     }
     b->huff_lds = huff_lds_bytes(lut_cap);
     b->idct_lds = idct_lds_bytes(max_tile_blocks);
     if (b->huff_lds + huff_window_bytes() + huff_stage_bytes() > 160 * 1024 || b->idct_lds > 160 * 1024) return MJX_ERR_UNSUPPORTED_FORMAT;
     {
         const size_t pad = std::max(b->ctx->spec_lds_pad, std::max(b->ctx->merge_lds_pad, b->ctx->write_lds_pad));
-        if (configure_kernels(b->huff_lds + huff_window_bytes() + huff_stage_bytes() + pad, b->idct_lds) != 0) { (void)hipGetLastError(); return MJX_ERR_DEVICE; }
+        const size_t want_huff = b->huff_lds + huff_window_bytes() + huff_stage_bytes() + pad;
+        if (want_huff > b->ctx->configured_huff || b->idct_lds > b->ctx->configured_idct) {
+            if (configure_kernels(std::max(want_huff, b->ctx->configured_huff), std::max(b->idct_lds, b->ctx->configured_idct)) != 0) { (void)hipGetLastError(); return MJX_ERR_DEVICE; }
+            b->ctx->configured_huff = std::max(want_huff, b->ctx->configured_huff);
+            b->ctx->configured_idct = std::max(b->idct_lds, b->ctx->configured_idct);
+        }
     }
     return MJX_OK;
 }
@@ -430,8 +542,21 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
 {
     const Chunk &c = b->chunks[ci];
     if (c.count == 0 || c.nsub == 0) return MJX_OK;
+    // Two streams (the default): the entropy stage of every chunk runs on `stream`, stage B on `stream2`, chained by events --
+    // so the pixel kernel of chunk k (HBM stores, LDS) always shares the device with the entropy kernels of chunk k+1
+    // (instruction issue, latency) instead of two kernels of one kind meeting by chance.  Odd chunks use the second set of
+    // scratch buffers; the entropy stage of chunk k+2 waits for stage B of chunk k, which reads the set it writes.
     const bool second = b->dual && (ci & 1) && !force_first;
-    hipStream_t st = second ? b->ctx->stream2 : b->ctx->stream;
+    const int set = second ? 1 : 0;
+    hipStream_t st = b->ctx->stream;
+    hipStream_t sp = (b->ctx->stream2 && !force_first) ? b->ctx->stream2 : b->ctx->stream;
+    if (sp != st && !b->ev_entropy[0]) {
+        for (int k = 0; k < 2; k++) {
+            HIPOK(hipEventCreateWithFlags(&b->ev_entropy[k], hipEventDisableTiming));
+            HIPOK(hipEventCreateWithFlags(&b->ev_pixels[k], hipEventDisableTiming));
+        }
+    }
+    if (sp != st && (stages & MJX_STAGE_ENTROPY) && b->pixels_recorded[set]) HIPOK(hipStreamWaitEvent(st, b->ev_pixels[set], 0));
 #define SCR(x) (second ? b->alt.x : b->x)
     const DevImage *imgs = b->d_images + c.first;
     const uint32_t nimg = uint32_t(c.count);
@@ -480,12 +605,21 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
             prof_end(b, st);
         }
     }
+    if (sp != st && (stages & MJX_STAGE_ENTROPY)) {
+        HIPOK(hipEventRecord(b->ev_entropy[set], st));
+        b->entropy_recorded[set] = true;
+    }
     if (stages & MJX_STAGE_PIXELS) {
-        prof_begin(b, MJX_K_IDCT_COLOR, st);
-        if (c.plane_words) HIPOK(hipMemsetAsync(SCR(d_planes), 0, size_t(c.plane_words) * 8, st));
-        launch_idct_color(st, (c.max_tiles + kTilesPerWgHost - 1) / kTilesPerWgHost, nimg, b->idct_lds, imgs, SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_qm, b->d_rgb, c.mode_mask, SCR(d_planes), b->d_img_flags);
-        if (c.plane_words) launch_ref_color(st, c.max_pixel_wgs, nimg, imgs, SCR(d_planes), b->d_rgb, b->d_img_flags);
-        prof_end(b, st);
+        if (sp != st && b->entropy_recorded[set]) HIPOK(hipStreamWaitEvent(sp, b->ev_entropy[set], 0));
+        prof_begin(b, MJX_K_IDCT_COLOR, sp);
+        if (c.plane_words) HIPOK(hipMemsetAsync(SCR(d_planes), 0, size_t(c.plane_words) * 8, sp));
+        launch_idct_color(sp, (c.max_tiles + kTilesPerWgHost - 1) / kTilesPerWgHost, nimg, b->idct_lds, imgs, SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_qm, b->d_rgb, c.mode_mask, SCR(d_planes), b->d_img_flags);
+        if (c.plane_words) launch_ref_color(sp, c.max_pixel_wgs, nimg, imgs, SCR(d_planes), b->d_rgb, b->d_img_flags);
+        prof_end(b, sp);
+        if (sp != st) {
+            HIPOK(hipEventRecord(b->ev_pixels[set], sp));
+            b->pixels_recorded[set] = true;
+        }
     }
     HIPOK(hipGetLastError());
     return MJX_OK;
@@ -522,11 +656,20 @@ struct DestuffPlan {
     ~DestuffPlan() { (void)hipFree(d_raw); (void)hipFree(d_segbase); }
 };
 
+// Pinned host memory lent to build_batch for the host mirrors of its small pools (mjx_decode_batch: an asynchronous copy from
+// pageable memory is staged by the runtime and waits for the stream's earlier transfers -- the host thread would stall behind
+// the previous group's DMA).
+struct PinnedBump {
+    uint8_t *base = nullptr;
+    size_t cap = 0, used = 0;
+};
+
 // Builds a batch from plans.  Scan bytes come from the plans' host pointers (or, for the images listed in `ds`, from
 // the device-side de-stuffing of their raw bytes), or (src != nullptr) are copied on the device from `src`'s pool,
 // `times` repetitions of its images.
 int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opts &opts, const mjx_batch *src,
-                size_t times, mjx_batch **out, int *status, DestuffPlan *ds = nullptr)
+                size_t times, mjx_batch **out, int *status, DestuffPlan *ds = nullptr, bool async_upload = false,
+                uint32_t *pinned_words = nullptr, size_t pinned_cap = 0, PinnedBump *pin = nullptr)
 {
     mjx_batch *b = new (std::nothrow) mjx_batch;
     if (!b) return MJX_ERR_NOMEM;
@@ -545,6 +688,8 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
     std::vector<uint64_t> scan_off(nu, 0), lin_off(nu, 0);
     std::vector<uint32_t> lut_off(nu, 0), lut_n(nu, 0), seg_off(nu, 0);
     size_t scan_pool = 0, lin_pool = 0, lut_pool = 0;
+    std::vector<char> lut_first(nu, 1);                     // 0: the image shares an earlier image's tables
+    std::unordered_multimap<uint64_t, size_t> lut_seen;
     b->h_segs.clear();
     for (size_t k = 0; k < nu; k++) {
         if (plans[k].status != MJX_OK) continue;
@@ -552,9 +697,34 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
         scan_pool += align_up(size_t(scan_region_bytes(plans[k].himg.nsub, plans[k].himg.sub_bits)), 256);
         lin_off[k] = lin_pool;
         lin_pool += align_up(plans[k].scan_len, 16) + 16;
-        lut_off[k] = uint32_t(lut_pool);
-        lut_n[k] = uint32_t(plans[k].lut.size());
-        lut_pool += plans[k].lut.size();
+        if (src) {                          // replicated on the device: the source batch's table pool, its offsets
+            lut_off[k] = src->himages[k].lut_off;
+            lut_n[k] = uint32_t(plans[k].lut.size());
+            lut_pool = src->lut_pool_entries;
+        } else
+        {   // identical decode tables (every file written with the Annex-K tables, for one) are stored once: the table pool
+            // of a batch then stays in L2 for the staging loads of every workgroup, and the upload shrinks by 12 KB per file
+            const std::vector<LutEntry> &l = plans[k].lut;
+            uint64_t hsh = 1469598103934665603ull;
+            for (LutEntry e : l) hsh = (hsh ^ e) * 1099511628211ull;
+            bool found = false;
+            auto range = lut_seen.equal_range(hsh);
+            for (auto it = range.first; it != range.second; ++it) {
+                const size_t j = it->second;
+                if (plans[j].lut.size() == l.size() && std::memcmp(plans[j].lut.data(), l.data(), l.size() * sizeof(LutEntry)) == 0) {
+                    lut_off[k] = lut_off[j];
+                    lut_first[k] = 0;
+                    found = true;
+                    break;
+                }
+            }
+            lut_n[k] = uint32_t(l.size());
+            if (!found) {
+                lut_seen.emplace(hsh, k);
+                lut_off[k] = uint32_t(lut_pool);
+                lut_pool += l.size();
+            }
+        }
         seg_off[k] = uint32_t(b->h_segs.size() / 2);
         b->h_segs.insert(b->h_segs.end(), plans[k].seg.begin(), plans[k].seg.end());
     }
@@ -612,55 +782,157 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
     for (size_t i = 0; i < n; i++)
         if (b->info[i].role != 1) b->visible.push_back(i);
     b->rgb_pool_bytes = rgb_pool;
+    b->lut_pool_entries = lut_pool;
     plan_chunks(b);
+    if (pinned_words && std::max<size_t>(b->chunks.size(), 1) * kMaxFix <= pinned_cap) {    // lent by the caller (mjx_decode_batch)
+        b->h_mismatch = pinned_words;
+        b->h_mismatch_owned = false;
+        std::memset(b->h_mismatch, 0, std::max<size_t>(b->chunks.size(), 1) * kMaxFix * sizeof(uint32_t));
+    }
 
     int rc = MJX_OK;
     auto dev = [&]() -> int {
+        hipStream_t up = ctx->upload;
         HIPOK(hipSetDevice(ctx->device));
-        HIPOK(hipMalloc(&b->d_images, std::max<size_t>(n, 1) * sizeof(DevImage)));
-        HIPOK(hipMemcpy(b->d_images, b->himages.data(), n * sizeof(DevImage), hipMemcpyHostToDevice));
-        HIPOK(hipMalloc(&b->d_scan, b->scan_pool_bytes + 256));
-        HIPOK(hipMalloc(&b->d_lut, std::max<size_t>(lut_pool, 8) * sizeof(LutEntry)));
-        HIPOK(hipMalloc(&b->d_qm, std::max<size_t>(nu, 1) * 192 * sizeof(float)));
-        HIPOK(hipMalloc(&b->d_segs, std::max<size_t>(b->h_segs.size(), 2) * sizeof(uint32_t)));
-        if (!b->h_segs.empty()) HIPOK(hipMemcpy(b->d_segs, b->h_segs.data(), b->h_segs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        std::vector<char> on_device(nu, 0);
+        if (ds) for (size_t idx : ds->plan_index) on_device[idx] = 1;
+        bool one_copy = false;
+        const uint8_t *span0 = nullptr;
+        size_t span_bytes = 0;
+        {
+            const uint8_t *prev_end = nullptr;
+            size_t payload = 0, count = 0;
+            bool ordered = true;
+            for (size_t k = 0; k < nu && ordered; k++) {
+                const ImagePlan &p = plans[k];
+                if (p.status != MJX_OK || on_device[k] || p.scan_len == 0) continue;
+                if (!span0) span0 = p.scan;
+                if (prev_end && p.scan < prev_end) ordered = false;
+                if ((size_t(p.scan - span0) & 15u) != 0) ordered = false;             // (staging offsets stay 16-byte aligned)
+                prev_end = p.scan + p.scan_len;
+                payload += p.scan_len;
+                count++;
+            }
+            // (only inside the context's own pinned arena: the gaps between the scans are read as well)
+            const bool in_arena = span0 && ctx->parse_arena && span0 >= ctx->parse_arena && prev_end <= ctx->parse_arena + ctx->parse_arena_cap;
+            if (ordered && in_arena && count > 1 && size_t(prev_end - span0) <= payload + payload / 4 + 4096) {
+                one_copy = true;
+                span_bytes = size_t(prev_end - span0);
+                lin_pool = align_up(span_bytes, 16) + 16;
+                for (size_t k = 0; k < nu; k++)
+                    if (plans[k].status == MJX_OK && !on_device[k] && plans[k].scan_len) lin_off[k] = size_t(plans[k].scan - span0);
+                if (ds) one_copy = false;                                                // (device-side de-stuffing keeps its own offsets)
+            }
+        }
+        // the images that have a scan of their own to interleave
+        std::vector<InterleaveImg> ii;
+        uint32_t max_pieces = 0;
+        if (!src)
+            for (size_t k = 0; k < nu; k++) {
+                const ImagePlan &p = plans[k];
+                if (p.status != MJX_OK || p.himg.nsub == 0) continue;
+                ii.push_back(InterleaveImg{0, uint32_t(p.scan_len), uint32_t(k)});              // (lin_off is filled in below)
+                max_pieces = std::max<uint32_t>(max_pieces, scan_region_cols(p.himg.nsub) * scan_region_rows(p.himg.sub_bits));
+            }
+        {
+            DevArena ar;
+            auto layout = [&]() -> int {
+                // the small pools first, back to back: they go up in one transfer from one host block (meta_*)
+                ar.take(&b->d_images, std::max<size_t>(n, 1) * sizeof(DevImage));
+                ar.take(&b->d_lut, std::max<size_t>(lut_pool, 8) * sizeof(LutEntry));
+                ar.take(&b->d_qm, std::max<size_t>(nu, 1) * 192 * sizeof(float));
+                ar.take(&b->d_segs, std::max<size_t>(b->h_segs.size(), 2) * sizeof(uint32_t));
+                ar.take(&b->d_ii, std::max<size_t>(ii.size(), 1) * sizeof(InterleaveImg));
+                ar.take(&b->d_meta_end, 16);
+                ar.take(&b->d_scan, b->scan_pool_bytes + 256);
+                if (!src) ar.take(&b->d_lin, lin_pool + 256);
+                return allocate_work_buffers(b, ar);
+            };
+            { const int rcl = layout(); if (rcl != MJX_OK) return rcl; }
+            if (std::getenv("MJX_NO_ARENA")) ar.separate = &b->separate_allocs;
+            else { const int rcg = arena_get(ctx, ar.off, &b->arena, &b->arena_bytes); if (rcg != MJX_OK) return rcg; }
+            ar.base = b->arena;
+            ar.off = 0;
+            ar.measuring = false;
+            { const int rcl = layout(); if (rcl != MJX_OK) return rcl; }
+        }
+        const bool meta_block = b->arena != nullptr;                 // (MJX_NO_ARENA: separate buffers, separate copies)
+        const size_t meta_bytes = meta_block ? size_t(reinterpret_cast<uint8_t *>(b->d_meta_end) - reinterpret_cast<uint8_t *>(b->d_images)) : 0;
+        uint8_t *meta = nullptr;                                     // host mirror of [d_images, d_meta_end)
+        if (meta_block) {
+            if (pin && pin->used + meta_bytes <= pin->cap) {          // pinned (lent by mjx_decode_batch): a truly asynchronous copy
+                meta = pin->base + pin->used;
+                pin->used += (meta_bytes + 255) & ~size_t(255);
+            } else {
+                b->h_meta.resize(meta_bytes);
+                meta = b->h_meta.data();
+            }
+        }
+        auto mirror = [&](const void *dev) { return meta + (reinterpret_cast<const uint8_t *>(dev) - reinterpret_cast<const uint8_t *>(b->d_images)); };
+        if (meta_block) {
+            std::memcpy(mirror(b->d_images), b->himages.data(), n * sizeof(DevImage));
+            if (!b->h_segs.empty()) std::memcpy(mirror(b->d_segs), b->h_segs.data(), b->h_segs.size() * sizeof(uint32_t));
+        } else {
+            HIPOK(hipMemcpyAsync(b->d_images, b->himages.data(), n * sizeof(DevImage), hipMemcpyHostToDevice, up));
+            if (!b->h_segs.empty()) HIPOK(hipMemcpyAsync(b->d_segs, b->h_segs.data(), b->h_segs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, up));
+        }
         if (src) {
             if (src->scan_pool_bytes != scan_pool) return MJX_ERR_INVALID_ARG;
+            if (meta_block) HIPOK(hipMemcpyAsync(b->d_images, meta, meta_bytes, hipMemcpyHostToDevice, up));
+            // (on the upload stream, which is synchronised below: a device-to-device hipMemcpy on the null stream may return
+            // before the copy has happened, and the decode streams are not ordered behind the null stream -- a decode kernel
+            // that starts on a table pool of zeros never leaves its first symbol)
             for (size_t rep = 0; rep < times; rep++)
-                HIPOK(hipMemcpy(b->d_scan + rep * scan_pool, src->d_scan, scan_pool, hipMemcpyDeviceToDevice));
-            HIPOK(hipMemcpy(b->d_lut, src->d_lut, std::max<size_t>(lut_pool, 8) * sizeof(LutEntry), hipMemcpyDeviceToDevice));
-            HIPOK(hipMemcpy(b->d_qm, src->d_qm, std::max<size_t>(nu, 1) * 192 * sizeof(float), hipMemcpyDeviceToDevice));
+                HIPOK(hipMemcpyAsync(b->d_scan + rep * scan_pool, src->d_scan, scan_pool, hipMemcpyDeviceToDevice, up));
+            HIPOK(hipMemcpyAsync(b->d_lut, src->d_lut, std::max<size_t>(lut_pool, 8) * sizeof(LutEntry), hipMemcpyDeviceToDevice, up));
+            HIPOK(hipMemcpyAsync(b->d_qm, src->d_qm, std::max<size_t>(nu, 1) * 192 * sizeof(float), hipMemcpyDeviceToDevice, up));
         } else {
             const bool timing = std::getenv("MJX_TIMING") != nullptr;
             auto now = [] { return std::chrono::steady_clock::now(); };
             auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) { return std::chrono::duration<double, std::milli>(b2 - a).count(); };
             const auto t0 = now();
-            std::vector<LutEntry> hl(std::max<size_t>(lut_pool, 8), 0);
-            std::vector<float> hq(std::max<size_t>(nu, 1) * 192, 0.f);
-            std::vector<char> on_device(nu, 0);
-            if (ds) for (size_t idx : ds->plan_index) on_device[idx] = 1;
+            LutEntry *h_lut;
+            float *h_qm;
+            if (meta_block) {
+                h_lut = reinterpret_cast<LutEntry *>(mirror(b->d_lut));
+                h_qm = reinterpret_cast<float *>(mirror(b->d_qm));
+            } else {
+                b->h_lut.assign(std::max<size_t>(lut_pool, 8), 0);
+                b->h_qm.assign(std::max<size_t>(nu, 1) * 192, 0.f);
+                h_lut = b->h_lut.data();
+                h_qm = b->h_qm.data();
+            }
             for (size_t k = 0; k < nu; k++) {
                 const ImagePlan &p = plans[k];
                 if (p.status != MJX_OK) continue;
-                std::memcpy(hl.data() + lut_off[k], p.lut.data(), p.lut.size() * sizeof(LutEntry));
-                std::memcpy(hq.data() + k * 192, p.qmult, sizeof p.qmult);
+                if (lut_first[k]) std::memcpy(h_lut + lut_off[k], p.lut.data(), p.lut.size() * sizeof(LutEntry));
+                std::memcpy(h_qm + k * 192, p.qmult, sizeof p.qmult);
+            }
+            if (!meta_block) {
+                HIPOK(hipMemcpyAsync(b->d_lut, b->h_lut.data(), b->h_lut.size() * sizeof(LutEntry), hipMemcpyHostToDevice, up));
+                HIPOK(hipMemcpyAsync(b->d_qm, b->h_qm.data(), b->h_qm.size() * sizeof(float), hipMemcpyHostToDevice, up));
             }
             const auto t1 = now();
-            // every scan goes up straight from the caller's buffer into a linear staging buffer (a host-side staging copy of
+            // Every scan goes up straight from the caller's buffer into a linear staging buffer (a host-side staging copy of
             // the whole pool -- first-touch page faults included -- cost six times the transfer itself); k_scan_interleave then
             // builds the lane-interleaved regions the kernels read, padding with the 0xAA the reference reads past the end of
-            // a scan (huffman.rs:236-246)
-            uint8_t *d_lin = nullptr;
-            HIPOK(hipMalloc(&d_lin, lin_pool + 256));
-            struct LinFree { uint8_t *p; ~LinFree() { (void)hipFree(p); } } lin_free{d_lin};
-            for (size_t k = 0; k < nu; k++) {
-                const ImagePlan &p = plans[k];
-                if (p.status != MJX_OK || on_device[k] || p.scan_len == 0) continue;
-                HIPOK(hipMemcpyAsync(d_lin + lin_off[k], p.scan, p.scan_len, hipMemcpyHostToDevice, ctx->stream));
+            // a scan (huffman.rs:236-246).  When the scans lie close together in host memory in upload order (the pinned
+            // arena mjx_decode_batch de-stuffs into) they go up as ONE transfer, gaps included: 512 separate 1 MB copies reached
+            // 36 GB/s, one copy runs at the link's rate.
+            if (one_copy) {
+                HIPOK(hipMemcpyAsync(b->d_lin, span0, span_bytes, hipMemcpyHostToDevice, up));
+            } else {
+                for (size_t k = 0; k < nu; k++) {
+                    const ImagePlan &p = plans[k];
+                    if (p.status != MJX_OK || on_device[k] || p.scan_len == 0) continue;
+                    HIPOK(hipMemcpyAsync(b->d_lin + lin_off[k], p.scan, p.scan_len, hipMemcpyHostToDevice, up));
+                }
             }
-            HIPOK(hipStreamSynchronize(ctx->stream));
+            if (timing && !async_upload) {
+                HIPOK(hipStreamSynchronize(up));
+                std::fprintf(stderr, "[mjx] staging %.2f ms, H2D of %.1f MB (%s) %.2f ms\n", ms(t0, t1), lin_pool / 1e6, one_copy ? "one transfer" : "per scan", ms(t1, now()));
+            }
             const auto t2 = now();
-            if (timing) std::fprintf(stderr, "[mjx] staging %.2f ms, H2D of %.1f MB %.2f ms\n", ms(t0, t1), lin_pool / 1e6, ms(t1, t2));
             if (ds && !ds->imgs.empty()) {                 // compact the stuffed scans straight into the staging buffer
                 std::vector<DestuffImg> di;
                 for (size_t j = 0; j < ds->imgs.size(); j++) {
@@ -673,45 +945,47 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
                     DestuffImg *d_di = nullptr;
                     HIPOK(hipMalloc(&d_di, di.size() * sizeof(DestuffImg)));
                     int rc3 = MJX_OK;
-                    if (hipMemcpy(d_di, di.data(), di.size() * sizeof(DestuffImg), hipMemcpyHostToDevice) != hipSuccess) rc3 = MJX_ERR_DEVICE;
+                    if (hipMemcpyAsync(d_di, di.data(), di.size() * sizeof(DestuffImg), hipMemcpyHostToDevice, up) != hipSuccess) rc3 = MJX_ERR_DEVICE;
                     if (rc3 == MJX_OK) {
-                        launch_destuff_scatter(ctx->stream, ds->max_seg, uint32_t(di.size()), d_di, ds->d_raw, ds->d_segbase, d_lin);
-                        if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc3 = MJX_ERR_DEVICE;
+                        launch_destuff_scatter(up, ds->max_seg, uint32_t(di.size()), d_di, ds->d_raw, ds->d_segbase, b->d_lin);
+                        if (hipStreamSynchronize(up) != hipSuccess || hipGetLastError() != hipSuccess) rc3 = MJX_ERR_DEVICE;
                     }
                     (void)hipFree(d_di);
                     if (rc3 != MJX_OK) return rc3;
                 }
             }
             {   // linear -> lane-interleaved
-                std::vector<InterleaveImg> ii;
-                uint32_t max_pieces = 0;
-                for (size_t k = 0; k < nu; k++) {
-                    const ImagePlan &p = plans[k];
-                    if (p.status != MJX_OK || p.himg.nsub == 0) continue;
-                    ii.push_back(InterleaveImg{lin_off[k], uint32_t(p.scan_len), uint32_t(k)});
-                    max_pieces = std::max<uint32_t>(max_pieces, scan_region_cols(p.himg.nsub) * scan_region_rows(p.himg.sub_bits));
+                for (InterleaveImg &x : ii) x.lin_off = lin_off[x.image];
+                if (meta_block) {
+                    if (!ii.empty()) std::memcpy(mirror(b->d_ii), ii.data(), ii.size() * sizeof(InterleaveImg));
+                    HIPOK(hipMemcpyAsync(b->d_images, meta, meta_bytes, hipMemcpyHostToDevice, up));       // every small pool at once
+                } else if (!ii.empty()) {
+                    b->h_ii.assign(reinterpret_cast<const unsigned char *>(ii.data()), reinterpret_cast<const unsigned char *>(ii.data() + ii.size()));
+                    HIPOK(hipMemcpyAsync(b->d_ii, b->h_ii.data(), b->h_ii.size(), hipMemcpyHostToDevice, up));
                 }
                 if (!ii.empty()) {
-                    InterleaveImg *d_ii = nullptr;
-                    HIPOK(hipMalloc(&d_ii, ii.size() * sizeof(InterleaveImg)));
-                    int rc3 = MJX_OK;
-                    if (hipMemcpy(d_ii, ii.data(), ii.size() * sizeof(InterleaveImg), hipMemcpyHostToDevice) != hipSuccess) rc3 = MJX_ERR_DEVICE;
-                    for (size_t at = 0; rc3 == MJX_OK && at < ii.size(); at += 32768)
-                        launch_scan_interleave(ctx->stream, max_pieces, uint32_t(std::min<size_t>(32768, ii.size() - at)), d_ii + at, b->d_images, d_lin, b->d_scan, b->d_segs);
-                    if (rc3 == MJX_OK && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)) rc3 = MJX_ERR_DEVICE;
-                    (void)hipFree(d_ii);
-                    if (rc3 != MJX_OK) return rc3;
+                    const InterleaveImg *d_ii = static_cast<const InterleaveImg *>(b->d_ii);
+                    for (size_t at = 0; at < ii.size(); at += 32768)
+                        launch_scan_interleave(up, max_pieces, uint32_t(std::min<size_t>(32768, ii.size() - at)), d_ii + at, b->d_images, b->d_lin, b->d_scan, b->d_segs);
+                    HIPOK(hipGetLastError());
                 }
-                if (timing) std::fprintf(stderr, "[mjx] interleave %.2f ms\n", ms(t2, now()));
+                if (timing && !async_upload) {
+                    HIPOK(hipStreamSynchronize(up));
+                    std::fprintf(stderr, "[mjx] interleave %.2f ms\n", ms(t2, now()));
+                }
             }
-            HIPOK(hipMemcpy(b->d_lut, hl.data(), hl.size() * sizeof(LutEntry), hipMemcpyHostToDevice));
-            HIPOK(hipMemcpy(b->d_qm, hq.data(), hq.size() * sizeof(float), hipMemcpyHostToDevice));
         }
-        const auto ta = std::chrono::steady_clock::now();
-        const int rca = allocate_work_buffers(b);
-        if (std::getenv("MJX_TIMING"))
-            std::fprintf(stderr, "[mjx] work buffers %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta).count());
-        return rca;
+        if (async_upload && !ds) {
+            // the caller goes on (parsing and uploading the next group of files) while the DMA engine works; the decode
+            // streams wait for this event before their first kernel (run_chunk)
+            HIPOK(hipEventCreateWithFlags(&b->uploaded, hipEventDisableTiming));
+            HIPOK(hipEventRecord(b->uploaded, up));
+            b->upload_pending = true;
+        } else {
+            HIPOK(hipStreamSynchronize(up));
+
+        }
+        return MJX_OK;
     };
     rc = dev();
     if (rc != MJX_OK) return rc;
@@ -740,7 +1014,10 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     if (!c) return MJX_ERR_NOMEM;
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MJX_ERR_DEVICE; }
-    if (const char *e = std::getenv("MJX_STREAMS")) c->nstreams = std::atoi(e) == 2 ? 2 : 1;
+    if (hipStreamCreateWithFlags(&c->upload, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return MJX_ERR_DEVICE; }
+    if (const char *e = std::getenv("MJX_CACHE_GB")) c->cache_limit = size_t(std::max(0L, std::atol(e))) << 30;
+    c->nstreams = 2;
+    if (const char *e = std::getenv("MJX_STREAMS")) c->nstreams = std::atoi(e) == 1 ? 1 : 2;
     if (c->nstreams == 2 && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) c->nstreams = 1;
     if (const char *e = std::getenv("MJX_SPEC_LDS_PAD")) c->spec_lds_pad = size_t(std::atoi(e));
     if (const char *e = std::getenv("MJX_MERGE_LDS_PAD")) c->merge_lds_pad = size_t(std::atoi(e));
@@ -761,7 +1038,10 @@ extern "C" void mjx_ctx_destroy(mjx_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->upload) { (void)hipStreamSynchronize(ctx->upload); (void)hipStreamDestroy(ctx->upload); }
     if (ctx->parse_arena) (void)hipHostFree(ctx->parse_arena);
+    if (ctx->pin_small) (void)hipHostFree(ctx->pin_small);
+    for (auto &blk : ctx->cache) (void)hipFree(blk.first);
     delete ctx;
 }
 
@@ -870,7 +1150,7 @@ extern "C" int mjx_validate(const mjx_scan_desc *desc, const mjx_opts *opts)
 extern "C" int mjx_batch_tile(mjx_ctx *ctx, const mjx_batch *src, size_t times, mjx_batch **out)
 {
     return guarded([&]() -> int {
-    if (!ctx || !src || !out || times == 0) return MJX_ERR_INVALID_ARG;
+    if (!ctx || !src || !out || times == 0 || !src->parts.empty()) return MJX_ERR_INVALID_ARG;
     *out = nullptr;
     // rebuild light-weight plans from the source batch's device images (geometry only; tables stay on the device)
     const size_t nu = src->info.size();
@@ -915,6 +1195,7 @@ extern "C" void mjx_batch_free(mjx_batch *b)
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     (void)sync_streams(b);
+    if (b->ctx->upload) (void)hipStreamSynchronize(b->ctx->upload);
     release(b);
 }
 
@@ -922,11 +1203,20 @@ extern "C" int mjx_batch_decode(mjx_batch *b, unsigned stages)
 {
     return guarded([&]() -> int {
     if (!b) return MJX_ERR_INVALID_ARG;
+    if (!b->parts.empty()) {
+        for (mjx_batch *part : b->parts) { const int rc = mjx_batch_decode(part, stages); if (rc != MJX_OK) return rc; }
+        return MJX_OK;
+    }
     if (stages == 0) stages = MJX_STAGE_ALL;
     HIPOK(hipSetDevice(b->ctx->device));
     if ((stages & MJX_STAGE_PIXELS) && !(stages & MJX_STAGE_ENTROPY)) {
         // stage-B-only sweep: the coefficients of every chunk must still be resident
         if (!b->decoded_entropy || (!b->opts.keep_coefs && b->chunks.size() > 1)) return MJX_ERR_INVALID_ARG;
+    }
+    if (b->upload_pending) {                     // asynchronous upload (mjx_decode_batch): kernels start behind it
+        HIPOK(hipStreamWaitEvent(b->ctx->stream, b->uploaded, 0));
+        if (b->ctx->stream2) HIPOK(hipStreamWaitEvent(b->ctx->stream2, b->uploaded, 0));
+        b->upload_pending = false;
     }
     for (size_t ci = 0; ci < b->chunks.size(); ci++) {
         const int rc = run_chunk(b, ci, stages, b->ctx->fix_passes);
@@ -945,6 +1235,10 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
 {
     return guarded([&]() -> int {
     if (!b) return MJX_ERR_INVALID_ARG;
+    if (!b->parts.empty()) {
+        for (mjx_batch *part : b->parts) { const int rc = mjx_batch_wait(part); if (rc != MJX_OK) return rc; }
+        return MJX_OK;
+    }
     HIPOK(hipSetDevice(b->ctx->device));
     { const int rc0 = sync_streams(b); if (rc0 != MJX_OK) return rc0; }
     collect_events(b);
@@ -957,6 +1251,7 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
             if (c.merge_wgs == 0) continue;
             const int passes = std::min(b->ctx->fix_passes, kMaxFix);
             if (b->h_mismatch[ci * kMaxFix + passes - 1] == 0) continue;
+            if (std::getenv("MJX_TIMING")) std::fprintf(stderr, "[mjx] chunk %zu unconverged after %d rounds (%u re-decodes in the last): repairing\n", ci, passes, b->h_mismatch[ci * kMaxFix + passes - 1]);
             // repair: restart this chunk's synchronisation (its state arrays may have been reused by a later chunk),
             // then keep running fix passes -- each one extends the verified prefix -- until one finds nothing.
             HIPOK(hipMemsetAsync(b->d_status + c.first, 0, c.count * sizeof(int), b->ctx->stream));
@@ -966,6 +1261,7 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
                 rc = run_chunk(b, ci, MJX_STAGE_ENTROPY, kMaxFix, PH_FIX, true);
                 if (rc != MJX_OK) return rc;
                 HIPOK(hipStreamSynchronize(b->ctx->stream));
+                if (std::getenv("MJX_TIMING")) std::fprintf(stderr, "[mjx]   repair rounds: %u re-decodes left\n", b->h_mismatch[ci * kMaxFix + kMaxFix - 1]);
                 if (b->h_mismatch[ci * kMaxFix + kMaxFix - 1] == 0) break;
             }
             rc = run_chunk(b, ci, MJX_STAGE_ALL, 0, PH_TAIL, true);
@@ -1002,12 +1298,24 @@ inline bool visible_index(const mjx_batch *b, size_t i, size_t &ii)
     ii = b->visible[i];
     return true;
 }
+// A batch returned by mjx_decode_batch is a directory of the batches its groups of files were decoded in: picture i of the
+// caller -> (the group's batch, the picture's index inside it).  Other batches route to themselves.
+inline bool route(const mjx_batch *b, size_t i, mjx_batch *&pb, size_t &pi)
+{
+    if (!b) return false;
+    if (b->parts.empty()) { pb = const_cast<mjx_batch *>(b); pi = i; return true; }
+    if (i >= b->part_index.size()) return false;
+    pb = b->parts[b->part_index[i].first];
+    pi = b->part_index[i].second;
+    return true;
+}
 }   // namespace
 
-extern "C" size_t mjx_batch_size(const mjx_batch *b) { return b ? b->visible.size() : 0; }
+extern "C" size_t mjx_batch_size(const mjx_batch *b) { return !b ? 0 : (b->parts.empty() ? b->visible.size() : b->part_index.size()); }
 
 extern "C" int mjx_batch_status(const mjx_batch *b, size_t iu)
 {
+    if (b && !b->parts.empty()) { mjx_batch *pb; size_t pi; return route(b, iu, pb, pi) ? mjx_batch_status(pb, pi) : MJX_ERR_INVALID_ARG; }
     size_t i;
     if (!visible_index(b, iu, i)) return MJX_ERR_INVALID_ARG;
     return b->info[i].status;
@@ -1016,6 +1324,7 @@ extern "C" int mjx_batch_status(const mjx_batch *b, size_t iu)
 extern "C" int mjx_batch_image_info(const mjx_batch *b, size_t iu, uint32_t *width, uint32_t *height,
                                     uint32_t *blocks_per_mcu, uint32_t *mcus)
 {
+    if (b && !b->parts.empty()) { mjx_batch *pb; size_t pi; return route(b, iu, pb, pi) ? mjx_batch_image_info(pb, pi, width, height, blocks_per_mcu, mcus) : MJX_ERR_INVALID_ARG; }
     size_t i;
     if (!visible_index(b, iu, i)) return MJX_ERR_INVALID_ARG;
     const ImageInfo &inf = b->info[i];
@@ -1028,6 +1337,7 @@ extern "C" int mjx_batch_image_info(const mjx_batch *b, size_t iu, uint32_t *wid
 
 extern "C" int mjx_batch_rgb_device(const mjx_batch *b, size_t iu, void **dev_ptr, size_t *bytes)
 {
+    if (b && !b->parts.empty()) { mjx_batch *pb; size_t pi; return route(b, iu, pb, pi) ? mjx_batch_rgb_device(pb, pi, dev_ptr, bytes) : MJX_ERR_INVALID_ARG; }
     size_t i;
     if (!visible_index(b, iu, i) || !dev_ptr) return MJX_ERR_INVALID_ARG;
     const ImageInfo &inf = b->info[i];
@@ -1039,6 +1349,7 @@ extern "C" int mjx_batch_rgb_device(const mjx_batch *b, size_t iu, void **dev_pt
 
 extern "C" int mjx_batch_copy_rgb(mjx_batch *b, size_t iu, uint8_t *host_rgb)
 {
+    if (b && !b->parts.empty()) { mjx_batch *pb; size_t pi; return route(b, iu, pb, pi) ? mjx_batch_copy_rgb(pb, pi, host_rgb) : MJX_ERR_INVALID_ARG; }
     return guarded([&]() -> int {
     size_t i;
     if (!visible_index(b, iu, i) || !host_rgb) return MJX_ERR_INVALID_ARG;
@@ -1053,6 +1364,7 @@ extern "C" int mjx_batch_copy_rgb(mjx_batch *b, size_t iu, uint8_t *host_rgb)
 
 extern "C" int mjx_batch_copy_coefs(mjx_batch *b, size_t iu, int16_t *host_coefs, size_t cap_blocks, size_t *nblocks)
 {
+    if (b && !b->parts.empty()) { mjx_batch *pb; size_t pi; return route(b, iu, pb, pi) ? mjx_batch_copy_coefs(pb, pi, host_coefs, cap_blocks, nblocks) : MJX_ERR_INVALID_ARG; }
     return guarded([&]() -> int {
     size_t i;
     if (!visible_index(b, iu, i) || !host_coefs) return MJX_ERR_INVALID_ARG;
@@ -1099,16 +1411,17 @@ extern "C" int mjx_batch_compare_rgb(mjx_batch *a, const size_t *ia, mjx_batch *
         if (n == 0) return MJX_OK;
         if (n > 0x7fffffffu / 64) return MJX_ERR_INVALID_ARG;
         HIPOK(hipSetDevice(a->ctx->device));
-        { const int rcs = sync_streams(a); if (rcs != MJX_OK) return rcs; }
-        { const int rcs = sync_streams(b); if (rcs != MJX_OK) return rcs; }
+        HIPOK(hipDeviceSynchronize());                       // (every stream of either batch, parts included)
         std::vector<RgbPair> pairs(n);
         std::vector<char> bad(n, 0);
         uint64_t max_bytes = 0;
         for (size_t k = 0; k < n; k++) {
-            size_t xa, xb;
-            if (!visible_index(a, ia[k], xa) || !visible_index(b, ib[k], xb)) return MJX_ERR_INVALID_ARG;
-            const ImageInfo &fa = a->info[xa], &fb = b->info[xb];
-            pairs[k] = RgbPair{fa.rgb_off, fb.rgb_off, fa.rgb_bytes};
+            mjx_batch *pa, *pb;
+            size_t ka, kb, xa, xb;
+            if (!route(a, ia[k], pa, ka) || !route(b, ib[k], pb, kb)) return MJX_ERR_INVALID_ARG;
+            if (!visible_index(pa, ka, xa) || !visible_index(pb, kb, xb)) return MJX_ERR_INVALID_ARG;
+            const ImageInfo &fa = pa->info[xa], &fb = pb->info[xb];
+            pairs[k] = RgbPair{pa->d_rgb + fa.rgb_off, pb->d_rgb + fb.rgb_off, fa.rgb_bytes};
             if (fa.status != MJX_OK || fb.status != MJX_OK || fa.width != fb.width || fa.height != fb.height) {
                 bad[k] = 1;
                 pairs[k].bytes = 0;
@@ -1127,7 +1440,7 @@ extern "C" int mjx_batch_compare_rgb(mjx_batch *a, const size_t *ia, mjx_batch *
                              hipMemset(d_max, 0, n * 4) != hipSuccess || hipMemset(d_cnt, 0, n * 8) != hipSuccess))
             rc = MJX_ERR_DEVICE;
         if (rc == MJX_OK) {
-            launch_rgb_compare(a->ctx->stream, uint32_t(n), max_bytes, d_pairs, a->d_rgb, b->d_rgb, d_max, d_cnt);
+            launch_rgb_compare(a->ctx->stream, uint32_t(n), max_bytes, d_pairs, d_max, d_cnt);
             if (hipStreamSynchronize(a->ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess ||
                 hipMemcpy(hmax.data(), d_max, n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
                 hipMemcpy(hcnt.data(), d_cnt, n * 8, hipMemcpyDeviceToHost) != hipSuccess)
@@ -1148,6 +1461,20 @@ extern "C" int mjx_batch_bytes(const mjx_batch *b, uint64_t *scan_bytes, uint64_
 {
     return guarded([&]() -> int {
     if (!b) return MJX_ERR_INVALID_ARG;
+    if (!b->parts.empty()) {
+        uint64_t acc[4] = {0, 0, 0, 0};
+        for (const mjx_batch *part : b->parts) {
+            uint64_t v[4] = {0, 0, 0, 0};
+            const int rc = mjx_batch_bytes(part, &v[0], &v[1], coef_bytes ? &v[2] : nullptr, &v[3]);
+            if (rc != MJX_OK) return rc;
+            for (int k = 0; k < 4; k++) acc[k] += v[k];
+        }
+        if (scan_bytes) *scan_bytes = acc[0];
+        if (rgb_bytes) *rgb_bytes = acc[1];
+        if (coef_bytes) *coef_bytes = acc[2];
+        if (pixels) *pixels = acc[3];
+        return MJX_OK;
+    }
     if (scan_bytes) *scan_bytes = b->scan_bytes;
     if (rgb_bytes) *rgb_bytes = b->rgb_bytes;
     if (pixels) *pixels = b->pixels;
@@ -1171,6 +1498,18 @@ extern "C" int mjx_batch_bytes(const mjx_batch *b, uint64_t *scan_bytes, uint64_
 extern "C" int mjx_batch_geometry(const mjx_batch *b, uint64_t *subsequences, uint64_t *blocks, uint64_t *chunks)
 {
     if (!b) return MJX_ERR_INVALID_ARG;
+    if (!b->parts.empty()) {
+        uint64_t acc[3] = {0, 0, 0};
+        for (const mjx_batch *part : b->parts) {
+            uint64_t v[3];
+            (void)mjx_batch_geometry(part, &v[0], &v[1], &v[2]);
+            for (int k = 0; k < 3; k++) acc[k] += v[k];
+        }
+        if (subsequences) *subsequences = acc[0];
+        if (blocks) *blocks = acc[1];
+        if (chunks) *chunks = acc[2];
+        return MJX_OK;
+    }
     uint64_t ns = 0, nb = 0;
     for (size_t i = 0; i < b->info.size(); i++) {
         if (b->info[i].status != MJX_OK) continue;
@@ -1187,6 +1526,19 @@ extern "C" int mjx_batch_kernel_ms(mjx_batch *b, double ms[MJX_K_COUNT], uint64_
 {
     return guarded([&]() -> int {
     if (!b) return MJX_ERR_INVALID_ARG;
+    if (!b->parts.empty()) {
+        double acc[MJX_K_COUNT] = {0};
+        uint64_t cnt[MJX_K_COUNT] = {0};
+        for (mjx_batch *part : b->parts) {
+            double m[MJX_K_COUNT];
+            uint64_t l[MJX_K_COUNT];
+            const int rc = mjx_batch_kernel_ms(part, m, l, reset);
+            if (rc != MJX_OK) return rc;
+            for (int k = 0; k < MJX_K_COUNT; k++) { acc[k] += m[k]; cnt[k] += l[k]; }
+        }
+        for (int k = 0; k < MJX_K_COUNT; k++) { if (ms) ms[k] = acc[k]; if (launches) launches[k] = cnt[k]; }
+        return MJX_OK;
+    }
     HIPOK(hipSetDevice(b->ctx->device));
     { const int rcs = sync_streams(b); if (rcs != MJX_OK) return rcs; }
     collect_events(b);
@@ -1221,27 +1573,54 @@ extern "C" int mjx_decode_scans(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t
     });
 }
 
+// The outer surface for a list of files, pipelined ("double-buffered chunks: H2D of chunk k+1 overlaps the
+// kernels of chunk k"; the seam it replaces is jpeg/mod.rs:371-417, parse -> de-stuff -> decode of one file).  The files are
+// cut into groups of compressed data (12 MB first, doubling up to 96 MB: small groups give the device work early, large ones keep
+// the per-group launch overhead low).  Host threads walk the markers and de-stuff group after group into
+// the context's pinned arena; as soon as a group is parsed the calling thread plans it, enqueues its upload (one DMA
+// transfer per group, on the upload stream) and its kernels (on the decode streams, behind the upload's event), and
+// turns to the next group -- so parsing of group g+2, the transfer of group g+1 and the kernels of group g run at the
+// same time, and the call takes about as long as the slowest of the three (on PCIe Gen5: the transfer).
 extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const size_t *lens, size_t n, const mjx_opts *opts,
                                 unsigned threads, uint8_t **rgb_dev, int *status, mjx_batch **out)
 {
     return guarded([&]() -> int {
     if (!ctx || !out || ((!jpegs || !lens) && n)) return MJX_ERR_INVALID_ARG;
     *out = nullptr;
-    std::vector<mjx_scan_desc> descs(n);
-    std::vector<int> prc(n, MJX_OK);
-    // host side: every file is parsed on its own; a file that does not parse keeps an empty descriptor and its status
+    std::lock_guard<std::mutex> serial(ctx->batch_mu);        // the pinned arena is shared state of the context
+    mjx_opts o{};
+    if (opts) o = *opts;
+    const bool timing = std::getenv("MJX_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     unsigned nt = threads ? threads : std::thread::hardware_concurrency();
     nt = std::max(1u, std::min(nt, 32u));
     nt = unsigned(std::min<size_t>(nt, std::max<size_t>(n, 1)));
-    const bool timing = std::getenv("MJX_TIMING") != nullptr;
-    const auto tb0 = std::chrono::steady_clock::now();
+    // groups: small ones first so that the device has work early, then ~kGroupBytes each; kept coefficients and device-side
+    // de-stuffing take the whole list as one group (one batch, as mjx_batch_create would build it)
+    size_t group_bytes = size_t(96) << 20;
+    if (const char *e = std::getenv("MJX_GROUP_MB")) { const long v = std::atol(e); if (v > 0) group_bytes = size_t(v) << 20; }
+    const bool single = o.keep_coefs || o.device_destuff || n <= 8;
+    std::vector<size_t> gfirst{0};
+    {
+        size_t acc = 0, target = single ? ~size_t(0) : group_bytes / 8;
+        for (size_t i = 0; i < n; i++) {
+            acc += lens[i];
+            if (acc >= target && i + 1 < n) {
+                gfirst.push_back(i + 1);
+                acc = 0;
+                target = std::min(group_bytes, target * 2);
+            }
+        }
+        gfirst.push_back(n);
+    }
+    const size_t ngroups = gfirst.size() - 1;
     // one arena for all the de-stuffed scans (a slice of len + 64 bytes per file; what does not fit -- files with many
     // restart markers, multi-scan files -- is allocated by the parser): hundreds of megabyte-sized malloc / free pairs cost
-    // several times the parsing, and more with few threads
+    // several times the parsing.  Pinned: the scans are uploaded straight from it by DMA.
     std::vector<size_t> slice(n + 1, 0);
     for (size_t i = 0; i < n; i++) slice[i + 1] = slice[i] + ((lens[i] + 64 + 63) & ~size_t(63));
     if (ctx->parse_arena_cap < slice[n]) {
-        // (pinned: the scans are uploaded straight from it by DMA)
         HIPOK(hipSetDevice(ctx->device));
         if (ctx->parse_arena) (void)hipHostFree(ctx->parse_arena);
         ctx->parse_arena = nullptr;
@@ -1252,46 +1631,113 @@ extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const
         ctx->parse_arena_cap = slice[n] + slice[n] / 4 + 64;
     }
     uint8_t *const arena = ctx->parse_arena;
+    PinnedBump pin;
+    {
+        const size_t want = std::min<size_t>(size_t(256) << 20, n * (size_t(20) << 10) + (size_t(1) << 20));
+        if (ctx->pin_small_cap < want) {
+            if (ctx->pin_small) (void)hipHostFree(ctx->pin_small);
+            ctx->pin_small = nullptr;
+            ctx->pin_small_cap = 0;
+            void *pp = nullptr;
+            if (hipHostMalloc(&pp, want, hipHostMallocDefault) == hipSuccess) { ctx->pin_small = static_cast<uint8_t *>(pp); ctx->pin_small_cap = want; }
+            else (void)hipGetLastError();
+        }
+        pin.base = ctx->pin_small;
+        pin.cap = ctx->pin_small_cap;
+    }
+    std::vector<mjx_scan_desc> descs(n);
+    std::vector<int> prc(n, MJX_OK);
+    std::vector<std::vector<ImagePlan>> file_plans(n);
+    // host side: files are parsed in list order by a pool of threads; a group is ready when all its files are
     std::atomic<size_t> next{0};
+    std::vector<std::atomic<size_t>> done(ngroups);
+    for (auto &d : done) d.store(0);
+    std::vector<uint32_t> group_of(n);
+    for (size_t g = 0; g < ngroups; g++)
+        for (size_t i = gfirst[g]; i < gfirst[g + 1]; i++) group_of[i] = uint32_t(g);
+    std::mutex mu;
+    std::condition_variable cv;
     auto work = [&] {
         for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
-            prc[i] = mjx::parse_into(jpegs[i], lens[i], opts, &descs[i], arena + slice[i], slice[i + 1] - slice[i]);
-            if (prc[i] != MJX_OK) std::memset(&descs[i], 0, sizeof descs[i]);
+            int rc;
+            try {
+                rc = mjx::parse_into(jpegs[i], lens[i], &o, &descs[i], arena + slice[i], slice[i + 1] - slice[i]);
+            } catch (...) {
+                rc = MJX_ERR_NOMEM;
+            }
+            prc[i] = rc;
+            if (rc != MJX_OK) std::memset(&descs[i], 0, sizeof descs[i]);
+            try {
+                plan_input(descs[i], o, file_plans[i]);          // geometry + decode tables, also on the worker
+            } catch (...) {
+                file_plans[i].clear();
+            }
+            const size_t g = group_of[i];
+            if (done[g].fetch_add(1) + 1 == gfirst[g + 1] - gfirst[g]) {
+                std::lock_guard<std::mutex> lk(mu);
+                cv.notify_all();
+            }
         }
     };
-    {
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
-        work();
-        for (std::thread &t : pool) t.join();
+    std::vector<std::thread> pool;
+    struct Joiner {                                            // (the workers borrow this frame: never leave it before they are done)
+        std::vector<std::thread> &p;
+        std::atomic<size_t> &next;
+        size_t n;
+        ~Joiner() { next.store(n); for (std::thread &t : p) if (t.joinable()) t.join(); }
+    } joiner{pool, next, n};
+    for (unsigned t = 0; t < nt; t++) pool.emplace_back(work);
+
+    mjx_batch *dir = new (std::nothrow) mjx_batch;
+    if (!dir) return MJX_ERR_NOMEM;
+    struct Owner { mjx_batch *b; ~Owner() { if (b) { (void)hipDeviceSynchronize(); release(b); } } } owner{dir};
+    dir->ctx = ctx;
+    dir->opts = o;
+    dir->part_index.resize(n);
+    HIPOK(hipHostMalloc(reinterpret_cast<void **>(&dir->h_mismatch), ngroups * 8 * kMaxFix * sizeof(uint32_t), hipHostMallocDefault));
+    int rc = MJX_OK;
+    for (size_t g = 0; g < ngroups && rc == MJX_OK; g++) {
+        const size_t f0 = gfirst[g], cnt = gfirst[g + 1] - f0;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return done[g].load() == cnt; });
+        }
+        const double t_parsed = since();
+        mjx_batch *part = nullptr;
+        std::vector<ImagePlan> plans;
+        plans.reserve(cnt);
+        for (size_t i = 0; i < cnt; i++) {
+            if (file_plans[f0 + i].empty()) { rc = MJX_ERR_NOMEM; break; }
+            for (ImagePlan &pl : file_plans[f0 + i]) plans.push_back(std::move(pl));
+        }
+        if (rc != MJX_OK) break;
+        constexpr size_t kPinnedPerPart = 8 * kMaxFix;
+        rc = build_batch(ctx, plans, o, nullptr, 1, &part, nullptr, nullptr, true, dir->h_mismatch + g * kPinnedPerPart, kPinnedPerPart, &pin);
+        if (rc != MJX_OK) break;
+        dir->parts.push_back(part);
+        if (part->visible.size() != cnt) { rc = MJX_ERR_DEVICE; break; }
+        for (size_t i = 0; i < cnt; i++) dir->part_index[f0 + i] = {uint32_t(g), uint32_t(i)};
+        const double t_built = since();
+        rc = mjx_batch_decode(part, MJX_STAGE_ALL);
+        if (timing) std::fprintf(stderr, "[mjx] group %zu: %zu files, parsed at %.2f ms, uploaded+planned at %.2f, enqueued at %.2f\n", g, cnt, t_parsed, t_built, since());
     }
-    const auto tb1 = std::chrono::steady_clock::now();
-    std::vector<int> st(n, MJX_OK);
-    int rc = mjx_batch_create(ctx, descs.data(), n, opts, out, st.data());
-    const auto tb2 = std::chrono::steady_clock::now();
+    joiner.next.store(n);
+    for (std::thread &t : pool) if (t.joinable()) t.join();
     for (size_t i = 0; i < n; i++) mjx_free_scan(&descs[i]);
-    const auto tb2b = std::chrono::steady_clock::now();
+    if (rc == MJX_OK) rc = mjx_batch_wait(dir);
+    if (timing) std::fprintf(stderr, "[mjx] decode_batch: %zu files in %zu groups, %u threads, %.2f ms\n", n, ngroups, nt, since());
     if (rc != MJX_OK) return rc;
-    rc = mjx_batch_decode(*out, MJX_STAGE_ALL);
-    const auto tb2c = std::chrono::steady_clock::now();
-    if (rc == MJX_OK) rc = mjx_batch_wait(*out);
-    if (timing) {
-        const auto tb3 = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[mjx]   free %.2f ms, enqueue %.2f ms, wait %.2f ms\n", std::chrono::duration<double, std::milli>(tb2b - tb2).count(),
-                     std::chrono::duration<double, std::milli>(tb2c - tb2b).count(), std::chrono::duration<double, std::milli>(tb3 - tb2c).count());
-        auto msf = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) { return std::chrono::duration<double, std::milli>(b2 - a).count(); };
-        std::fprintf(stderr, "[mjx] decode_batch: parse (%u threads) %.2f ms, create %.2f ms, free + decode + wait %.2f ms\n", nt, msf(tb0, tb1), msf(tb1, tb2), msf(tb2, tb3));
-    }
-    if (rc != MJX_OK) { mjx_batch_free(*out); *out = nullptr; return rc; }
     for (size_t i = 0; i < n; i++) {
-        const int si = prc[i] != MJX_OK ? prc[i] : mjx_batch_status(*out, i);
+        const int si = prc[i] != MJX_OK ? prc[i] : mjx_batch_status(dir, i);
         if (status) status[i] = si;
         if (rgb_dev) {
             void *p = nullptr;
-            if (si == MJX_OK) (void)mjx_batch_rgb_device(*out, i, &p, nullptr);
+            if (si == MJX_OK) (void)mjx_batch_rgb_device(dir, i, &p, nullptr);
             rgb_dev[i] = static_cast<uint8_t *>(p);
         }
     }
+    owner.b = nullptr;
+    *out = dir;
     return MJX_OK;
     });
 }

@@ -72,8 +72,8 @@ struct DestuffImg {
     uint32_t seg0, nseg;                 // this image's slots in the per-segment count / base arrays
 };
 
-// mjx_batch_compare_rgb: one pair of pictures (byte offsets into the two RGB pools)
-struct RgbPair { uint64_t off_a, off_b, bytes; };
+// mjx_batch_compare_rgb: one pair of pictures (device pointers: the pictures may live in different pools)
+struct RgbPair { const uint8_t *a, *b; uint64_t bytes; };
 
 // MCUs per stage-B tile: a power of two so that lane -> (MCU, strip) is a shift, and at most 256 strips per row.
 inline uint32_t tile_mcus(uint32_t bpm, uint32_t hmax)
@@ -122,8 +122,8 @@ void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t
 // multi-scan pictures: component streams (raster order) -> the picture's stream in MCU order, tile offsets, DC values
 void launch_planar_gather(hipStream_t st, uint32_t max_tiles, uint32_t nimg, const DevImage *images, uint32_t *entries,
                           uint32_t *tile_eoff, int32_t *dcbuf, uint32_t *img_flags);
-void launch_rgb_compare(hipStream_t st, uint32_t npairs, uint64_t max_bytes, const RgbPair *pairs, const uint8_t *rgb_a,
-                        const uint8_t *rgb_b, uint32_t *maxdiff, unsigned long long *ndiff);
+void launch_rgb_compare(hipStream_t st, uint32_t npairs, uint64_t max_bytes, const RgbPair *pairs, uint32_t *maxdiff,
+                        unsigned long long *ndiff);
 void launch_ref_color(hipStream_t st, uint32_t max_pixel_wgs, uint32_t nimg, const DevImage *images,
                       const unsigned long long *planes, uint8_t *rgb, const uint32_t *img_flags);
 #endif

@@ -1735,14 +1735,13 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
 // (mjx_batch_compare_rgb: the parity gate of bench.py and the batch-scale tests compare tens of gigabytes of output
 // without copying them to the host.)  One workgroup per 16 KiB of a pair; per pair the largest absolute byte
 // difference and the number of differing bytes.
-extern "C" __global__ __launch_bounds__(256) void k_rgb_compare(const RgbPair *pairs, const uint8_t *rgb_a,
-                                                                 const uint8_t *rgb_b, uint32_t *maxdiff,
+extern "C" __global__ __launch_bounds__(256) void k_rgb_compare(const RgbPair *pairs, uint32_t *maxdiff,
                                                                  unsigned long long *ndiff)
 {
     const RgbPair p = pairs[blockIdx.y];
     const uint64_t base = uint64_t(blockIdx.x) * 16384u;
     if (base >= p.bytes) return;
-    const uint8_t *a = rgb_a + p.off_a, *b = rgb_b + p.off_b;
+    const uint8_t *a = p.a, *b = p.b;
     uint32_t mx = 0, cnt = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++) {
@@ -1897,12 +1896,12 @@ void launch_planar_gather(hipStream_t st, uint32_t max_tiles, uint32_t nimg, con
     hipLaunchKernelGGL(k_planar_copy, dim3(max_tiles, nimg), dim3(256), 0, st, images, entries, tile_eoff, dcbuf, img_flags);
 }
 
-void launch_rgb_compare(hipStream_t st, uint32_t npairs, uint64_t max_bytes, const RgbPair *pairs, const uint8_t *rgb_a,
-                        const uint8_t *rgb_b, uint32_t *maxdiff, unsigned long long *ndiff)
+void launch_rgb_compare(hipStream_t st, uint32_t npairs, uint64_t max_bytes, const RgbPair *pairs, uint32_t *maxdiff,
+                        unsigned long long *ndiff)
 {
     const uint32_t gx = uint32_t((max_bytes + 16383) / 16384);
     if (gx == 0 || npairs == 0) return;
-    hipLaunchKernelGGL(k_rgb_compare, dim3(gx, npairs), dim3(256), 0, st, pairs, rgb_a, rgb_b, maxdiff, ndiff);
+    hipLaunchKernelGGL(k_rgb_compare, dim3(gx, npairs), dim3(256), 0, st, pairs, maxdiff, ndiff);
 }
 
 void launch_ref_color(hipStream_t st, uint32_t max_pixel_wgs, uint32_t nimg, const DevImage *images,
