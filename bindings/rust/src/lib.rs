@@ -88,6 +88,8 @@ pub struct mjx_image {
 
 pub enum mjx_ctx {}
 pub enum mjx_batch {}
+pub enum mjx_pool {}
+pub enum mjx_pool_result {}
 
 extern "C" {
     pub fn mjx_parse(jpeg: *const u8, len: usize, opts: *const mjx_opts, out: *mut mjx_scan_desc) -> c_int;
@@ -122,6 +124,16 @@ extern "C" {
                             rgb_dev: *mut *mut u8, status: *mut c_int, out: *mut *mut mjx_batch) -> c_int;
     pub fn mjx_decode_batch(ctx: *mut mjx_ctx, jpegs: *const *const u8, lens: *const usize, n: usize, opts: *const mjx_opts,
                             threads: c_uint, rgb_dev: *mut *mut u8, status: *mut c_int, out: *mut *mut mjx_batch) -> c_int;
+    pub fn mjx_pool_create(devices: *const c_int, n_devices: usize, out: *mut *mut mjx_pool) -> c_int;
+    pub fn mjx_pool_destroy(pool: *mut mjx_pool);
+    pub fn mjx_pool_devices(pool: *const mjx_pool) -> usize;
+    pub fn mjx_pool_device(pool: *const mjx_pool, slot: usize) -> c_int;
+    pub fn mjx_pool_decode_batch(pool: *mut mjx_pool, jpegs: *const *const u8, lens: *const usize, n: usize, opts: *const mjx_opts,
+                                 threads_per_device: c_uint, slot_of: *mut c_int, rgb_dev: *mut *mut u8, status: *mut c_int,
+                                 out: *mut *mut mjx_pool_result) -> c_int;
+    pub fn mjx_pool_result_locate(r: *const mjx_pool_result, i: usize, slot: *mut usize, batch: *mut *mut mjx_batch,
+                                  index: *mut usize) -> c_int;
+    pub fn mjx_pool_result_free(r: *mut mjx_pool_result);
     pub fn mjx_strerror(code: c_int) -> *const c_char;
     pub fn mjx_version() -> *const c_char;
 }

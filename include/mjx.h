@@ -199,6 +199,26 @@ int mjx_decode_scans(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t n, const m
 int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const size_t *lens, size_t n, const mjx_opts *opts,
                      unsigned threads, uint8_t **rgb_dev, int *status, mjx_batch **out);
 
+/* ---- multi-GPU front: one context + one host thread + one work queue per device, no collective ----------
+ * Pictures are independent (decoder.rs:162-343 touches only `self`), so a list of files shards over the GPUs of a node
+ * without any exchange: file i goes to device slot i mod N, every slot decodes its share with the pipelined
+ * mjx_decode_batch on its own device, outputs stay where they were produced.  `devices` may name a device more than once
+ * (two slots on one GPU).  One mjx_pool_decode_batch call at a time per pool. */
+typedef struct mjx_pool mjx_pool;
+typedef struct mjx_pool_result mjx_pool_result;
+int mjx_pool_create(const int *devices, size_t n_devices, mjx_pool **out);
+void mjx_pool_destroy(mjx_pool *pool);
+size_t mjx_pool_devices(const mjx_pool *pool);
+int mjx_pool_device(const mjx_pool *pool, size_t slot);          /* HIP device of a slot, -1 if out of range */
+/* slot_of[i] / rgb_dev[i] / status[i] (each optional, n entries): the slot that decoded file i, its device pointer (owned
+ * by *out, NULL on failure) and status.  Release with mjx_pool_result_free. */
+int mjx_pool_decode_batch(mjx_pool *pool, const uint8_t *const *jpegs, const size_t *lens, size_t n, const mjx_opts *opts,
+                          unsigned threads_per_device, int *slot_of, uint8_t **rgb_dev, int *status, mjx_pool_result **out);
+/* file i of the call -> its slot, the slot's batch and the picture's index inside it (for mjx_batch_image_info,
+ * mjx_batch_copy_rgb, ...) */
+int mjx_pool_result_locate(const mjx_pool_result *r, size_t i, size_t *slot, mjx_batch **batch, size_t *index);
+void mjx_pool_result_free(mjx_pool_result *r);
+
 const char *mjx_strerror(int code);
 /* library build info: "mjx <version> gfx950 subseq=<bits> ..." */
 const char *mjx_version(void);

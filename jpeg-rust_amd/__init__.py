@@ -103,6 +103,13 @@ SYMBOLS = {
     "mjx_batch_geometry": (_int, [_vp] + [_P(ctypes.c_uint64)] * 3),
     "mjx_batch_kernel_ms": (_int, [_vp, _P(ctypes.c_double), _P(ctypes.c_uint64), _int]),
     "mjx_decode_scans": (_int, [_vp, _P(ScanDesc), _sz, _P(Opts), _P(_P(ctypes.c_uint8)), _P(_int), _P(_vp)]),
+    "mjx_pool_create": (_int, [_P(_int), _sz, _P(_vp)]),
+    "mjx_pool_destroy": (None, [_vp]),
+    "mjx_pool_devices": (_sz, [_vp]),
+    "mjx_pool_device": (_int, [_vp, _sz]),
+    "mjx_pool_decode_batch": (_int, [_vp, _P(ctypes.c_char_p), _P(_sz), _sz, _P(Opts), ctypes.c_uint, _P(_int), _P(_P(ctypes.c_uint8)), _P(_int), _P(_vp)]),
+    "mjx_pool_result_locate": (_int, [_vp, _sz, _P(_sz), _P(_vp), _P(_sz)]),
+    "mjx_pool_result_free": (None, [_vp]),
     "mjx_strerror": (ctypes.c_char_p, [_int]),
     "mjx_version": (ctypes.c_char_p, []),
 }
@@ -486,6 +493,79 @@ def decode_batch(ctx, datas, strict_ref=False, layout=LAYOUT_STANDARD, threads=0
     o = _opts(strict_ref, layout)
     _check(lib().mjx_decode_batch(ctx.h, arr, lens, n, ctypes.byref(o), int(threads), ptrs, st, ctypes.byref(h)), "mjx_decode_batch")
     return Batch(ctx, _handle=h), list(st)[:n]
+
+
+class Pool:
+    """mjx_pool: one context, host thread and work queue per device slot; file i of a call goes to slot i mod N."""
+
+    def __init__(self, devices):
+        self.h = _vp()
+        arr = (_int * len(devices))(*[int(d) for d in devices])
+        _check(lib().mjx_pool_create(arr, len(devices), ctypes.byref(self.h)), "mjx_pool_create(%s)" % list(devices))
+
+    def __len__(self):
+        return int(lib().mjx_pool_devices(self.h))
+
+    def device(self, slot):
+        return int(lib().mjx_pool_device(self.h, slot))
+
+    def decode_batch(self, datas, strict_ref=False, layout=LAYOUT_STANDARD, threads_per_device=0):
+        """-> PoolResult; .slot_of[i], .status[i], .rgb(i)"""
+        n = len(datas)
+        arr = (ctypes.c_char_p * max(n, 1))(*[bytes(d) for d in datas])
+        lens = (_sz * max(n, 1))(*[len(d) for d in datas])
+        st = (_int * max(n, 1))()
+        slots = (_int * max(n, 1))()
+        ptrs = (_P(ctypes.c_uint8) * max(n, 1))()
+        h = _vp()
+        o = _opts(strict_ref, layout)
+        _check(lib().mjx_pool_decode_batch(self.h, arr, lens, n, ctypes.byref(o), int(threads_per_device), slots, ptrs, st,
+                                           ctypes.byref(h)), "mjx_pool_decode_batch")
+        return PoolResult(h, list(slots)[:n], list(st)[:n], [ctypes.cast(p, _vp).value for p in ptrs][:n])
+
+    def close(self):
+        if self.h:
+            lib().mjx_pool_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        if sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PoolResult:
+    def __init__(self, h, slot_of, status, ptrs):
+        self.h, self.slot_of, self.status, self.ptrs = h, slot_of, status, ptrs
+
+    def locate(self, i):
+        slot, idx, b = _sz(), _sz(), _vp()
+        _check(lib().mjx_pool_result_locate(self.h, i, ctypes.byref(slot), ctypes.byref(b), ctypes.byref(idx)))
+        return slot.value, b, idx.value
+
+    def rgb(self, i):
+        _, b, idx = self.locate(i)
+        v = [ctypes.c_uint32() for _ in range(4)]
+        lib().mjx_batch_image_info(b, idx, *[ctypes.byref(x) for x in v])
+        out = np.empty((v[1].value, v[0].value, 3), np.uint8)
+        _check(lib().mjx_batch_copy_rgb(b, idx, out.ctypes.data_as(_vp)), "mjx_batch_copy_rgb")
+        return out
+
+    def close(self):
+        if self.h:
+            lib().mjx_pool_result_free(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        if sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def decode(data, strict_ref=False, layout=LAYOUT_STANDARD):

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 
 HIP_SOURCES = ["mjx_kernels.hip", "mjx_api.hip"]
-CXX_SOURCES = ["mjx_parse.cpp", "mjx_lut.cpp", "mjx_plan.cpp"]
+CXX_SOURCES = ["mjx_parse.cpp", "mjx_lut.cpp", "mjx_plan.cpp", "mjx_pool.cpp"]
 HEADERS = ["mjx_huff.h", "mjx_kernels.h", "mjx_plan.h", os.path.join(ROOT, "include", "mjx.h")]
 
 
@@ -85,10 +85,11 @@ def build_emul(force=False):
     d = os.path.join(ROOT, "tests", "emul")
     src = os.path.join(d, "huff_emul.cpp")
     out = os.path.join(d, "libhuff_emul.so")
-    deps = [src] + [os.path.join(CSRC, s) for s in CXX_SOURCES + ["mjx_huff.h", "mjx_plan.h"]]
+    host_only = [s for s in CXX_SOURCES if s != "mjx_pool.cpp"]      # (the pool needs the device entry points)
+    deps = [src] + [os.path.join(CSRC, s) for s in host_only + ["mjx_huff.h", "mjx_plan.h"]]
     if os.path.exists(src) and (force or _newer(out, deps)):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-              "-o", out, src] + [os.path.join(CSRC, s) for s in CXX_SOURCES])
+              "-o", out, src] + [os.path.join(CSRC, s) for s in host_only])
     return out
 
 

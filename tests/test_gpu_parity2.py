@@ -191,3 +191,36 @@ def test_bench_two_ranks_over_gloo_on_one_gpu(tmp_path):
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["parity"]["ok"] and rec["parity"]["tiled_max_abs_diff"] == 0
     assert rec["parity"]["t0_equal"] and rec["parity"]["max_abs_diff"] <= 1
+
+
+# ---- multi-GPU front: per-device work queues, no collective -------------------------------------------------
+def test_pool_shards_files_over_device_slots(mjx, orc, data_dir=None):
+    """mjx_pool with two slots on the one GPU of the test box: file i goes to slot i mod 2, every slot decodes its share on
+    its own context and host thread, a file that does not parse keeps its status, and every picture matches the oracle."""
+    root = os.path.join(ROOT, "tests")
+    names = ["lena.jpeg", "2x2-chroma.jpeg", "huff_simple0.jpg", "lena-bw.jpeg"]
+    datas = [open(os.path.join(root, "data", n), "rb").read() for n in names]
+    datas += [mjx.synth_jpeg(w, h, s, 75, seed=i) for i, (w, h, s) in enumerate([(640, 480, "420"), (333, 217, "444"), (1920, 1080, "420"),
+                                                                                 (64, 48, "gray"), (100, 60, "422")])]
+    datas += [b"not a jpeg", open(os.path.join(root, "golden", "pil", "ms2_420_big.jpg"), "rb").read(),
+              open(os.path.join(root, "golden", "pil", "dri_420_r5.jpg"), "rb").read()]
+    datas = datas * 3
+    pool = mjx.Pool([0, 0])
+    assert len(pool) == 2 and pool.device(0) == 0 and pool.device(1) == 0 and pool.device(2) == -1
+    for _ in range(2):                                                   # the queues are persistent: a second call reuses them
+        res = pool.decode_batch(datas, threads_per_device=4)
+        assert res.slot_of == [i % 2 for i in range(len(datas))]
+        for i, d in enumerate(datas):
+            try:
+                ref = orc.decode(d, layout=orc.LAYOUT_STD, ext_dri=True, ext_multiscan=True)
+            except orc.OracleError:
+                assert res.status[i] != mjx.OK and not res.ptrs[i], i
+                continue
+            assert res.status[i] == mjx.OK and res.ptrs[i], (i, res.status[i])
+            assert res.locate(i)[0] == i % 2
+            assert np.abs(res.rgb(i).astype(int) - ref.rgb.astype(int)).max() <= TOL, i
+        res.close()
+    empty = pool.decode_batch([])
+    assert empty.status == []
+    empty.close()
+    pool.close()

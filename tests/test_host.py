@@ -442,3 +442,12 @@ def _corrupt_stream_file(jw, w, h, comps, seed, max_size=15, qmax=40):
     assert blocks > need + 8
     qt = [int(v) for v in rng.integers(1, qmax, 64)]
     return jw.write_jpeg(w, h, frame, {0: qt}, {(0, 0): dc_tab, (1, 0): ac_tab}, ent), need
+
+
+def test_pool_without_a_gpu_fails_loudly(mjx):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(mjx.MjxError) as e:
+        mjx.Pool([0, 0])
+    assert e.value.code == mjx.ERR_DEVICE
