@@ -12,7 +12,9 @@ gloo (host TCP) -- the north star says "no RCCL", and that holds for the harness
 
 The JSON line carries, besides the contract fields:
   roofline      dominant kernel (by summed HIP-event time over the timed region): algorithmic bytes per launch / average
-                launch duration vs the 8 TB/s HBM3E peak; frac_physical = the same with the bytes the kernel really moves
+                launch duration vs the 8 TB/s HBM3E peak; frac_physical = the same with the bytes the kernel really moves.
+                The library overlaps the entropy stage with stage B on two streams, so these durations include contention;
+  roofline_isolated  is the same object from a one-stream pass over the same batch: the kernel's stand-alone duration
   roofline_e2e  whole path: sum over images of (S + 3*W*H) (SURVEY.md s8(d) B_e2e) / sum of all kernel time
   kernels       per kernel class: launches, total ms
   parity        the gate behind `value`: every picture of the timed batch compared on the device with its
@@ -436,6 +438,25 @@ def main():
         if not op["t0_equal"]:
             failures.append("coefficient stream differs from the oracle")
     batch.close()
+
+    if not args.no_extra and world == 1 and args.streams != 1:
+        # The library runs the entropy stage and stage B on two streams (overlapped), so the kernel durations of the timed
+        # region above include the contention between them.  The same workload on one stream gives every kernel's
+        # stand-alone duration: the roofline of the kernel itself, next to the overlapped one.
+        os.environ["MJX_STREAMS"] = "1"
+        ctx1 = mjx.Context(device, profiling=True)
+        os.environ.pop("MJX_STREAMS")
+        iso_steps = max(2, min(args.steps, 3))
+        r1, b1 = run_config(mjx, ctx1, datas, args.images_per_gpu, args.stages, iso_steps, 1, args.chunk_images, args.device_destuff, sync_all)
+        b1.close()
+        rl1 = rooflines(r1, iso_steps, args.stages, args.width == 3840 and args.height == 2160 and args.quality == 75)
+        out["roofline_isolated"] = dict(rl1["roofline"], note="same workload with MJX_STREAMS=1 (no overlap between the entropy stage and stage B): "
+                                        "the dominant kernel's stand-alone duration", steps=iso_steps,
+                                        value_single_stream=round(r1["by"]["pixels"] * iso_steps / r1["elapsed"] / 1e6, 2))
+        out["kernel_rooflines_isolated"] = rl1["kernel_rooflines"]
+        if r1["tiled_max_abs_diff"] != 0:
+            failures.append("single-stream pass: tiled pictures differ from their originals")
+        ctx1.close()
 
     extra = []
     if not args.no_extra and world == 1 and args.stages == "all":

@@ -1018,7 +1018,17 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     if (const char *e = std::getenv("MJX_CACHE_GB")) c->cache_limit = size_t(std::max(0L, std::atol(e))) << 30;
     c->nstreams = 2;
     if (const char *e = std::getenv("MJX_STREAMS")) c->nstreams = std::atoi(e) == 1 ? 1 : 2;
-    if (c->nstreams == 2 && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) c->nstreams = 1;
+    if (c->nstreams == 2) {
+        // stage B's stream gets the higher priority (MJX_PIXEL_PRIORITY=0: equal): its workgroups are placed first when a CU
+        // frees resources, so the pixel kernel keeps close to its stand-alone pace and the entropy kernels fill what it leaves
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const char *pe = std::getenv("MJX_PIXEL_PRIORITY");
+        const bool prio = !pe || std::atoi(pe) != 0;
+        const hipError_t e2 = (prio && hi != lo) ? hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi)
+                                                 : hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+        if (e2 != hipSuccess) { (void)hipGetLastError(); c->stream2 = nullptr; c->nstreams = 1; }
+    }
     if (const char *e = std::getenv("MJX_SPEC_LDS_PAD")) c->spec_lds_pad = size_t(std::atoi(e));
     if (const char *e = std::getenv("MJX_MERGE_LDS_PAD")) c->merge_lds_pad = size_t(std::atoi(e));
     if (const char *e = std::getenv("MJX_WRITE_LDS_PAD")) c->write_lds_pad = size_t(std::atoi(e));
