@@ -10,7 +10,11 @@
  * and cannot be compiled here (no rustc/cargo).  The oracle is pinned against
  * the four sample JPEGs the reference holds and the known answers recorded in
  * SURVEY.md s4 (coefficient-stream SHA-256s, bit counts, huff_simple0 pixels);
- * see tests/test_oracle_golden.py.
+ * see tests/test_oracle_golden.py.  By the project's rule that makes the parity UNPINNED (no reference-owned
+ * vector, no run of the reference).  What stands in for a pin is a second, independent restatement in Python /
+ * numpy float32 written from the Rust sources (tests/golden/ref_emul.py): the two agree byte for byte on the
+ * sample files (coefficients, bits consumed, every RGB byte of the reference's own layout) and on synthetic,
+ * 16-bit-DQT, panicking and semantically corrupt inputs.
  *
  * Every function cites the reference file:line it restates
  * (paths relative to /root/reference/src).
