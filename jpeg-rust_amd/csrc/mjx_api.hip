@@ -219,7 +219,10 @@ struct mjx_batch {
 namespace {
 
 constexpr int kMaxFix = 16;
-constexpr uint32_t kTilesPerWgHost = 8;       // must equal kTilesPerWg in mjx_kernels.hip
+#ifndef MJX_TILES_PER_WG
+#define MJX_TILES_PER_WG 16
+#endif
+constexpr uint32_t kTilesPerWgHost = MJX_TILES_PER_WG;       // must equal kTilesPerWg in mjx_kernels.hip
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

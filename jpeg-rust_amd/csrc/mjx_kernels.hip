@@ -276,7 +276,10 @@ __device__ __forceinline__ SubLoc locate_sub(const DevImage &im, const HuffImage
 #define MJX_WIN_DWORDS 8
 #endif
 constexpr int kWinDwords = MJX_WIN_DWORDS;
-constexpr int kWinStride = kWinDwords + 1;      // odd stride: lanes spread over all banks
+#ifndef MJX_WIN_PAD
+#define MJX_WIN_PAD 1
+#endif
+constexpr int kWinStride = kWinDwords + MJX_WIN_PAD;      // odd stride: lanes spread over all banks
 struct LdsWindow {
     const unsigned char *lds;    // lane's window
     uint32_t wbase;              // stream byte offset of the window's first dword (as of the last fill the caller noted)
@@ -1371,8 +1374,14 @@ __device__ __forceinline__ void store4(uint8_t *dst, const Rgb4 &v, bool aligned
 // A workgroup walks kTilesPerWg consecutive tiles of one image.  While it transforms tile t it already holds the loads
 // of tile t+1 in flight (stream offsets, up to kPrefetch entries per lane, the lane's DC), so the HBM round trips of a
 // tile overlap the arithmetic of the previous one instead of sitting on the workgroup's critical path.
-constexpr int kPrefetch = 8;         // stream entries per lane held in registers (2048 per tile; the rest is re-read)
-constexpr int kTilesPerWg = 8;
+#ifndef MJX_PREFETCH
+#define MJX_PREFETCH 8
+#endif
+#ifndef MJX_TILES_PER_WG
+#define MJX_TILES_PER_WG 16
+#endif
+constexpr int kPrefetch = MJX_PREFETCH;         // stream entries per lane held in registers (2048 per tile; the rest is re-read)
+constexpr int kTilesPerWg = MJX_TILES_PER_WG;
 #ifndef MJX_TILE420
 #define MJX_TILE420 32
 #endif

@@ -7,7 +7,7 @@ C=$R/jpeg-rust_amd/csrc; mkdir -p $R/ab /tmp/mjxv_$NAME
 for s in mjx_kernels.hip mjx_api.hip; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize "$@" -c $C/$s -o /tmp/mjxv_$NAME/$s.o -I$R/include -I$C &
 done
-for s in mjx_lut.cpp mjx_parse.cpp mjx_plan.cpp; do
+for s in mjx_lut.cpp mjx_parse.cpp mjx_plan.cpp mjx_pool.cpp; do
   g++ -O2 -std=c++17 -fPIC "$@" -c $C/$s -o /tmp/mjxv_$NAME/$s.o -I$R/include -I$C
 done
 wait
