@@ -245,7 +245,7 @@ def run_config(mjx, ctx, datas, per_gpu, stages, steps, warmup, chunk_images=0, 
         sync_all()
     elapsed = time.perf_counter() - t0
     bad = [i for i in range(len(batch)) if batch.status(i) != mjx.OK]
-    assert not bad, "images failed: %s" % bad[:8]
+    assert not bad or os.environ.get("MJX_BENCH_IGNORE_STATUS"), "images failed: %s" % bad[:8]     # (the switch: measurement builds that decode garbage)
     kms = batch.kernel_ms()
     by = batch.bytes()
     kernels = {k: {"launches": v[1], "ms": round(v[0], 4)} for k, v in kms.items() if v[1]}

@@ -224,3 +224,37 @@ def test_pool_shards_files_over_device_slots(mjx, orc, data_dir=None):
     assert empty.status == []
     empty.close()
     pool.close()
+
+
+def test_pipelined_decode_batch_equals_the_batch_api(mjx, gpu_ctx):
+    """mjx_decode_batch cuts its list into groups that are parsed, uploaded and decoded in overlap; with groups of 1 MB a list
+    of 70 mixed files becomes a dozen groups.  Every picture must equal, bit for bit, what the one-batch path
+    (mjx_parse + mjx_batch_create + mjx_batch_decode) gives -- compared on the device across the group batches."""
+    import subprocess
+    rng = np.random.default_rng(9)
+    datas = []
+    for i in range(70):
+        w, h = int(rng.integers(8, 700)), int(rng.integers(8, 500))
+        datas.append(mjx.synth_jpeg(w, h, ["420", "422", "444", "gray", "440"][i % 5], int(rng.integers(20, 98)), seed=i, dqt16=(i % 7 == 0)))
+    datas[13] = b"garbage" * 10
+    root = os.path.join(ROOT, "tests")
+    datas[29] = open(os.path.join(root, "golden", "pil", "ms_420_big.jpg"), "rb").read()
+    datas[41] = open(os.path.join(root, "golden", "pil", "dri_420_720p_rows.jpg"), "rb").read()
+    os.environ["MJX_GROUP_MB"] = "1"
+    try:
+        grouped, st = mjx.decode_batch(gpu_ctx, datas, threads=6)
+    finally:
+        os.environ.pop("MJX_GROUP_MB")
+    assert grouped.geometry()["chunks"] >= 3                       # several groups, each a batch of its own
+    good = [i for i in range(len(datas)) if i != 13]
+    assert st[13] != mjx.OK and all(st[i] == mjx.OK for i in good)
+    one = mjx.Batch(gpu_ctx, [mjx.ParsedScan(datas[i]) for i in good])
+    one.decode()
+    one.wait()
+    mx, cnt = grouped.compare_rgb(good, one, list(range(len(good))))
+    assert int(mx.max()) == 0 and int(cnt.sum()) == 0
+    assert grouped.status(13) != mjx.OK and len(grouped) == len(datas)
+    info = grouped.info(29)
+    assert (info["width"], info["height"]) == (640, 480)
+    one.close()
+    grouped.close()

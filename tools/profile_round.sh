@@ -19,6 +19,9 @@ done
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $O/pmc_sqA -o out --output-format csv -- python3 bench.py $Q --steps 1 --warmup 0 --images-per-gpu 256 > $O/pmc_sqA.log 2>&1
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR -d $O/pmc_sqB -o out --output-format csv -- python3 bench.py $Q --steps 1 --warmup 0 --images-per-gpu 256 > $O/pmc_sqB.log 2>&1
 unset MJX_STREAMS
+python3 tools/single_image_times.py > $O/single_images.txt 2>&1
+python3 tools/e2e_from_files.py 512 0 > $O/e2e_512.txt 2>&1
+python3 tools/e2e_from_files.py 2048 0 > $O/e2e_2048.txt 2>&1
 python3 tools/collect_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/traffic.json 256 > /dev/null
 python3 tools/pmc_summary.py $O/pmc_sqA/*counter_collection.csv $O/pmc_sqB/*counter_collection.csv > $O/pmc_sq_summary.txt 2>&1
 cp $O/stats2/*kernel_stats.csv $O/kernel_stats_2048x4K_2streams.csv 2>/dev/null
