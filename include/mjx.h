@@ -192,10 +192,15 @@ int mjx_batch_kernel_ms(mjx_batch *b, double ms[MJX_K_COUNT], uint64_t launches[
 int mjx_decode_scans(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t n, const mjx_opts *opts,
                      uint8_t **rgb_dev, int *status, mjx_batch **out);
 
-/* The outer surface for a batch of files: JPEGImage::parse of jpeg/mod.rs:202 for n files at once --
- * marker walk + de-stuffing on `threads` host threads (0 = as many as the machine has, at most 32), then create + decode
- * + wait on the GPU.  status[i] receives the parse / plan / decode status of file i, rgb_dev[i] a device pointer owned by
- * *out (NULL on failure); mjx_batch_image_info(*out, i, ...) gives the dimensions.  Release with mjx_batch_free. */
+/* The outer surface for a batch of files: JPEGImage::parse of jpeg/mod.rs:202 for n files at once,
+ * pipelined -- the list is cut into groups of compressed data (12 MB first, doubling up to 96 MB); `threads` host threads
+ * (0 = as many as the machine has, at most 32) walk the markers and de-stuff group after group into pinned memory, every
+ * group goes up in one DMA transfer on an upload stream of its own, and its kernels start behind that transfer's event,
+ * so parsing, transfer and decode of successive groups overlap.  status[i] receives the parse / plan / decode status of
+ * file i, rgb_dev[i] a device pointer owned by *out (NULL on failure); mjx_batch_image_info(*out, i, ...) gives the
+ * dimensions.  *out is a directory of the groups' batches: every per-picture accessor, mjx_batch_decode / _wait / _bytes /
+ * _geometry / _kernel_ms / _compare_rgb work on it, mjx_batch_tile does not.  Calls on one context are serialised (the
+ * pinned arena belongs to the context).  Release with mjx_batch_free. */
 int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const size_t *lens, size_t n, const mjx_opts *opts,
                      unsigned threads, uint8_t **rgb_dev, int *status, mjx_batch **out);
 
