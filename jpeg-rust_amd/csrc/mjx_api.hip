@@ -1016,7 +1016,16 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     mjx_ctx *c = new (std::nothrow) mjx_ctx;
     if (!c) return MJX_ERR_NOMEM;
     c->device = device;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MJX_ERR_DEVICE; }
+    {
+        // MJX_HIGH_PRIO = entropy | pixels | none: which of the two decode streams is created with the high priority
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const char *hp = std::getenv("MJX_HIGH_PRIO");
+        const bool ent_high = hp && std::strcmp(hp, "entropy") == 0 && hi != lo;
+        const hipError_t e1 = ent_high ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi)
+                                       : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e1 != hipSuccess) { (void)hipGetLastError(); delete c; return MJX_ERR_DEVICE; }
+    }
     if (hipStreamCreateWithFlags(&c->upload, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return MJX_ERR_DEVICE; }
     if (const char *e = std::getenv("MJX_CACHE_GB")) c->cache_limit = size_t(std::max(0L, std::atol(e))) << 30;
     c->nstreams = 2;
@@ -1026,8 +1035,8 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
         // frees resources, so the pixel kernel keeps close to its stand-alone pace and the entropy kernels fill what it leaves
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        const char *pe = std::getenv("MJX_PIXEL_PRIORITY");
-        const bool prio = !pe || std::atoi(pe) != 0;
+        const char *pe = std::getenv("MJX_PIXEL_PRIORITY"), *hp = std::getenv("MJX_HIGH_PRIO");
+        const bool prio = hp ? std::strcmp(hp, "pixels") == 0 : (!pe || std::atoi(pe) != 0);
         const hipError_t e2 = (prio && hi != lo) ? hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi)
                                                  : hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
         if (e2 != hipSuccess) { (void)hipGetLastError(); c->stream2 = nullptr; c->nstreams = 1; }
