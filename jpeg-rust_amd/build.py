@@ -5,6 +5,8 @@
     ../oracle/libmjx_oracle.so  CPU oracle, test infrastructure only  (make, gcc)
     ../tests/emul/libhuff_emul.so CPU emulation of the entropy algorithm, test infrastructure only (g++)
 """
+import contextlib
+import fcntl
 import os
 import shutil
 import subprocess
@@ -34,6 +36,32 @@ def _run(cmd, cwd=None):
     return r.stdout
 
 
+@contextlib.contextmanager
+def _build_lock():
+    """One builder at a time: `torchrun` starts N ranks together and each calls build(); the first one in builds, the
+    others wait here and then find everything up to date."""
+    with open(os.path.join(PKG, ".build.lock"), "w") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+
+def _link(cmd, out):
+    """Runs a link command that writes `out` (named after "-o") into a temporary name and renames it into place: a
+    process that has the old file mapped keeps its inode."""
+    tmp = "%s.tmp.%d" % (out, os.getpid())
+    cmd = [tmp if c == out else c for c in cmd]
+    try:
+        log = _run(cmd)
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    return log
+
+
 def hipcc_path():
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -59,7 +87,7 @@ def build_product(force=False, verbose=False):
         o = os.path.join(objdir, s + ".o")
         log += _run(["g++", "-O2", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, s), "-o", o] + inc)
         objs.append(o)
-    log += _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    log += _link([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, out)
     if verbose:
         print(log)
     return out
@@ -69,7 +97,7 @@ def build_synth(force=False):
     src = os.path.join(PKG, "synth", "mjx_synth.c")
     out = os.path.join(PKG, "synth", "libmjx_synth.so")
     if force or _newer(out, [src]):
-        _run(["gcc", "-O2", "-fPIC", "-shared", "-o", out, src, "-lm"])
+        _link(["gcc", "-O2", "-fPIC", "-shared", "-o", out, src, "-lm"], out)
     return out
 
 
@@ -88,8 +116,8 @@ def build_emul(force=False):
     host_only = [s for s in CXX_SOURCES if s != "mjx_pool.cpp"]      # (the pool needs the device entry points)
     deps = [src] + [os.path.join(CSRC, s) for s in host_only + ["mjx_huff.h", "mjx_plan.h"]]
     if os.path.exists(src) and (force or _newer(out, deps)):
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-              "-o", out, src] + [os.path.join(CSRC, s) for s in host_only])
+        _link(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+               "-o", out, src] + [os.path.join(CSRC, s) for s in host_only], out)
     return out
 
 
@@ -98,19 +126,20 @@ def build_cli(force=False):
     src = os.path.join(CSRC, "mjx_cli.cpp")
     out = os.path.join(PKG, "mjx_cli")
     if force or _newer(out, [src, os.path.join(CSRC, "jpeg.hpp"), os.path.join(PKG, "libmjx.so")]):
-        _run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", out, src,
-              "-L" + PKG, "-lmjx", "-Wl,-rpath," + PKG, "-Wl,-rpath,$ORIGIN"])
+        _link(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", out, src,
+               "-L" + PKG, "-lmjx", "-Wl,-rpath," + PKG, "-Wl,-rpath,$ORIGIN"], out)
     return out
 
 
 def build_all(force=False, verbose=False):
-    return {
-        "libmjx": build_product(force, verbose),
-        "cli": build_cli(force),
-        "synth": build_synth(force),
-        "oracle": build_oracle(force),
-        "emul": build_emul(force),
-    }
+    with _build_lock():
+        return {
+            "libmjx": build_product(force, verbose),
+            "cli": build_cli(force),
+            "synth": build_synth(force),
+            "oracle": build_oracle(force),
+            "emul": build_emul(force),
+        }
 
 
 if __name__ == "__main__":
