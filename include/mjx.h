@@ -193,8 +193,9 @@ int mjx_decode_scans(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t n, const m
                      uint8_t **rgb_dev, int *status, mjx_batch **out);
 
 /* The outer surface for a batch of files: JPEGImage::parse of jpeg/mod.rs:202 for n files at once,
- * pipelined -- the list is cut into groups of compressed data (12 MB first, doubling up to 96 MB); `threads` host threads
- * (0 = as many as the machine has, at most 32) walk the markers and de-stuff group after group into pinned memory, every
+ * pipelined -- the list is cut into groups of compressed data (12 MB first, doubling up to 96 MB, 192 MB for long lists);
+ * `threads` host threads (0 = half the processors the process may use -- affinity mask and cgroup quota counted --,
+ * between 4 and 32) walk the markers and de-stuff group after group into pinned memory, every
  * group goes up in one DMA transfer on an upload stream of its own, and its kernels start behind that transfer's event,
  * so parsing, transfer and decode of successive groups overlap.  status[i] receives the parse / plan / decode status of
  * file i, rgb_dev[i] a device pointer owned by *out (NULL on failure); mjx_batch_image_info(*out, i, ...) gives the

@@ -4,6 +4,7 @@
 // hand-off in JPEGImage::parse (src/jpeg/mod.rs:388-417).  One context = one HIP device + one stream; a batch owns
 // every device buffer of its images; mjx_batch_decode only enqueues kernels (no allocation, no host sync).
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include "mjx.h"
 #include "mjx_kernels.h"
@@ -447,14 +448,9 @@ int allocate_work_buffers(mjx_batch *b, DevArena &ar)
     ar.take(&b->d_entries, size_t(b->opts.keep_coefs ? std::max<uint64_t>(total_entries, 4) : max_entries) * 4 + 64);
     ar.take(&b->d_tile_eoff, size_t(b->opts.keep_coefs ? std::max<uint32_t>(total_tiles_arr, 1) : max_tiles_arr) * 4 + 16);
     ar.take(&b->d_ebase, size_t(max_nsub) * sizeof(uint32_t));
-    ar.take(&b->d_img_entries, std::max<size_t>(b->info.size(), 1) * sizeof(uint32_t));
-    if (!ar.measuring) HIPOK(hipMemsetAsync(b->d_img_entries, 0, std::max<size_t>(b->info.size(), 1) * sizeof(uint32_t), b->ctx->upload));
-    ar.take(&b->d_img_flags, std::max<size_t>(b->info.size(), 1) * sizeof(uint32_t));
-    if (!ar.measuring) HIPOK(hipMemsetAsync(b->d_img_flags, 0, std::max<size_t>(b->info.size(), 1) * sizeof(uint32_t), b->ctx->upload));
     ar.take(&b->d_dc, size_t(coef_blocks) * sizeof(int32_t) + 64);
     ar.take(&b->d_rgb, std::max<size_t>(b->rgb_pool_bytes, 16));
-    ar.take(&b->d_status, std::max<size_t>(b->info.size(), 1) * sizeof(int));
-    if (!ar.measuring) HIPOK(hipMemsetAsync(b->d_status, 0, std::max<size_t>(b->info.size(), 1) * sizeof(int), b->ctx->upload));
+    // (d_img_entries, d_img_flags, d_status: laid out by build_batch inside the block of small pools, whose upload clears them)
     const size_t mm = std::max<size_t>(b->chunks.size(), 1) * kMaxFix * sizeof(uint32_t);
     ar.take(&b->d_mismatch, mm);
     if (!ar.measuring && !b->h_mismatch) {
@@ -846,6 +842,11 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
                 ar.take(&b->d_qm, std::max<size_t>(nu, 1) * 192 * sizeof(float));
                 ar.take(&b->d_segs, std::max<size_t>(b->h_segs.size(), 2) * sizeof(uint32_t));
                 ar.take(&b->d_ii, std::max<size_t>(ii.size(), 1) * sizeof(InterleaveImg));
+                // per-image words the kernels expect to be zero: inside the block, so that its one transfer clears them (three
+                // hipMemsetAsync calls were six fill kernels in front of every group's transfer in mjx_decode_batch)
+                ar.take(&b->d_img_entries, std::max<size_t>(n, 1) * sizeof(uint32_t));
+                ar.take(&b->d_img_flags, std::max<size_t>(n, 1) * sizeof(uint32_t));
+                ar.take(&b->d_status, std::max<size_t>(n, 1) * sizeof(int));
                 ar.take(&b->d_meta_end, 16);
                 ar.take(&b->d_scan, b->scan_pool_bytes + 256);
                 if (!src) ar.take(&b->d_lin, lin_pool + 256);
@@ -872,10 +873,17 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opt
             }
         }
         auto mirror = [&](const void *dev) { return meta + (reinterpret_cast<const uint8_t *>(dev) - reinterpret_cast<const uint8_t *>(b->d_images)); };
+        const size_t zero_words = std::max<size_t>(n, 1);
         if (meta_block) {
+            std::memset(mirror(b->d_img_entries), 0, zero_words * sizeof(uint32_t));
+            std::memset(mirror(b->d_img_flags), 0, zero_words * sizeof(uint32_t));
+            std::memset(mirror(b->d_status), 0, zero_words * sizeof(int));
             std::memcpy(mirror(b->d_images), b->himages.data(), n * sizeof(DevImage));
             if (!b->h_segs.empty()) std::memcpy(mirror(b->d_segs), b->h_segs.data(), b->h_segs.size() * sizeof(uint32_t));
         } else {
+            HIPOK(hipMemsetAsync(b->d_img_entries, 0, zero_words * sizeof(uint32_t), up));
+            HIPOK(hipMemsetAsync(b->d_img_flags, 0, zero_words * sizeof(uint32_t), up));
+            HIPOK(hipMemsetAsync(b->d_status, 0, zero_words * sizeof(int), up));
             HIPOK(hipMemcpyAsync(b->d_images, b->himages.data(), n * sizeof(DevImage), hipMemcpyHostToDevice, up));
             if (!b->h_segs.empty()) HIPOK(hipMemcpyAsync(b->d_segs, b->h_segs.data(), b->h_segs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, up));
         }
@@ -1595,6 +1603,28 @@ extern "C" int mjx_decode_scans(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t
     });
 }
 
+namespace {
+// processors this process may use: the hardware's count, cut down to the affinity mask and to the cgroup's CPU quota
+unsigned usable_processors()
+{
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n, std::max(1u, unsigned(CPU_COUNT(&set))));
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {              // cgroup v2: "<quota> <period>" or "max <period>"
+        long long quota = 0, period = 0;
+        if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+            n = std::min(n, std::max(1u, unsigned((quota + period - 1) / period)));
+        std::fclose(f);
+    } else {
+        long long quota = -1, period = 0;                                     // cgroup v1
+        if (FILE *q = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(q, "%lld", &quota) != 1) quota = -1; std::fclose(q); }
+        if (FILE *pf = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(pf, "%lld", &period) != 1) period = 0; std::fclose(pf); }
+        if (quota > 0 && period > 0) n = std::min(n, std::max(1u, unsigned((quota + period - 1) / period)));
+    }
+    return n;
+}
+}   // namespace
+
 // The outer surface for a list of files, pipelined ("double-buffered chunks: H2D of chunk k+1 overlaps the
 // kernels of chunk k"; the seam it replaces is jpeg/mod.rs:371-417, parse -> de-stuff -> decode of one file).  The files are
 // cut into groups of compressed data (12 MB first, doubling up to 96 MB: small groups give the device work early, large ones keep
@@ -1615,17 +1645,24 @@ extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const
     const bool timing = std::getenv("MJX_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
-    unsigned nt = threads ? threads : std::thread::hardware_concurrency();
+    // parse threads: half the processors the process may use (cgroup quota included), the rest is for the calling thread
+    // and the runtime's own threads -- with a quota of 16 processors 8 threads were faster than 16, 24 or 32
+    unsigned nt = threads ? threads : std::max(4u, usable_processors() / 2);
     nt = std::max(1u, std::min(nt, 32u));
     nt = unsigned(std::min<size_t>(nt, std::max<size_t>(n, 1)));
-    // groups: small ones first so that the device has work early, then ~kGroupBytes each; kept coefficients and device-side
-    // de-stuffing take the whole list as one group (one batch, as mjx_batch_create would build it)
-    size_t group_bytes = size_t(96) << 20;
+    // groups: small ones first so that the device has work early (12 MB, doubling), then group_bytes each.  Consecutive
+    // transfers start 0.3 ms apart whatever stream they are on (measured with a copy stream of their own, and with three),
+    // so long lists get larger groups: 192 MB from 1.5 GB on, 96 MB below.  Smaller groups again at the end of the list
+    // (so that less is left to decode when the last transfer has landed) were tried: no gain.  Kept coefficients and
+    // device-side de-stuffing take the whole list as one group (one batch, as mjx_batch_create would build it).
+    size_t total_bytes = 0;
+    for (size_t i = 0; i < n; i++) total_bytes += lens[i];
+    size_t group_bytes = size_t(total_bytes >= (size_t(1536) << 20) ? 192 : 96) << 20;
     if (const char *e = std::getenv("MJX_GROUP_MB")) { const long v = std::atol(e); if (v > 0) group_bytes = size_t(v) << 20; }
     const bool single = o.keep_coefs || o.device_destuff || n <= 8;
     std::vector<size_t> gfirst{0};
     {
-        size_t acc = 0, target = single ? ~size_t(0) : group_bytes / 8;
+        size_t acc = 0, target = single ? ~size_t(0) : std::min(group_bytes / 8, size_t(12) << 20);
         for (size_t i = 0; i < n; i++) {
             acc += lens[i];
             if (acc >= target && i + 1 < n) {
