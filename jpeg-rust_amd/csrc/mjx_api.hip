@@ -220,10 +220,6 @@ struct mjx_batch {
 namespace {
 
 constexpr int kMaxFix = 16;
-#ifndef MJX_TILES_PER_WG
-#define MJX_TILES_PER_WG 16
-#endif
-constexpr uint32_t kTilesPerWgHost = MJX_TILES_PER_WG;       // must equal kTilesPerWg in mjx_kernels.hip
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -612,7 +608,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         if (sp != st && b->entropy_recorded[set]) HIPOK(hipStreamWaitEvent(sp, b->ev_entropy[set], 0));
         prof_begin(b, MJX_K_IDCT_COLOR, sp);
         if (c.plane_words) HIPOK(hipMemsetAsync(SCR(d_planes), 0, size_t(c.plane_words) * 8, sp));
-        launch_idct_color(sp, (c.max_tiles + kTilesPerWgHost - 1) / kTilesPerWgHost, nimg, b->idct_lds, imgs, SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_qm, b->d_rgb, c.mode_mask, SCR(d_planes), b->d_img_flags);
+        launch_idct_color(sp, c.max_tiles, nimg, b->idct_lds, imgs, SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_qm, b->d_rgb, c.mode_mask, SCR(d_planes), b->d_img_flags);
         if (c.plane_words) launch_ref_color(sp, c.max_pixel_wgs, nimg, imgs, SCR(d_planes), b->d_rgb, b->d_img_flags);
         prof_end(b, sp);
         if (sp != st) {

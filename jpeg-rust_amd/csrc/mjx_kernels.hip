@@ -22,6 +22,8 @@
 
 #include "mjx_kernels.h"
 
+#include <algorithm>
+
 namespace mjx {
 
 // ------------------------------------------------------------------------------------------------
@@ -1644,7 +1646,7 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
                                                      const uint32_t *__restrict__ tile_eoff,
                                                      const int32_t *__restrict__ dcbuf, const float *__restrict__ qmult,
                                                      uint8_t *__restrict__ rgb, unsigned long long *__restrict__ planes,
-                                                     const uint32_t *__restrict__ img_flags)
+                                                     const uint32_t *__restrict__ img_flags, uint32_t tiles_per_wg)
 {
     // (its own symbol: dynamic LDS arrays of one name share their alignment, and the entropy kernels ask for 2 KiB)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_px[];
@@ -1662,9 +1664,9 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
     const uint32_t total_blocks = im.himg.total_blocks;
     const uint32_t tile_blocks = T * bpm;
     const uint32_t ntiles = (nmcu + T - 1) / T;
-    const uint32_t tile0 = blockIdx.x * kTilesPerWg;
+    const uint32_t tile0 = blockIdx.x * tiles_per_wg;             // (tiles_per_wg <= kTilesPerWg: few for small launches, see launch_idct_color)
     if (tile0 >= ntiles) return;
-    const uint32_t tile1 = min(ntiles, tile0 + kTilesPerWg);
+    const uint32_t tile1 = min(ntiles, tile0 + tiles_per_wg);
     const uint32_t tid = threadIdx.x;
     const uint32_t *__restrict__ src = entries + im.ent_off;
     const uint32_t *__restrict__ eoff = tile_eoff + im.tile_off;
@@ -1673,7 +1675,7 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
     const bool aligned = ((width * 3u) & 3u) == 0 && (im.rgb_off & 3u) == 0;
     // The stream offsets of all the workgroup's tiles are fetched once: a tile's entries can then be requested without
     // first waiting for its offsets (two dependent round trips per tile were what paced the tile loop).
-    if (tid <= uint32_t(kTilesPerWg)) s_eoff[tid] = eoff[min(tile0 + tid, ntiles)];
+    if (tid <= tiles_per_wg) s_eoff[tid] = eoff[min(tile0 + tid, ntiles)];
     __syncthreads();
     TileFetch cur;
     tile_fetch<LANES>(src, s_eoff, dcs, tile0, tile_blocks, total_blocks, cur);
@@ -1889,12 +1891,19 @@ void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t
                        const uint32_t *entries, const uint32_t *tile_eoff, const int32_t *dcbuf, const float *qmult,
                        uint8_t *rgb, uint32_t mode_mask, unsigned long long *planes, const uint32_t *img_flags)
 {
+    // A workgroup walks up to kTilesPerWg consecutive tiles of its image (offsets fetched once, the next tile's loads in
+    // flight during this tile's arithmetic) -- when the launch has tiles to spare: with fewer than a few rounds of 3
+    // workgroups x 256 CUs the tiles are spread instead (one picture of 512x512 is 43 tiles: 3 workgroups took 195 us,
+    // 43 take 20).
+    const uint64_t total = uint64_t(max_tiles) * nimg;
+    const uint32_t tpw = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(kTilesPerWg), total / 3072)));
+    const uint32_t gx = (max_tiles + tpw - 1) / tpw;
     if (mode_mask & 1u)
-        hipLaunchKernelGGL(k_idct_color<0>, dim3(max_tiles, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags);
+        hipLaunchKernelGGL(k_idct_color<0>, dim3(gx, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags, tpw);
     if (mode_mask & 2u)
-        hipLaunchKernelGGL(k_idct_color<1>, dim3(max_tiles, nimg), dim3(kLanes420), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags);
+        hipLaunchKernelGGL(k_idct_color<1>, dim3(gx, nimg), dim3(kLanes420), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags, tpw);
     if (mode_mask & 4u)
-        hipLaunchKernelGGL(k_idct_color<2>, dim3(max_tiles, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags);
+        hipLaunchKernelGGL(k_idct_color<2>, dim3(gx, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags, tpw);
 }
 
 void launch_planar_gather(hipStream_t st, uint32_t max_tiles, uint32_t nimg, const DevImage *images, uint32_t *entries,
