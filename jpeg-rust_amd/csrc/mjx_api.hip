@@ -55,6 +55,8 @@ struct mjx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // stage B runs here, the entropy stage on `stream` (MJX_STREAMS=1: everything on `stream`), see run_chunk
+    uint64_t latency_nsub = 32768;  // batches of at most this many 512-byte subsequences (16 MB of scans: 64 of the 1024 workgroup
+                                    // slots of k_huff_spec) get 256-byte subsequences, see build_batch (MJX_LATENCY_NSUB, 0 = never)
     hipStream_t upload = nullptr;   // H2D of the compressed scans + the upload-time kernels (de-stuffing, interleaving): a stream of
                                     // its own, so that the upload of one group of files overlaps the decode of the group before
     // Device blocks of released batches, kept for the next ones: giving tens of gigabytes back to the driver and asking for
@@ -662,10 +664,26 @@ struct PinnedBump {
 // Builds a batch from plans.  Scan bytes come from the plans' host pointers (or, for the images listed in `ds`, from
 // the device-side de-stuffing of their raw bytes), or (src != nullptr) are copied on the device from `src`'s pool,
 // `times` repetitions of its images.
-int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans, const mjx_opts &opts, const mjx_batch *src,
+int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_opts &opts, const mjx_batch *src,
                 size_t times, mjx_batch **out, int *status, DestuffPlan *ds = nullptr, bool async_upload = false,
-                uint32_t *pinned_words = nullptr, size_t pinned_cap = 0, PinnedBump *pin = nullptr)
+                uint32_t *pinned_words = nullptr, size_t pinned_cap = 0, PinnedBump *pin = nullptr, bool latency_plan = true)
 {
+    // A batch too small to fill the device (one picture, a handful) is bound by the serial chain of a lane -- ~810 symbols
+    // of a 512-byte subsequence per decode pass, 0.29 us each -- not by throughput: its scans are cut into subsequences of
+    // half the length (twice the lanes, half the chain; a quarter does not synchronise within the enqueued rounds any more).
+    // One 512x512 picture: k_huff_spec 235 -> 118 us, k_huff_write 376 -> 194 us, the merge rounds 163 -> 188 us.
+    std::vector<ImagePlan> replanned;
+    const std::vector<ImagePlan> *use = &plans_in;
+    if (!src && latency_plan && ctx->latency_nsub > 0) {       // (not for the groups of a pipelined list: they overlap, throughput counts)
+        uint64_t total = 0;
+        for (const ImagePlan &p : plans_in) if (p.status == MJX_OK) total += p.himg.nsub;
+        if (total > 0 && total <= ctx->latency_nsub) {
+            replanned = plans_in;
+            for (ImagePlan &p : replanned) if (p.status == MJX_OK) replan_subsequences(p, uint32_t(kSubseqBits) / 2);
+            use = &replanned;
+        }
+    }
+    const std::vector<ImagePlan> &plans = *use;
     mjx_batch *b = new (std::nothrow) mjx_batch;
     if (!b) return MJX_ERR_NOMEM;
     struct Owner {                      // releases the half-built batch on every early exit, exceptions included
@@ -1034,6 +1052,7 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     if (const char *e = std::getenv("MJX_CACHE_GB")) c->cache_limit = size_t(std::max(0L, std::atol(e))) << 30;
     c->nstreams = 2;
     if (const char *e = std::getenv("MJX_STREAMS")) c->nstreams = std::atoi(e) == 1 ? 1 : 2;
+    if (const char *e = std::getenv("MJX_LATENCY_NSUB")) c->latency_nsub = uint64_t(std::max(0L, std::atol(e)));
     if (c->nstreams == 2) {
         // stage B's stream gets the higher priority (MJX_PIXEL_PRIORITY=0: equal): its workgroups are placed first when a CU
         // frees resources, so the pixel kernel keeps close to its stand-alone pace and the entropy kernels fill what it leaves
@@ -1272,23 +1291,33 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
     // (pathological stream that stays unsynchronised across a whole 32 KiB workgroup span), redo that chunk with
     // more passes until a pass counts zero.
     if (b->decoded_entropy) {
+        bool first_set_rewritten = false;
         for (size_t ci = 0; ci < b->chunks.size(); ci++) {
             const Chunk &c = b->chunks[ci];
             if (c.merge_wgs == 0) continue;
             const int passes = std::min(b->ctx->fix_passes, kMaxFix);
             if (b->h_mismatch[ci * kMaxFix + passes - 1] == 0) continue;
             if (std::getenv("MJX_TIMING")) std::fprintf(stderr, "[mjx] chunk %zu unconverged after %d rounds (%u re-decodes in the last): repairing\n", ci, passes, b->h_mismatch[ci * kMaxFix + passes - 1]);
-            // repair: restart this chunk's synchronisation (its state arrays may have been reused by a later chunk),
-            // then keep running fix passes -- each one extends the verified prefix -- until one finds nothing.
+            // repair: keep running fix passes -- each one extends the verified prefix -- until one finds nothing.  If a later
+            // chunk has reused this chunk's state arrays (or the chunk ran on the second set, which the repair does not
+            // use), its synchronisation starts again from the speculative decode; otherwise -- a batch of one chunk, the
+            // usual case of a small batch with short subsequences -- the rounds simply continue where they stopped.
+            const bool second_set = b->dual && (ci & 1);
+            const bool intact = !second_set && !first_set_rewritten && (b->dual ? ci + 2 >= b->chunks.size() : ci + 1 >= b->chunks.size());
+            if (!intact) first_set_rewritten = true;             // (a restarted repair runs on the first set, whatever the chunk)
             HIPOK(hipMemsetAsync(b->d_status + c.first, 0, c.count * sizeof(int), b->ctx->stream));
-            int rc = run_chunk(b, ci, MJX_STAGE_ENTROPY, 0, PH_SYNC, true);
-            if (rc != MJX_OK) return rc;
+            int rc = MJX_OK;
+            if (!intact) {
+                rc = run_chunk(b, ci, MJX_STAGE_ENTROPY, 0, PH_SYNC, true);
+                if (rc != MJX_OK) return rc;
+            }
+            const int more = intact ? passes : kMaxFix;
             for (;;) {
-                rc = run_chunk(b, ci, MJX_STAGE_ENTROPY, kMaxFix, PH_FIX, true);
+                rc = run_chunk(b, ci, MJX_STAGE_ENTROPY, more, PH_FIX, true);
                 if (rc != MJX_OK) return rc;
                 HIPOK(hipStreamSynchronize(b->ctx->stream));
-                if (std::getenv("MJX_TIMING")) std::fprintf(stderr, "[mjx]   repair rounds: %u re-decodes left\n", b->h_mismatch[ci * kMaxFix + kMaxFix - 1]);
-                if (b->h_mismatch[ci * kMaxFix + kMaxFix - 1] == 0) break;
+                if (std::getenv("MJX_TIMING")) std::fprintf(stderr, "[mjx]   repair rounds: %u re-decodes left\n", b->h_mismatch[ci * kMaxFix + more - 1]);
+                if (b->h_mismatch[ci * kMaxFix + more - 1] == 0) break;
             }
             rc = run_chunk(b, ci, MJX_STAGE_ALL, 0, PH_TAIL, true);
             if (rc != MJX_OK) return rc;
@@ -1767,7 +1796,7 @@ extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const
         }
         if (rc != MJX_OK) break;
         constexpr size_t kPinnedPerPart = 8 * kMaxFix;
-        rc = build_batch(ctx, plans, o, nullptr, 1, &part, nullptr, nullptr, true, dir->h_mismatch + g * kPinnedPerPart, kPinnedPerPart, &pin);
+        rc = build_batch(ctx, plans, o, nullptr, 1, &part, nullptr, nullptr, true, dir->h_mismatch + g * kPinnedPerPart, kPinnedPerPart, &pin, ngroups == 1);
         if (rc != MJX_OK) break;
         dir->parts.push_back(part);
         if (part->visible.size() != cnt) { rc = MJX_ERR_DEVICE; break; }

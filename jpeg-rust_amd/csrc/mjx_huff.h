@@ -105,7 +105,7 @@ struct HuffImage {
     uint32_t total_bits;                 // scan_len * 8
     uint32_t total_blocks;               // MCUs to decode * bpm
     uint32_t nsub;                       // ceil(total_bits / sub_bits)
-    uint32_t sub_bits;                   // bits per subsequence: a multiple of kCpBits in [kSubseqBits, kMaxSubseqBits]
+    uint32_t sub_bits;                   // bits per subsequence: a multiple of kCpBits, at most kMaxSubseqBits (kSubseqBits .. 5/4 of it; less in small batches)
     uint32_t pad_[3];
 };
 
@@ -113,13 +113,15 @@ struct HuffImage {
 // rings) is allocated for all its lanes: an image of 4.1 workgroups' worth of 512-byte subsequences would hold five
 // workgroups' LDS, the fifth for a single wave's work.  When at most 25 % longer subsequences make the image fit into
 // one workgroup less, they are chosen instead.
-MJX_HD uint32_t choose_subseq_bits(uint32_t total_bits)
+// `base`: the length to start from -- kSubseqBits, or less when a batch is too small to fill the device and shorter
+// subsequences (more lanes, shorter serial chains) cut its latency (see replan_subsequences).
+MJX_HD uint32_t choose_subseq_bits(uint32_t total_bits, uint32_t base = uint32_t(kSubseqBits))
 {
-    const uint32_t nsub = (total_bits + kSubseqBits - 1) / uint32_t(kSubseqBits), nwg = nsub / uint32_t(kHuffWg);
-    if (nwg == 0 || nsub % uint32_t(kHuffWg) == 0) return kSubseqBits;
+    const uint32_t nsub = (total_bits + base - 1) / base, nwg = nsub / uint32_t(kHuffWg);
+    if (nwg == 0 || nsub % uint32_t(kHuffWg) == 0) return base;
     const uint32_t lanes = nwg * uint32_t(kHuffWg);
     const uint32_t bits = ((total_bits + lanes - 1) / lanes + kCpBits - 1) / kCpBits * kCpBits;
-    return (bits >= uint32_t(kSubseqBits) && bits <= uint32_t(kSubseqBits) * 5 / 4) ? bits : uint32_t(kSubseqBits);
+    return (bits >= base && bits <= base * 5 / 4) ? bits : base;
 }
 static_assert(sizeof(HuffImage) % 16 == 0, "the decode tables follow HuffImage in LDS and are staged in 16-byte pieces");
 

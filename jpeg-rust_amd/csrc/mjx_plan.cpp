@@ -79,6 +79,46 @@ static int plan_ref_layout(ImagePlan &p)
     return MJX_OK;
 }
 
+// Cuts the scan of a planned picture into subsequences of about `base_bits` bits: p.seg holds the first bit of every
+// segment (one segment without restart intervals); sets himg.sub_bits, himg.nsub and the first subsequence of every segment.
+void replan_subsequences(ImagePlan &p, uint32_t base_bits)
+{
+    if (p.role == 2 || p.seg.size() < 2 * (size_t(p.nseg) + 1)) return;        // (role 2: no scan of its own)
+    base_bits = std::max<uint32_t>(uint32_t(kCpBits), std::min<uint32_t>(base_bits, uint32_t(kSubseqBits)) / uint32_t(kCpBits) * uint32_t(kCpBits));
+    const uint32_t top = base_bits * 5 / 4;
+    auto bit0 = [&](uint32_t g) { return p.seg[2 * size_t(g) + 1]; };
+    p.himg.sub_bits = choose_subseq_bits(p.himg.total_bits, base_bits);
+    if (p.nseg == 1 && p.restart_mcus == 0) {
+        p.himg.nsub = (p.himg.total_bits + p.himg.sub_bits - 1) / p.himg.sub_bits;
+        p.seg[0] = 0;
+        p.seg[2] = p.himg.nsub;
+        return;
+    }
+    auto count = [&](uint32_t bits) {
+        uint32_t n = 0;
+        for (uint32_t g = 0; g < p.nseg; g++) {
+            const uint32_t len = bit0(g + 1) - bit0(g);
+            n += len ? (len + bits - 1) / bits : 1u;
+        }
+        return n;
+    };
+    // the same workgroup-filling rule as choose_subseq_bits, on the segmented count
+    uint32_t sub = count(p.himg.sub_bits);
+    const uint32_t nwg = sub / uint32_t(kHuffWg);
+    if (nwg > 0 && sub % uint32_t(kHuffWg) != 0)
+        for (uint32_t bits = p.himg.sub_bits + kCpBits; bits <= top; bits += kCpBits)
+            if (count(bits) <= nwg * uint32_t(kHuffWg)) { p.himg.sub_bits = bits; break; }
+    sub = 0;
+    for (uint32_t g = 0; g <= p.nseg; g++) {
+        if (g > 0) {
+            const uint32_t len = bit0(g) - bit0(g - 1);
+            sub += len ? (len + p.himg.sub_bits - 1) / p.himg.sub_bits : 1u;
+        }
+        p.seg[2 * size_t(g)] = sub;
+    }
+    p.himg.nsub = sub;
+}
+
 int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p, bool scan_part)
 {
     p = ImagePlan{};
@@ -215,13 +255,11 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p, bool 
     p.himg.bpm = p.bpm;
     p.himg.total_bits = uint32_t(p.scan_len * 8);
     p.himg.total_blocks = p.nmcu * p.bpm;
-    p.himg.sub_bits = choose_subseq_bits(p.himg.total_bits);
     p.restart_mcus = d.restart_interval;
     p.seg.clear();
     if (p.restart_mcus == 0) {
         p.nseg = 1;
-        p.himg.nsub = (p.himg.total_bits + p.himg.sub_bits - 1) / p.himg.sub_bits;
-        p.seg = {0u, 0u, p.himg.nsub, p.himg.total_bits};
+        p.seg = {0u, 0u, 0u, p.himg.total_bits};
     } else {
         // Each restart interval is decoded on its own: its first subsequence starts in a known state, subsequences do
         // not straddle intervals, and the DC predictors start again (T.81 E.2.4).  REF_COMPAT has no meaning here: the
@@ -229,38 +267,16 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p, bool 
         if (p.layout == MJX_LAYOUT_REF_COMPAT) return fail(MJX_ERR_DRI_UNSUPPORTED);
         p.nseg = (p.nmcu + p.restart_mcus - 1) / p.restart_mcus;
         if (d.n_restart + 1 < p.nseg) return fail(MJX_ERR_TRUNCATED);              // fewer RSTn markers than intervals
-        std::vector<uint32_t> bit0(p.nseg + 1);
         for (uint32_t g = 0; g <= p.nseg; g++) {
             const uint64_t byte0 = g == 0 ? 0 : (g - 1 < d.n_restart ? d.restart_offsets[g - 1] : p.scan_len);
             if (byte0 > p.scan_len) return fail(MJX_ERR_INVALID_ARG);
-            bit0[g] = g == p.nseg ? p.himg.total_bits : uint32_t(byte0 * 8);
-            if (g > 0 && bit0[g] < bit0[g - 1]) return fail(MJX_ERR_INVALID_ARG);
+            const uint32_t bit0 = g == p.nseg ? p.himg.total_bits : uint32_t(byte0 * 8);
+            if (g > 0 && bit0 < p.seg[2 * g - 1]) return fail(MJX_ERR_INVALID_ARG);
+            p.seg.push_back(0u);
+            p.seg.push_back(bit0);
         }
-        auto count = [&](uint32_t bits) {
-            uint32_t n = 0;
-            for (uint32_t g = 0; g < p.nseg; g++) {
-                const uint32_t len = bit0[g + 1] - bit0[g];
-                n += len ? (len + bits - 1) / bits : 1u;
-            }
-            return n;
-        };
-        // the same workgroup-filling rule as choose_subseq_bits, on the segmented count
-        uint32_t sub = count(p.himg.sub_bits);
-        const uint32_t nwg = sub / uint32_t(kHuffWg);
-        if (nwg > 0 && sub % uint32_t(kHuffWg) != 0)
-            for (uint32_t bits = p.himg.sub_bits + kCpBits; bits <= uint32_t(kSubseqBits) * 5 / 4; bits += kCpBits)
-                if (count(bits) <= nwg * uint32_t(kHuffWg)) { p.himg.sub_bits = bits; sub = count(bits); break; }
-        sub = 0;
-        for (uint32_t g = 0; g <= p.nseg; g++) {
-            if (g > 0) {
-                const uint32_t len = bit0[g] - bit0[g - 1];
-                sub += len ? (len + p.himg.sub_bits - 1) / p.himg.sub_bits : 1u;
-            }
-            p.seg.push_back(sub);
-            p.seg.push_back(bit0[g]);
-        }
-        p.himg.nsub = sub;
     }
+    replan_subsequences(p, uint32_t(kSubseqBits));
 
     }   // !gather
 

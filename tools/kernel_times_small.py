@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
 mjx = ge.load_package()
 ctx = mjx.Context(0, profiling=True)
-cases = [(n, open(os.path.join(ROOT, "tests", "data", n), "rb").read()) for n in ["lena.jpeg", "huff_simple0.jpg"]]
+cases = [(n, open(os.path.join(ROOT, "tests", "data", n), "rb").read()) for n in ["lena.jpeg", "lena-bw.jpeg", "2x2-chroma.jpeg", "huff_simple0.jpg"]]
 cases.append(("synthetic 4K q75", mjx.synth_jpeg(3840, 2160, "420", 75, seed=3)))
 cases.append(("synthetic 1080p q75", mjx.synth_jpeg(1920, 1080, "420", 75, seed=3)))
 for name, data in cases:
