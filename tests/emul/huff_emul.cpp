@@ -77,8 +77,17 @@ struct HostCps {
 // Emulates the kernel sequence  k_huff_spec -> k_huff_merge rounds -> k_huff_scan -> k_huff_write -> DC prediction.
 // `mode`: 0 = rounds see a snapshot of the previous round's exits (what fully concurrent lanes see in the worst case),
 //         1 = rounds update in place in subsequence order (what a single lane walking the items would see).
+// `sub_base_bits`: 0 = the subsequence length plan_image chooses; otherwise the scan is re-cut into subsequences of about
+// that many bits (replan_subsequences: what build_batch does for batches too small to fill the device).
+extern "C" int emul_decode_coefs_sub(const uint8_t *jpeg, size_t len, int layout, int mode, unsigned sub_base_bits, int16_t *out,
+                                     size_t cap_blocks, size_t *nblocks, int *stats /* [8] */);
 extern "C" int emul_decode_coefs(const uint8_t *jpeg, size_t len, int layout, int mode, int16_t *out,
                                  size_t cap_blocks, size_t *nblocks, int *stats /* [8] */)
+{
+    return emul_decode_coefs_sub(jpeg, len, layout, mode, 0, out, cap_blocks, nblocks, stats);
+}
+extern "C" int emul_decode_coefs_sub(const uint8_t *jpeg, size_t len, int layout, int mode, unsigned sub_base_bits, int16_t *out,
+                                     size_t cap_blocks, size_t *nblocks, int *stats /* [8] */)
 {
     mjx_opts opts{};
     opts.layout = uint8_t(layout);
@@ -88,6 +97,7 @@ extern "C" int emul_decode_coefs(const uint8_t *jpeg, size_t len, int layout, in
     ImagePlan plan;
     rc = plan_image(d, opts, plan);
     if (rc) { mjx_free_scan(&d); return rc; }
+    if (sub_base_bits) replan_subsequences(plan, sub_base_bits);
     if (plan.restart_mcus) { mjx_free_scan(&d); return MJX_ERR_DRI_UNSUPPORTED; }   // (restart intervals: GPU tests only)
     const HuffImage &img = plan.himg;
     const HostBits bits{plan.scan, plan.scan_len};

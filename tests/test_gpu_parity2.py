@@ -258,3 +258,44 @@ def test_pipelined_decode_batch_equals_the_batch_api(mjx, gpu_ctx):
     assert (info["width"], info["height"]) == (640, 480)
     one.close()
     grouped.close()
+
+
+def test_small_batches_with_short_subsequences_equal_the_long_ones(mjx, orc, tmp_path):
+    """A batch too small to fill the device is cut into 256-byte subsequences (build_batch; MJX_LATENCY_NSUB=0 switches
+    that off).  Both cuts must give the same coefficients and the same pixels -- checked on the sample files, restart
+    intervals, a multi-scan file and the slowly synchronising picture (which then needs the in-place repair rounds) --
+    and the coefficients must be the oracle's."""
+    import subprocess, sys
+    script = tmp_path / "cuts.py"
+    script.write_text(
+        "import os, sys, hashlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge\n"
+        "mjx = ge.load_package()\n"
+        "ctx = mjx.Context(0)\n"
+        "root = os.path.join(%r, 'tests')\n"
+        "names = ['data/lena.jpeg', 'data/lena-bw.jpeg', 'data/2x2-chroma.jpeg', 'golden/pil/dri_420_720p_rows.jpg', 'golden/pil/ms_420_big.jpg',\n"
+        "         'golden/pil/slow_sync_444_q99.jpg', 'golden/pil/opt_420_q85.jpg']\n"
+        "datas = [open(os.path.join(root, n), 'rb').read() for n in names] + [mjx.synth_jpeg(1920, 1080, '420', 90, seed=4)]\n"
+        "for i, d in enumerate(datas):\n"
+        "    b = mjx.Batch(ctx, [mjx.ParsedScan(d)], keep_coefs=True)\n"
+        "    b.decode(); b.wait()\n"
+        "    assert b.status(0) == 0, i\n"
+        "    print(i, b.geometry()['subsequences'], hashlib.sha256(b.coefs(0).tobytes()).hexdigest(), hashlib.sha256(b.rgb(0).tobytes()).hexdigest())\n"
+        "    b.close()\n" % (ROOT, ROOT))
+    outs = []
+    for env_extra in ({}, {"MJX_LATENCY_NSUB": "0"}):
+        out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        outs.append([l.split() for l in out.stdout.strip().splitlines()])
+    assert len(outs[0]) == len(outs[1]) == 8
+    more = 0
+    for short, long_ in zip(outs[0], outs[1]):
+        assert short[2:] == long_[2:], (short, long_)                # same coefficients, same pixels
+        more += int(short[1]) > int(long_[1])
+    assert more >= 6                                                  # ... from different cuts (tiny scans are one subsequence either way)
+    # and the coefficients are the oracle's
+    data = open(os.path.join(ROOT, "tests", "data", "lena.jpeg"), "rb").read()
+    ref = orc.decode(data, layout=orc.LAYOUT_STD)
+    import hashlib
+    assert hashlib.sha256(np.ascontiguousarray(orc.interleave(ref)).tobytes()).hexdigest() == outs[0][0][2]

@@ -119,11 +119,14 @@ def emul(mjx):
     lib.emul_decode_coefs.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]
 
-    def run(data, layout, mode=0):
+    lib.emul_decode_coefs_sub.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_void_p,
+                                          ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]
+
+    def run(data, layout, mode=0, sub_bits=0):
         cap = 400000
         out = np.zeros((cap, 64), np.int16)
         nb, st = ctypes.c_size_t(), (ctypes.c_int * 8)()
-        rc = lib.emul_decode_coefs(data, len(data), layout, mode, out.ctypes.data, cap, ctypes.byref(nb), st)
+        rc = lib.emul_decode_coefs_sub(data, len(data), layout, mode, sub_bits, out.ctypes.data, cap, ctypes.byref(nb), st)
         return rc, out[: nb.value].copy(), list(st)
     return run
 
@@ -146,6 +149,19 @@ def test_emulated_decode_synthetic(mjx, orc, emul, w, h, sub, q):
         rc, coefs, st = emul(data, 0, wg)
         ref = orc.decode(data, layout=orc.LAYOUT_STD)
         assert rc == 0 and np.array_equal(coefs, orc.interleave(ref)), (wg, st)
+
+
+@pytest.mark.parametrize("sub_bits", [2048, 1024, 256, 3000])
+def test_emulated_decode_with_short_subsequences(mjx, orc, emul, sub_bits):
+    """Batches too small to fill the device are re-cut into shorter subsequences (replan_subsequences, build_batch): the
+    same kernel sequence must reach the same coefficients whatever the length (3000 is rounded down to a multiple of the
+    checkpoint distance)."""
+    for data in (_read("lena.jpeg"), _read("2x2-chroma.jpeg"), mjx.synth_jpeg(333, 217, "444", 85, seed=5),
+                 mjx.synth_jpeg(1280, 720, "420", 92, seed=11), mjx.synth_jpeg(27, 546, "444", 99, seed=2)):
+        ref = orc.decode(data, layout=orc.LAYOUT_STD)
+        for mode in (0, 1):
+            rc, coefs, st = emul(data, 0, mode, sub_bits)
+            assert rc == 0 and np.array_equal(coefs, orc.interleave(ref)), (sub_bits, mode, st)
 
 
 def test_emulated_decode_with_optimised_tables(mjx, orc, emul):
