@@ -55,6 +55,8 @@ struct mjx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // stage B runs here, the entropy stage on `stream` (MJX_STREAMS=1: everything on `stream`), see run_chunk
+    std::vector<std::pair<uint32_t *, size_t>> pinned_cache;   // small pinned blocks (a batch's mirror of its round counts) kept for
+                                                               // the next batch: hipHostMalloc + hipHostFree were 0.2 ms of a one-shot decode
     uint64_t latency_nsub = 32768;  // batches of at most this many 512-byte subsequences (16 MB of scans: 64 of the 1024 workgroup
                                     // slots of k_huff_spec) get 256-byte subsequences, see build_batch (MJX_LATENCY_NSUB, 0 = never)
     hipStream_t upload = nullptr;   // H2D of the compressed scans + the upload-time kernels (de-stuffing, interleaving): a stream of
@@ -159,6 +161,7 @@ struct mjx_batch {
     size_t arena_bytes = 0;
     uint8_t *arena = nullptr;           // the one device allocation every d_* pointer below points into (see DevArena)
     bool h_mismatch_owned = true;
+    size_t h_mismatch_bytes = 0;        // size of the pinned block behind h_mismatch (when owned)
     uint8_t *d_lin = nullptr;
     void *d_ii = nullptr;
     size_t lut_pool_entries = 0;        // entries of the decode-table pool (identical tables stored once)
@@ -272,6 +275,35 @@ void arena_put(mjx_ctx *ctx, uint8_t *p, size_t bytes)
     (void)hipFree(p);
 }
 
+// Small pinned blocks (whole pages), recycled through the context.
+uint32_t *pinned_get(mjx_ctx *ctx, size_t bytes, size_t *got)
+{
+    bytes = (bytes + 4095) & ~size_t(4095);
+    {
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        for (size_t k = 0; k < ctx->pinned_cache.size(); k++)
+            if (ctx->pinned_cache[k].second >= bytes && ctx->pinned_cache[k].second <= 4 * bytes) {
+                uint32_t *p = ctx->pinned_cache[k].first;
+                *got = ctx->pinned_cache[k].second;
+                ctx->pinned_cache.erase(ctx->pinned_cache.begin() + long(k));
+                return p;
+            }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    *got = bytes;
+    return static_cast<uint32_t *>(p);
+}
+void pinned_put(mjx_ctx *ctx, uint32_t *p, size_t bytes)
+{
+    if (!p) return;
+    if (ctx && bytes <= (size_t(1) << 20)) {
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        if (ctx->pinned_cache.size() < 32) { ctx->pinned_cache.emplace_back(p, bytes); return; }
+    }
+    (void)hipHostFree(p);
+}
+
 void release(mjx_batch *b)
 {
     if (!b) return;
@@ -286,7 +318,7 @@ void release(mjx_batch *b)
     for (auto &e : b->event_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     arena_put(b->ctx, b->arena, b->arena_bytes);            // every other device pointer of the batch is a slice of it
     for (void *q : b->separate_allocs) (void)hipFree(q);
-    if (b->h_mismatch && b->h_mismatch_owned) (void)hipHostFree(b->h_mismatch);
+    if (b->h_mismatch && b->h_mismatch_owned) pinned_put(b->ctx, b->h_mismatch, b->h_mismatch_bytes);
     delete b;
 }
 
@@ -452,7 +484,8 @@ int allocate_work_buffers(mjx_batch *b, DevArena &ar)
     const size_t mm = std::max<size_t>(b->chunks.size(), 1) * kMaxFix * sizeof(uint32_t);
     ar.take(&b->d_mismatch, mm);
     if (!ar.measuring && !b->h_mismatch) {
-        HIPOK(hipHostMalloc(reinterpret_cast<void **>(&b->h_mismatch), mm, hipHostMallocDefault));
+        b->h_mismatch = pinned_get(b->ctx, mm, &b->h_mismatch_bytes);
+        if (!b->h_mismatch) return MJX_ERR_NOMEM;
         std::memset(b->h_mismatch, 0, mm);
     }
     if (b->ctx->nstreams == 2 && b->chunks.size() > 1) {          // second scratch set for the chunks on stream2
@@ -1087,6 +1120,7 @@ extern "C" void mjx_ctx_destroy(mjx_ctx *ctx)
     if (ctx->parse_arena) (void)hipHostFree(ctx->parse_arena);
     if (ctx->pin_small) (void)hipHostFree(ctx->pin_small);
     for (auto &blk : ctx->cache) (void)hipFree(blk.first);
+    for (auto &blk : ctx->pinned_cache) (void)hipHostFree(blk.first);
     delete ctx;
 }
 
@@ -1778,7 +1812,8 @@ extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const
     dir->ctx = ctx;
     dir->opts = o;
     dir->part_index.resize(n);
-    HIPOK(hipHostMalloc(reinterpret_cast<void **>(&dir->h_mismatch), ngroups * 8 * kMaxFix * sizeof(uint32_t), hipHostMallocDefault));
+    dir->h_mismatch = pinned_get(ctx, ngroups * 8 * kMaxFix * sizeof(uint32_t), &dir->h_mismatch_bytes);
+    if (!dir->h_mismatch) return MJX_ERR_NOMEM;
     int rc = MJX_OK;
     for (size_t g = 0; g < ngroups && rc == MJX_OK; g++) {
         const size_t f0 = gfirst[g], cnt = gfirst[g + 1] - f0;
