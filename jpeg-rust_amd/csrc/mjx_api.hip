@@ -57,6 +57,8 @@ struct mjx_ctx {
     hipStream_t stream2 = nullptr;  // stage B runs here, the entropy stage on `stream` (MJX_STREAMS=1: everything on `stream`), see run_chunk
     std::vector<std::pair<uint32_t *, size_t>> pinned_cache;   // small pinned blocks (a batch's mirror of its round counts) kept for
                                                                // the next batch: hipHostMalloc + hipHostFree were 0.2 ms of a one-shot decode
+    uint32_t merge_loop_max = 192;  // chunks with at most this many merge workgroups run their rounds in one launch (MJX_MERGE_LOOP=0: never)
+    uint32_t latency_sub_bits = 512;                            // ... and the shortest length they may get (MJX_LATENCY_SUB_BITS)
     uint64_t latency_nsub = 32768;  // batches of at most this many 512-byte subsequences (16 MB of scans: 64 of the 1024 workgroup
                                     // slots of k_huff_spec) get 256-byte subsequences, see build_batch (MJX_LATENCY_NSUB, 0 = never)
     hipStream_t upload = nullptr;   // H2D of the compressed scans + the upload-time kernels (de-stuffing, interleaving): a stream of
@@ -106,6 +108,7 @@ struct Chunk {
     uint64_t coef_base = 0;        // first block of the chunk inside the per-block arrays (keep_coefs) or 0
     uint64_t entries = 0, ent_base = 0;   // capacity of the chunk's stream regions; first entry (keep_coefs) or 0
     uint32_t tiles = 0, tile_base = 0;    // tile offsets (+1 sentinel per image)
+    uint32_t loop_participants = 0;     // > 0: the merge rounds run as one launch (k_huff_merge_loop) with this many workgroups
     uint32_t max_wg = 0, merge_wgs = 0, max_tiles = 0, lut_cap = 0, max_tile_blocks = 0, mode_mask = 0, max_segs = 0, bpm_mask = 0, max_restart_segs = 0;
     uint64_t plane_words = 0;      // REF_COMPAT scratch of the chunk
     uint32_t max_pixel_wgs = 0;
@@ -172,6 +175,7 @@ struct mjx_batch {
     std::vector<unsigned char> h_ii;
     hipEvent_t ev_entropy[2] = {nullptr, nullptr}, ev_pixels[2] = {nullptr, nullptr};   // per scratch set, see run_chunk
     bool entropy_recorded[2] = {false, false}, pixels_recorded[2] = {false, false};
+    uint32_t *d_loopctl = nullptr;      // 8 control words per chunk for k_huff_merge_loop (zero between launches)
     hipEvent_t uploaded = nullptr;      // recorded on ctx->upload behind the last upload command; the decode streams wait for it
     bool upload_pending = false;
     // mjx_decode_batch decodes its files in groups (upload of one group overlaps the decode of the one before): the batch
@@ -225,6 +229,7 @@ struct mjx_batch {
 namespace {
 
 constexpr int kMaxFix = 16;
+constexpr uint32_t kLoopRounds = 48;      // rounds k_huff_merge_loop runs at most (noise at quality 99-100 needs 12-15 with 512-byte subsequences)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -411,6 +416,7 @@ void plan_chunks(mjx_batch *b)
                 c.blocks += (inf.nblocks + 7) & ~uint64_t(7);          // regions of DC differences start on 32-byte sectors
                 c.max_wg = std::max<uint32_t>(c.max_wg, (d.himg.nsub + kHuffWg - 1) / kHuffWg);
                 if (d.himg.nsub > 1) c.merge_wgs = std::max<uint32_t>(c.merge_wgs, (d.himg.nsub - 1 + kMergeWg - 1) / kMergeWg);
+                if (d.himg.nsub > 1) c.loop_participants += (d.himg.nsub - 1 + kMergeWg - 1) / kMergeWg;      // workgroups x with x * kMergeWg + 1 < nsub
                 const uint32_t T = 1u << d.log2_tile;
                 if (d.role != 1) {
                     c.max_tiles = std::max<uint32_t>(c.max_tiles, (d.nmcu + T - 1) / T);
@@ -432,6 +438,9 @@ void plan_chunks(mjx_batch *b)
             c.count++;
             i++;
         }
+        // one launch for all the merge rounds only when its workgroups are certain to be resident together (they wait for one
+        // another): a quarter of the device's 3 x 256 slots, so that other work on the device cannot starve them for long
+        if (c.loop_participants > b->ctx->merge_loop_max) c.loop_participants = 0;
         coef_running += c.blocks;
         ent_running += c.entries;
         tile_running += c.tiles;
@@ -599,7 +608,15 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     }
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_FIX)) {
         HIPOK(hipMemsetAsync(b->d_mismatch + ci * kMaxFix, 0, kMaxFix * sizeof(uint32_t), st));
-        if (c.merge_wgs > 0) {
+        if (c.merge_wgs > 0 && c.loop_participants > 0 && fix_passes > 0) {
+            // (the count of the last round run lands where the last enqueued round's would: mjx_batch_wait and k_huff_scan look there)
+            prof_begin(b, MJX_K_HUFF_FIX, st);
+            launch_huff_merge_loop(st, c.merge_wgs, nimg, b->huff_lds, b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps),
+                                   b->d_mismatch + ci * kMaxFix + fix_passes - 1, b->d_segs, b->d_loopctl + ci * 8, c.loop_participants, kLoopRounds);
+            prof_end(b, st);
+            HIPOK(hipMemcpyAsync(b->h_mismatch + ci * kMaxFix, b->d_mismatch + ci * kMaxFix, kMaxFix * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, st));
+        } else if (c.merge_wgs > 0) {
             for (int k = 0; k < fix_passes; k++) {
                 prof_begin(b, MJX_K_HUFF_FIX, st);
                 launch_huff_merge(st, c.merge_wgs, nimg, b->huff_lds, b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps),
@@ -702,18 +719,28 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
                 uint32_t *pinned_words = nullptr, size_t pinned_cap = 0, PinnedBump *pin = nullptr, bool latency_plan = true)
 {
     // A batch too small to fill the device (one picture, a handful) is bound by the serial chain of a lane -- ~810 symbols
-    // of a 512-byte subsequence per decode pass, 0.29 us each -- not by throughput: its scans are cut into subsequences of
-    // half the length (twice the lanes, half the chain; a quarter does not synchronise within the enqueued rounds any more).
-    // One 512x512 picture: k_huff_spec 235 -> 118 us, k_huff_write 376 -> 194 us, the merge rounds 163 -> 188 us.
+    // of a 512-byte subsequence per decode pass, 0.29 us each -- not by throughput: its scans are cut into shorter subsequences
+    // (more lanes, shorter chains).  Short subsequences synchronise over several of them, i.e. over more rounds than are worth
+    // enqueuing one by one, so the cut is tied to k_huff_merge_loop (all rounds in one launch, as many as it takes): the shortest
+    // of 64 / 128 / 256 bytes with which the batch still fits that kernel's residency limit; 64 bytes only for tiny batches (the
+    // rounds get longer with the number of subsequences: one 4K picture 0.77 ms with 128 bytes, 0.83 with 64; lena.jpeg 0.43 / 0.37).
+    // One 512x512 picture, 512 -> 64 bytes: k_huff_spec 235 -> 41 us, k_huff_write 376 -> 61 us, merge rounds 163 -> 137 us.
     std::vector<ImagePlan> replanned;
     const std::vector<ImagePlan> *use = &plans_in;
-    if (!src && latency_plan && ctx->latency_nsub > 0) {       // (not for the groups of a pipelined list: they overlap, throughput counts)
+    if (!src && latency_plan && ctx->latency_nsub > 0 && ctx->merge_loop_max > 0) {       // (not for the groups of a pipelined list: they overlap, throughput counts)
         uint64_t total = 0;
         for (const ImagePlan &p : plans_in) if (p.status == MJX_OK) total += p.himg.nsub;
         if (total > 0 && total <= ctx->latency_nsub) {
-            replanned = plans_in;
-            for (ImagePlan &p : replanned) if (p.status == MJX_OK) replan_subsequences(p, uint32_t(kSubseqBits) / 2);
-            use = &replanned;
+            for (uint32_t bits = std::max<uint32_t>(ctx->latency_sub_bits, total <= 1024 ? 512u : 1024u); bits < uint32_t(kSubseqBits); bits *= 2) {
+                std::vector<ImagePlan> cut = plans_in;
+                uint64_t wgs = 0;
+                for (ImagePlan &p : cut) {
+                    if (p.status != MJX_OK) continue;
+                    replan_subsequences(p, bits);
+                    if (p.himg.nsub > 1) wgs += (p.himg.nsub - 1 + kMergeWg - 1) / kMergeWg;
+                }
+                if (wgs <= ctx->merge_loop_max) { replanned.swap(cut); use = &replanned; break; }
+            }
         }
     }
     const std::vector<ImagePlan> &plans = *use;
@@ -894,6 +921,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
                 ar.take(&b->d_img_entries, std::max<size_t>(n, 1) * sizeof(uint32_t));
                 ar.take(&b->d_img_flags, std::max<size_t>(n, 1) * sizeof(uint32_t));
                 ar.take(&b->d_status, std::max<size_t>(n, 1) * sizeof(int));
+                ar.take(&b->d_loopctl, std::max<size_t>(b->chunks.size(), 1) * 8 * sizeof(uint32_t));
                 ar.take(&b->d_meta_end, 16);
                 ar.take(&b->d_scan, b->scan_pool_bytes + 256);
                 if (!src) ar.take(&b->d_lin, lin_pool + 256);
@@ -925,12 +953,14 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
             std::memset(mirror(b->d_img_entries), 0, zero_words * sizeof(uint32_t));
             std::memset(mirror(b->d_img_flags), 0, zero_words * sizeof(uint32_t));
             std::memset(mirror(b->d_status), 0, zero_words * sizeof(int));
+            std::memset(mirror(b->d_loopctl), 0, std::max<size_t>(b->chunks.size(), 1) * 8 * sizeof(uint32_t));
             std::memcpy(mirror(b->d_images), b->himages.data(), n * sizeof(DevImage));
             if (!b->h_segs.empty()) std::memcpy(mirror(b->d_segs), b->h_segs.data(), b->h_segs.size() * sizeof(uint32_t));
         } else {
             HIPOK(hipMemsetAsync(b->d_img_entries, 0, zero_words * sizeof(uint32_t), up));
             HIPOK(hipMemsetAsync(b->d_img_flags, 0, zero_words * sizeof(uint32_t), up));
             HIPOK(hipMemsetAsync(b->d_status, 0, zero_words * sizeof(int), up));
+            HIPOK(hipMemsetAsync(b->d_loopctl, 0, std::max<size_t>(b->chunks.size(), 1) * 8 * sizeof(uint32_t), up));
             HIPOK(hipMemcpyAsync(b->d_images, b->himages.data(), n * sizeof(DevImage), hipMemcpyHostToDevice, up));
             if (!b->h_segs.empty()) HIPOK(hipMemcpyAsync(b->d_segs, b->h_segs.data(), b->h_segs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, up));
         }
@@ -1086,6 +1116,8 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     c->nstreams = 2;
     if (const char *e = std::getenv("MJX_STREAMS")) c->nstreams = std::atoi(e) == 1 ? 1 : 2;
     if (const char *e = std::getenv("MJX_LATENCY_NSUB")) c->latency_nsub = uint64_t(std::max(0L, std::atol(e)));
+    if (const char *e = std::getenv("MJX_LATENCY_SUB_BITS")) c->latency_sub_bits = uint32_t(std::max(256L, std::min(long(kSubseqBits), std::atol(e))));
+    if (const char *e = std::getenv("MJX_MERGE_LOOP")) c->merge_loop_max = uint32_t(std::min(192L, std::max(0L, std::atol(e) == 1 ? 192L : std::atol(e))));
     if (c->nstreams == 2) {
         // stage B's stream gets the higher priority (MJX_PIXEL_PRIORITY=0: equal): its workgroups are placed first when a CU
         // frees resources, so the pixel kernel keeps close to its stand-alone pace and the entropy kernels fill what it leaves

@@ -598,6 +598,111 @@ extern "C" __global__ __launch_bounds__(64) void k_huff_merge_tail(const DevImag
     merge_finish(it, im, x, g_exit, g_cps);
 }
 
+// ---- the merge rounds of a small batch in one launch ------------------------------------------------------------------
+// A batch that leaves the device mostly empty (one picture, a handful) pays for its rounds in launches: six rounds enqueued =
+// twelve kernels and six memsets in a row, most of them for nothing once the states have settled, and a picture that needs a
+// seventh round pays a trip to the host.  When all merge workgroups of a chunk fit on the device at once (launch_huff_merge_loop
+// checks), one launch runs the rounds in a loop with a device-wide barrier between them, until a round re-decodes nothing
+// (the same proof of the fixed point as above) or `max_rounds` are spent.  Stragglers are not handed to a second kernel:
+// occupancy is no concern here, a workgroup runs all its items to the end.
+//   ctl[0] barrier arrivals (monotonic), ctl[1] workgroups that have left, ctl[2..4] re-decodes of round r in ctl[2 + r % 3];
+//   the last workgroup to leave zeroes ctl for the next launch.  `verdict` receives the count of the last round run.
+__device__ __forceinline__ void grid_barrier(uint32_t *arrivals, uint32_t target)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();                                                   // release what the workgroup has written
+        atomicAdd(arrivals, 1u);
+        while (__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    __threadfence();                                                       // acquire what the others have written
+}
+
+extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge_loop(const DevImage *images, const uint8_t *scan_pool,
+                                                                     const LutEntry *lut_pool, SubseqState *g_entry,
+                                                                     SubseqState *g_exit, uint32_t *g_cps, uint32_t *verdict,
+                                                                     uint32_t win_off, const uint32_t *segs, uint32_t *ctl,
+                                                                     uint32_t participants, uint32_t max_rounds)
+{
+    extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, windows (= item exchange), wave counts
+    uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
+    uint32_t *s_cnt = s_win + kMergeWg * kMergeStride;
+    const DevImage &im = images[blockIdx.y];
+    if (!im.valid || blockIdx.x * kMergeWg + 1 >= im.himg.nsub) return;    // (not among the participants: the host counts the same way)
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const HuffImage *h;
+    const LutEntry *lut;
+    stage_tables(im, lut_pool, smem, h, lut);
+    const unsigned char *bytes = scan_pool + im.scan_off;
+    uint32_t *my_win = s_win + tid * kMergeStride;
+    uint32_t last = 0;
+    for (uint32_t round = 0; round < max_rounds; round++) {
+        uint32_t *count = ctl + 2 + round % 3;
+        if (tid == 0) ctl[2 + (round + 1) % 3] = 0;                        // the next round's count (nobody reads or adds to it in this round)
+        MergeItem it{blockIdx.x * kMergeWg + tid + 1, 0, 0, 0, 0, 0};
+        bool active = false;
+        if (it.s < im.himg.nsub) {
+            const SubseqState prev = g_exit[im.sub_off + it.s - 1];
+            active = !same_entry(prev, g_entry[im.sub_off + it.s]);
+            if (im.nseg > 1 && locate_sub(im, im.himg, segs, it.s).seg_sub0 == it.s) active = false;
+            it.p = prev.p;
+            it.zc = prev.z | (uint32_t(prev.c) << 8);
+            if (active) g_entry[im.sub_off + it.s] = make_state(prev.p, prev.z, prev.c);
+        }
+        {
+            const unsigned long long mm = __ballot(active);
+            if (lane == 0 && mm) atomicAdd(count, uint32_t(__popcll(mm)));
+        }
+        for (;;) {
+            if (active) {
+                SubseqState x;
+                if (merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x, segs)) {
+                    merge_finish(it, im, x, g_exit, g_cps);
+                    active = false;
+                }
+            }
+            const unsigned long long mask = __ballot(active);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+            if (lane == 0) s_cnt[wave] = uint32_t(__popcll(mask));
+            __syncthreads();                                               // (also: every lane is done with its window)
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < kMergeWg / 64; w++) {
+                const uint32_t c = s_cnt[w];
+                before += w < wave ? c : 0u;
+                total += c;
+            }
+            if (total == 0) break;
+            if (active) {
+                uint32_t *slot = s_win + (before + rank) * kItemDwords;
+                slot[0] = it.s; slot[1] = it.p; slot[2] = it.zc; slot[3] = it.n; slot[4] = it.m; slot[5] = it.k;
+            }
+            __syncthreads();
+            active = tid < total;
+            if (active) {
+                const uint32_t *slot = s_win + tid * kItemDwords;
+                it.s = slot[0]; it.p = slot[1]; it.zc = slot[2]; it.n = slot[3]; it.m = slot[4]; it.k = slot[5];
+            }
+            __syncthreads();                                               // the exchange area becomes windows again
+        }
+        grid_barrier(ctl, (round + 1) * participants);
+        last = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (last == 0) break;
+    }
+    // leave: the last workgroup out publishes the verdict and clears the control words for the next launch
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(ctl + 1, 1u) + 1 == participants) {
+            *verdict = last;
+            ctl[0] = 0; ctl[2] = 0; ctl[3] = 0; ctl[4] = 0;
+            __threadfence();
+            ctl[1] = 0;
+        }
+    }
+}
+
 // Workgroup-wide exclusive scan helper (256 lanes): returns the exclusive prefix of v, total in *total.
 __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t *s_tmp, uint32_t *total)
 {
@@ -1854,6 +1959,14 @@ void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
     hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches, uint32_t(tables_lds), items, item_count, segs, prev_mismatches);
     const size_t tail_lds = tables_lds + size_t(64) * kMergeStride * 4;
     hipLaunchKernelGGL(k_huff_merge_tail, dim3(nimg, max_wg * (kMergeWg / 64)), dim3(64), tail_lds, st, images, scan_pool, lut_pool, exit_, cps, uint32_t(tables_lds), items, item_count, segs);
+}
+
+void launch_huff_merge_loop(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
+                            const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
+                            uint32_t *cps, uint32_t *verdict, const uint32_t *segs, uint32_t *ctl, uint32_t participants, uint32_t max_rounds)
+{
+    const size_t lds = tables_lds + size_t(kMergeWg) * kMergeStride * 4 + (kMergeWg / 64) * 4 + pad_lds;
+    hipLaunchKernelGGL(k_huff_merge_loop, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, verdict, uint32_t(tables_lds), segs, ctl, participants, max_rounds);
 }
 
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,

@@ -151,7 +151,7 @@ def test_emulated_decode_synthetic(mjx, orc, emul, w, h, sub, q):
         assert rc == 0 and np.array_equal(coefs, orc.interleave(ref)), (wg, st)
 
 
-@pytest.mark.parametrize("sub_bits", [2048, 1024, 256, 3000])
+@pytest.mark.parametrize("sub_bits", [2048, 1024, 512, 256, 3000])
 def test_emulated_decode_with_short_subsequences(mjx, orc, emul, sub_bits):
     """Batches too small to fill the device are re-cut into shorter subsequences (replan_subsequences, build_batch): the
     same kernel sequence must reach the same coefficients whatever the length (3000 is rounded down to a multiple of the
