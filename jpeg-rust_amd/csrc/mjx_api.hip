@@ -57,7 +57,9 @@ struct mjx_ctx {
     hipStream_t stream2 = nullptr;  // stage B runs here, the entropy stage on `stream` (MJX_STREAMS=1: everything on `stream`), see run_chunk
     std::vector<std::pair<uint32_t *, size_t>> pinned_cache;   // small pinned blocks (a batch's mirror of its round counts) kept for
                                                                // the next batch: hipHostMalloc + hipHostFree were 0.2 ms of a one-shot decode
-    uint32_t merge_loop_max = 192;  // chunks with at most this many merge workgroups run their rounds in one launch (MJX_MERGE_LOOP=0: never)
+    bool loop_fault = false;        // test knob (MJX_LOOP_FAULT=1): the loop waits for a workgroup that does not exist and must give up
+    uint32_t merge_loop_max = 64;   // chunks with at most this many merge workgroups (of the 768 the device holds) run their rounds in
+                                    // one launch, k_huff_merge_loop (MJX_MERGE_LOOP=n, 0 = never)
     uint32_t latency_sub_bits = 512;                            // ... and the shortest length they may get (MJX_LATENCY_SUB_BITS)
     uint64_t latency_nsub = 32768;  // batches of at most this many 512-byte subsequences (16 MB of scans: 64 of the 1024 workgroup
                                     // slots of k_huff_spec) get 256-byte subsequences, see build_batch (MJX_LATENCY_NSUB, 0 = never)
@@ -439,7 +441,8 @@ void plan_chunks(mjx_batch *b)
             i++;
         }
         // one launch for all the merge rounds only when its workgroups are certain to be resident together (they wait for one
-        // another): a quarter of the device's 3 x 256 slots, so that other work on the device cannot starve them for long
+        // another): a twelfth of the device's 3 x 256 slots, so that a dozen such launches (other contexts, other processes) still
+        // fit side by side; a launch that cannot get its workgroups together gives up by itself (kLoopGaveUp)
         if (c.loop_participants > b->ctx->merge_loop_max) c.loop_participants = 0;
         coef_running += c.blocks;
         ent_running += c.entries;
@@ -612,7 +615,8 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
             // (the count of the last round run lands where the last enqueued round's would: mjx_batch_wait and k_huff_scan look there)
             prof_begin(b, MJX_K_HUFF_FIX, st);
             launch_huff_merge_loop(st, c.merge_wgs, nimg, b->huff_lds, b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps),
-                                   b->d_mismatch + ci * kMaxFix + fix_passes - 1, b->d_segs, b->d_loopctl + ci * 8, c.loop_participants, kLoopRounds);
+                                   b->d_mismatch + ci * kMaxFix + fix_passes - 1, b->d_segs, b->d_loopctl + ci * 8,
+                                   c.loop_participants + (b->ctx->loop_fault ? 1u : 0u), kLoopRounds, b->ctx->loop_fault ? 1u << 12 : 1u << 22);
             prof_end(b, st);
             HIPOK(hipMemcpyAsync(b->h_mismatch + ci * kMaxFix, b->d_mismatch + ci * kMaxFix, kMaxFix * sizeof(uint32_t),
                                  hipMemcpyDeviceToHost, st));
@@ -1117,7 +1121,8 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     if (const char *e = std::getenv("MJX_STREAMS")) c->nstreams = std::atoi(e) == 1 ? 1 : 2;
     if (const char *e = std::getenv("MJX_LATENCY_NSUB")) c->latency_nsub = uint64_t(std::max(0L, std::atol(e)));
     if (const char *e = std::getenv("MJX_LATENCY_SUB_BITS")) c->latency_sub_bits = uint32_t(std::max(256L, std::min(long(kSubseqBits), std::atol(e))));
-    if (const char *e = std::getenv("MJX_MERGE_LOOP")) c->merge_loop_max = uint32_t(std::min(192L, std::max(0L, std::atol(e) == 1 ? 192L : std::atol(e))));
+    if (const char *e = std::getenv("MJX_LOOP_FAULT")) c->loop_fault = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MJX_MERGE_LOOP")) c->merge_loop_max = uint32_t(std::min(192L, std::max(0L, std::atol(e))));
     if (c->nstreams == 2) {
         // stage B's stream gets the higher priority (MJX_PIXEL_PRIORITY=0: equal): its workgroups are placed first when a CU
         // frees resources, so the pixel kernel keeps close to its stand-alone pace and the entropy kernels fill what it leaves
@@ -1364,6 +1369,12 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
             const int passes = std::min(b->ctx->fix_passes, kMaxFix);
             if (b->h_mismatch[ci * kMaxFix + passes - 1] == 0) continue;
             if (std::getenv("MJX_TIMING")) std::fprintf(stderr, "[mjx] chunk %zu unconverged after %d rounds (%u re-decodes in the last): repairing\n", ci, passes, b->h_mismatch[ci * kMaxFix + passes - 1]);
+            if (b->h_mismatch[ci * kMaxFix + passes - 1] == 0xffffffffu && b->chunks[ci].loop_participants) {
+                // k_huff_merge_loop could not get its workgroups resident together and gave up: its control words are in an
+                // unknown state; this chunk goes on with one launch per round, now and in later decodes
+                b->chunks[ci].loop_participants = 0;
+                HIPOK(hipMemsetAsync(b->d_loopctl + ci * 8, 0, 8 * sizeof(uint32_t), b->ctx->stream));
+            }
             // repair: keep running fix passes -- each one extends the verified prefix -- until one finds nothing.  If a later
             // chunk has reused this chunk's state arrays (or the chunk ran on the second set, which the repair does not
             // use), its synchronisation starts again from the speculative decode; otherwise -- a batch of one chunk, the

@@ -111,7 +111,8 @@ void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
 // with x * merge_wg_lanes() + 1 < nsub(image): all of them must be resident at once (the caller checks against merge_loop_capacity()).
 void launch_huff_merge_loop(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                             const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
-                            uint32_t *cps, uint32_t *verdict, const uint32_t *segs, uint32_t *ctl, uint32_t participants, uint32_t max_rounds);
+                            uint32_t *cps, uint32_t *verdict, const uint32_t *segs, uint32_t *ctl, uint32_t participants, uint32_t max_rounds,
+                            uint32_t spin_limit);      // spin_limit: polls of a barrier (~1.5 us each) before a workgroup gives up
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,
                       uint32_t *ebase, uint32_t *img_entries, uint32_t *img_flags, const uint32_t *segs,
                       const uint32_t *verdict /* device word: re-decodes of the last synchronisation round, or null */);

@@ -605,25 +605,41 @@ extern "C" __global__ __launch_bounds__(64) void k_huff_merge_tail(const DevImag
 // checks), one launch runs the rounds in a loop with a device-wide barrier between them, until a round re-decodes nothing
 // (the same proof of the fixed point as above) or `max_rounds` are spent.  Stragglers are not handed to a second kernel:
 // occupancy is no concern here, a workgroup runs all its items to the end.
-//   ctl[0] barrier arrivals (monotonic), ctl[1] workgroups that have left, ctl[2..4] re-decodes of round r in ctl[2 + r % 3];
-//   the last workgroup to leave zeroes ctl for the next launch.  `verdict` receives the count of the last round run.
-__device__ __forceinline__ void grid_barrier(uint32_t *arrivals, uint32_t target)
+//   ctl[0] barrier arrivals (monotonic), ctl[1] workgroups that have left, ctl[2..4] re-decodes of round r in ctl[2 + r % 3],
+//   ctl[5] set when a workgroup has given up waiting; the last workgroup to leave zeroes ctl for the next launch.
+//   `verdict` receives the count of the last round run, or kLoopGaveUp.
+// The workgroups wait for one another, so all of them must be resident at once.  The host only uses the kernel for chunks far
+// below the device's capacity (launch_huff_merge_loop), but it cannot see what else the device is running (other processes,
+// other contexts' loops): a workgroup that has waited a few seconds at a barrier gives up, raises ctl[5], and everybody leaves --
+// the states are a valid intermediate result at any time, and mjx_batch_wait continues with the launch-per-round kernels.
+constexpr uint32_t kLoopGaveUp = 0xffffffffu;
+__device__ __forceinline__ bool grid_barrier(uint32_t *ctl, uint32_t target, uint32_t *s_flag, uint32_t spin_limit)
 {
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();                                                   // release what the workgroup has written
-        atomicAdd(arrivals, 1u);
-        while (__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+        atomicAdd(ctl, 1u);
+        uint32_t spins = 0, gave_up = 0;
+        while (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(8);
+            if ((++spins & 1023u) == 0 && (spins >= spin_limit || __hip_atomic_load(ctl + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(ctl + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gave_up = 1;
+                break;
+            }
+        }
+        *s_flag = gave_up;
     }
     __syncthreads();
     __threadfence();                                                       // acquire what the others have written
+    return *s_flag == 0;
 }
 
 extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge_loop(const DevImage *images, const uint8_t *scan_pool,
                                                                      const LutEntry *lut_pool, SubseqState *g_entry,
                                                                      SubseqState *g_exit, uint32_t *g_cps, uint32_t *verdict,
                                                                      uint32_t win_off, const uint32_t *segs, uint32_t *ctl,
-                                                                     uint32_t participants, uint32_t max_rounds)
+                                                                     uint32_t participants, uint32_t max_rounds, uint32_t spin_limit)
 {
     extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, windows (= item exchange), wave counts
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
@@ -637,7 +653,8 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge_loop(const D
     const unsigned char *bytes = scan_pool + im.scan_off;
     uint32_t *my_win = s_win + tid * kMergeStride;
     uint32_t last = 0;
-    for (uint32_t round = 0; round < max_rounds; round++) {
+    bool gave_up = __hip_atomic_load(ctl + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;       // (dispatched after the others had given up)
+    for (uint32_t round = 0; round < max_rounds && !gave_up; round++) {
         uint32_t *count = ctl + 2 + round % 3;
         if (tid == 0) ctl[2 + (round + 1) % 3] = 0;                        // the next round's count (nobody reads or adds to it in this round)
         MergeItem it{blockIdx.x * kMergeWg + tid + 1, 0, 0, 0, 0, 0};
@@ -686,7 +703,7 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge_loop(const D
             }
             __syncthreads();                                               // the exchange area becomes windows again
         }
-        grid_barrier(ctl, (round + 1) * participants);
+        if (!grid_barrier(ctl, (round + 1) * participants, s_cnt + kMergeWg / 64, spin_limit)) { gave_up = true; break; }
         last = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (last == 0) break;
     }
@@ -694,9 +711,10 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge_loop(const D
     __syncthreads();
     if (tid == 0) {
         __threadfence();
+        if (gave_up) *verdict = kLoopGaveUp;
         if (atomicAdd(ctl + 1, 1u) + 1 == participants) {
-            *verdict = last;
-            ctl[0] = 0; ctl[2] = 0; ctl[3] = 0; ctl[4] = 0;
+            if (!gave_up && !__hip_atomic_load(ctl + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) *verdict = last;
+            ctl[0] = 0; ctl[2] = 0; ctl[3] = 0; ctl[4] = 0; ctl[5] = 0;
             __threadfence();
             ctl[1] = 0;
         }
@@ -1912,6 +1930,7 @@ int configure_kernels(size_t huff_lds, size_t idct_lds)
         const int cap = int(huff_lds);
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_spec), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_merge), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_merge_loop), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_write), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     }
     if (e == hipSuccess && idct_lds > 64 * 1024) {
@@ -1963,10 +1982,11 @@ void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
 
 void launch_huff_merge_loop(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                             const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
-                            uint32_t *cps, uint32_t *verdict, const uint32_t *segs, uint32_t *ctl, uint32_t participants, uint32_t max_rounds)
+                            uint32_t *cps, uint32_t *verdict, const uint32_t *segs, uint32_t *ctl, uint32_t participants, uint32_t max_rounds,
+                            uint32_t spin_limit)
 {
-    const size_t lds = tables_lds + size_t(kMergeWg) * kMergeStride * 4 + (kMergeWg / 64) * 4 + pad_lds;
-    hipLaunchKernelGGL(k_huff_merge_loop, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, verdict, uint32_t(tables_lds), segs, ctl, participants, max_rounds);
+    const size_t lds = tables_lds + size_t(kMergeWg) * kMergeStride * 4 + (kMergeWg / 64 + 1) * 4 + pad_lds;
+    hipLaunchKernelGGL(k_huff_merge_loop, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, verdict, uint32_t(tables_lds), segs, ctl, participants, max_rounds, spin_limit);
 }
 
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,

@@ -299,3 +299,36 @@ def test_small_batches_with_short_subsequences_equal_the_long_ones(mjx, orc, tmp
     ref = orc.decode(data, layout=orc.LAYOUT_STD)
     import hashlib
     assert hashlib.sha256(np.ascontiguousarray(orc.interleave(ref)).tobytes()).hexdigest() == outs[0][0][2]
+
+
+def test_merge_loop_that_cannot_assemble_gives_up_and_the_rounds_go_on(mjx, orc, tmp_path):
+    """k_huff_merge_loop runs all merge rounds of a small chunk in one launch; its workgroups wait for one another at a
+    device-wide barrier.  If they cannot all be resident (a device crowded by other processes) a workgroup gives up after a
+    while, everybody leaves, and mjx_batch_wait continues with one launch per round.  MJX_LOOP_FAULT=1 makes the kernel wait
+    for a workgroup that does not exist: the pictures must come out right all the same, also on the second decode of the
+    same batch (the chunk has stopped using the loop by then)."""
+    import subprocess, sys
+    script = tmp_path / "fault.py"
+    script.write_text(
+        "import os, sys, time, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "import __graft_entry__ as ge, oracle_binding as orc\n"
+        "mjx = ge.load_package()\n"
+        "ctx = mjx.Context(0)\n"
+        "root = os.path.join(%r, 'tests')\n"
+        "datas = [open(os.path.join(root, n), 'rb').read() for n in ('data/lena.jpeg', 'golden/pil/slow_sync_444_q99.jpg', 'golden/pil/dri_420_720p_rows.jpg')]\n"
+        "datas.append(mjx.synth_jpeg(1920, 1080, '420', 85, seed=3))\n"
+        "t = time.perf_counter()\n"
+        "for d in datas:\n"
+        "    ref = orc.decode(d, layout=orc.LAYOUT_STD, ext_dri=True)\n"
+        "    b = mjx.Batch(ctx, [mjx.ParsedScan(d)], keep_coefs=True)\n"
+        "    for rep in range(2):\n"
+        "        b.decode(); b.wait()\n"
+        "        assert b.status(0) == 0\n"
+        "        assert np.array_equal(b.coefs(0), orc.interleave(ref))\n"
+        "        assert np.abs(b.rgb(0).astype(int) - ref.rgb.astype(int)).max() <= 1\n"
+        "    b.close()\n"
+        "print('fault ok')\n" % (ROOT, ROOT, ROOT))
+    for extra in ({"MJX_LOOP_FAULT": "1"}, {"MJX_MERGE_LOOP": "0"}):
+        out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "fault ok" in out.stdout, str(extra) + out.stdout[-2000:] + out.stderr[-2000:]
