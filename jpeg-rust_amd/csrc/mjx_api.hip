@@ -1120,7 +1120,7 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     c->nstreams = 2;
     if (const char *e = std::getenv("MJX_STREAMS")) c->nstreams = std::atoi(e) == 1 ? 1 : 2;
     if (const char *e = std::getenv("MJX_LATENCY_NSUB")) c->latency_nsub = uint64_t(std::max(0L, std::atol(e)));
-    if (const char *e = std::getenv("MJX_LATENCY_SUB_BITS")) c->latency_sub_bits = uint32_t(std::max(256L, std::min(long(kSubseqBits), std::atol(e))));
+    if (const char *e = std::getenv("MJX_LATENCY_SUB_BITS")) c->latency_sub_bits = uint32_t(std::max(512L, std::min(long(kSubseqBits), std::atol(e))));
     if (const char *e = std::getenv("MJX_LOOP_FAULT")) c->loop_fault = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_MERGE_LOOP")) c->merge_loop_max = uint32_t(std::min(192L, std::max(0L, std::atol(e))));
     if (c->nstreams == 2) {
