@@ -57,6 +57,7 @@ struct mjx_ctx {
     hipStream_t stream2 = nullptr;  // stage B runs here, the entropy stage on `stream` (MJX_STREAMS=1: everything on `stream`), see run_chunk
     std::vector<std::pair<uint32_t *, size_t>> pinned_cache;   // small pinned blocks (a batch's mirror of its round counts) kept for
                                                                // the next batch: hipHostMalloc + hipHostFree were 0.2 ms of a one-shot decode
+    bool dc_one_pass = true;        // DC prediction of the common MCU shapes in one pass, k_dc_scan_t (MJX_DC_ONE_PASS=0: two passes)
     bool loop_fault = false;        // test knob (MJX_LOOP_FAULT=1): the loop waits for a workgroup that does not exist and must give up
     uint32_t merge_loop_max = 64;   // chunks with at most this many merge workgroups (of the 768 the device holds) run their rounds in
                                     // one launch, k_huff_merge_loop (MJX_MERGE_LOOP=n, 0 = never)
@@ -178,6 +179,8 @@ struct mjx_batch {
     hipEvent_t ev_entropy[2] = {nullptr, nullptr}, ev_pixels[2] = {nullptr, nullptr};   // per scratch set, see run_chunk
     bool entropy_recorded[2] = {false, false}, pixels_recorded[2] = {false, false};
     uint32_t *d_loopctl = nullptr;      // 8 control words per chunk for k_huff_merge_loop (zero between launches)
+    uint32_t *d_segflag[2] = {nullptr, nullptr};   // per scratch set: "running sums published" flags of k_dc_scan_t, one per (image, segment);
+    uint32_t dc_gen[2] = {0, 0};                   // zero at creation, a flag is valid when it equals the set's launch count
     hipEvent_t uploaded = nullptr;      // recorded on ctx->upload behind the last upload command; the decode streams wait for it
     bool upload_pending = false;
     // mjx_decode_batch decodes its files in groups (upload of one group overlaps the decode of the one before): the batch
@@ -648,7 +651,8 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
                           SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_status, b->d_img_flags, b->d_segs, SCR(d_exit));
         prof_end(b, st);
         prof_begin(b, MJX_K_DC_SCAN, st);
-        launch_dc_scan(st, c.max_segs, nimg, imgs, dcb, SCR(d_segsum), b->d_img_flags, c.bpm_mask, c.max_restart_segs);
+        launch_dc_scan(st, c.max_segs, nimg, imgs, dcb, SCR(d_segsum), b->d_img_flags, c.bpm_mask, c.max_restart_segs,
+                       b->ctx->dc_one_pass ? b->d_segflag[set] : nullptr, ++b->dc_gen[set]);
         prof_end(b, st);
         if (c.has_gather) {
             prof_begin(b, MJX_K_GATHER, st);
@@ -911,6 +915,8 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
                 ii.push_back(InterleaveImg{0, uint32_t(p.scan_len), uint32_t(k)});              // (lin_off is filled in below)
                 max_pieces = std::max<uint32_t>(max_pieces, scan_region_cols(p.himg.nsub) * scan_region_rows(p.himg.sub_bits));
             }
+        size_t segflag_words = 6;                                       // (as max_segsum in allocate_work_buffers)
+        for (const Chunk &c : b->chunks) segflag_words = std::max<size_t>(segflag_words, size_t(c.max_segs) * c.count * 6);
         {
             DevArena ar;
             auto layout = [&]() -> int {
@@ -926,6 +932,8 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
                 ar.take(&b->d_img_flags, std::max<size_t>(n, 1) * sizeof(uint32_t));
                 ar.take(&b->d_status, std::max<size_t>(n, 1) * sizeof(int));
                 ar.take(&b->d_loopctl, std::max<size_t>(b->chunks.size(), 1) * 8 * sizeof(uint32_t));
+                ar.take(&b->d_segflag[0], 2 * segflag_words * sizeof(uint32_t));      // (segflag_words counts 32-bit words: 3 x 64 bit per segment)
+                b->d_segflag[1] = b->d_segflag[0] + segflag_words;
                 ar.take(&b->d_meta_end, 16);
                 ar.take(&b->d_scan, b->scan_pool_bytes + 256);
                 if (!src) ar.take(&b->d_lin, lin_pool + 256);
@@ -958,6 +966,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
             std::memset(mirror(b->d_img_flags), 0, zero_words * sizeof(uint32_t));
             std::memset(mirror(b->d_status), 0, zero_words * sizeof(int));
             std::memset(mirror(b->d_loopctl), 0, std::max<size_t>(b->chunks.size(), 1) * 8 * sizeof(uint32_t));
+            std::memset(mirror(b->d_segflag[0]), 0, 2 * segflag_words * sizeof(uint32_t));
             std::memcpy(mirror(b->d_images), b->himages.data(), n * sizeof(DevImage));
             if (!b->h_segs.empty()) std::memcpy(mirror(b->d_segs), b->h_segs.data(), b->h_segs.size() * sizeof(uint32_t));
         } else {
@@ -965,6 +974,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
             HIPOK(hipMemsetAsync(b->d_img_flags, 0, zero_words * sizeof(uint32_t), up));
             HIPOK(hipMemsetAsync(b->d_status, 0, zero_words * sizeof(int), up));
             HIPOK(hipMemsetAsync(b->d_loopctl, 0, std::max<size_t>(b->chunks.size(), 1) * 8 * sizeof(uint32_t), up));
+            HIPOK(hipMemsetAsync(b->d_segflag[0], 0, 2 * segflag_words * sizeof(uint32_t), up));
             HIPOK(hipMemcpyAsync(b->d_images, b->himages.data(), n * sizeof(DevImage), hipMemcpyHostToDevice, up));
             if (!b->h_segs.empty()) HIPOK(hipMemcpyAsync(b->d_segs, b->h_segs.data(), b->h_segs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, up));
         }
@@ -1121,6 +1131,7 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     if (const char *e = std::getenv("MJX_STREAMS")) c->nstreams = std::atoi(e) == 1 ? 1 : 2;
     if (const char *e = std::getenv("MJX_LATENCY_NSUB")) c->latency_nsub = uint64_t(std::max(0L, std::atol(e)));
     if (const char *e = std::getenv("MJX_LATENCY_SUB_BITS")) c->latency_sub_bits = uint32_t(std::max(512L, std::min(long(kSubseqBits), std::atol(e))));
+    if (const char *e = std::getenv("MJX_DC_ONE_PASS")) c->dc_one_pass = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_LOOP_FAULT")) c->loop_fault = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_MERGE_LOOP")) c->merge_loop_max = uint32_t(std::min(192L, std::max(0L, std::atol(e))));
     if (c->nstreams == 2) {

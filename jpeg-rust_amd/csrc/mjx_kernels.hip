@@ -1361,6 +1361,101 @@ __global__ __launch_bounds__(256) void k_dc_apply_t(const DevImage *images, int3
     }
 }
 
+// One pass instead of k_dc_sums_t + k_dc_apply_t (the differences are read once, not twice: 1.6 instead of 2.4 GB of traffic
+// per 1024 4K pictures): the workgroup of segment x keeps its differences in registers, publishes the running sums up to and
+// including its segment -- what segment x - 1 published plus its own totals -- and then writes the predictions.  Workgroups
+// are dispatched in the order of their linear id, so the workgroup a segment waits for has always been started before it
+// and waits only for still earlier ones: no residency condition, unlike k_huff_merge_loop.  The image is the fast grid
+// dimension: segment x of all images, then segment x + 1 of all images -- with the segment as the fast dimension the
+// sixteen workgroups of a picture start together and wait for one another in a chain (5.2 instead of 1.0 ms per step).
+//   segflag[(image, segment)][component] = gen << 32 | running sum: valid once its upper half equals `gen` (the words are zero
+//   when the batch is created and `gen` grows with every launch on this set of buffers).
+template <int BPM>
+__global__ __launch_bounds__(256) void k_dc_scan_t(const DevImage *images, int32_t *dcbuf, uint32_t *segsum,
+                                                   uint32_t max_segs, const uint32_t *img_flags, uint32_t gen)
+{
+    __shared__ int32_t s_wsum[4][3];
+    __shared__ int32_t s_carry[3];
+    const uint32_t img = blockIdx.x, seg = blockIdx.y;         // (the image is the fast dimension, see above)
+    const DevImage &im = images[img];
+    const uint32_t seg0 = seg * kDcSegMcus;
+    if (!im.valid || im.bpm != BPM || seg0 >= im.nmcu || img_flags[im.status_idx] || im.nseg > 1) return;
+    const uint32_t seg1 = min(im.nmcu, seg0 + kDcSegMcus);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t v[kDcLaneMcus * BPM];
+    int32_t *p;
+    const uint32_t nvalid = dc_lane_load<BPM>(im, dcbuf, seg0, seg1, v, p);
+    uint32_t comp[BPM];
+#pragma unroll
+    for (int j = 0; j < BPM; j++) comp[j] = im.blk_comp[j];
+    int32_t sum[3] = {0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < BPM; j++) {
+        int32_t t = 0;
+#pragma unroll
+        for (int m = 0; m < kDcLaneMcus; m++) t += v[m * BPM + j];
+        sum[0] += comp[j] == 0 ? t : 0;
+        sum[1] += comp[j] == 1 ? t : 0;
+        sum[2] += comp[j] == 2 ? t : 0;
+    }
+    int32_t incl[3] = {sum[0], sum[1], sum[2]};
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int32_t o = __shfl_up(incl[c], d);
+            if (lane >= uint32_t(d)) incl[c] += o;
+        }
+    }
+    if (lane == 63) { s_wsum[wave][0] = incl[0]; s_wsum[wave][1] = incl[1]; s_wsum[wave][2] = incl[2]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {                                      // carry in from the segment before, carry out to the one behind
+        // One 64-bit word per component, `gen` in its upper half: a word validates itself, so plain device-scope atomics do
+        // (performed at the memory side, coherent across the XCDs) -- release / acquire fences write back and invalidate the
+        // whole L2 of the XCD, 16 384 times per launch: 3.6 instead of 1.0 ms per step.
+        const uint32_t c = threadIdx.x;
+        unsigned long long *words = reinterpret_cast<unsigned long long *>(segsum);
+        const size_t at = (size_t(img) * max_segs + seg) * 3 + c;
+        int32_t carry = 0;
+        if (seg > 0) {
+            unsigned long long w;
+            while (uint32_t((w = atomicAdd(words + at - 3, 0ull)) >> 32) != gen) __builtin_amdgcn_s_sleep(1);
+            carry = int32_t(uint32_t(w));
+        }
+        s_carry[c] = carry;
+        const int32_t out = carry + s_wsum[0][c] + s_wsum[1][c] + s_wsum[2][c] + s_wsum[3][c];
+        (void)atomicExch(words + at, (static_cast<unsigned long long>(gen) << 32) | uint32_t(out));
+    }
+    __syncthreads();
+    int32_t base[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        base[c] = s_carry[c] + incl[c] - sum[c];
+#pragma unroll
+        for (uint32_t w = 0; w < 4; w++) base[c] += w < wave ? s_wsum[w][c] : 0;
+    }
+#pragma unroll
+    for (int m = 0; m < kDcLaneMcus; m++)
+#pragma unroll
+        for (int j = 0; j < BPM; j++) {
+            const uint32_t c = comp[j];
+            const int32_t r = (c == 0 ? base[0] : (c == 1 ? base[1] : base[2])) + v[m * BPM + j];
+            v[m * BPM + j] = r;
+            base[0] = c == 0 ? r : base[0];
+            base[1] = c == 1 ? r : base[1];
+            base[2] = c == 2 ? r : base[2];
+        }
+    if (nvalid == kDcLaneMcus) {
+#pragma unroll
+        for (int q = 0; q < kDcLaneMcus * BPM / 4; q++)
+            reinterpret_cast<Int4 *>(p)[q] = Int4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    } else {
+#pragma unroll
+        for (int i = 0; i < kDcLaneMcus * BPM; i++)
+            if (uint32_t(i) < nvalid * BPM) p[i] = v[i];
+    }
+}
+
 // Restart intervals: the DC predictors start again at 0 in every interval (T.81 E.2.4), so the
 // prediction is independent per interval: one lane walks the blocks of one interval.
 extern "C" __global__ __launch_bounds__(256) void k_dc_restart(const DevImage *images, int32_t *dcbuf,
@@ -2005,9 +2100,18 @@ void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
 }
 
 void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int32_t *dcbuf,
-                    int32_t *segsum, const uint32_t *img_flags, uint32_t bpm_mask, uint32_t max_restart_segs)
+                    int32_t *segsum, const uint32_t *img_flags, uint32_t bpm_mask, uint32_t max_restart_segs,
+                    uint32_t *segflag, uint32_t gen)
 {
     const dim3 grid(max_segs, nimg), wg(256);
+    if (segflag) {          // the common MCU shapes in one pass (k_dc_scan_t); segflag == nullptr: two passes as before
+        const dim3 grid(nimg, max_segs);
+        if (bpm_mask & (1u << 1)) hipLaunchKernelGGL(k_dc_scan_t<1>, grid, wg, 0, st, images, dcbuf, segflag, max_segs, img_flags, gen);
+        if (bpm_mask & (1u << 3)) hipLaunchKernelGGL(k_dc_scan_t<3>, grid, wg, 0, st, images, dcbuf, segflag, max_segs, img_flags, gen);
+        if (bpm_mask & (1u << 4)) hipLaunchKernelGGL(k_dc_scan_t<4>, grid, wg, 0, st, images, dcbuf, segflag, max_segs, img_flags, gen);
+        if (bpm_mask & (1u << 6)) hipLaunchKernelGGL(k_dc_scan_t<6>, grid, wg, 0, st, images, dcbuf, segflag, max_segs, img_flags, gen);
+        bpm_mask &= ~kDcFastShapes;
+    }
 #define MJX_DC_PASS(KERNEL)                                                                                              \
     if (bpm_mask & (1u << 1)) hipLaunchKernelGGL(KERNEL##_t<1>, grid, wg, 0, st, images, dcbuf, segsum, max_segs, img_flags); \
     if (bpm_mask & (1u << 3)) hipLaunchKernelGGL(KERNEL##_t<3>, grid, wg, 0, st, images, dcbuf, segsum, max_segs, img_flags); \
