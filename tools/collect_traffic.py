@@ -18,7 +18,8 @@ def per_launch(d, counter):
 
 fetch, write = per_launch(sys.argv[1], "FETCH_SIZE"), per_launch(sys.argv[2], "WRITE_SIZE")
 alias = {"k_huff_spec": "huff_sync", "k_huff_merge": "huff_fix", "k_huff_merge_tail": "huff_fix_tail", "k_huff_scan": "huff_scan",
-         "k_huff_write": "huff_write", "k_idct_color": "idct_color", "k_dc_sums_t": "dc_sums", "k_dc_apply_t": "dc_apply"}
+         "k_huff_write": "huff_write", "k_idct_color": "idct_color", "k_dc_sums_t": "dc_sums", "k_dc_apply_t": "dc_apply", "k_dc_scan_t": "dc_scan",
+         "k_huff_merge_loop": "huff_fix_loop"}
 out = {"images_per_launch": int(sys.argv[4]) if len(sys.argv) > 4 else 128, "note": "bytes per launch; fetch = 2 x FETCH_SIZE (gfx950 correction), write = WRITE_SIZE",
        "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
