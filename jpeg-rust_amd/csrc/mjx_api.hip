@@ -62,6 +62,9 @@ struct mjx_ctx {
     uint32_t merge_loop_max = 64;   // chunks with at most this many merge workgroups (of the 768 the device holds) run their rounds in
                                     // one launch, k_huff_merge_loop (MJX_MERGE_LOOP=n, 0 = never)
     uint32_t latency_sub_bits = 512;                            // ... and the shortest length they may get (MJX_LATENCY_SUB_BITS)
+    uint64_t medium_nsub = 65536;   // batches of up to this many 512-byte subsequences (32 MB of scans, ~32 4K pictures) that are too large for
+                                    // the loop kernel get 256-byte subsequences with launch-per-round merges (MJX_MEDIUM_NSUB, 0 = never):
+                                    // 12 / 16 / 24 / 32 4K pictures 1.34 / 1.39 / 1.47 / 1.55 -> 1.08 / 1.12 / 1.20 / 1.33 ms; 64 pictures: no gain
     uint64_t latency_nsub = 32768;  // batches of at most this many 512-byte subsequences (16 MB of scans: 64 of the 1024 workgroup
                                     // slots of k_huff_spec) get 256-byte subsequences, see build_batch (MJX_LATENCY_NSUB, 0 = never)
     hipStream_t upload = nullptr;   // H2D of the compressed scans + the upload-time kernels (de-stuffing, interleaving): a stream of
@@ -750,6 +753,13 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
                 if (wgs <= ctx->merge_loop_max) { replanned.swap(cut); use = &replanned; break; }
             }
         }
+        // too many merge workgroups for the loop kernel, but still far from filling the device (up to ~64 4K pictures): half-length
+        // subsequences with the enqueued rounds (content that needs more than six of them pays one trip to the host)
+        if (use == &plans_in && total > 0 && total <= ctx->medium_nsub) {
+            replanned = plans_in;
+            for (ImagePlan &p : replanned) if (p.status == MJX_OK) replan_subsequences(p, uint32_t(kSubseqBits) / 2);
+            use = &replanned;
+        }
     }
     const std::vector<ImagePlan> &plans = *use;
     mjx_batch *b = new (std::nothrow) mjx_batch;
@@ -1130,6 +1140,7 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     c->nstreams = 2;
     if (const char *e = std::getenv("MJX_STREAMS")) c->nstreams = std::atoi(e) == 1 ? 1 : 2;
     if (const char *e = std::getenv("MJX_LATENCY_NSUB")) c->latency_nsub = uint64_t(std::max(0L, std::atol(e)));
+    if (const char *e = std::getenv("MJX_MEDIUM_NSUB")) c->medium_nsub = uint64_t(std::max(0L, std::atol(e)));
     if (const char *e = std::getenv("MJX_LATENCY_SUB_BITS")) c->latency_sub_bits = uint32_t(std::max(512L, std::min(long(kSubseqBits), std::atol(e))));
     if (const char *e = std::getenv("MJX_DC_ONE_PASS")) c->dc_one_pass = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_LOOP_FAULT")) c->loop_fault = std::atoi(e) != 0;
