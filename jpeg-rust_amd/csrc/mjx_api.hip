@@ -58,15 +58,16 @@ struct mjx_ctx {
     std::vector<std::pair<uint32_t *, size_t>> pinned_cache;   // small pinned blocks (a batch's mirror of its round counts) kept for
                                                                // the next batch: hipHostMalloc + hipHostFree were 0.2 ms of a one-shot decode
     bool dc_one_pass = true;        // DC prediction of the common MCU shapes in one pass, k_dc_scan_t (MJX_DC_ONE_PASS=0: two passes)
-    bool loop_fault = false;        // test knob (MJX_LOOP_FAULT=1): the loop waits for a workgroup that does not exist and must give up
+    // Batches too small to fill the device (DESIGN s11), see build_batch:
     uint32_t merge_loop_max = 64;   // chunks with at most this many merge workgroups (of the 768 the device holds) run their rounds in
                                     // one launch, k_huff_merge_loop (MJX_MERGE_LOOP=n, 0 = never)
-    uint32_t latency_sub_bits = 512;                            // ... and the shortest length they may get (MJX_LATENCY_SUB_BITS)
+    bool loop_fault = false;        // test knob (MJX_LOOP_FAULT=1): that launch waits for a workgroup that does not exist and must give up
+    uint64_t latency_nsub = 32768;  // batches of at most this many 512-byte subsequences (16 MB of scans: 64 of the 1024 workgroup slots of
+                                    // k_huff_spec) are cut into shorter subsequences when they fit the loop kernel (MJX_LATENCY_NSUB, 0 = never),
+    uint32_t latency_sub_bits = 512;                            // ... this many bits at least (MJX_LATENCY_SUB_BITS)
     uint64_t medium_nsub = 65536;   // batches of up to this many 512-byte subsequences (32 MB of scans, ~32 4K pictures) that are too large for
                                     // the loop kernel get 256-byte subsequences with launch-per-round merges (MJX_MEDIUM_NSUB, 0 = never):
                                     // 12 / 16 / 24 / 32 4K pictures 1.34 / 1.39 / 1.47 / 1.55 -> 1.08 / 1.12 / 1.20 / 1.33 ms; 64 pictures: no gain
-    uint64_t latency_nsub = 32768;  // batches of at most this many 512-byte subsequences (16 MB of scans: 64 of the 1024 workgroup
-                                    // slots of k_huff_spec) get 256-byte subsequences, see build_batch (MJX_LATENCY_NSUB, 0 = never)
     hipStream_t upload = nullptr;   // H2D of the compressed scans + the upload-time kernels (de-stuffing, interleaving): a stream of
                                     // its own, so that the upload of one group of files overlaps the decode of the group before
     // Device blocks of released batches, kept for the next ones: giving tens of gigabytes back to the driver and asking for
@@ -1391,12 +1392,15 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
             const int passes = std::min(b->ctx->fix_passes, kMaxFix);
             if (b->h_mismatch[ci * kMaxFix + passes - 1] == 0) continue;
             if (std::getenv("MJX_TIMING")) std::fprintf(stderr, "[mjx] chunk %zu unconverged after %d rounds (%u re-decodes in the last): repairing\n", ci, passes, b->h_mismatch[ci * kMaxFix + passes - 1]);
-            if (b->h_mismatch[ci * kMaxFix + passes - 1] == 0xffffffffu && b->chunks[ci].loop_participants) {
-                // k_huff_merge_loop could not get its workgroups resident together and gave up: its control words are in an
-                // unknown state; this chunk goes on with one launch per round, now and in later decodes
+            // k_huff_merge_loop could not get its workgroups resident together and gave up (count = all ones): its control words
+            // are in an unknown state; the chunk goes on with one launch per round, now and in later decodes
+            auto loop_gave_up = [&](uint32_t count) -> int {
+                if (count != 0xffffffffu || !b->chunks[ci].loop_participants) return MJX_OK;
                 b->chunks[ci].loop_participants = 0;
                 HIPOK(hipMemsetAsync(b->d_loopctl + ci * 8, 0, 8 * sizeof(uint32_t), b->ctx->stream));
-            }
+                return MJX_OK;
+            };
+            { const int rcg = loop_gave_up(b->h_mismatch[ci * kMaxFix + passes - 1]); if (rcg != MJX_OK) return rcg; }
             // repair: keep running fix passes -- each one extends the verified prefix -- until one finds nothing.  If a later
             // chunk has reused this chunk's state arrays (or the chunk ran on the second set, which the repair does not
             // use), its synchronisation starts again from the speculative decode; otherwise -- a batch of one chunk, the
@@ -1417,6 +1421,7 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
                 HIPOK(hipStreamSynchronize(b->ctx->stream));
                 if (std::getenv("MJX_TIMING")) std::fprintf(stderr, "[mjx]   repair rounds: %u re-decodes left\n", b->h_mismatch[ci * kMaxFix + more - 1]);
                 if (b->h_mismatch[ci * kMaxFix + more - 1] == 0) break;
+                { const int rcg = loop_gave_up(b->h_mismatch[ci * kMaxFix + more - 1]); if (rcg != MJX_OK) return rcg; }
             }
             rc = run_chunk(b, ci, MJX_STAGE_ALL, 0, PH_TAIL, true);
             if (rc != MJX_OK) return rc;
