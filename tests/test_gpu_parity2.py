@@ -260,7 +260,7 @@ def test_pipelined_decode_batch_equals_the_batch_api(mjx, gpu_ctx):
     grouped.close()
 
 
-def test_small_batches_with_short_subsequences_equal_the_long_ones(mjx, orc, tmp_path):
+def test_small_batches_with_short_subsequences_equal_the_long_ones(mjx, orc, tmp_path):   # (and every other runtime switch)
     """A batch too small to fill the device is cut into 256-byte subsequences (build_batch; MJX_LATENCY_NSUB=0 switches
     that off).  Both cuts must give the same coefficients and the same pixels -- checked on the sample files, restart
     intervals, a multi-scan file and the slowly synchronising picture (which then needs the in-place repair rounds) --
@@ -282,19 +282,35 @@ def test_small_batches_with_short_subsequences_equal_the_long_ones(mjx, orc, tmp
         "    b.decode(); b.wait()\n"
         "    assert b.status(0) == 0, i\n"
         "    print(i, b.geometry()['subsequences'], hashlib.sha256(b.coefs(0).tobytes()).hexdigest(), hashlib.sha256(b.rgb(0).tobytes()).hexdigest())\n"
-        "    b.close()\n" % (ROOT, ROOT))
+        "    b.close()\n"
+        "b = mjx.Batch(ctx, [mjx.ParsedScan(d) for d in datas * 3], keep_coefs=True)      # ... and as one batch of 24 (the medium cut)\n"
+        "b.decode(); b.wait()\n"
+        "for i in range(len(datas)):\n"
+        "    j = 2 * len(datas) + i\n"
+        "    assert b.status(j) == 0, j\n"
+        "    print(100 + i, b.geometry()['subsequences'], hashlib.sha256(b.coefs(j).tobytes()).hexdigest(), hashlib.sha256(b.rgb(j).tobytes()).hexdigest())\n"
+        "b.close()\n" % (ROOT, ROOT))
     outs = []
-    base_env = {k: v for k, v in os.environ.items() if k not in ("MJX_LATENCY_NSUB", "MJX_MERGE_LOOP", "MJX_LATENCY_SUB_BITS")}
-    for env_extra in ({}, {"MJX_LATENCY_NSUB": "0"}):
+    switches = ("MJX_LATENCY_NSUB", "MJX_MEDIUM_NSUB", "MJX_MERGE_LOOP", "MJX_LATENCY_SUB_BITS", "MJX_DC_ONE_PASS", "MJX_STREAMS")
+    base_env = {k: v for k, v in os.environ.items() if k not in switches}
+    # every runtime switch of the small-batch path and of the DC prediction: the bytes must not depend on any of them
+    variants = ({}, {"MJX_LATENCY_NSUB": "0", "MJX_MEDIUM_NSUB": "0"}, {"MJX_MERGE_LOOP": "0"}, {"MJX_DC_ONE_PASS": "0"},
+                {"MJX_LATENCY_SUB_BITS": "1024"}, {"MJX_STREAMS": "1"})
+    for env_extra in variants:
         out = subprocess.run([sys.executable, str(script)], env=dict(base_env, **env_extra), capture_output=True, text=True, timeout=600)
-        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        assert out.returncode == 0, str(env_extra) + out.stdout[-2000:] + out.stderr[-2000:]
         outs.append([l.split() for l in out.stdout.strip().splitlines()])
-    assert len(outs[0]) == len(outs[1]) == 8
+    assert all(len(o) == 16 for o in outs)
     more = 0
-    for short, long_ in zip(outs[0], outs[1]):
-        assert short[2:] == long_[2:], (short, long_)                # same coefficients, same pixels
+    for k, other in enumerate(outs[1:]):
+        for short, long_ in zip(outs[0], other):
+            assert short[0] == long_[0] and short[2:] == long_[2:], (variants[k + 1], short, long_)      # same coefficients, same pixels
+    for short, long_ in zip(outs[0][:8], outs[1][:8]):
         more += int(short[1]) > int(long_[1])
     assert more >= 6                                                  # ... from different cuts (tiny scans are one subsequence either way)
+    assert int(outs[0][8][1]) > int(outs[1][8][1])                   # the batch of 24 as well
+    for a, b2 in zip(outs[0][:8], outs[0][8:]):
+        assert a[2:] == b2[2:]                                        # a picture alone = the same picture inside the batch
     # and the coefficients are the oracle's
     data = open(os.path.join(ROOT, "tests", "data", "lena.jpeg"), "rb").read()
     ref = orc.decode(data, layout=orc.LAYOUT_STD)
