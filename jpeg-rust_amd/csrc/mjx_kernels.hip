@@ -629,9 +629,9 @@ __device__ __forceinline__ bool grid_barrier(uint32_t *ctl, uint32_t target, uin
             }
         }
         *s_flag = gave_up;
-    }
+        __threadfence();                                                   // acquire what the others have written (one fence per
+    }                                                                      // workgroup: its waves share the CU's L1 and the XCD's L2)
     __syncthreads();
-    __threadfence();                                                       // acquire what the others have written
     return *s_flag == 0;
 }
 
