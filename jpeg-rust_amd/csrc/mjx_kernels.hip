@@ -505,20 +505,18 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
         if (active) g_entry[im.sub_off + it.s] = make_state(prev.p, prev.z, prev.c);
     }
     {   // nothing to repair in this workgroup?  (not __syncthreads_or: its static LDS word would be padded to kLutAlign)
-        const bool wave_any = __builtin_amdgcn_ballot_w64(active) != 0;    // (all lanes vote: outside the branch)
-        if (lane == 0) s_cnt[wave] = wave_any;
+        const unsigned long long mm = __builtin_amdgcn_ballot_w64(active);   // (all lanes vote: outside the branch)
+        if (lane == 0) s_cnt[wave] = uint32_t(__popcll(mm));
         __syncthreads();
         uint32_t any = 0;
-        for (uint32_t w = 0; w < kMergeWg / 64; w++) any |= s_cnt[w];
+        for (uint32_t w = 0; w < kMergeWg / 64; w++) any += s_cnt[w];
         if (!any) return;
+        if (tid == 0) atomicAdd(mismatches, any);                          // one atomic per workgroup, not per wave: all of them hit one word
+        __syncthreads();                                                   // (s_cnt is written again in the slice loop)
     }
     const HuffImage *h;
     const LutEntry *lut;
     stage_tables(im, lut_pool, smem, h, lut);
-    {
-        const unsigned long long mm = __ballot(active);
-        if (lane == 0 && mm) atomicAdd(mismatches, uint32_t(__popcll(mm)));
-    }
     const unsigned char *bytes = scan_pool + im.scan_off;          // the image's (lane-interleaved) region
     uint32_t *my_win = s_win + tid * kMergeStride;
     for (int slice = 0;; slice++) {
