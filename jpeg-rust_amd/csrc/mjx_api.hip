@@ -628,10 +628,11 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
             HIPOK(hipMemcpyAsync(b->h_mismatch + ci * kMaxFix, b->d_mismatch + ci * kMaxFix, kMaxFix * sizeof(uint32_t),
                                  hipMemcpyDeviceToHost, st));
         } else if (c.merge_wgs > 0) {
+            HIPOK(hipMemsetAsync(SCR(d_pull), 0, size_t(nimg) * std::max(fix_passes, 1) * sizeof(uint32_t), st));      // the straggler counts of every round
             for (int k = 0; k < fix_passes; k++) {
                 prof_begin(b, MJX_K_HUFF_FIX, st);
                 launch_huff_merge(st, c.merge_wgs, nimg, b->huff_lds, b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps),
-                                  b->d_mismatch + ci * kMaxFix + k, SCR(d_items), SCR(d_pull), b->d_segs,
+                                  b->d_mismatch + ci * kMaxFix + k, SCR(d_items), SCR(d_pull) + size_t(k) * nimg, b->d_segs,
                                   k > 0 ? b->d_mismatch + ci * kMaxFix + k - 1 : nullptr);
                 prof_end(b, st);
             }

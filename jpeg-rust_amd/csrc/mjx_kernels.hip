@@ -2066,7 +2066,7 @@ void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
                        uint32_t *cps, uint32_t *mismatches, uint32_t *items, uint32_t *item_count, const uint32_t *segs,
                        const uint32_t *prev_mismatches)
 {
-    (void)hipMemsetAsync(item_count, 0, size_t(nimg) * sizeof(uint32_t), st);
+    // (item_count: this round's straggler counts, one per image, zeroed by the caller -- one memset for all the rounds of a chunk)
     const size_t lds = tables_lds + size_t(kMergeWg) * kMergeStride * 4 + (kMergeWg / 64) * 4 + pad_lds;
     hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches, uint32_t(tables_lds), items, item_count, segs, prev_mismatches);
     const size_t tail_lds = tables_lds + size_t(64) * kMergeStride * 4;
