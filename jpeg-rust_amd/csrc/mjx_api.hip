@@ -55,6 +55,7 @@ struct mjx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // stage B runs here, the entropy stage on `stream` (MJX_STREAMS=1: everything on `stream`), see run_chunk
+    hipStream_t stream3 = nullptr;  // MJX_STREAMS=3: the entropy stage of the odd chunks (they have their own scratch set), beside that of the even ones
     std::vector<std::pair<uint32_t *, size_t>> pinned_cache;   // small pinned blocks (a batch's mirror of its round counts) kept for
                                                                // the next batch: hipHostMalloc + hipHostFree were 0.2 ms of a one-shot decode
     bool dc_one_pass = true;        // DC prediction of the common MCU shapes in one pass, k_dc_scan_t (MJX_DC_ONE_PASS=0: two passes)
@@ -88,7 +89,7 @@ struct mjx_ctx {
     int fix_passes = 6;            // synchronisation rounds enqueued up front (the last one must re-decode nothing; rounds
                                    // behind an empty one leave at once)
     // Extra dynamic LDS per entropy kernel = occupancy caps for experiments (MJX_SPEC/MERGE/WRITE_LDS_PAD); 0 in production.
-    size_t spec_lds_pad = 0, merge_lds_pad = 0, write_lds_pad = 0;
+    size_t spec_lds_pad = 0, merge_lds_pad = 0, write_lds_pad = 0, idct_lds_pad = 0;
     size_t configured_huff = 0, configured_idct = 0;   // dynamic-LDS limits the kernels were last configured for
 };
 
@@ -197,7 +198,7 @@ struct mjx_batch {
     std::vector<uint32_t> h_segs;       // host copy (mjx_batch_tile rebuilds plans from it)
     SubseqState *d_entry = nullptr, *d_exit = nullptr;
     uint32_t *d_blkbase = nullptr;
-    uint32_t *d_cps = nullptr;          // [chunk subsequences / 256][2 kMaxCp][256] checkpoint words
+    uint32_t *d_cps = nullptr;          // [chunk subsequences / 256][kMaxCp][256] checkpoints (two words each)
     uint32_t *d_pull = nullptr;         // [chunk images] straggler counts of k_huff_merge (per round)
     uint32_t *d_items = nullptr;        // [max_nsub][6] stragglers handed from k_huff_merge to k_huff_merge_tail
     uint32_t max_nsub = 1, max_chunk_images = 1;
@@ -558,10 +559,11 @@ int allocate_work_buffers(mjx_batch *b, DevArena &ar)
     {
         const size_t pad = std::max(b->ctx->spec_lds_pad, std::max(b->ctx->merge_lds_pad, b->ctx->write_lds_pad));
         const size_t want_huff = b->huff_lds + huff_window_bytes() + huff_stage_bytes() + pad;
-        if (want_huff > b->ctx->configured_huff || b->idct_lds > b->ctx->configured_idct) {
-            if (configure_kernels(std::max(want_huff, b->ctx->configured_huff), std::max(b->idct_lds, b->ctx->configured_idct)) != 0) { (void)hipGetLastError(); return MJX_ERR_DEVICE; }
+        const size_t want_idct = b->idct_lds + b->ctx->idct_lds_pad;
+        if (want_huff > b->ctx->configured_huff || want_idct > b->ctx->configured_idct) {
+            if (configure_kernels(std::max(want_huff, b->ctx->configured_huff), std::max(want_idct, b->ctx->configured_idct)) != 0) { (void)hipGetLastError(); return MJX_ERR_DEVICE; }
             b->ctx->configured_huff = std::max(want_huff, b->ctx->configured_huff);
-            b->ctx->configured_idct = std::max(b->idct_lds, b->ctx->configured_idct);
+            b->ctx->configured_idct = std::max(want_idct, b->ctx->configured_idct);
         }
     }
     return MJX_OK;
@@ -597,7 +599,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     // scratch buffers; the entropy stage of chunk k+2 waits for stage B of chunk k, which reads the set it writes.
     const bool second = b->dual && (ci & 1) && !force_first;
     const int set = second ? 1 : 0;
-    hipStream_t st = b->ctx->stream;
+    hipStream_t st = (second && b->ctx->stream3) ? b->ctx->stream3 : b->ctx->stream;
     hipStream_t sp = (b->ctx->stream2 && !force_first) ? b->ctx->stream2 : b->ctx->stream;
     if (sp != st && !b->ev_entropy[0]) {
         for (int k = 0; k < 2; k++) {
@@ -653,7 +655,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         prof_end(b, st);
         prof_begin(b, MJX_K_HUFF_WRITE, st);
         launch_huff_write(st, c.max_wg, nimg, b->huff_lds, b->ctx->write_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_blkbase), SCR(d_ebase),
-                          SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_status, b->d_img_flags, b->d_segs, SCR(d_exit));
+                              SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_status, b->d_img_flags, b->d_segs, SCR(d_exit));
         prof_end(b, st);
         prof_begin(b, MJX_K_DC_SCAN, st);
         launch_dc_scan(st, c.max_segs, nimg, imgs, dcb, SCR(d_segsum), b->d_img_flags, c.bpm_mask, c.max_restart_segs,
@@ -673,7 +675,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         if (sp != st && b->entropy_recorded[set]) HIPOK(hipStreamWaitEvent(sp, b->ev_entropy[set], 0));
         prof_begin(b, MJX_K_IDCT_COLOR, sp);
         if (c.plane_words) HIPOK(hipMemsetAsync(SCR(d_planes), 0, size_t(c.plane_words) * 8, sp));
-        launch_idct_color(sp, c.max_tiles, nimg, b->idct_lds, imgs, SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_qm, b->d_rgb, c.mode_mask, SCR(d_planes), b->d_img_flags);
+        launch_idct_color(sp, c.max_tiles, nimg, b->idct_lds + b->ctx->idct_lds_pad, imgs, SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_qm, b->d_rgb, c.mode_mask, SCR(d_planes), b->d_img_flags);
         if (c.plane_words) launch_ref_color(sp, c.max_pixel_wgs, nimg, imgs, SCR(d_planes), b->d_rgb, b->d_img_flags);
         prof_end(b, sp);
         if (sp != st) {
@@ -690,6 +692,7 @@ int sync_streams(const mjx_batch *b)
 {
     HIPOK(hipStreamSynchronize(b->ctx->stream));
     if (b->ctx->stream2) HIPOK(hipStreamSynchronize(b->ctx->stream2));
+    if (b->ctx->stream3) HIPOK(hipStreamSynchronize(b->ctx->stream3));
     return MJX_OK;
 }
 
@@ -1140,7 +1143,8 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     if (hipStreamCreateWithFlags(&c->upload, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return MJX_ERR_DEVICE; }
     if (const char *e = std::getenv("MJX_CACHE_GB")) c->cache_limit = size_t(std::max(0L, std::atol(e))) << 30;
     c->nstreams = 2;
-    if (const char *e = std::getenv("MJX_STREAMS")) c->nstreams = std::atoi(e) == 1 ? 1 : 2;
+    bool third = true;              // MJX_STREAMS=1: one stream, 2: entropy stage + stage B, 3 (default): the odd chunks' entropy stage on a stream of its own
+    if (const char *e = std::getenv("MJX_STREAMS")) { c->nstreams = std::atoi(e) == 1 ? 1 : 2; third = std::atoi(e) >= 3; }
     if (const char *e = std::getenv("MJX_LATENCY_NSUB")) c->latency_nsub = uint64_t(std::max(0L, std::atol(e)));
     if (const char *e = std::getenv("MJX_MEDIUM_NSUB")) c->medium_nsub = uint64_t(std::max(0L, std::atol(e)));
     if (const char *e = std::getenv("MJX_LATENCY_SUB_BITS")) c->latency_sub_bits = uint32_t(std::max(512L, std::min(long(kSubseqBits), std::atol(e))));
@@ -1148,19 +1152,23 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     if (const char *e = std::getenv("MJX_LOOP_FAULT")) c->loop_fault = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_MERGE_LOOP")) c->merge_loop_max = uint32_t(std::min(192L, std::max(0L, std::atol(e))));
     if (c->nstreams == 2) {
-        // stage B's stream gets the higher priority (MJX_PIXEL_PRIORITY=0: equal): its workgroups are placed first when a CU
-        // frees resources, so the pixel kernel keeps close to its stand-alone pace and the entropy kernels fill what it leaves
+        // With two streams stage B's gets the higher priority (MJX_PIXEL_PRIORITY=0: equal): its workgroups are placed first when
+        // a CU frees resources, so the pixel kernel keeps close to its stand-alone pace and the entropy kernels fill what it
+        // leaves.  With three (two chunks' entropy stages side by side: the write pass waits for HBM, the synchronisation
+        // passes for instruction issue) equal priorities measured better: 30.1 against 30.5 ms per step, 31.3 with two streams.
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         const char *pe = std::getenv("MJX_PIXEL_PRIORITY"), *hp = std::getenv("MJX_HIGH_PRIO");
-        const bool prio = hp ? std::strcmp(hp, "pixels") == 0 : (!pe || std::atoi(pe) != 0);
+        const bool prio = hp ? std::strcmp(hp, "pixels") == 0 : (pe ? std::atoi(pe) != 0 : !third);
         const hipError_t e2 = (prio && hi != lo) ? hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi)
                                                  : hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
         if (e2 != hipSuccess) { (void)hipGetLastError(); c->stream2 = nullptr; c->nstreams = 1; }
+        if (third && c->stream2 && hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->stream3 = nullptr; }
     }
     if (const char *e = std::getenv("MJX_SPEC_LDS_PAD")) c->spec_lds_pad = size_t(std::atoi(e));
     if (const char *e = std::getenv("MJX_MERGE_LDS_PAD")) c->merge_lds_pad = size_t(std::atoi(e));
     if (const char *e = std::getenv("MJX_WRITE_LDS_PAD")) c->write_lds_pad = size_t(std::atoi(e));
+    if (const char *e = std::getenv("MJX_IDCT_LDS_PAD")) c->idct_lds_pad = size_t(std::atoi(e));
     if (const char *e = std::getenv("MJX_FIX_PASSES")) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= kMaxFix) c->fix_passes = v;
@@ -1177,6 +1185,7 @@ extern "C" void mjx_ctx_destroy(mjx_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->stream3) { (void)hipStreamSynchronize(ctx->stream3); (void)hipStreamDestroy(ctx->stream3); }
     if (ctx->upload) { (void)hipStreamSynchronize(ctx->upload); (void)hipStreamDestroy(ctx->upload); }
     if (ctx->parse_arena) (void)hipHostFree(ctx->parse_arena);
     if (ctx->pin_small) (void)hipHostFree(ctx->pin_small);
@@ -1356,6 +1365,7 @@ extern "C" int mjx_batch_decode(mjx_batch *b, unsigned stages)
     if (b->upload_pending) {                     // asynchronous upload (mjx_decode_batch): kernels start behind it
         HIPOK(hipStreamWaitEvent(b->ctx->stream, b->uploaded, 0));
         if (b->ctx->stream2) HIPOK(hipStreamWaitEvent(b->ctx->stream2, b->uploaded, 0));
+        if (b->ctx->stream3) HIPOK(hipStreamWaitEvent(b->ctx->stream3, b->uploaded, 0));
         b->upload_pending = false;
     }
     for (size_t ci = 0; ci < b->chunks.size(); ci++) {

@@ -29,7 +29,10 @@ namespace mjx {
 constexpr int kSubseqBytes = MJX_SUBSEQ_BYTES;  // bytes of scan per lane, at least (HuffImage::sub_bits is the image's value)
 constexpr int kSubseqBits = kSubseqBytes * 8;
 constexpr int kMaxSubseqBits = 2 * kSubseqBits;
-constexpr int kCpBits = 256;                   // bits between two checkpoints of a subsequence
+#ifndef MJX_CP_BITS
+#define MJX_CP_BITS 256
+#endif
+constexpr int kCpBits = MJX_CP_BITS;           // bits between two checkpoints of a subsequence
 #ifndef MJX_HUFF_WG
 #define MJX_HUFF_WG 512
 #endif
@@ -157,11 +160,11 @@ struct NullSink {
 //   while a decode is running they temporarily hold the counts from the start to the checkpoint.
 constexpr int kMaxCp = kMaxSubseqBits / kCpBits - 1;      // checkpoints of the longest subsequence
 constexpr uint32_t kCpValid = 0x80000000u, kCpStateMask = 0x8000ffffu;
+struct CpPair { uint32_t w, m; };                                // the two words of a checkpoint (one 8-byte access)
 struct NoCheckpoints {
     MJX_HD uint32_t get(uint32_t) const { return 0; }             // word 0 of checkpoint k (may prefetch k+1)
     MJX_HD uint32_t get_m(uint32_t) const { return 0; }           // word 1 of checkpoint k (previous decode)
-    MJX_HD uint32_t get_plain(uint32_t) const { return 0; }       // word 0 of a checkpoint recorded by *this* decode
-    MJX_HD uint32_t get_m_plain(uint32_t) const { return 0; }     // word 1 of a checkpoint recorded by *this* decode
+    MJX_HD CpPair get_pair(uint32_t) const { return CpPair{0, 0}; }   // both words of a checkpoint
     MJX_HD void set(uint32_t, uint32_t, uint32_t) const {}        // both words
 };
 
@@ -388,14 +391,11 @@ template <class CpStore>
 MJX_HD void checkpoint_fixup(CpStore &cps, uint32_t k, uint32_t n_total, uint32_t m_total)
 {
     for (uint32_t j0 = 0; j0 < k; j0 += 4) {
-        uint32_t wv[4], mv[4];
-        for (uint32_t q = 0; q < 4; q++) {
-            wv[q] = j0 + q < k ? cps.get_plain(j0 + q) : 0u;
-            mv[q] = j0 + q < k ? cps.get_m_plain(j0 + q) : 0u;
-        }
+        CpPair v[4];
+        for (uint32_t q = 0; q < 4; q++) v[q] = j0 + q < k ? cps.get_pair(j0 + q) : CpPair{0u, 0u};
         for (uint32_t q = 0; q < 4; q++)
             if (j0 + q < k)
-                cps.set(j0 + q, (wv[q] & kCpStateMask) | ((n_total - ((wv[q] >> 16) & 0x7fffu)) << 16), m_total - mv[q]);
+                cps.set(j0 + q, (v[q].w & kCpStateMask) | ((n_total - ((v[q].w >> 16) & 0x7fffu)) << 16), m_total - v[q].m);
     }
 }
 

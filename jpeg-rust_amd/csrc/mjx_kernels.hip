@@ -46,38 +46,35 @@ struct LaneBits {
     __device__ __forceinline__ uint4 piece(uint32_t k) const { return *reinterpret_cast<const uint4 *>(base + (col + k * row_stride)); }
 };
 
-// Checkpoint words live in HBM in blocks of 256 consecutive subsequences; inside a block they are row-major by word
-// (row 2k = state word of checkpoint k, row 2k+1 = its entry count, rows 1 KiB apart), so the lanes of a wave touch
-// adjacent words of a row and a workgroup's checkpoints stay within one 30 KB region.  In merge rounds the previous
-// decode's state word is requested one boundary ahead (~45 symbols), so the comparison at the boundary does not
-// expose a round trip.  Addresses are `uniform base + 32-bit lane offset` (a chunk's checkpoints stay far below
-// 4 GiB: its stream capacity is capped in plan_chunks).
-constexpr uint32_t kCpRow = 256, kCpRowBytes = kCpRow * 4;
+// Checkpoints live in HBM in blocks of 256 consecutive subsequences; inside a block they are row-major by checkpoint
+// (row k = the two words of checkpoint k -- state | blocks, stream entries -- of the block's 256 subsequences, one 8-byte
+// pair each, rows 2 KiB apart), so the lanes of a wave touch adjacent pairs of a row and a workgroup's checkpoints stay
+// within one region.  In merge rounds the previous decode's state word is requested one boundary ahead (~45 symbols),
+// so the comparison at the boundary does not expose a round trip.  Addresses are `uniform base + 32-bit lane offset` (a
+// chunk's checkpoints stay far below 4 GiB: its stream capacity is capped in plan_chunks).
+constexpr uint32_t kCpRow = 256, kCpRowBytes = kCpRow * 8;
 __device__ __forceinline__ uint32_t cps_byte_off(uint32_t idx)
 {
-    return (idx / kCpRow) * (2 * kMaxCp * kCpRowBytes) + (idx % kCpRow) * 4;
+    return (idx / kCpRow) * (kMaxCp * kCpRowBytes) + (idx % kCpRow) * 8;
 }
 
 struct GlobalCps {
     unsigned char *base;    // the chunk's checkpoint array (wave-uniform)
     uint32_t off;           // cps_byte_off(subsequence index in the chunk)
     uint32_t next;          // prefetched state word of the previous decode
-    __device__ __forceinline__ uint32_t &word(uint32_t row) const { return *reinterpret_cast<uint32_t *>(base + (off + row * kCpRowBytes)); }
-    __device__ __forceinline__ void prime() { next = word(0); }
+    __device__ __forceinline__ uint2 &pair(uint32_t k) const { return *reinterpret_cast<uint2 *>(base + (off + k * kCpRowBytes)); }
+    __device__ __forceinline__ uint32_t &word(uint32_t k, uint32_t j) const { return *reinterpret_cast<uint32_t *>(base + (off + k * kCpRowBytes + 4 * j)); }
+    __device__ __forceinline__ void prime() { next = word(0, 0); }
     __device__ __forceinline__ uint32_t get(uint32_t k)
     {
         const uint32_t v = next;
-        if (k + 1 < uint32_t(kMaxCp)) next = word(2 * (k + 1));
+        if (k + 1 < uint32_t(kMaxCp)) next = word(k + 1, 0);
         return v;
     }
-    __device__ __forceinline__ uint32_t get_m(uint32_t k) const { return word(2 * k + 1); }
-    __device__ __forceinline__ uint32_t get_plain(uint32_t k) const { return word(2 * k); }
-    __device__ __forceinline__ uint32_t get_m_plain(uint32_t k) const { return word(2 * k + 1); }
-    __device__ __forceinline__ void set(uint32_t k, uint32_t v, uint32_t m) const
-    {
-        word(2 * k) = v;
-        word(2 * k + 1) = m;
-    }
+    __device__ __forceinline__ uint32_t get_m(uint32_t k) const { return word(k, 1); }
+    __device__ __forceinline__ uint32_t get_w(uint32_t k) const { return word(k, 0); }
+    __device__ __forceinline__ CpPair get_pair(uint32_t k) const { const uint2 v = pair(k); return CpPair{v.x, v.y}; }
+    __device__ __forceinline__ void set(uint32_t k, uint32_t v, uint32_t m) const { pair(k) = make_uint2(v, m); }
 };
 
 struct __attribute__((packed, aligned(4))) Entry4 { uint32_t a, b, c, d; };
@@ -116,7 +113,11 @@ struct LaneRing {
         if constexpr (GROUP >= 4) {
             static_assert(GROUP == 4 || GROUP == 8, "one or two 16-byte stores");
             const uint4 *src = reinterpret_cast<const uint4 *>(ring + (flushed & (kRing - 1)));
+#ifdef MJX_EXP_STORE_SMALL              // (measurement builds only: the same store instructions, into 8 KB per image -- they stay in L2)
+            uint4 *dst = reinterpret_cast<uint4 *>(out + (flushed & 0x7f8u));
+#else
             uint4 *dst = reinterpret_cast<uint4 *>(out + flushed);
+#endif
             const uint4 v0 = src[0], v1 = src[GROUP / 4 - 1];
 #ifndef MJX_EXP_NOSTORE                 // (measurement builds only: what the write pass costs without its global stores)
             dst[0] = v0;
@@ -408,6 +409,7 @@ constexpr int kMergeWin = 16, kMergeStride = kMergeWin + 1, kItemDwords = 6;    
 #endif
 constexpr int kHeadSlices = MJX_HEAD_SLICES;
 struct MergeItem { uint32_t s, p, zc, n, m, k; };
+constexpr uint32_t kSliceCps = kCpBits >= 256 ? 1u : 256u / uint32_t(kCpBits);
 
 // One slice of one item: decode from (p, z, c) to the next checkpoint boundary (or the end of the subsequence).
 // Returns true when the item is finished (its exit and checkpoints are final), false when `it` holds the progress.
@@ -422,7 +424,7 @@ __device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, c
     x = make_state(it.p, it.zc & 0xffu, it.zc >> 8, it.n, it.m);
     const uint32_t pl = it.p - sub_start;
     if (it.p >= sub_start && pl <= end_bit) {                      // (else nothing starts inside s)
-        const uint32_t old_word = it.k < uint32_t(kMaxCp) ? cps.get_plain(it.k) : 0u;   // requested early
+        const uint32_t old_word = it.k < uint32_t(kMaxCp) ? cps.get_w(it.k) : 0u;   // requested early
         const uint32_t wi1 = (pl + 31u) >> 5, wbase = (wi1 ? 4u * wi1 - 4u : 0u) & ~15u;
         const LaneBits bits{region, it.s * 16u, im.scan_cols * 16u};
 #pragma unroll
@@ -440,29 +442,44 @@ __device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, c
         st.n = it.n;
         lane_add_m(st, it.m);
         const uint32_t end_wn = wn_after(end_bit);
-        uint32_t stop_wn = wn_after((it.k + 1) * kCpBits);
-        stop_wn = stop_wn < end_wn ? stop_wn : end_wn;
         uint32_t blk = 0;
         NullSink sink;
-        while (st.wn < stop_wn) (void)symbol_step<false>(st, win, lut, h, blk, sink);
-        if (st.wn >= end_wn) {                                     // left the subsequence without merging
-            fin = true;
-            x = make_state(lane_pos(st) + sub_start, lane_z(st), lane_c(st, h), st.n, lane_m(st));
-        } else {
-            const uint32_t state = cp_state_word(st);
-            if ((old_word & kCpStateMask) == state) {              // met the previous decode's path
-                const SubseqState old_exit = g_exit[im.sub_off + it.s];
-                fin = true;
-                x = make_state(old_exit.p, old_exit.z, old_exit.c, st.n + ((old_word >> 16) & 0x7fffu),
-                               lane_m(st) + cps.get_m_plain(it.k));
-            } else {
-                cps.set(it.k, state | (st.n << 16), lane_m(st));
-                it.k++;
-                it.p = lane_pos(st) + sub_start;
-                it.zc = lane_z(st) | (lane_c(st, h) << 8);
-                it.n = st.n;
-                it.m = lane_m(st);
+        // a slice = kSliceCps checkpoint intervals (256 bits, ~50 symbols, whatever the checkpoint spacing)
+        uint32_t old_words[kSliceCps];
+        old_words[0] = old_word;
+#pragma unroll
+        for (uint32_t q = 1; q < kSliceCps; q++) old_words[q] = it.k + q < uint32_t(kMaxCp) ? cps.get_w(it.k + q) : 0u;
+        bool more = true;
+#pragma unroll
+        for (uint32_t q = 0; q < kSliceCps; q++) {
+            if (more) {
+                uint32_t stop_wn = wn_after((it.k + 1) * kCpBits);
+                stop_wn = stop_wn < end_wn ? stop_wn : end_wn;
+                while (st.wn < stop_wn) (void)symbol_step<false>(st, win, lut, h, blk, sink);
+                if (st.wn >= end_wn) {                                     // left the subsequence without merging
+                    fin = true;
+                    more = false;
+                    x = make_state(lane_pos(st) + sub_start, lane_z(st), lane_c(st, h), st.n, lane_m(st));
+                } else {
+                    const uint32_t state = cp_state_word(st);
+                    if ((old_words[q] & kCpStateMask) == state) {          // met the previous decode's path
+                        const SubseqState old_exit = g_exit[im.sub_off + it.s];
+                        fin = true;
+                        more = false;
+                        x = make_state(old_exit.p, old_exit.z, old_exit.c, st.n + ((old_words[q] >> 16) & 0x7fffu),
+                                       lane_m(st) + cps.get_m(it.k));
+                    } else {
+                        cps.set(it.k, state | (st.n << 16), lane_m(st));
+                        it.k++;
+                    }
+                }
             }
+        }
+        if (!fin) {
+            it.p = lane_pos(st) + sub_start;
+            it.zc = lane_z(st) | (lane_c(st, h) << 8);
+            it.n = st.n;
+            it.m = lane_m(st);
         }
     } else {
         fin = true;

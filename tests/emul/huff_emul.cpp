@@ -67,9 +67,8 @@ struct TickSink {
 struct HostCps {
     uint32_t *w;     // 2 words per checkpoint
     uint32_t get(uint32_t k) const { return w[2 * k]; }
-    uint32_t get_plain(uint32_t k) const { return w[2 * k]; }
     uint32_t get_m(uint32_t k) const { return w[2 * k + 1]; }
-    uint32_t get_m_plain(uint32_t k) const { return w[2 * k + 1]; }
+    CpPair get_pair(uint32_t k) const { return CpPair{w[2 * k], w[2 * k + 1]}; }
     void set(uint32_t k, uint32_t v, uint32_t m) const { w[2 * k] = v; w[2 * k + 1] = m; }
 };
 }   // namespace
