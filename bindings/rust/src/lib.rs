@@ -128,6 +128,7 @@ extern "C" {
     pub fn mjx_pool_destroy(pool: *mut mjx_pool);
     pub fn mjx_pool_devices(pool: *const mjx_pool) -> usize;
     pub fn mjx_pool_device(pool: *const mjx_pool, slot: usize) -> c_int;
+    pub fn mjx_pool_set_deal(pool: *mut mjx_pool, deal: c_int) -> c_int;
     pub fn mjx_pool_decode_batch(pool: *mut mjx_pool, jpegs: *const *const u8, lens: *const usize, n: usize, opts: *const mjx_opts,
                                  threads_per_device: c_uint, slot_of: *mut c_int, rgb_dev: *mut *mut u8, status: *mut c_int,
                                  out: *mut *mut mjx_pool_result) -> c_int;

@@ -207,15 +207,20 @@ int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const size_t *le
 
 /* ---- multi-GPU front: one context + one host thread + one work queue per device, no collective ----------
  * Pictures are independent (decoder.rs:162-343 touches only `self`), so a list of files shards over the GPUs of a node
- * without any exchange: file i goes to device slot i mod N, every slot decodes its share with the pipelined
- * mjx_decode_batch on its own device, outputs stay where they were produced.  `devices` may name a device more than once
- * (two slots on one GPU).  One mjx_pool_decode_batch call at a time per pool. */
+ * without any exchange: every slot decodes its share with the pipelined mjx_decode_batch on its own device, outputs stay
+ * where they were produced.  Files are dealt to the slots by compressed bytes (each file to the slot with the fewest bytes
+ * so far, the lowest slot on a tie: i mod N for a list of equal files, level queues for a skewed one) or round robin
+ * (mjx_pool_set_deal).  `devices` may name a device more than once (two slots on one GPU).  One mjx_pool_decode_batch
+ * call at a time per pool.  A slot whose device fails fails its own files (their status is the slot's error, the call
+ * returns it); the other slots' results stay valid. */
 typedef struct mjx_pool mjx_pool;
 typedef struct mjx_pool_result mjx_pool_result;
 int mjx_pool_create(const int *devices, size_t n_devices, mjx_pool **out);
 void mjx_pool_destroy(mjx_pool *pool);
 size_t mjx_pool_devices(const mjx_pool *pool);
 int mjx_pool_device(const mjx_pool *pool, size_t slot);          /* HIP device of a slot, -1 if out of range */
+enum { MJX_POOL_DEAL_BY_BYTES = 0, MJX_POOL_DEAL_ROUND_ROBIN = 1 };
+int mjx_pool_set_deal(mjx_pool *pool, int deal);
 /* slot_of[i] / rgb_dev[i] / status[i] (each optional, n entries): the slot that decoded file i, its device pointer (owned
  * by *out, NULL on failure) and status.  Release with mjx_pool_result_free. */
 int mjx_pool_decode_batch(mjx_pool *pool, const uint8_t *const *jpegs, const size_t *lens, size_t n, const mjx_opts *opts,

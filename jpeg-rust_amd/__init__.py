@@ -107,6 +107,7 @@ SYMBOLS = {
     "mjx_pool_destroy": (None, [_vp]),
     "mjx_pool_devices": (_sz, [_vp]),
     "mjx_pool_device": (_int, [_vp, _sz]),
+    "mjx_pool_set_deal": (_int, [_vp, _int]),
     "mjx_pool_decode_batch": (_int, [_vp, _P(ctypes.c_char_p), _P(_sz), _sz, _P(Opts), ctypes.c_uint, _P(_int), _P(_P(ctypes.c_uint8)), _P(_int), _P(_vp)]),
     "mjx_pool_result_locate": (_int, [_vp, _sz, _P(_sz), _P(_vp), _P(_sz)]),
     "mjx_pool_result_free": (None, [_vp]),
@@ -496,7 +497,8 @@ def decode_batch(ctx, datas, strict_ref=False, layout=LAYOUT_STANDARD, threads=0
 
 
 class Pool:
-    """mjx_pool: one context, host thread and work queue per device slot; file i of a call goes to slot i mod N."""
+    """mjx_pool: one context, host thread and work queue per device slot; the files of a call are dealt to the slots by
+    compressed bytes (i mod N for equal files) or round robin (set_deal)."""
 
     def __init__(self, devices):
         self.h = _vp()
@@ -509,8 +511,11 @@ class Pool:
     def device(self, slot):
         return int(lib().mjx_pool_device(self.h, slot))
 
-    def decode_batch(self, datas, strict_ref=False, layout=LAYOUT_STANDARD, threads_per_device=0):
-        """-> PoolResult; .slot_of[i], .status[i], .rgb(i)"""
+    def set_deal(self, round_robin):
+        _check(lib().mjx_pool_set_deal(self.h, 1 if round_robin else 0), "mjx_pool_set_deal")
+
+    def decode_batch(self, datas, strict_ref=False, layout=LAYOUT_STANDARD, threads_per_device=0, device_destuff=False):
+        """-> PoolResult; .slot_of[i], .status[i], .rgb(i), .rc (the call's return code: a failed slot fails its own files only)"""
         n = len(datas)
         arr = (ctypes.c_char_p * max(n, 1))(*[bytes(d) for d in datas])
         lens = (_sz * max(n, 1))(*[len(d) for d in datas])
@@ -518,10 +523,13 @@ class Pool:
         slots = (_int * max(n, 1))()
         ptrs = (_P(ctypes.c_uint8) * max(n, 1))()
         h = _vp()
-        o = _opts(strict_ref, layout)
-        _check(lib().mjx_pool_decode_batch(self.h, arr, lens, n, ctypes.byref(o), int(threads_per_device), slots, ptrs, st,
-                                           ctypes.byref(h)), "mjx_pool_decode_batch")
-        return PoolResult(h, list(slots)[:n], list(st)[:n], [ctypes.cast(p, _vp).value for p in ptrs][:n])
+        o = _opts(strict_ref, layout, device_destuff=device_destuff)
+        rc = lib().mjx_pool_decode_batch(self.h, arr, lens, n, ctypes.byref(o), int(threads_per_device), slots, ptrs, st, ctypes.byref(h))
+        if not h:
+            _check(rc, "mjx_pool_decode_batch")
+        res = PoolResult(h, list(slots)[:n], list(st)[:n], [ctypes.cast(p, _vp).value for p in ptrs][:n])
+        res.rc = int(rc)
+        return res
 
     def close(self):
         if self.h:
@@ -545,6 +553,29 @@ class PoolResult:
         slot, idx, b = _sz(), _sz(), _vp()
         _check(lib().mjx_pool_result_locate(self.h, i, ctypes.byref(slot), ctypes.byref(b), ctypes.byref(idx)))
         return slot.value, b, idx.value
+
+    def compare_rgb(self, mine, theirs):
+        """On-device comparison of picture mine[k] with picture theirs[k] of this result (they may lie in different slots'
+        batches on one device) -> (max |difference| per pair, differing bytes per pair), see Batch.compare_rgb."""
+        n = len(mine)
+        mx = np.zeros(max(n, 1), np.uint32)
+        cnt = np.zeros(max(n, 1), np.uint64)
+        groups = {}
+        for k in range(n):
+            _, ba, ia = self.locate(mine[k])
+            _, bb, ib = self.locate(theirs[k])
+            groups.setdefault((ba.value, bb.value), []).append((k, ia, ib))
+        for (ha, hb), items in groups.items():
+            m = len(items)
+            ia = (_sz * m)(*[x[1] for x in items])
+            ib = (_sz * m)(*[x[2] for x in items])
+            gm = np.zeros(m, np.uint32)
+            gc = np.zeros(m, np.uint64)
+            _check(lib().mjx_batch_compare_rgb(_vp(ha), ia, _vp(hb), ib, m, gm.ctypes.data_as(_P(ctypes.c_uint32)),
+                                               gc.ctypes.data_as(_P(ctypes.c_uint64))), "mjx_batch_compare_rgb")
+            for j, x in enumerate(items):
+                mx[x[0]], cnt[x[0]] = gm[j], gc[j]
+        return mx[:n], cnt[:n]
 
     def rgb(self, i):
         _, b, idx = self.locate(i)

@@ -63,6 +63,7 @@ struct mjx_ctx {
     uint32_t merge_loop_max = 64;   // chunks with at most this many merge workgroups (of the 768 the device holds) run their rounds in
                                     // one launch, k_huff_merge_loop (MJX_MERGE_LOOP=n, 0 = never)
     bool loop_fault = false;        // test knob (MJX_LOOP_FAULT=1): that launch waits for a workgroup that does not exist and must give up
+    bool dc_fault = false;          // test knob (MJX_DC_FAULT=1): a workgroup of k_dc_scan_t never publishes its sums; the ones behind it must give up
     uint64_t latency_nsub = 32768;  // batches of at most this many 512-byte subsequences (16 MB of scans: 64 of the 1024 workgroup slots of
                                     // k_huff_spec) are cut into shorter subsequences when they fit the loop kernel (MJX_LATENCY_NSUB, 0 = never),
     uint32_t latency_sub_bits = 512;                            // ... this many bits at least (MJX_LATENCY_SUB_BITS)
@@ -186,6 +187,7 @@ struct mjx_batch {
     uint32_t *d_loopctl = nullptr;      // 8 control words per chunk for k_huff_merge_loop (zero between launches)
     uint32_t *d_segflag[2] = {nullptr, nullptr};   // per scratch set: "running sums published" flags of k_dc_scan_t, one per (image, segment);
     uint32_t dc_gen[2] = {0, 0};                   // zero at creation, a flag is valid when it equals the set's launch count
+    bool dc_two_pass = false;           // k_dc_scan_t gave up once on this batch (a workgroup waited too long for its predecessor): two passes from now on
     hipEvent_t uploaded = nullptr;      // recorded on ctx->upload behind the last upload command; the decode streams wait for it
     bool upload_pending = false;
     // mjx_decode_batch decodes its files in groups (upload of one group overlaps the decode of the one before): the batch
@@ -213,7 +215,7 @@ struct mjx_batch {
     size_t rgb_pool_bytes = 0;
     int *d_status = nullptr;
     unsigned long long *d_planes = nullptr;   // REF_COMPAT: f32 planes with write-order keys (chunk scratch)
-    uint32_t *d_mismatch = nullptr;     // [chunks][kMaxFix]
+    uint32_t *d_mismatch = nullptr;     // [chunks][kMisWords]: re-decodes of every synchronisation round; [kMaxFix]: set when the one-pass DC prediction gave up
     uint32_t *h_mismatch = nullptr;     // pinned mirror
     size_t huff_lds = 0, idct_lds = 0;
     bool decoded_entropy = false;
@@ -239,6 +241,7 @@ struct mjx_batch {
 namespace {
 
 constexpr int kMaxFix = 16;
+constexpr int kMisWords = kMaxFix + 4;     // words per chunk in d_mismatch / h_mismatch: the rounds' counts, then [kMaxFix] "k_dc_scan_t gave up"
 constexpr uint32_t kLoopRounds = 48;      // rounds k_huff_merge_loop runs at most (noise at quality 99-100 needs 12-15 with 512-byte subsequences)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -501,7 +504,7 @@ int allocate_work_buffers(mjx_batch *b, DevArena &ar)
     ar.take(&b->d_dc, size_t(coef_blocks) * sizeof(int32_t) + 64);
     ar.take(&b->d_rgb, std::max<size_t>(b->rgb_pool_bytes, 16));
     // (d_img_entries, d_img_flags, d_status: laid out by build_batch inside the block of small pools, whose upload clears them)
-    const size_t mm = std::max<size_t>(b->chunks.size(), 1) * kMaxFix * sizeof(uint32_t);
+    const size_t mm = std::max<size_t>(b->chunks.size(), 1) * kMisWords * sizeof(uint32_t);
     ar.take(&b->d_mismatch, mm);
     if (!ar.measuring && !b->h_mismatch) {
         b->h_mismatch = pinned_get(b->ctx, mm, &b->h_mismatch_bytes);
@@ -619,27 +622,23 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         prof_end(b, st);
     }
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_FIX)) {
-        HIPOK(hipMemsetAsync(b->d_mismatch + ci * kMaxFix, 0, kMaxFix * sizeof(uint32_t), st));
+        HIPOK(hipMemsetAsync(b->d_mismatch + ci * kMisWords, 0, kMisWords * sizeof(uint32_t), st));
         if (c.merge_wgs > 0 && c.loop_participants > 0 && fix_passes > 0) {
             // (the count of the last round run lands where the last enqueued round's would: mjx_batch_wait and k_huff_scan look there)
             prof_begin(b, MJX_K_HUFF_FIX, st);
             launch_huff_merge_loop(st, c.merge_wgs, nimg, b->huff_lds, b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps),
-                                   b->d_mismatch + ci * kMaxFix + fix_passes - 1, b->d_segs, b->d_loopctl + ci * 8,
+                                   b->d_mismatch + ci * kMisWords + fix_passes - 1, b->d_segs, b->d_loopctl + ci * 8,
                                    c.loop_participants + (b->ctx->loop_fault ? 1u : 0u), kLoopRounds, b->ctx->loop_fault ? 1u << 12 : 1u << 22);
             prof_end(b, st);
-            HIPOK(hipMemcpyAsync(b->h_mismatch + ci * kMaxFix, b->d_mismatch + ci * kMaxFix, kMaxFix * sizeof(uint32_t),
-                                 hipMemcpyDeviceToHost, st));
         } else if (c.merge_wgs > 0) {
             HIPOK(hipMemsetAsync(SCR(d_pull), 0, size_t(nimg) * std::max(fix_passes, 1) * sizeof(uint32_t), st));      // the straggler counts of every round
             for (int k = 0; k < fix_passes; k++) {
                 prof_begin(b, MJX_K_HUFF_FIX, st);
                 launch_huff_merge(st, c.merge_wgs, nimg, b->huff_lds, b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps),
-                                  b->d_mismatch + ci * kMaxFix + k, SCR(d_items), SCR(d_pull) + size_t(k) * nimg, b->d_segs,
-                                  k > 0 ? b->d_mismatch + ci * kMaxFix + k - 1 : nullptr);
+                                  b->d_mismatch + ci * kMisWords + k, SCR(d_items), SCR(d_pull) + size_t(k) * nimg, b->d_segs,
+                                  k > 0 ? b->d_mismatch + ci * kMisWords + k - 1 : nullptr);
                 prof_end(b, st);
             }
-            HIPOK(hipMemcpyAsync(b->h_mismatch + ci * kMaxFix, b->d_mismatch + ci * kMaxFix, kMaxFix * sizeof(uint32_t),
-                                 hipMemcpyDeviceToHost, st));
         }
     }
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_TAIL)) {
@@ -649,7 +648,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         const uint32_t *verdict = nullptr;
         if (c.merge_wgs > 0) {
             const int last = (phases & PH_FIX) ? fix_passes - 1 : kMaxFix - 1;
-            if (last >= 0) verdict = b->d_mismatch + ci * kMaxFix + last;
+            if (last >= 0) verdict = b->d_mismatch + ci * kMisWords + last;
         }
         launch_huff_scan(st, nimg, imgs, SCR(d_exit), SCR(d_blkbase), SCR(d_ebase), b->d_img_entries, b->d_img_flags, b->d_segs, verdict);
         prof_end(b, st);
@@ -659,7 +658,8 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         prof_end(b, st);
         prof_begin(b, MJX_K_DC_SCAN, st);
         launch_dc_scan(st, c.max_segs, nimg, imgs, dcb, SCR(d_segsum), b->d_img_flags, c.bpm_mask, c.max_restart_segs,
-                       b->ctx->dc_one_pass ? b->d_segflag[set] : nullptr, ++b->dc_gen[set]);
+                       (b->ctx->dc_one_pass && !b->dc_two_pass) ? b->d_segflag[set] : nullptr, ++b->dc_gen[set],
+                       b->d_mismatch + ci * kMisWords + kMaxFix, b->ctx->dc_fault ? 1u << 10 : 1u << 20, b->ctx->dc_fault);
         prof_end(b, st);
         if (c.has_gather) {
             prof_begin(b, MJX_K_GATHER, st);
@@ -667,6 +667,9 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
             prof_end(b, st);
         }
     }
+    // what the host looks at in mjx_batch_wait: the rounds' counts and the "DC prediction gave up" word
+    if ((stages & MJX_STAGE_ENTROPY) && (phases & (PH_FIX | PH_TAIL)))
+        HIPOK(hipMemcpyAsync(b->h_mismatch + ci * kMisWords, b->d_mismatch + ci * kMisWords, kMisWords * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     if (sp != st && (stages & MJX_STAGE_ENTROPY)) {
         HIPOK(hipEventRecord(b->ev_entropy[set], st));
         b->entropy_recorded[set] = true;
@@ -880,10 +883,10 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
     b->rgb_pool_bytes = rgb_pool;
     b->lut_pool_entries = lut_pool;
     plan_chunks(b);
-    if (pinned_words && std::max<size_t>(b->chunks.size(), 1) * kMaxFix <= pinned_cap) {    // lent by the caller (mjx_decode_batch)
+    if (pinned_words && std::max<size_t>(b->chunks.size(), 1) * kMisWords <= pinned_cap) {    // lent by the caller (mjx_decode_batch)
         b->h_mismatch = pinned_words;
         b->h_mismatch_owned = false;
-        std::memset(b->h_mismatch, 0, std::max<size_t>(b->chunks.size(), 1) * kMaxFix * sizeof(uint32_t));
+        std::memset(b->h_mismatch, 0, std::max<size_t>(b->chunks.size(), 1) * kMisWords * sizeof(uint32_t));
     }
 
     int rc = MJX_OK;
@@ -1150,6 +1153,7 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     if (const char *e = std::getenv("MJX_LATENCY_SUB_BITS")) c->latency_sub_bits = uint32_t(std::max(512L, std::min(long(kSubseqBits), std::atol(e))));
     if (const char *e = std::getenv("MJX_DC_ONE_PASS")) c->dc_one_pass = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_LOOP_FAULT")) c->loop_fault = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MJX_DC_FAULT")) c->dc_fault = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_MERGE_LOOP")) c->merge_loop_max = uint32_t(std::min(192L, std::max(0L, std::atol(e))));
     if (c->nstreams == 2) {
         // With two streams stage B's gets the higher priority (MJX_PIXEL_PRIORITY=0: equal): its workgroups are placed first when
@@ -1399,10 +1403,26 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
         bool first_set_rewritten = false;
         for (size_t ci = 0; ci < b->chunks.size(); ci++) {
             const Chunk &c = b->chunks[ci];
+            // The one-pass DC prediction hands running sums from workgroup to workgroup; a workgroup that waited too long for
+            // its predecessor (one that was never dispatched in front of it: nothing promises the dispatch order) gave up and
+            // said so here.  The chunk's DC values are then part differences, part predictions: it is decoded again -- on the
+            // first scratch set, with the two-pass kernels, which wait for nobody -- and so is everything this batch decodes later.
+            if (b->h_mismatch[ci * kMisWords + kMaxFix] != 0) {
+                if (std::getenv("MJX_TIMING")) std::fprintf(stderr, "[mjx] chunk %zu: one-pass DC prediction gave up, decoding the chunk again with two passes\n", ci);
+                b->dc_two_pass = true;
+                first_set_rewritten = true;
+                HIPOK(hipMemsetAsync(b->d_status + c.first, 0, c.count * sizeof(int), b->ctx->stream));
+                const int rcd = run_chunk(b, ci, MJX_STAGE_ALL, std::min(b->ctx->fix_passes, kMaxFix), PH_ENTROPY_ALL, true);
+                if (rcd != MJX_OK) return rcd;
+                HIPOK(hipStreamSynchronize(b->ctx->stream));
+                collect_events(b);
+                b->last_chunk_resident = int(ci);
+                b->resident_second = false;
+            }
             if (c.merge_wgs == 0) continue;
             const int passes = std::min(b->ctx->fix_passes, kMaxFix);
-            if (b->h_mismatch[ci * kMaxFix + passes - 1] == 0) continue;
-            if (std::getenv("MJX_TIMING")) std::fprintf(stderr, "[mjx] chunk %zu unconverged after %d rounds (%u re-decodes in the last): repairing\n", ci, passes, b->h_mismatch[ci * kMaxFix + passes - 1]);
+            if (b->h_mismatch[ci * kMisWords + passes - 1] == 0) continue;
+            if (std::getenv("MJX_TIMING")) std::fprintf(stderr, "[mjx] chunk %zu unconverged after %d rounds (%u re-decodes in the last): repairing\n", ci, passes, b->h_mismatch[ci * kMisWords + passes - 1]);
             // k_huff_merge_loop could not get its workgroups resident together and gave up (count = all ones): its control words
             // are in an unknown state; the chunk goes on with one launch per round, now and in later decodes
             auto loop_gave_up = [&](uint32_t count) -> int {
@@ -1411,7 +1431,7 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
                 HIPOK(hipMemsetAsync(b->d_loopctl + ci * 8, 0, 8 * sizeof(uint32_t), b->ctx->stream));
                 return MJX_OK;
             };
-            { const int rcg = loop_gave_up(b->h_mismatch[ci * kMaxFix + passes - 1]); if (rcg != MJX_OK) return rcg; }
+            { const int rcg = loop_gave_up(b->h_mismatch[ci * kMisWords + passes - 1]); if (rcg != MJX_OK) return rcg; }
             // repair: keep running fix passes -- each one extends the verified prefix -- until one finds nothing.  If a later
             // chunk has reused this chunk's state arrays (or the chunk ran on the second set, which the repair does not
             // use), its synchronisation starts again from the speculative decode; otherwise -- a batch of one chunk, the
@@ -1430,9 +1450,9 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
                 rc = run_chunk(b, ci, MJX_STAGE_ENTROPY, more, PH_FIX, true);
                 if (rc != MJX_OK) return rc;
                 HIPOK(hipStreamSynchronize(b->ctx->stream));
-                if (std::getenv("MJX_TIMING")) std::fprintf(stderr, "[mjx]   repair rounds: %u re-decodes left\n", b->h_mismatch[ci * kMaxFix + more - 1]);
-                if (b->h_mismatch[ci * kMaxFix + more - 1] == 0) break;
-                { const int rcg = loop_gave_up(b->h_mismatch[ci * kMaxFix + more - 1]); if (rcg != MJX_OK) return rcg; }
+                if (std::getenv("MJX_TIMING")) std::fprintf(stderr, "[mjx]   repair rounds: %u re-decodes left\n", b->h_mismatch[ci * kMisWords + more - 1]);
+                if (b->h_mismatch[ci * kMisWords + more - 1] == 0) break;
+                { const int rcg = loop_gave_up(b->h_mismatch[ci * kMisWords + more - 1]); if (rcg != MJX_OK) return rcg; }
             }
             rc = run_chunk(b, ci, MJX_STAGE_ALL, 0, PH_TAIL, true);
             if (rc != MJX_OK) return rc;
@@ -1902,7 +1922,7 @@ extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const
     dir->ctx = ctx;
     dir->opts = o;
     dir->part_index.resize(n);
-    dir->h_mismatch = pinned_get(ctx, ngroups * 8 * kMaxFix * sizeof(uint32_t), &dir->h_mismatch_bytes);
+    dir->h_mismatch = pinned_get(ctx, ngroups * 8 * kMisWords * sizeof(uint32_t), &dir->h_mismatch_bytes);
     if (!dir->h_mismatch) return MJX_ERR_NOMEM;
     int rc = MJX_OK;
     for (size_t g = 0; g < ngroups && rc == MJX_OK; g++) {
@@ -1920,7 +1940,7 @@ extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const
             for (ImagePlan &pl : file_plans[f0 + i]) plans.push_back(std::move(pl));
         }
         if (rc != MJX_OK) break;
-        constexpr size_t kPinnedPerPart = 8 * kMaxFix;
+        constexpr size_t kPinnedPerPart = 8 * kMisWords;
         rc = build_batch(ctx, plans, o, nullptr, 1, &part, nullptr, nullptr, true, dir->h_mismatch + g * kPinnedPerPart, kPinnedPerPart, &pin, ngroups == 1);
         if (rc != MJX_OK) break;
         dir->parts.push_back(part);

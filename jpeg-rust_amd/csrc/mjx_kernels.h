@@ -122,7 +122,9 @@ void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
                        int32_t *dcbuf, int *status, const uint32_t *img_flags, const uint32_t *segs, const SubseqState *exit_);
 void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int32_t *dcbuf,
                     int32_t *segsum, const uint32_t *img_flags, uint32_t bpm_mask, uint32_t max_restart_segs,
-                    uint32_t *segflag = nullptr, uint32_t gen = 0);
+                    uint32_t *segflag = nullptr, uint32_t gen = 0,
+                    uint32_t *fail = nullptr /* device word, set when the one-pass kernel gave up waiting */, uint32_t spin_limit = 1u << 20,
+                    bool fault = false /* test knob: a workgroup never publishes */);
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint32_t *entries, const uint32_t *tile_eoff, const int32_t *dcbuf, const float *qmult,
                        uint8_t *rgb, uint32_t mode_mask, unsigned long long *planes, const uint32_t *img_flags);

@@ -1385,12 +1385,21 @@ __global__ __launch_bounds__(256) void k_dc_apply_t(const DevImage *images, int3
 // sixteen workgroups of a picture start together and wait for one another in a chain (5.2 instead of 1.0 ms per step).
 //   segflag[(image, segment)][component] = gen << 32 | running sum: valid once its upper half equals `gen` (the words are zero
 //   when the batch is created and `gen` grows with every launch on this set of buffers).
+// Nothing promises the dispatch order, so the wait is bounded: after `spin_limit` polls a workgroup gives up -- it sets *fail,
+// publishes a poisoned word (upper half gen | kDcPoison) so that the segments behind it give up at once instead of waiting
+// their own limit, and leaves without writing.  The host sees *fail in mjx_batch_wait and decodes the chunk again with the
+// two-pass kernels (k_dc_sums_t / k_dc_apply_t), which wait for nobody.  `fault` (test knob): segment 0 of the chunk's first
+// image never publishes.
+constexpr uint32_t kDcPoison = 0x80000000u;
 template <int BPM>
 __global__ __launch_bounds__(256) void k_dc_scan_t(const DevImage *images, int32_t *dcbuf, uint32_t *segsum,
-                                                   uint32_t max_segs, const uint32_t *img_flags, uint32_t gen)
+                                                   uint32_t max_segs, const uint32_t *img_flags, uint32_t gen, uint32_t *fail,
+                                                   uint32_t spin_limit, uint32_t fault)
 {
     __shared__ int32_t s_wsum[4][3];
     __shared__ int32_t s_carry[3];
+    __shared__ uint32_t s_gave_up;
+    if (threadIdx.x == 0) s_gave_up = 0;
     const uint32_t img = blockIdx.x, seg = blockIdx.y;         // (the image is the fast dimension, see above)
     const DevImage &im = images[img];
     const uint32_t seg0 = seg * kDcSegMcus;
@@ -1432,16 +1441,28 @@ __global__ __launch_bounds__(256) void k_dc_scan_t(const DevImage *images, int32
         unsigned long long *words = reinterpret_cast<unsigned long long *>(segsum);
         const size_t at = (size_t(img) * max_segs + seg) * 3 + c;
         int32_t carry = 0;
+        bool gave_up = false;
         if (seg > 0) {
             unsigned long long w;
-            while (uint32_t((w = atomicAdd(words + at - 3, 0ull)) >> 32) != gen) __builtin_amdgcn_s_sleep(1);
+            uint32_t polls = 0;
+            while (uint32_t((w = atomicAdd(words + at - 3, 0ull)) >> 32) != gen) {
+                if (uint32_t(w >> 32) == (gen | kDcPoison) || ++polls >= spin_limit) { gave_up = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
             carry = int32_t(uint32_t(w));
         }
         s_carry[c] = carry;
         const int32_t out = carry + s_wsum[0][c] + s_wsum[1][c] + s_wsum[2][c] + s_wsum[3][c];
-        (void)atomicExch(words + at, (static_cast<unsigned long long>(gen) << 32) | uint32_t(out));
+        if (gave_up) {
+            s_gave_up = 1;
+            atomicOr(fail, 1u);
+            (void)atomicExch(words + at, static_cast<unsigned long long>(gen | kDcPoison) << 32);
+        } else if (!(fault && img == 0 && seg == 0)) {
+            (void)atomicExch(words + at, (static_cast<unsigned long long>(gen) << 32) | uint32_t(out));
+        }
     }
     __syncthreads();
+    if (s_gave_up) return;                                      // (the segment keeps its differences; the chunk is decoded again)
     int32_t base[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -2116,15 +2137,15 @@ void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
 
 void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int32_t *dcbuf,
                     int32_t *segsum, const uint32_t *img_flags, uint32_t bpm_mask, uint32_t max_restart_segs,
-                    uint32_t *segflag, uint32_t gen)
+                    uint32_t *segflag, uint32_t gen, uint32_t *fail, uint32_t spin_limit, bool fault)
 {
     const dim3 grid(max_segs, nimg), wg(256);
     if (segflag) {          // the common MCU shapes in one pass (k_dc_scan_t); segflag == nullptr: two passes as before
         const dim3 grid(nimg, max_segs);
-        if (bpm_mask & (1u << 1)) hipLaunchKernelGGL(k_dc_scan_t<1>, grid, wg, 0, st, images, dcbuf, segflag, max_segs, img_flags, gen);
-        if (bpm_mask & (1u << 3)) hipLaunchKernelGGL(k_dc_scan_t<3>, grid, wg, 0, st, images, dcbuf, segflag, max_segs, img_flags, gen);
-        if (bpm_mask & (1u << 4)) hipLaunchKernelGGL(k_dc_scan_t<4>, grid, wg, 0, st, images, dcbuf, segflag, max_segs, img_flags, gen);
-        if (bpm_mask & (1u << 6)) hipLaunchKernelGGL(k_dc_scan_t<6>, grid, wg, 0, st, images, dcbuf, segflag, max_segs, img_flags, gen);
+        if (bpm_mask & (1u << 1)) hipLaunchKernelGGL(k_dc_scan_t<1>, grid, wg, 0, st, images, dcbuf, segflag, max_segs, img_flags, gen, fail, spin_limit, fault ? 1u : 0u);
+        if (bpm_mask & (1u << 3)) hipLaunchKernelGGL(k_dc_scan_t<3>, grid, wg, 0, st, images, dcbuf, segflag, max_segs, img_flags, gen, fail, spin_limit, fault ? 1u : 0u);
+        if (bpm_mask & (1u << 4)) hipLaunchKernelGGL(k_dc_scan_t<4>, grid, wg, 0, st, images, dcbuf, segflag, max_segs, img_flags, gen, fail, spin_limit, fault ? 1u : 0u);
+        if (bpm_mask & (1u << 6)) hipLaunchKernelGGL(k_dc_scan_t<6>, grid, wg, 0, st, images, dcbuf, segflag, max_segs, img_flags, gen, fail, spin_limit, fault ? 1u : 0u);
         bpm_mask &= ~kDcFastShapes;
     }
 #define MJX_DC_PASS(KERNEL)                                                                                              \

@@ -9,6 +9,7 @@
 #include "mjx.h"
 
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -41,7 +42,7 @@ void worker_loop(Worker *w)
         }
         try {
             job();
-        } catch (...) {
+        } catch (...) {          // (a job reports through its own state; one that throws has set nothing: see mjx_pool_decode_batch)
         }
         {
             std::lock_guard<std::mutex> lk(w->mu);
@@ -56,6 +57,8 @@ void worker_loop(Worker *w)
 struct mjx_pool {
     std::vector<Worker *> workers;
     std::mutex call_mu;
+    int deal = MJX_POOL_DEAL_BY_BYTES;
+    int fault_slot = -1;             // test knob (MJX_POOL_FAULT_SLOT=k): slot k's device "fails" -- its job returns MJX_ERR_DEVICE
 };
 
 struct mjx_pool_result {
@@ -80,6 +83,8 @@ extern "C" int mjx_pool_create(const int *devices, size_t n_devices, mjx_pool **
             p->workers.push_back(w);
         }
         if (rc != MJX_OK) { mjx_pool_destroy(p); return rc; }
+        if (const char *e = std::getenv("MJX_POOL_FAULT_SLOT")) p->fault_slot = std::atoi(e);
+        if (const char *e = std::getenv("MJX_POOL_DEAL")) p->deal = std::strcmp(e, "rr") == 0 ? MJX_POOL_DEAL_ROUND_ROBIN : MJX_POOL_DEAL_BY_BYTES;
         *out = p;
         return MJX_OK;
     } catch (...) {
@@ -110,66 +115,119 @@ extern "C" int mjx_pool_device(const mjx_pool *pool, size_t slot)
     return (pool && slot < pool->workers.size()) ? pool->workers[slot]->device : -1;
 }
 
+extern "C" int mjx_pool_set_deal(mjx_pool *pool, int deal)
+{
+    if (!pool || (deal != MJX_POOL_DEAL_BY_BYTES && deal != MJX_POOL_DEAL_ROUND_ROBIN)) return MJX_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> serial(pool->call_mu);
+    pool->deal = deal;
+    return MJX_OK;
+}
+
+namespace {
+// Everything the workers of one call touch lives here, on the heap, and the call does not leave before every worker it has
+// posted a job to is done with it.
+struct PoolCall {
+    std::vector<std::vector<const uint8_t *>> ptrs;
+    std::vector<std::vector<size_t>> sizes;
+    std::vector<std::vector<int>> st;
+    std::vector<std::vector<uint8_t *>> rgb;
+    mjx_pool_result res;
+};
+}   // namespace
+
 extern "C" int mjx_pool_decode_batch(mjx_pool *pool, const uint8_t *const *jpegs, const size_t *lens, size_t n, const mjx_opts *opts,
                                      unsigned threads_per_device, int *slot_of, uint8_t **rgb_dev, int *status,
                                      mjx_pool_result **out)
 {
     if (!pool || !out || ((!jpegs || !lens) && n)) return MJX_ERR_INVALID_ARG;
     *out = nullptr;
+    std::lock_guard<std::mutex> serial(pool->call_mu);
+    const size_t N = pool->workers.size();
+    PoolCall *call = nullptr;
+    size_t posted = 0;
+    int rc = MJX_OK;
     try {
-        std::lock_guard<std::mutex> serial(pool->call_mu);
-        const size_t N = pool->workers.size();
-        mjx_pool_result *r = new mjx_pool_result;
-        r->batches.assign(N, nullptr);
-        r->slot_rc.assign(N, MJX_OK);
-        r->slot_of.resize(n);
-        r->index_in_slot.resize(n);
-        // file i -> slot i mod N (north_star); the slot's list keeps the files in order
-        std::vector<std::vector<const uint8_t *>> ptrs(N);
-        std::vector<std::vector<size_t>> sizes(N), files(N);
+        call = new PoolCall;
+        mjx_pool_result &r = call->res;
+        r.batches.assign(N, nullptr);
+        r.slot_rc.assign(N, MJX_OK);
+        r.slot_of.resize(n);
+        r.index_in_slot.resize(n);
+        call->ptrs.resize(N);
+        call->sizes.resize(N);
+        // Dealing.  Pictures are independent, so any assignment is correct; what matters is that the slots
+        // finish together.  By compressed bytes (default): file i goes to the slot that has been dealt the fewest bytes so
+        // far, the lowest slot on a tie -- for a list of equal files that is i mod N, for a skewed one (large files at
+        // every N-th place, a run of small ones) the queues stay level where round robin would not.  Round robin: i mod N.
+        std::vector<uint64_t> load(N, 0);
         for (size_t i = 0; i < n; i++) {
-            const size_t s = i % N;
-            r->slot_of[i] = uint32_t(s);
-            r->index_in_slot[i] = uint32_t(ptrs[s].size());
-            ptrs[s].push_back(jpegs[i]);
-            sizes[s].push_back(lens[i]);
-            files[s].push_back(i);
+            size_t s = i % N;
+            if (pool->deal == MJX_POOL_DEAL_BY_BYTES) {
+                s = 0;
+                for (size_t k = 1; k < N; k++) if (load[k] < load[s]) s = k;
+            }
+            load[s] += uint64_t(lens[i]) + 4096;             // (+ a constant per file: lists of tiny files are dealt by count)
+            r.slot_of[i] = uint32_t(s);
+            r.index_in_slot[i] = uint32_t(call->ptrs[s].size());
+            call->ptrs[s].push_back(jpegs[i]);
+            call->sizes[s].push_back(lens[i]);
         }
-        std::vector<std::vector<int>> st(N);
-        std::vector<std::vector<uint8_t *>> rgb(N);
+        call->st.resize(N);
+        call->rgb.resize(N);
+        for (size_t s = 0; s < N; s++) {
+            call->st[s].assign(call->ptrs[s].size(), MJX_OK);
+            call->rgb[s].assign(call->ptrs[s].size(), nullptr);
+        }
+        // every allocation is behind us: hand out the jobs (one per slot that has files; a std::function of this size
+        // allocates nothing)
+        const int fault_slot = pool->fault_slot;
         for (size_t s = 0; s < N; s++) {
             Worker *w = pool->workers[s];
-            st[s].assign(ptrs[s].size(), MJX_OK);
-            rgb[s].assign(ptrs[s].size(), nullptr);
+            if (call->ptrs[s].empty()) continue;
+            r.slot_rc[s] = MJX_ERR_DEVICE;                   // (stays, should the job die before it has a return code)
             std::lock_guard<std::mutex> lk(w->mu);
             w->done = false;
-            w->job = [&, s, w] {
-                if (ptrs[s].empty()) return;
-                r->slot_rc[s] = mjx_decode_batch(w->ctx, ptrs[s].data(), sizes[s].data(), ptrs[s].size(), opts, threads_per_device,
-                                                 rgb[s].data(), st[s].data(), &r->batches[s]);
+            w->job = [call, s, w, opts, threads_per_device, fault_slot] {
+                if (int(s) == fault_slot) return;            // this slot's device has "failed": MJX_ERR_DEVICE stands
+                call->res.slot_rc[s] = mjx_decode_batch(w->ctx, call->ptrs[s].data(), call->sizes[s].data(), call->ptrs[s].size(), opts,
+                                                        threads_per_device, call->rgb[s].data(), call->st[s].data(), &call->res.batches[s]);
             };
             w->has_job = true;
             w->cv.notify_all();
+            posted |= size_t(1) << s;
         }
-        for (size_t s = 0; s < N; s++) {                           // the host aggregates: wait for every queue
-            Worker *w = pool->workers[s];
-            std::unique_lock<std::mutex> lk(w->mu);
-            w->cv.wait(lk, [&] { return w->done; });
-        }
-        int rc = MJX_OK;
-        for (size_t i = 0; i < n; i++) {
-            const size_t s = r->slot_of[i], k = r->index_in_slot[i];
-            const int slot_rc = r->slot_rc[s];
-            if (slot_rc != MJX_OK) rc = slot_rc;
-            if (slot_of) slot_of[i] = int(s);
-            if (status) status[i] = slot_rc != MJX_OK ? slot_rc : st[s][k];
-            if (rgb_dev) rgb_dev[i] = slot_rc != MJX_OK ? nullptr : rgb[s][k];
-        }
-        *out = r;
-        return rc;
     } catch (...) {
+        rc = MJX_ERR_NOMEM;
+    }
+    for (size_t s = 0; s < N; s++) {                               // the host aggregates: wait for every queue that got a job
+        if (!((posted >> s) & 1)) continue;
+        Worker *w = pool->workers[s];
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv.wait(lk, [&] { return w->done; });
+    }
+    if (rc != MJX_OK || !call) {
+        if (call) for (mjx_batch *b : call->res.batches) mjx_batch_free(b);
+        delete call;
+        return rc != MJX_OK ? rc : MJX_ERR_NOMEM;
+    }
+    // A slot that failed fails its own files only: the others keep their results, the call returns the failure.
+    mjx_pool_result *r = new (std::nothrow) mjx_pool_result(std::move(call->res));
+    if (!r) {
+        for (mjx_batch *b : call->res.batches) mjx_batch_free(b);
+        delete call;
         return MJX_ERR_NOMEM;
     }
+    for (size_t i = 0; i < n; i++) {
+        const size_t s = r->slot_of[i], k = r->index_in_slot[i];
+        const int slot_rc = r->slot_rc[s];
+        if (slot_rc != MJX_OK) rc = slot_rc;
+        if (slot_of) slot_of[i] = int(s);
+        if (status) status[i] = slot_rc != MJX_OK ? slot_rc : call->st[s][k];
+        if (rgb_dev) rgb_dev[i] = slot_rc != MJX_OK ? nullptr : call->rgb[s][k];
+    }
+    delete call;
+    *out = r;
+    return rc;
 }
 
 extern "C" int mjx_pool_result_locate(const mjx_pool_result *r, size_t i, size_t *slot, mjx_batch **batch, size_t *index)

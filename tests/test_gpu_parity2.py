@@ -206,6 +206,7 @@ def test_pool_shards_files_over_device_slots(mjx, orc, data_dir=None):
               open(os.path.join(root, "golden", "pil", "dri_420_r5.jpg"), "rb").read()]
     datas = datas * 3
     pool = mjx.Pool([0, 0])
+    pool.set_deal(round_robin=True)
     assert len(pool) == 2 and pool.device(0) == 0 and pool.device(1) == 0 and pool.device(2) == -1
     for _ in range(2):                                                   # the queues are persistent: a second call reuses them
         res = pool.decode_batch(datas, threads_per_device=4)
@@ -224,6 +225,90 @@ def test_pool_shards_files_over_device_slots(mjx, orc, data_dir=None):
     assert empty.status == []
     empty.close()
     pool.close()
+
+
+def test_pool_with_eight_slots_decodes_a_scaled_down_config_5(mjx, orc):
+    """BASELINE config 5 in miniature on the one GPU of the test box: 16 384 pictures, 64 unique, eight device slots (all on
+    device 0).  Round robin must give file i to slot i mod 8; dealing by bytes must keep the eight queues level; every
+    picture equals its unique original bit for bit (compared on the device, across the slots' batches), and four pictures of
+    every slot match the oracle."""
+    uniq = [mjx.synth_jpeg(128, 96, "420", 75, seed=s) for s in range(64)]
+    refs = [orc.decode(d, layout=orc.LAYOUT_STD) for d in uniq]
+    datas = [uniq[i % 64] for i in range(16384)]
+    pool = mjx.Pool([0] * 8)
+    assert len(pool) == 8
+    for rr in (True, False):
+        pool.set_deal(round_robin=rr)
+        res = pool.decode_batch(datas, threads_per_device=2)
+        assert res.rc == mjx.OK and all(s == mjx.OK for s in res.status)
+        if rr:
+            assert res.slot_of == [i % 8 for i in range(len(datas))]
+        load = [0] * 8
+        for i, s in enumerate(res.slot_of):
+            load[s] += len(datas[i])
+        assert max(load) <= (1.10 if rr else 1.01) * min(load), load      # (round robin: a slot sees the same 8 of the 64 sizes over and over)
+        idx = list(range(64, len(datas)))
+        mx, cnt = res.compare_rgb(idx, [i % 64 for i in idx])
+        assert int(mx.max()) == 0 and int(cnt.sum()) == 0
+        seen = {}
+        for i in range(len(datas)):
+            s = res.slot_of[i]
+            if seen.get(s, 0) < 4:
+                seen[s] = seen.get(s, 0) + 1
+                assert res.locate(i)[0] == s
+                assert np.abs(res.rgb(i).astype(int) - refs[i % 64].rgb.astype(int)).max() <= TOL, i
+        assert len(seen) == 8
+        res.close()
+    pool.close()
+
+
+def test_pool_slot_that_fails_keeps_the_other_slots_results(mjx, orc):
+    """A device that errors must not poison the others: MJX_POOL_FAULT_SLOT=3 makes slot 3 of an eight-slot pool fail its call.
+    Its files report the device error and have no picture, the call returns the error, and every file of the seven other
+    slots is decoded and matches the oracle."""
+    datas = [mjx.synth_jpeg(160 + 16 * (i % 5), 96, ("420", "444", "422")[i % 3], 80, seed=i) for i in range(64)]
+    os.environ["MJX_POOL_FAULT_SLOT"] = "3"
+    try:
+        pool = mjx.Pool([0] * 8)
+    finally:
+        del os.environ["MJX_POOL_FAULT_SLOT"]
+    pool.set_deal(round_robin=True)
+    res = pool.decode_batch(datas, threads_per_device=2)
+    assert res.rc == mjx.ERR_DEVICE
+    for i, d in enumerate(datas):
+        if i % 8 == 3:
+            assert res.status[i] == mjx.ERR_DEVICE and not res.ptrs[i], i
+        else:
+            assert res.status[i] == mjx.OK and res.ptrs[i], (i, res.status[i])
+            ref = orc.decode(d, layout=orc.LAYOUT_STD)
+            assert np.abs(res.rgb(i).astype(int) - ref.rgb.astype(int)).max() <= TOL, i
+    res.close()
+    pool.close()
+
+
+def test_pool_deals_a_skewed_list_by_bytes(mjx, orc):
+    """A list whose every eighth file is a hundred times the size of the others: round robin gives all of them to slot 0;
+    dealt by compressed bytes the eight queues stay level.  The pictures are right either way."""
+    big = [mjx.synth_jpeg(1920, 1080, "420", 85, seed=100 + k) for k in range(4)]
+    small = [mjx.synth_jpeg(96, 64, "420", 60, seed=k) for k in range(16)]
+    datas = [big[(i // 8) % 4] if i % 8 == 0 else small[i % 16] for i in range(256)]
+    pool = mjx.Pool([0] * 8)
+    loads = {}
+    for rr in (True, False):
+        pool.set_deal(round_robin=rr)
+        res = pool.decode_batch(datas, threads_per_device=2)
+        assert res.rc == mjx.OK and all(s == mjx.OK for s in res.status)
+        load = [0] * 8
+        for i, s in enumerate(res.slot_of):
+            load[s] += len(datas[i])
+        loads[rr] = load
+        for i in (0, 1, 8, 9, 255):
+            ref = orc.decode(datas[i], layout=orc.LAYOUT_STD)
+            assert np.abs(res.rgb(i).astype(int) - ref.rgb.astype(int)).max() <= TOL, i
+        res.close()
+    pool.close()
+    assert max(loads[True]) > 20 * min(loads[True])                   # round robin: slot 0 carries every large file
+    assert max(loads[False]) <= 1.25 * min(loads[False]), loads[False]
 
 
 def test_pipelined_decode_batch_equals_the_batch_api(mjx, gpu_ctx):
@@ -349,3 +434,40 @@ def test_merge_loop_that_cannot_assemble_gives_up_and_the_rounds_go_on(mjx, orc,
     for extra in ({"MJX_LOOP_FAULT": "1"}, {"MJX_MERGE_LOOP": "0"}):
         out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "fault ok" in out.stdout, str(extra) + out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_dc_prediction_that_never_hears_from_its_predecessor_gives_up_and_two_passes_finish(mjx, orc, tmp_path):
+    """k_dc_scan_t hands the running DC sums from one workgroup to the next through memory; a workgroup waits for the segment
+    before it.  Nothing promises that the one it waits for was dispatched first, so the wait is bounded: after its limit a
+    workgroup gives up, says so, and mjx_batch_wait decodes the chunk again with the two-pass kernels.  MJX_DC_FAULT=1 makes
+    segment 0 of a chunk's first picture keep its sums to itself: the pictures (several DC segments each, one chunk and
+    several, also next to pictures that take other kernels) must come out right all the same, on the first decode and on
+    the ones after it (the batch stays with two passes)."""
+    import subprocess, sys
+    script = tmp_path / "dcfault.py"
+    script.write_text(
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "import __graft_entry__ as ge, oracle_binding as orc\n"
+        "mjx = ge.load_package()\n"
+        "ctx = mjx.Context(0)\n"
+        "root = os.path.join(%r, 'tests')\n"
+        "datas = [mjx.synth_jpeg(1920, 1080, '420', 80, seed=5), mjx.synth_jpeg(1280, 720, '444', 70, seed=6),\n"
+        "         open(os.path.join(root, 'data/lena.jpeg'), 'rb').read(), mjx.synth_jpeg(2048, 1536, '420', 60, seed=7),\n"
+        "         open(os.path.join(root, 'golden/pil/dri_420_720p_rows.jpg'), 'rb').read()]\n"
+        "refs = [orc.decode(d, layout=orc.LAYOUT_STD, ext_dri=True) for d in datas]\n"
+        "for chunk in (0, 2):\n"
+        "    b = mjx.Batch(ctx, [mjx.ParsedScan(d) for d in datas], keep_coefs=True, chunk_images=chunk)\n"
+        "    for rep in range(3):\n"
+        "        b.decode(); b.wait()\n"
+        "        for i, ref in enumerate(refs):\n"
+        "            assert b.status(i) == 0, (chunk, rep, i, b.status(i))\n"
+        "            assert np.array_equal(b.coefs(i), orc.interleave(ref)), (chunk, rep, i)\n"
+        "            assert np.abs(b.rgb(i).astype(int) - ref.rgb.astype(int)).max() <= 1, (chunk, rep, i)\n"
+        "    b.close()\n"
+        "print('dc fault ok')\n" % (ROOT, ROOT, ROOT))
+    for extra in ({"MJX_DC_FAULT": "1", "MJX_TIMING": "1"}, {"MJX_DC_FAULT": "1", "MJX_STREAMS": "1"}, {"MJX_DC_ONE_PASS": "0"}):
+        out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "dc fault ok" in out.stdout, str(extra) + out.stdout[-2000:] + out.stderr[-2000:]
+        if "MJX_TIMING" in extra:
+            assert "one-pass DC prediction gave up" in out.stderr, out.stderr[-2000:]
