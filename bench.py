@@ -61,7 +61,7 @@ def parse_args():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU baseline (0 = every core the job may use: affinity mask capped by the cgroup quota)")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs and e2e_from_bytes (main line only)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle legs of the parity gate (the on-device check stays)")
-    ap.add_argument("--parity-images", type=int, default=4, help="pictures of the timed batch checked against the CPU oracle")
+    ap.add_argument("--parity-images", type=int, default=16, help="pictures of the timed batch checked against the CPU oracle (decoded in parallel on the host cores)")
     return ap.parse_args()
 
 
@@ -169,7 +169,8 @@ def cpu_baseline(datas, width, height, threads, keep_rgb):
     usable, quota = usable_cores()
     threads = max(1, min(threads or usable, 1024))
     sample = [datas[i % len(datas)] for i in range(threads)]
-    shapes = [(height, width)] * keep_rgb + [(1, 1)] * (len(sample) - keep_rgb)       # (RGB kept for the first few only)
+    keep_rgb = min(keep_rgb, len(sample))
+    shapes = [(height, width)] * keep_rgb + [(1, 1)] * (len(sample) - keep_rgb)       # (RGB kept for the parity gate)
     t = time.perf_counter()
     px, st, rgbs = orc.decode_many(sample, threads, layout=orc.LAYOUT_REF, faithful=True, rgb_shapes=shapes)
     dt = time.perf_counter() - t
@@ -181,6 +182,8 @@ def cpu_baseline(datas, width, height, threads, keep_rgb):
         "value": round(px / dt / 1e6, 4), "unit": "Mpixels/s", "cores": threads, "kind": "port",
         "one_core": {"value": round(px1 / dt1 / 1e6, 4), "unit": "Mpixels/s", "cores": 1, "seconds": round(dt1, 2)},
         "host": {"nproc": cores, "cpu_model": cpu_model(), "usable_cores": usable, "cgroup_cpu_quota": quota},
+        "extrapolated_full_batch_s": {"this_run_batch": None, "config5_16384x4K": round(16384 * 3840 * 2160 / (px / dt), 1),
+                                      "note": "linear: pixels of the batch / the all-core rate above (SURVEY s8(d))"},
         "sample": "%d pictures of the same %dx%d batch, one per thread on %d threads = every core the job may use (host: %d logical "
                   "CPUs, cgroup quota %s), reference algorithm restated "
                   "in C (oracle/: O(n^4) float IDCT with cosf per term, linear-search Huffman, the reference's own layout; "
@@ -317,8 +320,10 @@ def oracle_parity(mjx, batch, datas, period, k):
     res = {"images": len(picks), "max_abs_diff": 0, "t0_equal": True, "differing_fraction": 0.0}
     diffs = 0
     total = 0
-    for i in picks:
-        ref = orc.decode(datas[i % period], layout=orc.LAYOUT_STD)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max(1, min(len(picks), usable_cores()[0]))) as ex:      # (the C call releases the GIL: one picture per core)
+        refs = list(ex.map(lambda i: orc.decode(datas[i % period], layout=orc.LAYOUT_STD), picks))
+    for i, ref in zip(picks, refs):
         try:
             t0 = bool(np.array_equal(batch.coefs(i), orc.interleave(ref)))
         except mjx.MjxError:
@@ -401,7 +406,7 @@ def main():
     datas = make_inputs(mjx, args.width, args.height, args.subsampling, args.quality, seeds)
     if args.streams:
         os.environ["MJX_STREAMS"] = str(args.streams)
-    ctx = mjx.Context(device, profiling=True)
+    ctx = mjx.Context(device, profiling=True, throughput_plan=True)       # (the batches are tiled from 64 unique pictures: cut them like the batch they become)
     host_side = {}
     rec, batch = run_config(mjx, ctx, datas, args.images_per_gpu, args.stages, args.steps, args.warmup, args.chunk_images,
                             args.device_destuff, sync_all, host_side=host_side)
@@ -420,6 +425,7 @@ def main():
                    "images_per_gpu": per_gpu, "width": args.width, "height": args.height, "subsampling": args.subsampling,
                    "quality": args.quality, "layout": "standard", "streams": args.streams or "library default",
                    "chunks_per_step": rec["chunks"],
+                   "subsequence_bytes": round(by["scan"] / max(rec["nsub"], 1), 1),      # mean scan bytes per lane of the entropy kernels (512..640: the throughput cut)
                    "sharding": "image i -> gpu i %% %d, no collective (harness barrier over gloo)" % world},
         "entropy_Gbit_per_s": round(by["scan"] * 8 * world * args.steps / elapsed / 1e9, 2),
         "bits_per_pixel": round(by["scan"] * 8 / max(by["pixels"], 1), 4),
@@ -450,7 +456,7 @@ def main():
         # region above include the contention between them.  The same workload on one stream gives every kernel's
         # stand-alone duration: the roofline of the kernel itself, next to the overlapped one.
         os.environ["MJX_STREAMS"] = "1"
-        ctx1 = mjx.Context(device, profiling=True)
+        ctx1 = mjx.Context(device, profiling=True, throughput_plan=True)
         os.environ.pop("MJX_STREAMS")
         iso_steps = max(2, min(args.steps, 3))
         r1, b1 = run_config(mjx, ctx1, datas, args.images_per_gpu, args.stages, iso_steps, 1, args.chunk_images, args.device_destuff, sync_all)
@@ -496,7 +502,9 @@ def main():
         out["e2e_from_bytes"] = e2e_from_bytes(mjx, ctx, datas, 512, args.width, args.height)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cb, ref_rgbs, ref_files = cpu_baseline(datas, args.width, args.height, args.cpu_threads, 0 if args.no_parity else 2)
+        # (every picture the baseline leg decodes is kept and compared with a REF_COMPAT decode on the GPU)
+        cb, ref_rgbs, ref_files = cpu_baseline(datas, args.width, args.height, args.cpu_threads, 0 if args.no_parity else 1 << 30)
+        cb["extrapolated_full_batch_s"]["this_run_batch"] = round(total_px / args.steps / (cb["value"] * 1e6), 1)
         out["cpu_baseline"] = cb
         if not args.no_parity:
             rp = ref_compat_parity(mjx, ctx, ref_files[:len(ref_rgbs)], ref_rgbs)

@@ -100,6 +100,7 @@ extern "C" {
     pub fn mjx_ctx_create(device: c_int, out: *mut *mut mjx_ctx) -> c_int;
     pub fn mjx_ctx_destroy(ctx: *mut mjx_ctx);
     pub fn mjx_ctx_set_profiling(ctx: *mut mjx_ctx, enable: c_int) -> c_int;
+    pub fn mjx_ctx_set_throughput_plan(ctx: *mut mjx_ctx, enable: c_int) -> c_int;
     pub fn mjx_batch_create(ctx: *mut mjx_ctx, descs: *const mjx_scan_desc, n: usize, opts: *const mjx_opts,
                             out: *mut *mut mjx_batch, status: *mut c_int) -> c_int;
     pub fn mjx_batch_tile(ctx: *mut mjx_ctx, src: *const mjx_batch, times: usize, out: *mut *mut mjx_batch) -> c_int;

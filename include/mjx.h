@@ -127,6 +127,13 @@ int mjx_ctx_create(int device, mjx_ctx **out);
 void mjx_ctx_destroy(mjx_ctx *ctx);
 /* 1: record HIP events around every kernel class of mjx_batch_decode (read with mjx_batch_kernel_ms) */
 int mjx_ctx_set_profiling(mjx_ctx *ctx, int enable);
+/* 1: batches of this context are always cut for throughput (512-byte subsequences).  By default a batch too small to fill the
+ * device is cut into shorter subsequences, which shortens its latency; a caller that builds a small batch only to replicate
+ * it on the device (mjx_batch_tile keeps the base's cut) switches that off, so that the large batch is cut like one that
+ * was created at its size.  Also the first mjx_decode_batch / mjx_batch_create on a fresh context allocates its device
+ * block and pinned buffers: expect that call to take several times as long as the ones after it (0.5 s against 50 ms for
+ * 2048 4K files). */
+int mjx_ctx_set_throughput_plan(mjx_ctx *ctx, int enable);
 
 /* JPEGDecoder::new(..).frame_header(..).scan_header(..).dimensions(..) + table setters for n images
  * (decoder.rs:55-152): validates, builds decode tables, packs and uploads the scans; device buffers for the

@@ -87,6 +87,7 @@ SYMBOLS = {
     "mjx_ctx_create": (_int, [_int, _P(_vp)]),
     "mjx_ctx_destroy": (None, [_vp]),
     "mjx_ctx_set_profiling": (_int, [_vp, _int]),
+    "mjx_ctx_set_throughput_plan": (_int, [_vp, _int]),
     "mjx_batch_create": (_int, [_vp, _P(ScanDesc), _sz, _P(Opts), _P(_vp), _P(_int)]),
     "mjx_batch_free": (None, [_vp]),
     "mjx_batch_tile": (_int, [_vp, _vp, _sz, _P(_vp)]),
@@ -181,11 +182,14 @@ class ParsedScan:
 
 # ---- device context / batch ----------------------------------------------------------------------------
 class Context:
-    def __init__(self, device=0, profiling=False):
+    def __init__(self, device=0, profiling=False, throughput_plan=False):
+        """throughput_plan: batches are always cut into 512-byte subsequences (for a small base that Batch.tile replicates)."""
         self.h = _vp()
         _check(lib().mjx_ctx_create(int(device), ctypes.byref(self.h)), "mjx_ctx_create(device=%d)" % device)
         if profiling:
             self.set_profiling(True)
+        if throughput_plan:
+            _check(lib().mjx_ctx_set_throughput_plan(self.h, 1))
 
     def set_profiling(self, on):
         _check(lib().mjx_ctx_set_profiling(self.h, int(bool(on))))

@@ -83,6 +83,7 @@ struct mjx_ctx {
     std::mutex batch_mu;            // mjx_decode_batch: one call at a time per context (the pinned arena is shared state)
     int nstreams = 2;
     bool profiling = false;
+    bool throughput_plan = false;   // mjx_ctx_set_throughput_plan: never cut a batch into short subsequences (a base that will be tiled)
     // mjx_decode_batch: pinned arena the files of a call are de-stuffed into; kept between calls (fresh pages cost ~0.35 us
     // per KB to fault in and unmap again -- four times the parsing itself), released with the context
     uint8_t *parse_arena = nullptr;
@@ -746,7 +747,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
     // One 512x512 picture, 512 -> 64 bytes: k_huff_spec 235 -> 41 us, k_huff_write 376 -> 61 us, merge rounds 163 -> 137 us.
     std::vector<ImagePlan> replanned;
     const std::vector<ImagePlan> *use = &plans_in;
-    if (!src && latency_plan && ctx->latency_nsub > 0 && ctx->merge_loop_max > 0) {       // (not for the groups of a pipelined list: they overlap, throughput counts)
+    if (!src && latency_plan && !ctx->throughput_plan && ctx->latency_nsub > 0 && ctx->merge_loop_max > 0) {       // (not for the groups of a pipelined list: they overlap, throughput counts)
         uint64_t total = 0;
         for (const ImagePlan &p : plans_in) if (p.status == MJX_OK) total += p.himg.nsub;
         if (total > 0 && total <= ctx->latency_nsub) {
@@ -772,9 +773,9 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
     const std::vector<ImagePlan> &plans = *use;
     mjx_batch *b = new (std::nothrow) mjx_batch;
     if (!b) return MJX_ERR_NOMEM;
-    struct Owner {                      // releases the half-built batch on every early exit, exceptions included
-        mjx_batch *b;
-        ~Owner() { if (b) release(b); }
+    struct Owner {                      // releases the half-built batch on every early exit, exceptions included -- behind the upload
+        mjx_batch *b;                   // stream: copies into the block may still be queued, and release() hands the block to the next batch
+        ~Owner() { if (b) { if (b->ctx && b->ctx->upload) (void)hipStreamSynchronize(b->ctx->upload); release(b); } }
     } owner{b};
     b->ctx = ctx;
     b->opts = opts;
@@ -1202,6 +1203,13 @@ extern "C" int mjx_ctx_set_profiling(mjx_ctx *ctx, int enable)
 {
     if (!ctx) return MJX_ERR_INVALID_ARG;
     ctx->profiling = enable != 0;
+    return MJX_OK;
+}
+
+extern "C" int mjx_ctx_set_throughput_plan(mjx_ctx *ctx, int enable)
+{
+    if (!ctx) return MJX_ERR_INVALID_ARG;
+    ctx->throughput_plan = enable != 0;
     return MJX_OK;
 }
 

@@ -2192,7 +2192,10 @@ void launch_rgb_compare(hipStream_t st, uint32_t npairs, uint64_t max_bytes, con
 {
     const uint32_t gx = uint32_t((max_bytes + 16383) / 16384);
     if (gx == 0 || npairs == 0) return;
-    hipLaunchKernelGGL(k_rgb_compare, dim3(gx, npairs), dim3(256), 0, st, pairs, maxdiff, ndiff);
+    for (uint32_t p0 = 0; p0 < npairs; p0 += 65535u) {                     // (a grid's y dimension holds 65 535 pairs)
+        const uint32_t np = std::min(65535u, npairs - p0);
+        hipLaunchKernelGGL(k_rgb_compare, dim3(gx, np), dim3(256), 0, st, pairs + p0, maxdiff + p0, ndiff + p0);
+    }
 }
 
 void launch_ref_color(hipStream_t st, uint32_t max_pixel_wgs, uint32_t nimg, const DevImage *images,

@@ -211,6 +211,28 @@ def test_cli_writes_the_reference_ppm(mjx, orc, gpu_ctx, data_dir, tmp_path):
     assert tok[:4] == ["P3", "333", "222", "255"]
     assert np.abs(np.array(tok[4:], dtype=np.int32).reshape(222, 333, 3) - ref.rgb.astype(np.int32)).max() <= TOL
     assert subprocess.call([cli, dri, str(out), "--strict"]) == mjx.ERR_DRI_UNSUPPORTED
+    # --p6: the binary twin of main.rs:35-39 -- same header line, then the pixels as raw bytes; it must hold exactly the numbers
+    # the text file holds, for a colour and for a greyscale picture (main.rs writes r g b for both)
+    for name in ("lena.jpeg", "lena-bw.jpeg"):
+        src = os.path.join(data_dir, name)
+        p3, p6 = tmp_path / "a.ppm", tmp_path / "b.ppm"
+        subprocess.check_call([cli, src, str(p3)])
+        subprocess.check_call([cli, src, str(p6), "--p6"])
+        raw = p6.read_bytes()
+        assert raw.startswith(b"P6\n512 512\n255\n")
+        body = raw[len(b"P6\n512 512\n255\n"):]
+        assert len(body) == 512 * 512 * 3
+        text = np.array(p3.read_text().split()[4:], dtype=np.int32)
+        assert np.array_equal(np.frombuffer(body, np.uint8).astype(np.int32), text)
+    # --ref-compat writes the reference's own (bug-compatible) picture
+    c3 = tmp_path / "c.ppm"
+    two = os.path.join(data_dir, "2x2-chroma.jpeg")
+    subprocess.check_call([cli, two, str(c3), "--p6", "--ref-compat"])
+    raw = c3.read_bytes()
+    hdr = b"P6\n750 595\n255\n"
+    assert raw.startswith(hdr)
+    ref = orc.decode(open(two, "rb").read(), layout=orc.LAYOUT_REF)
+    assert np.abs(np.frombuffer(raw[len(hdr):], np.uint8).reshape(595, 750, 3).astype(np.int32) - ref.rgb.astype(np.int32)).max() <= TOL
 
 
 # ---- hostile inputs: one bad image must not kill the batch, and nothing may fault on the device --------------------

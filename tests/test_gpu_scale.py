@@ -40,12 +40,14 @@ def _check_tiled_against_base(mjx, big, base, period):
 
 
 @pytest.mark.parametrize("w,h,count,unique", [(1920, 1080, 4096, 64), (3840, 2160, 2048, 64)])
-def test_full_size_batches_equal_their_originals_byte_for_byte(mjx, orc, gpu_ctx, w, h, count, unique):
+def test_full_size_batches_equal_their_originals_byte_for_byte(mjx, orc, w, h, count, unique):
     """BASELINE.json configs[3] (4096 x 1080p on one GPU) and configs[4]'s per-GPU share (2048 x 4K)."""
     datas = mjx.synth_batch(unique, w, h, "420", 75)
+    gpu_ctx = mjx.Context(0, throughput_plan=True)        # the base is cut like the batch it is tiled into (512-byte subsequences)
     base, scans = _unique_batch(mjx, orc, gpu_ctx, datas, n_oracle=4)
     big = base.tile(count // unique)
     assert len(big) == count
+    assert 512 <= big.bytes()["scan"] / big.geometry()["subsequences"] <= 640
     big.decode()
     big.wait()
     assert big.geometry()["chunks"] >= (2 if w == 3840 else 1)           # (the 4K batch spans several kernel chunks)
@@ -58,6 +60,7 @@ def test_full_size_batches_equal_their_originals_byte_for_byte(mjx, orc, gpu_ctx
     assert mx[0] > 0 and cnt[0] > 0 and mx[1] == 0
     big.close()
     base.close()
+    gpu_ctx.close()
 
 
 @pytest.mark.parametrize("keep", [False, True])

@@ -13,7 +13,7 @@ ap.add_argument("--warmup", type=int, default=1)
 ap.add_argument("--chunk-images", type=int, default=0)
 a = ap.parse_args()
 mjx = ge.load_package()
-ctx = mjx.Context(0, profiling=True)
+ctx = mjx.Context(0, profiling=True, throughput_plan=True)
 datas = [open(f, "rb").read() for f in a.files]
 base = mjx.Batch(ctx, [mjx.ParsedScan(d) for d in datas], chunk_images=a.chunk_images)
 assert all(s == mjx.OK for s in base.create_status), base.create_status
