@@ -45,8 +45,12 @@ typedef struct mjx_opts {
     uint8_t strict_ref;   /* 1: unknown / APP12 / APP14 markers are errors like the reference; 0: skip them */
     uint8_t layout;       /* MJX_LAYOUT_* */
     uint8_t keep_coefs;   /* 1: keep the whole batch's coefficient stream resident (T0 checks, stage-B-only sweeps) */
-    uint8_t device_destuff;/* mjx_parse: 1 = leave the entropy-coded segment byte-stuffed (desc.scan_is_stuffed = 1); the FF00 -> FF
-                             compaction of jpeg/mod.rs:371-385 then runs on the GPU inside mjx_batch_create */
+    uint8_t device_destuff;/* 1 = the host does not touch the entropy-coded bytes: mjx_parse copies them as they are
+                             (desc.scan_is_stuffed = 1), and the FF00 -> FF compaction of jpeg/mod.rs:371-385, the search for
+                             RSTn markers and the scan's length are the GPU's at upload (mjx_batch_create, mjx_decode_batch,
+                             the pool).  The picture is the same.  Not with strict_ref (the byte pass stays, for the
+                             reference's unguarded read behind a last FF) nor for multi-scan files (their scans are cut
+                             apart on the host). */
     uint32_t chunk_images;/* images per kernel chunk; 0 = library default */
 } mjx_opts;
 
@@ -85,7 +89,8 @@ typedef struct mjx_scan_desc {
     uint8_t qt_present;            /* bit i = slot i defined */
     mjx_hufftab dc[4], ac[4];      /* .huffman_dc_tables() / .huffman_ac_tables() decoder.rs:71-77 */
     uint8_t dc_present, ac_present;
-    uint8_t scan_is_stuffed;       /* 1: `scan` still holds FF00 pairs; mjx_batch_create de-stuffs on the device */
+    uint8_t scan_is_stuffed;       /* 1: `scan` still holds FF00 pairs and RSTn markers, scan_len is the stuffed length and
+                                      restart_offsets is empty: the device de-stuffs, finds the markers and the length */
     /* Restart intervals (T.81 B.2.4.4) -- beyond the reference, which panics on DRI (jpeg/mod.rs:424-428; strict_ref keeps
        that).  mjx_parse removes the RSTn markers from `scan` and lists where each further interval begins. */
     uint16_t restart_interval;     /* MCUs per interval, 0 = none */

@@ -487,15 +487,17 @@ class JPEGImage:
         return self._rgb
 
 
-def decode_batch(ctx, datas, strict_ref=False, layout=LAYOUT_STANDARD, threads=0):
-    """mjx_decode_batch: parse (host threads) + GPU decode of a list of files -> (Batch, [status per file])."""
+def decode_batch(ctx, datas, strict_ref=False, layout=LAYOUT_STANDARD, threads=0, device_destuff=False, keep_coefs=False):
+    """mjx_decode_batch: parse (host threads) + GPU decode of a list of files -> (Batch, [status per file]).
+    device_destuff: the host copies the entropy-coded bytes as they are; de-stuffing, restart markers and the scan's length
+    are found on the GPU."""
     n = len(datas)
     arr = (ctypes.c_char_p * max(n, 1))(*[bytes(d) for d in datas])
     lens = (_sz * max(n, 1))(*[len(d) for d in datas])
     st = (_int * max(n, 1))()
     ptrs = (_P(ctypes.c_uint8) * max(n, 1))()
     h = _vp()
-    o = _opts(strict_ref, layout)
+    o = _opts(strict_ref, layout, keep_coefs=keep_coefs, device_destuff=device_destuff)
     _check(lib().mjx_decode_batch(ctx.h, arr, lens, n, ctypes.byref(o), int(threads), ptrs, st, ctypes.byref(h)), "mjx_decode_batch")
     return Batch(ctx, _handle=h), list(st)[:n]
 

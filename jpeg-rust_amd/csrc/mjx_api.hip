@@ -177,6 +177,13 @@ struct mjx_batch {
     size_t h_mismatch_bytes = 0;        // size of the pinned block behind h_mismatch (when owned)
     uint8_t *d_lin = nullptr;
     void *d_ii = nullptr;
+    // scans that are de-stuffed on the device (ImagePlan::stuffed): raw bytes, per-scan descriptors, per-segment counts and bases,
+    // restart-marker list.  has_stuffed: the DevImages on the device hold geometry the host copies (himages, h_segs) do not.
+    uint8_t *d_raw = nullptr;
+    void *d_di = nullptr;
+    uint32_t *d_segcount = nullptr, *d_segbase = nullptr, *d_rst = nullptr;
+    std::vector<DestuffImg> h_di;
+    bool has_stuffed = false;
     size_t lut_pool_entries = 0;        // entries of the decode-table pool (identical tables stored once)
     void *d_meta_end = nullptr;         // [d_images, d_meta_end): the small pools, uploaded in one transfer
     std::vector<unsigned char> h_meta;  // ... from this host block, unless the caller lent pinned memory
@@ -456,6 +463,7 @@ void plan_chunks(mjx_batch *b)
         // another): a twelfth of the device's 3 x 256 slots, so that a dozen such launches (other contexts, other processes) still
         // fit side by side; a launch that cannot get its workgroups together gives up by itself (kLoopGaveUp)
         if (c.loop_participants > b->ctx->merge_loop_max) c.loop_participants = 0;
+        if (b->has_stuffed) c.loop_participants = 0;    // (its workgroups are counted from nsub, which only the device knows exactly for those scans)
         coef_running += c.blocks;
         ent_running += c.entries;
         tile_running += c.tiles;
@@ -713,16 +721,6 @@ void collect_events(mjx_batch *b)
     b->events.clear();
 }
 
-// Images whose scan arrives byte-stuffed: the FF00 -> FF compaction runs on the device (k_destuff_*).
-struct DestuffPlan {
-    uint8_t *d_raw = nullptr;
-    uint32_t *d_segbase = nullptr;
-    std::vector<DestuffImg> imgs;      // one per stuffed image; out_off is filled in by build_batch
-    std::vector<size_t> plan_index;    // which plan each entry belongs to
-    uint32_t max_seg = 0;
-    ~DestuffPlan() { (void)hipFree(d_raw); (void)hipFree(d_segbase); }
-};
-
 // Pinned host memory lent to build_batch for the host mirrors of its small pools (mjx_decode_batch: an asynchronous copy from
 // pageable memory is staged by the runtime and waits for the stream's earlier transfers -- the host thread would stall behind
 // the previous group's DMA).
@@ -731,11 +729,12 @@ struct PinnedBump {
     size_t cap = 0, used = 0;
 };
 
-// Builds a batch from plans.  Scan bytes come from the plans' host pointers (or, for the images listed in `ds`, from
-// the device-side de-stuffing of their raw bytes), or (src != nullptr) are copied on the device from `src`'s pool,
-// `times` repetitions of its images.
+// Builds a batch from plans.  Scan bytes come from the plans' host pointers -- de-stuffed, or (ImagePlan::stuffed) as they
+// stand in the file: those are compacted on the device (k_destuff_*), which also finds their length and restart markers
+// and writes the geometry that depends on them into the DevImages -- or (src != nullptr) are copied on the device from
+// `src`'s pool, `times` repetitions of its images.
 int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_opts &opts, const mjx_batch *src,
-                size_t times, mjx_batch **out, int *status, DestuffPlan *ds = nullptr, bool async_upload = false,
+                size_t times, mjx_batch **out, int *status, bool async_upload = false,
                 uint32_t *pinned_words = nullptr, size_t pinned_cap = 0, PinnedBump *pin = nullptr, bool latency_plan = true)
 {
     // A batch too small to fill the device (one picture, a handful) is bound by the serial chain of a lane -- ~810 symbols
@@ -747,7 +746,9 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
     // One 512x512 picture, 512 -> 64 bytes: k_huff_spec 235 -> 41 us, k_huff_write 376 -> 61 us, merge rounds 163 -> 137 us.
     std::vector<ImagePlan> replanned;
     const std::vector<ImagePlan> *use = &plans_in;
-    if (!src && latency_plan && !ctx->throughput_plan && ctx->latency_nsub > 0 && ctx->merge_loop_max > 0) {       // (not for the groups of a pipelined list: they overlap, throughput counts)
+    bool any_stuffed = false;
+    for (const ImagePlan &p : plans_in) any_stuffed = any_stuffed || (p.status == MJX_OK && p.stuffed);
+    if (!src && latency_plan && !any_stuffed && !ctx->throughput_plan && ctx->latency_nsub > 0 && ctx->merge_loop_max > 0) {       // (not for the groups of a pipelined list: they overlap, throughput counts)
         uint64_t total = 0;
         for (const ImagePlan &p : plans_in) if (p.status == MJX_OK) total += p.himg.nsub;
         if (total > 0 && total <= ctx->latency_nsub) {
@@ -785,18 +786,24 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
     // pools for the unique images
     // scan_off: the image's lane-interleaved region in the pool (what the kernels read, see LaneBits in mjx_kernels.hip);
     // lin_off: its linear de-stuffed scan in the staging buffer the region is built from at upload
-    std::vector<uint64_t> scan_off(nu, 0), lin_off(nu, 0);
+    std::vector<uint64_t> scan_off(nu, 0), lin_off(nu, 0), raw_off(nu, 0);
     std::vector<uint32_t> lut_off(nu, 0), lut_n(nu, 0), seg_off(nu, 0);
-    size_t scan_pool = 0, lin_pool = 0, lut_pool = 0;
+    size_t scan_pool = 0, lin_pool = 0, lut_pool = 0, raw_pool = 0;
+    auto layout_nsub = [](const ImagePlan &p) { return p.nsub_layout ? p.nsub_layout : p.himg.nsub; };
+    b->has_stuffed = any_stuffed && !src;
     std::vector<char> lut_first(nu, 1);                     // 0: the image shares an earlier image's tables
     std::unordered_multimap<uint64_t, size_t> lut_seen;
     b->h_segs.clear();
     for (size_t k = 0; k < nu; k++) {
         if (plans[k].status != MJX_OK) continue;
         scan_off[k] = scan_pool;
-        scan_pool += align_up(size_t(scan_region_bytes(plans[k].himg.nsub, plans[k].himg.sub_bits)), 256);
+        scan_pool += align_up(size_t(scan_region_bytes(layout_nsub(plans[k]), plans[k].himg.sub_bits)), 256);
         lin_off[k] = lin_pool;
         lin_pool += align_up(plans[k].scan_len, 16) + 16;
+        if (plans[k].stuffed && !src) {                     // raw bytes for the device-side compaction: whole 64-byte pieces + one behind
+            raw_off[k] = raw_pool;
+            raw_pool += align_up(plans[k].scan_len, 64) + 64;
+        }
         if (src) {                          // replicated on the device: the source batch's table pool, its offsets
             lut_off[k] = src->himages[k].lut_off;
             lut_n[k] = uint32_t(plans[k].lut.size());
@@ -843,7 +850,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
         fill_dev_image(p, d);
         d.status_idx = uint32_t(i);
         d.scan_off = rep * scan_pool + scan_off[k];
-        d.scan_cols = scan_region_cols(p.himg.nsub);
+        d.scan_cols = scan_region_cols(layout_nsub(p));
         d.lut_off = lut_off[k];
         d.lut_n = lut_n[k];
         d.qm_off = uint32_t(k * 192);
@@ -894,36 +901,53 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
     auto dev = [&]() -> int {
         hipStream_t up = ctx->upload;
         HIPOK(hipSetDevice(ctx->device));
-        std::vector<char> on_device(nu, 0);
-        if (ds) for (size_t idx : ds->plan_index) on_device[idx] = 1;
-        bool one_copy = false;
-        const uint8_t *span0 = nullptr;
-        size_t span_bytes = 0;
-        {
+        // Scans that lie close together in host memory in upload order (the pinned arena mjx_decode_batch parses into) go up
+        // as ONE transfer, gaps included; the de-stuffed ones into the linear staging buffer, the stuffed ones into the raw one.
+        struct Span { bool one = false; const uint8_t *p0 = nullptr; size_t bytes = 0; };
+        auto find_span = [&](bool stuffed, size_t align) {
+            Span sp;
             const uint8_t *prev_end = nullptr;
             size_t payload = 0, count = 0;
             bool ordered = true;
             for (size_t k = 0; k < nu && ordered; k++) {
                 const ImagePlan &p = plans[k];
-                if (p.status != MJX_OK || on_device[k] || p.scan_len == 0) continue;
-                if (!span0) span0 = p.scan;
+                if (p.status != MJX_OK || p.stuffed != stuffed || p.scan_len == 0 || !p.scan) continue;
+                if (!sp.p0) sp.p0 = p.scan;
                 if (prev_end && p.scan < prev_end) ordered = false;
-                if ((size_t(p.scan - span0) & 15u) != 0) ordered = false;             // (staging offsets stay 16-byte aligned)
+                if ((size_t(p.scan - sp.p0) & (align - 1)) != 0) ordered = false;        // (staging offsets stay aligned)
                 prev_end = p.scan + p.scan_len;
                 payload += p.scan_len;
                 count++;
             }
             // (only inside the context's own pinned arena: the gaps between the scans are read as well)
-            const bool in_arena = span0 && ctx->parse_arena && span0 >= ctx->parse_arena && prev_end <= ctx->parse_arena + ctx->parse_arena_cap;
-            if (ordered && in_arena && count > 1 && size_t(prev_end - span0) <= payload + payload / 4 + 4096) {
-                one_copy = true;
-                span_bytes = size_t(prev_end - span0);
-                lin_pool = align_up(span_bytes, 16) + 16;
-                for (size_t k = 0; k < nu; k++)
-                    if (plans[k].status == MJX_OK && !on_device[k] && plans[k].scan_len) lin_off[k] = size_t(plans[k].scan - span0);
-                if (ds) one_copy = false;                                                // (device-side de-stuffing keeps its own offsets)
+            const bool in_arena = sp.p0 && ctx->parse_arena && sp.p0 >= ctx->parse_arena && prev_end <= ctx->parse_arena + ctx->parse_arena_cap;
+            if (ordered && in_arena && count > 1 && size_t(prev_end - sp.p0) <= payload + payload / 4 + 4096 + 128 * count) {
+                sp.one = true;
+                sp.bytes = size_t(prev_end - sp.p0);
             }
+            return sp;
+        };
+        const Span lin_span = find_span(false, 16), raw_span = any_stuffed ? find_span(true, 64) : Span{};
+        const bool one_copy = lin_span.one;
+        if (lin_span.one) {
+            // (the stuffed scans' compacted copies follow the span in the linear buffer)
+            size_t at = align_up(lin_span.bytes, 16) + 16;
+            for (size_t k = 0; k < nu; k++) {
+                if (plans[k].status != MJX_OK) continue;
+                if (!plans[k].stuffed) { if (plans[k].scan_len && plans[k].scan) lin_off[k] = size_t(plans[k].scan - lin_span.p0); }
+                else { lin_off[k] = at; at += align_up(plans[k].scan_len, 16) + 16; }
+            }
+            lin_pool = at;
         }
+        if (raw_span.one) {
+            raw_pool = align_up(raw_span.bytes, 64) + 128;
+            for (size_t k = 0; k < nu; k++)
+                if (plans[k].status == MJX_OK && plans[k].stuffed) raw_off[k] = size_t(plans[k].scan - raw_span.p0);
+        }
+        // stuffed scans: what the device-side compaction needs per scan (k_destuff_*)
+        std::vector<DestuffImg> di;
+        uint32_t destuff_segs = 0, destuff_max_seg = 0, rst_words = 0;
+        bool destuff_restarts = false;
         // the images that have a scan of their own to interleave
         std::vector<InterleaveImg> ii;
         uint32_t max_pieces = 0;
@@ -931,8 +955,26 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
             for (size_t k = 0; k < nu; k++) {
                 const ImagePlan &p = plans[k];
                 if (p.status != MJX_OK || p.himg.nsub == 0) continue;
+                if (p.stuffed) {                                                                // (its length: written by k_destuff_prefix)
+                    DestuffImg x{};
+                    x.raw_off = raw_off[k];
+                    x.raw_len = p.scan_len;
+                    x.out_off = lin_off[k];
+                    x.seg0 = destuff_segs;
+                    x.nseg = uint32_t((p.scan_len + kDestuffSeg - 1) / kDestuffSeg);
+                    x.image = uint32_t(k);
+                    x.ii_index = uint32_t(ii.size());
+                    x.restarts = p.restart_mcus ? 1u : 0u;
+                    x.rst0 = rst_words;
+                    x.rst_cap = p.restart_mcus ? p.nseg + 8u : 0u;
+                    rst_words += x.rst_cap;
+                    destuff_segs += x.nseg;
+                    destuff_max_seg = std::max(destuff_max_seg, x.nseg);
+                    destuff_restarts = destuff_restarts || x.restarts;
+                    di.push_back(x);
+                }
                 ii.push_back(InterleaveImg{0, uint32_t(p.scan_len), uint32_t(k)});              // (lin_off is filled in below)
-                max_pieces = std::max<uint32_t>(max_pieces, scan_region_cols(p.himg.nsub) * scan_region_rows(p.himg.sub_bits));
+                max_pieces = std::max<uint32_t>(max_pieces, scan_region_cols(layout_nsub(p)) * scan_region_rows(p.himg.sub_bits));
             }
         size_t segflag_words = 6;                                       // (as max_segsum in allocate_work_buffers)
         for (const Chunk &c : b->chunks) segflag_words = std::max<size_t>(segflag_words, size_t(c.max_segs) * c.count * 6);
@@ -956,6 +998,13 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
                 ar.take(&b->d_meta_end, 16);
                 ar.take(&b->d_scan, b->scan_pool_bytes + 256);
                 if (!src) ar.take(&b->d_lin, lin_pool + 256);
+                if (!di.empty()) {
+                    ar.take(&b->d_raw, raw_pool + 256);
+                    ar.take(&b->d_di, di.size() * sizeof(DestuffImg));
+                    ar.take(&b->d_segcount, size_t(destuff_segs) * 2 * sizeof(uint32_t) + 16);
+                    ar.take(&b->d_segbase, size_t(destuff_segs) * 2 * sizeof(uint32_t) + 16);
+                    ar.take(&b->d_rst, size_t(rst_words) * sizeof(uint32_t) + 16);
+                }
                 return allocate_work_buffers(b, ar);
             };
             { const int rcl = layout(); if (rcl != MJX_OK) return rcl; }
@@ -1040,50 +1089,47 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
             // a scan (huffman.rs:236-246).  When the scans lie close together in host memory in upload order (the pinned
             // arena mjx_decode_batch de-stuffs into) they go up as ONE transfer, gaps included: 512 separate 1 MB copies reached
             // 36 GB/s, one copy runs at the link's rate.
+            // the small pools first: the de-stuffing kernels write the geometry they find into the DevImages
+            for (InterleaveImg &x : ii) x.lin_off = lin_off[x.image];
+            if (meta_block) {
+                if (!ii.empty()) std::memcpy(mirror(b->d_ii), ii.data(), ii.size() * sizeof(InterleaveImg));
+                HIPOK(hipMemcpyAsync(b->d_images, meta, meta_bytes, hipMemcpyHostToDevice, up));       // every small pool at once
+            } else if (!ii.empty()) {
+                b->h_ii.assign(reinterpret_cast<const unsigned char *>(ii.data()), reinterpret_cast<const unsigned char *>(ii.data() + ii.size()));
+                HIPOK(hipMemcpyAsync(b->d_ii, b->h_ii.data(), b->h_ii.size(), hipMemcpyHostToDevice, up));
+            }
             if (one_copy) {
-                HIPOK(hipMemcpyAsync(b->d_lin, span0, span_bytes, hipMemcpyHostToDevice, up));
+                HIPOK(hipMemcpyAsync(b->d_lin, lin_span.p0, lin_span.bytes, hipMemcpyHostToDevice, up));
             } else {
                 for (size_t k = 0; k < nu; k++) {
                     const ImagePlan &p = plans[k];
-                    if (p.status != MJX_OK || on_device[k] || p.scan_len == 0) continue;
+                    if (p.status != MJX_OK || p.stuffed || p.scan_len == 0 || !p.scan) continue;
                     HIPOK(hipMemcpyAsync(b->d_lin + lin_off[k], p.scan, p.scan_len, hipMemcpyHostToDevice, up));
                 }
             }
+            if (!di.empty()) {
+                if (raw_span.one) {
+                    HIPOK(hipMemcpyAsync(b->d_raw, raw_span.p0, raw_span.bytes, hipMemcpyHostToDevice, up));
+                } else {
+                    for (size_t k = 0; k < nu; k++) {
+                        const ImagePlan &p = plans[k];
+                        if (p.status != MJX_OK || !p.stuffed || p.scan_len == 0) continue;
+                        HIPOK(hipMemcpyAsync(b->d_raw + raw_off[k], p.scan, p.scan_len, hipMemcpyHostToDevice, up));
+                    }
+                }
+                b->h_di = di;                                                  // (kept alive behind the asynchronous copy)
+                HIPOK(hipMemcpyAsync(b->d_di, b->h_di.data(), b->h_di.size() * sizeof(DestuffImg), hipMemcpyHostToDevice, up));
+                launch_destuff(up, destuff_max_seg, uint32_t(di.size()), destuff_restarts, static_cast<const DestuffImg *>(b->d_di), b->d_raw,
+                               b->d_segcount, b->d_segbase, b->d_lin, b->d_rst, b->d_images, static_cast<InterleaveImg *>(b->d_ii), b->d_segs,
+                               b->d_img_flags);
+                HIPOK(hipGetLastError());
+            }
             if (timing && !async_upload) {
                 HIPOK(hipStreamSynchronize(up));
-                std::fprintf(stderr, "[mjx] staging %.2f ms, H2D of %.1f MB (%s) %.2f ms\n", ms(t0, t1), lin_pool / 1e6, one_copy ? "one transfer" : "per scan", ms(t1, now()));
+                std::fprintf(stderr, "[mjx] staging %.2f ms, H2D of %.1f MB (%s) %.2f ms\n", ms(t0, t1), (lin_pool + raw_pool) / 1e6, one_copy ? "one transfer" : "per scan", ms(t1, now()));
             }
             const auto t2 = now();
-            if (ds && !ds->imgs.empty()) {                 // compact the stuffed scans straight into the staging buffer
-                std::vector<DestuffImg> di;
-                for (size_t j = 0; j < ds->imgs.size(); j++) {
-                    if (plans[ds->plan_index[j]].status != MJX_OK) continue;
-                    DestuffImg x = ds->imgs[j];
-                    x.out_off = lin_off[ds->plan_index[j]];
-                    di.push_back(x);
-                }
-                if (!di.empty()) {
-                    DestuffImg *d_di = nullptr;
-                    HIPOK(hipMalloc(&d_di, di.size() * sizeof(DestuffImg)));
-                    int rc3 = MJX_OK;
-                    if (hipMemcpyAsync(d_di, di.data(), di.size() * sizeof(DestuffImg), hipMemcpyHostToDevice, up) != hipSuccess) rc3 = MJX_ERR_DEVICE;
-                    if (rc3 == MJX_OK) {
-                        launch_destuff_scatter(up, ds->max_seg, uint32_t(di.size()), d_di, ds->d_raw, ds->d_segbase, b->d_lin);
-                        if (hipStreamSynchronize(up) != hipSuccess || hipGetLastError() != hipSuccess) rc3 = MJX_ERR_DEVICE;
-                    }
-                    (void)hipFree(d_di);
-                    if (rc3 != MJX_OK) return rc3;
-                }
-            }
             {   // linear -> lane-interleaved
-                for (InterleaveImg &x : ii) x.lin_off = lin_off[x.image];
-                if (meta_block) {
-                    if (!ii.empty()) std::memcpy(mirror(b->d_ii), ii.data(), ii.size() * sizeof(InterleaveImg));
-                    HIPOK(hipMemcpyAsync(b->d_images, meta, meta_bytes, hipMemcpyHostToDevice, up));       // every small pool at once
-                } else if (!ii.empty()) {
-                    b->h_ii.assign(reinterpret_cast<const unsigned char *>(ii.data()), reinterpret_cast<const unsigned char *>(ii.data() + ii.size()));
-                    HIPOK(hipMemcpyAsync(b->d_ii, b->h_ii.data(), b->h_ii.size(), hipMemcpyHostToDevice, up));
-                }
                 if (!ii.empty()) {
                     const InterleaveImg *d_ii = static_cast<const InterleaveImg *>(b->d_ii);
                     for (size_t at = 0; at < ii.size(); at += 32768)
@@ -1096,7 +1142,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
                 }
             }
         }
-        if (async_upload && !ds) {
+        if (async_upload) {
             // the caller goes on (parsing and uploading the next group of files) while the DMA engine works; the decode
             // streams wait for this event before their first kernel (run_chunk)
             HIPOK(hipEventCreateWithFlags(&b->uploaded, hipEventDisableTiming));
@@ -1222,63 +1268,7 @@ extern "C" int mjx_batch_create(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t
     *out = nullptr;
     mjx_opts o{};
     if (opts) o = *opts;
-    std::vector<mjx_scan_desc> dd(descs, descs + n);
-    DestuffPlan ds;
-    bool any_stuffed = false;
-    for (size_t i = 0; i < n; i++) any_stuffed = any_stuffed || (dd[i].scan_is_stuffed && dd[i].scan);
-    if (any_stuffed) {
-        // upload the raw segments, count the bytes that survive de-stuffing: the de-stuffed length fixes the geometry
-        HIPOK(hipSetDevice(ctx->device));
-        size_t raw_bytes = 0;
-        uint32_t nseg_total = 0;
-        for (size_t i = 0; i < n; i++) {
-            if (!dd[i].scan_is_stuffed || !dd[i].scan) continue;
-            DestuffImg x{};
-            x.raw_off = raw_bytes;
-            x.raw_len = dd[i].scan_len;
-            x.seg0 = nseg_total;
-            x.nseg = uint32_t((dd[i].scan_len + kDestuffSeg - 1) / kDestuffSeg);
-            raw_bytes += align_up(dd[i].scan_len, 64) + 64;      // destuff_keep_mask loads whole 64-byte pieces
-            nseg_total += x.nseg;
-            ds.max_seg = std::max(ds.max_seg, x.nseg);
-            ds.imgs.push_back(x);
-            ds.plan_index.push_back(i);
-        }
-        std::vector<uint8_t> hraw(std::max<size_t>(raw_bytes, 16), 0);
-        for (size_t j = 0; j < ds.imgs.size(); j++)
-            std::memcpy(hraw.data() + ds.imgs[j].raw_off, dd[ds.plan_index[j]].scan, ds.imgs[j].raw_len);
-        DestuffImg *d_di = nullptr;
-        uint32_t *d_cnt = nullptr;
-        std::vector<uint32_t> cnt(std::max<uint32_t>(nseg_total, 1), 0);
-        int rc = MJX_OK;
-        if (hipMalloc(&ds.d_raw, hraw.size()) != hipSuccess || hipMalloc(&d_di, ds.imgs.size() * sizeof(DestuffImg)) != hipSuccess ||
-            hipMalloc(&d_cnt, cnt.size() * 4) != hipSuccess || hipMalloc(&ds.d_segbase, cnt.size() * 4) != hipSuccess)
-            rc = MJX_ERR_DEVICE;
-        if (rc == MJX_OK && (hipMemcpy(ds.d_raw, hraw.data(), hraw.size(), hipMemcpyHostToDevice) != hipSuccess ||
-                             hipMemcpy(d_di, ds.imgs.data(), ds.imgs.size() * sizeof(DestuffImg), hipMemcpyHostToDevice) != hipSuccess))
-            rc = MJX_ERR_DEVICE;
-        if (rc == MJX_OK && nseg_total) {
-            launch_destuff_count(ctx->stream, ds.max_seg, uint32_t(ds.imgs.size()), d_di, ds.d_raw, d_cnt);
-            if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess ||
-                hipMemcpy(cnt.data(), d_cnt, cnt.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
-                rc = MJX_ERR_DEVICE;
-        }
-        if (rc == MJX_OK) {
-            std::vector<uint32_t> base(cnt.size(), 0);
-            for (size_t j = 0; j < ds.imgs.size(); j++) {
-                uint64_t run = 0;
-                for (uint32_t sgi = 0; sgi < ds.imgs[j].nseg; sgi++) {
-                    base[ds.imgs[j].seg0 + sgi] = uint32_t(run);
-                    run += cnt[ds.imgs[j].seg0 + sgi];
-                }
-                dd[ds.plan_index[j]].scan_len = size_t(run);          // de-stuffed length
-            }
-            if (hipMemcpy(ds.d_segbase, base.data(), base.size() * 4, hipMemcpyHostToDevice) != hipSuccess) rc = MJX_ERR_DEVICE;
-        }
-        (void)hipFree(d_di);
-        (void)hipFree(d_cnt);
-        if (rc != MJX_OK) { (void)hipGetLastError(); return rc; }
-    }
+    const mjx_scan_desc *dd = descs;
     std::vector<ImagePlan> plans;
     std::vector<size_t> plan_of(n);                    // input i -> its picture's plan (multi-scan files add plans in front)
     plans.reserve(n);
@@ -1289,8 +1279,8 @@ extern "C" int mjx_batch_create(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t
     }
     if (std::getenv("MJX_TIMING"))
         std::fprintf(stderr, "[mjx] planning %zu inputs %.2f ms\n", n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
-    for (size_t &pi : ds.plan_index) pi = plan_of[pi];
-    return build_batch(ctx, plans, o, nullptr, 1, out, status, any_stuffed ? &ds : nullptr);
+    (void)plan_of;
+    return build_batch(ctx, plans, o, nullptr, 1, out, status);
     });
 }
 
@@ -1316,9 +1306,21 @@ extern "C" int mjx_batch_tile(mjx_ctx *ctx, const mjx_batch *src, size_t times, 
     // rebuild light-weight plans from the source batch's device images (geometry only; tables stay on the device)
     const size_t nu = src->info.size();
     std::vector<ImagePlan> plans(nu);
+    // scans that were de-stuffed on the device: their length, subsequence count and segment table were written there
+    std::vector<DevImage> dev_images;
+    std::vector<uint32_t> dev_segs;
+    if (src->has_stuffed) {
+        HIPOK(hipSetDevice(src->ctx->device));
+        HIPOK(hipStreamSynchronize(src->ctx->upload));
+        dev_images.resize(nu);
+        dev_segs.resize(src->h_segs.size());
+        HIPOK(hipMemcpy(dev_images.data(), src->d_images, nu * sizeof(DevImage), hipMemcpyDeviceToHost));
+        if (!dev_segs.empty()) HIPOK(hipMemcpy(dev_segs.data(), src->d_segs, dev_segs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    const std::vector<uint32_t> &segs_now = src->has_stuffed ? dev_segs : src->h_segs;
     for (size_t k = 0; k < nu; k++) {
         ImagePlan &p = plans[k];
-        const DevImage &d = src->himages[k];
+        const DevImage &d = src->has_stuffed ? dev_images[k] : src->himages[k];
         p.status = src->info[k].status;
         if (p.status != MJX_OK) continue;
         p.width = d.width; p.height = d.height; p.ncomp = d.ncomp; p.bpm = d.bpm; p.hmax = d.hmax; p.vmax = d.vmax;
@@ -1343,7 +1345,8 @@ extern "C" int mjx_batch_tile(mjx_ctx *ctx, const mjx_batch *src, size_t times, 
             p.src_comp[c] = d.src_comp[c];
             p.src_part[c] = d.nparts - d.src_back[c];
         }
-        p.seg.assign(src->h_segs.begin() + size_t(d.seg_off) * 2, src->h_segs.begin() + size_t(d.seg_off) * 2 + 2 * (size_t(d.nseg) + 1));
+        p.seg.assign(segs_now.begin() + size_t(d.seg_off) * 2, segs_now.begin() + size_t(d.seg_off) * 2 + 2 * (size_t(d.nseg) + 1));
+        p.nsub_layout = src->himages[k].scan_cols;        // (the region the source's pool was laid out for)
         p.scan = nullptr;
         p.scan_len = src->info[k].scan_len;
     }
@@ -1836,7 +1839,7 @@ extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const
     for (size_t i = 0; i < n; i++) total_bytes += lens[i];
     size_t group_bytes = size_t(total_bytes >= (size_t(1536) << 20) ? 192 : 96) << 20;
     if (const char *e = std::getenv("MJX_GROUP_MB")) { const long v = std::atol(e); if (v > 0) group_bytes = size_t(v) << 20; }
-    const bool single = o.keep_coefs || o.device_destuff || n <= 8;
+    const bool single = o.keep_coefs || n <= 8;
     std::vector<size_t> gfirst{0};
     {
         size_t acc = 0, target = single ? ~size_t(0) : std::min(group_bytes / 8, size_t(12) << 20);
@@ -1949,7 +1952,7 @@ extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const
         }
         if (rc != MJX_OK) break;
         constexpr size_t kPinnedPerPart = 8 * kMisWords;
-        rc = build_batch(ctx, plans, o, nullptr, 1, &part, nullptr, nullptr, true, dir->h_mismatch + g * kPinnedPerPart, kPinnedPerPart, &pin, ngroups == 1);
+        rc = build_batch(ctx, plans, o, nullptr, 1, &part, nullptr, true, dir->h_mismatch + g * kPinnedPerPart, kPinnedPerPart, &pin, ngroups == 1);
         if (rc != MJX_OK) break;
         dir->parts.push_back(part);
         if (part->visible.size() != cnt) { rc = MJX_ERR_DEVICE; break; }

@@ -42,6 +42,7 @@ struct DevImage {
     uint32_t nseg;          // 1 = no restart interval
     uint32_t restart_mcus;
     uint32_t ent_cap;       // entries the image's stream region holds
+    uint32_t n_rst_found;   // scans de-stuffed on the device: RSTn markers found (k_destuff_prefix)
     // multi-scan files: role 1 = one scan as a picture of its own (one component in raster order, or two
     // interleaved; entropy stage only; tile = one block, so tile_eoff holds an offset per block), role 2 = the picture
     // (no scan; the k_planar_* kernels build its stream from the role-1 images: component c comes from the image
@@ -64,12 +65,16 @@ struct InterleaveImg {
     uint32_t image;         // index into the DevImage array
 };
 
-// Device-side de-stuffing (jpeg/mod.rs:371-385 on the GPU): one image of an upload.
+// Device-side de-stuffing and marker scan (jpeg/mod.rs:371-385 on the GPU): one scan of an upload.
 constexpr int kDestuffSeg = 16384;       // raw bytes per workgroup
 struct DestuffImg {
-    uint64_t raw_off, raw_len;           // stuffed bytes in the raw staging buffer
-    uint64_t out_off;                    // where the de-stuffed scan goes in the scan pool
-    uint32_t seg0, nseg;                 // this image's slots in the per-segment count / base arrays
+    uint64_t raw_off, raw_len;           // stuffed bytes in the raw staging buffer (64-byte aligned, 64 bytes of padding behind)
+    uint64_t out_off;                    // where the de-stuffed scan goes in the linear staging buffer
+    uint32_t seg0, nseg;                 // this scan's slots in the per-segment count / base arrays (pairs: bytes kept, markers)
+    uint32_t image;                      // its DevImage
+    uint32_t ii_index;                   // its InterleaveImg (receives the de-stuffed length)
+    uint32_t restarts;                   // 1: the picture has restart intervals -- RSTn markers leave the stream and are listed
+    uint32_t rst0, rst_cap;              // the scan's slots in the marker list
 };
 
 // mjx_batch_compare_rgb: one pair of pictures (device pointers: the pictures may live in different pools)
@@ -94,10 +99,11 @@ size_t idct_lds_bytes(uint32_t max_tile_blocks);
 int configure_kernels(size_t huff_lds, size_t idct_lds);
 size_t huff_window_bytes();     // LDS the windowed entropy kernels need on top of huff_lds_bytes()
 size_t huff_stage_bytes();      // ... and the write pass's entry rings
-void launch_destuff_count(hipStream_t st, uint32_t max_seg, uint32_t nimg, const DestuffImg *imgs, const uint8_t *raw,
-                          uint32_t *segcount);
-void launch_destuff_scatter(hipStream_t st, uint32_t max_seg, uint32_t nimg, const DestuffImg *imgs, const uint8_t *raw,
-                            const uint32_t *segbase, uint8_t *pool);
+// count -> prefix (+ geometry into `images`) -> scatter (+ marker list) -> segment tables of the pictures with restart intervals;
+// segcount / segbase: two words per 16 KiB segment of every scan
+void launch_destuff(hipStream_t st, uint32_t max_seg, uint32_t nimg, bool any_restarts, const DestuffImg *imgs, const uint8_t *raw,
+                    uint32_t *segcount, uint32_t *segbase, uint8_t *pool, uint32_t *rst_off, DevImage *images, InterleaveImg *ii,
+                    uint32_t *segs, uint32_t *img_flags);
 void launch_scan_interleave(hipStream_t st, uint32_t max_pieces, uint32_t nimg, const InterleaveImg *imgs, const DevImage *images,
                             const uint8_t *linear, uint8_t *pool, const uint32_t *segs);
 void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,

@@ -760,69 +760,130 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t *s_tm
     return base + incl - v;
 }
 
-// ---- device-side de-stuffing -------------------------------------------------------------------------------
+// ---- device-side de-stuffing and marker scan ------------------------------------------------------------------
 // jpeg/mod.rs:371-385 copies the bytes after the SOS header and drops the 00 of every FF 00 pair.  Whether byte i is
 // dropped depends only on bytes i-1 and i (a dropped byte is 00, so it never starts a pair itself): keep(i) =
-// !(b[i] == 00 && b[i-1] == FF).  So the copy is a stream compaction: count the kept bytes per 16 KiB segment, prefix
-// the counts per image (host, a few dozen numbers per image), then every lane writes the kept bytes of its 64-byte
-// piece at segment base + workgroup-scan offset.  Runs once per upload, before any decode.
+// !(b[i] == 00 && b[i-1] == FF).  With restart intervals (beyond the reference) the RSTn markers leave
+// the stream as well, and that is local too: an FF is never the second byte of a pair the host parser consumes (those
+// are 00 or Dn), so every FF is looked at as a first byte -- FF followed by D0..D7 is a marker, both bytes go, and the
+// number of bytes kept in front of it is where the next interval begins.  So the copy is a stream compaction and the
+// marker list a second one:
+//   k_destuff_count     bytes kept and markers found per 16 KiB segment of every scan
+//   k_destuff_prefix    one workgroup per scan: exclusive sums of both over its segments; the scan's length is known now,
+//                       and with it the picture's geometry -- total_bits, the number of subsequences -- which is written into
+//                       the DevImage the decode kernels read (the host planned with the stuffed length as an upper bound and
+//                       never learns the exact one: nothing waits for the device)
+//   k_destuff_scatter   every lane writes the kept bytes of its 64-byte piece at segment base + workgroup-scan offset,
+//                       and the offsets of its markers into the scan's marker list
+//   k_restart_geometry  scans with restart intervals: the list becomes the picture's segment table (see locate_sub)
+// All of it runs once per upload, before any decode, on the upload stream.
 // keep flags of the 64 bytes [i0, i0+64) of `raw` as a bit mask (+ the bytes themselves in q[0..3]); returns the
-// number of kept bytes.  The raw staging buffer is 64-byte aligned per image and padded by 64 bytes (mjx_batch_create),
-// so the four 16-byte loads of a piece stay inside the image's own region.
+// number of kept bytes.  *rst_out: bit j set = a marker FF Dn begins at byte j (restarts only).  The raw staging buffer is
+// 64-byte aligned per image and padded by 64 bytes (build_batch), so the four 16-byte loads of a piece and the byte behind
+// it stay inside the image's own region.
 __device__ __forceinline__ uint32_t destuff_keep_mask(const uint8_t *raw, uint64_t i0, uint64_t raw_len, uint4 q[4],
-                                                      uint64_t *mask_out)
+                                                      uint64_t *mask_out, bool restarts, uint64_t *rst_out)
 {
-    uint64_t mask = 0;
+    uint64_t mask = 0, rst = 0;
     if (i0 < raw_len) {
         const uint4 *src = reinterpret_cast<const uint4 *>(raw + i0);
 #pragma unroll
         for (int k = 0; k < 4; k++) q[k] = src[k];
         uint32_t prev = i0 > 0 ? raw[i0 - 1] : 0u;
         const uint32_t n = uint32_t(min(uint64_t(64), raw_len - i0));
+        const uint32_t behind = i0 + 64 < raw_len ? raw[i0 + 64] : 0u;       // (a marker may straddle two pieces)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t w[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const uint32_t b = (w[j >> 2] >> ((j & 3) * 8)) & 0xffu;
-                if (!(b == 0x00u && prev == 0xffu) && uint32_t(k * 16 + j) < n) mask |= 1ull << (k * 16 + j);
+                const uint32_t jj = uint32_t(k * 16 + j);
+                const uint32_t next = j < 15 ? (w[(j + 1) >> 2] >> (((j + 1) & 3) * 8)) & 0xffu
+                                             : (k < 3 ? (k == 0 ? q[1].x : k == 1 ? q[2].x : q[3].x) & 0xffu : behind);
+                bool keep = !(b == 0x00u && prev == 0xffu);
+                if (restarts) {
+                    const bool marker = b == 0xffu && (next & 0xf8u) == 0xd0u && jj + 1 < n + (i0 + 64 < raw_len ? 1u : 0u);
+                    if (marker) { keep = false; if (jj < n) rst |= 1ull << jj; }
+                    if ((b & 0xf8u) == 0xd0u && prev == 0xffu) keep = false;
+                }
+                if (keep && jj < n) mask |= 1ull << jj;
                 prev = b;
             }
         }
     }
     *mask_out = mask;
+    *rst_out = rst;
     return uint32_t(__popcll(mask));
 }
 
 extern "C" __global__ __launch_bounds__(256) void k_destuff_count(const DestuffImg *imgs, const uint8_t *raw,
-                                                                   uint32_t *segcount)
+                                                                   uint2 *segcount)
 {
     __shared__ uint32_t s_tmp[4];
     const DestuffImg im = imgs[blockIdx.y];
     if (blockIdx.x >= im.nseg) return;
-    uint64_t mask;
+    uint64_t mask, rst;
     uint4 q[4];
-    const uint32_t cnt = destuff_keep_mask(raw + im.raw_off, uint64_t(blockIdx.x) * kDestuffSeg + threadIdx.x * 64ull, im.raw_len, q, &mask);
-    uint32_t total;
+    const uint32_t cnt = destuff_keep_mask(raw + im.raw_off, uint64_t(blockIdx.x) * kDestuffSeg + threadIdx.x * 64ull, im.raw_len, q, &mask,
+                                           im.restarts != 0, &rst);
+    uint32_t total, total_rst;
     (void)wg_exclusive_scan(cnt, s_tmp, &total);
-    if (threadIdx.x == 0) segcount[im.seg0 + blockIdx.x] = total;
+    (void)wg_exclusive_scan(uint32_t(__popcll(rst)), s_tmp, &total_rst);
+    if (threadIdx.x == 0) segcount[im.seg0 + blockIdx.x] = make_uint2(total, total_rst);
+}
+
+// One workgroup per scan: segment bases, the scan's de-stuffed length, the picture's geometry.
+extern "C" __global__ __launch_bounds__(256) void k_destuff_prefix(const DestuffImg *imgs, const uint2 *segcount, uint2 *segbase,
+                                                                    DevImage *images, InterleaveImg *ii, uint32_t *img_flags)
+{
+    __shared__ uint32_t s_tmp[4];
+    const DestuffImg im = imgs[blockIdx.x];
+    uint32_t run = 0, run_rst = 0;
+    for (uint32_t g0 = 0; g0 < im.nseg; g0 += 256) {
+        const uint32_t g = g0 + threadIdx.x;
+        const uint2 c = g < im.nseg ? segcount[im.seg0 + g] : make_uint2(0u, 0u);
+        uint32_t total, total_rst;
+        const uint32_t ex = wg_exclusive_scan(c.x, s_tmp, &total);
+        const uint32_t exr = wg_exclusive_scan(c.y, s_tmp, &total_rst);
+        if (g < im.nseg) segbase[im.seg0 + g] = make_uint2(run + ex, run_rst + exr);
+        run += total;
+        run_rst += total_rst;
+    }
+    if (threadIdx.x == 0) {
+        DevImage &d = images[im.image];
+        ii[im.ii_index].lin_len = run;
+        d.himg.total_bits = run * 8u;
+        d.n_rst_found = run_rst;
+        if (d.nseg <= 1) d.himg.nsub = (run * 8u + d.himg.sub_bits - 1) / d.himg.sub_bits;      // (else: k_restart_geometry)
+        if (run == 0) img_flags[d.status_idx] = 1u;                        // nothing but stuffing: reported as truncated
+    }
 }
 
 // The workgroup compacts its 16 KiB segment into LDS (each lane drops its kept bytes at its scan offset), then writes
 // the compacted bytes out in lane order, so a wave stores 64 consecutive bytes per instruction.
 extern "C" __global__ __launch_bounds__(256) void k_destuff_scatter(const DestuffImg *imgs, const uint8_t *raw,
-                                                                     const uint32_t *segbase, uint8_t *pool)
+                                                                     const uint2 *segbase, uint8_t *pool, uint32_t *rst_off)
 {
     __shared__ uint32_t s_tmp[4];
     __shared__ uint8_t s_out[kDestuffSeg];
     const DestuffImg im = imgs[blockIdx.y];
     if (blockIdx.x >= im.nseg) return;
     const uint64_t i0 = uint64_t(blockIdx.x) * kDestuffSeg + threadIdx.x * 64ull;
-    uint64_t mask;
+    uint64_t mask, rst;
     uint4 q[4];
-    const uint32_t cnt = destuff_keep_mask(raw + im.raw_off, i0, im.raw_len, q, &mask);
-    uint32_t total;
+    const uint32_t cnt = destuff_keep_mask(raw + im.raw_off, i0, im.raw_len, q, &mask, im.restarts != 0, &rst);
+    const uint2 base = segbase[im.seg0 + blockIdx.x];
+    uint32_t total, total_rst;
     uint32_t o = wg_exclusive_scan(cnt, s_tmp, &total);
+    if (im.restarts) {
+        uint32_t r = base.y + wg_exclusive_scan(uint32_t(__popcll(rst)), s_tmp, &total_rst);
+        for (uint64_t m = rst; m; m &= m - 1) {                             // where the interval behind each marker begins
+            const uint32_t j = uint32_t(__ffsll((long long)m)) - 1u;
+            if (r < im.rst_cap) rst_off[im.rst0 + r] = base.x + o + uint32_t(__popcll(mask & ((1ull << j) - 1ull)));
+            r++;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t w[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
@@ -831,8 +892,45 @@ extern "C" __global__ __launch_bounds__(256) void k_destuff_scatter(const Destuf
             if ((mask >> (k * 16 + j)) & 1) s_out[o++] = uint8_t(w[j >> 2] >> ((j & 3) * 8));
     }
     __syncthreads();
-    uint8_t *dst = pool + im.out_off + segbase[im.seg0 + blockIdx.x];
+    uint8_t *dst = pool + im.out_off + base.x;
     for (uint32_t i = threadIdx.x; i < total; i += 256) dst[i] = s_out[i];
+}
+
+// Restart intervals of a scan that was de-stuffed on the device: the marker list -> the picture's segment table, as
+// plan_image builds it from mjx_scan_desc.restart_offsets on the host -- segs[g] = (first subsequence, first bit) of
+// segment g, a segment of L bits takes ceil(L / sub_bits) subsequences (one when it is empty), and a sentinel (number
+// of subsequences, total bits).  Fewer markers than the picture's MCU count needs: truncated.  One workgroup per picture.
+extern "C" __global__ __launch_bounds__(256) void k_restart_geometry(const DestuffImg *imgs, DevImage *images, const uint32_t *rst_off,
+                                                                      uint32_t *segs, uint32_t *img_flags)
+{
+    __shared__ uint32_t s_tmp[4];
+    const DestuffImg im = imgs[blockIdx.x];
+    if (!im.restarts) return;
+    DevImage &d = images[im.image];
+    const uint32_t nseg = d.nseg, total_bits = d.himg.total_bits, sub_bits = d.himg.sub_bits;
+    const uint32_t found = min(d.n_rst_found, im.rst_cap);
+    uint2 *sg = reinterpret_cast<uint2 *>(segs) + d.seg_off;
+    auto bit0 = [&](uint32_t g) { return g == 0 ? 0u : (g - 1 < found ? min(rst_off[im.rst0 + g - 1] * 8u, total_bits) : total_bits); };
+    uint32_t run = 0;
+    for (uint32_t g0 = 0; g0 < nseg; g0 += 256) {
+        const uint32_t g = g0 + threadIdx.x;
+        uint32_t subs = 0, b0 = 0;
+        if (g < nseg) {
+            b0 = bit0(g);
+            const uint32_t b1 = g + 1 == nseg ? total_bits : bit0(g + 1);
+            const uint32_t len = b1 > b0 ? b1 - b0 : 0u;
+            subs = len ? (len + sub_bits - 1) / sub_bits : 1u;
+        }
+        uint32_t total;
+        const uint32_t ex = wg_exclusive_scan(subs, s_tmp, &total);
+        if (g < nseg) sg[g] = make_uint2(run + ex, b0);
+        run += total;
+    }
+    if (threadIdx.x == 0) {
+        sg[nseg] = make_uint2(run, total_bits);
+        d.himg.nsub = run;
+        if (found + 1 < nseg) img_flags[d.status_idx] = 1u;                 // fewer RSTn markers than intervals
+    }
 }
 
 // ---- lane-interleaved scan pool (see LaneBits) --------------------------------------------------------------------
@@ -2072,16 +2170,22 @@ int configure_kernels(size_t huff_lds, size_t idct_lds)
     return e == hipSuccess ? 0 : int(e);
 }
 
-void launch_destuff_count(hipStream_t st, uint32_t max_seg, uint32_t nimg, const DestuffImg *imgs, const uint8_t *raw,
-                          uint32_t *segcount)
+void launch_destuff(hipStream_t st, uint32_t max_seg, uint32_t nimg, bool any_restarts, const DestuffImg *imgs, const uint8_t *raw,
+                    uint32_t *segcount, uint32_t *segbase, uint8_t *pool, uint32_t *rst_off, DevImage *images, InterleaveImg *ii,
+                    uint32_t *segs, uint32_t *img_flags)
 {
-    hipLaunchKernelGGL(k_destuff_count, dim3(max_seg, nimg), dim3(256), 0, st, imgs, raw, segcount);
-}
-
-void launch_destuff_scatter(hipStream_t st, uint32_t max_seg, uint32_t nimg, const DestuffImg *imgs, const uint8_t *raw,
-                            const uint32_t *segbase, uint8_t *pool)
-{
-    hipLaunchKernelGGL(k_destuff_scatter, dim3(max_seg, nimg), dim3(256), 0, st, imgs, raw, segbase, pool);
+    if (nimg == 0) return;
+    for (uint32_t at = 0; at < nimg; at += 32768) {                          // (a grid's y dimension holds 65 535 images)
+        const uint32_t cnt = std::min<uint32_t>(32768, nimg - at);
+        hipLaunchKernelGGL(k_destuff_count, dim3(max_seg, cnt), dim3(256), 0, st, imgs + at, raw, reinterpret_cast<uint2 *>(segcount));
+    }
+    hipLaunchKernelGGL(k_destuff_prefix, dim3(nimg), dim3(256), 0, st, imgs, reinterpret_cast<const uint2 *>(segcount), reinterpret_cast<uint2 *>(segbase),
+                       images, ii, img_flags);
+    for (uint32_t at = 0; at < nimg; at += 32768) {
+        const uint32_t cnt = std::min<uint32_t>(32768, nimg - at);
+        hipLaunchKernelGGL(k_destuff_scatter, dim3(max_seg, cnt), dim3(256), 0, st, imgs + at, raw, reinterpret_cast<const uint2 *>(segbase), pool, rst_off);
+    }
+    if (any_restarts) hipLaunchKernelGGL(k_restart_geometry, dim3(nimg), dim3(256), 0, st, imgs, images, rst_off, segs, img_flags);
 }
 
 void launch_scan_interleave(hipStream_t st, uint32_t max_pieces, uint32_t nimg, const InterleaveImg *imgs, const DevImage *images,

@@ -267,9 +267,11 @@ size_t read_sos(const ByteView &f, size_t pos, ParserState &st, bool strict, boo
     const size_t remain = i < total ? total - i : 0;
     const uint8_t *src = remain ? f.span(i, remain) : nullptr;
     const bool restarts = st.restart_interval != 0;
-    if (restarts) keep_stuffed = false;                  // the device compaction does not know about RSTn
+    if (strict) keep_stuffed = false;                    // (strict_ref reports the reference's unguarded vec[i + 1]: that takes the byte pass)
+    // keep_stuffed (opts.device_destuff): no pass over the entropy-coded bytes at all -- they are copied as they are, FF00
+    // pairs and RSTn markers included; the device compacts them, lists the markers and works out the scan's length
     size_t max_rst = 0;
-    for (size_t k = 0; restarts && k + 1 < remain; k++) max_rst += (src[k] == 0xff && (src[k + 1] & 0xf8) == 0xd0);
+    for (size_t k = 0; restarts && !keep_stuffed && k + 1 < remain; k++) max_rst += (src[k] == 0xff && (src[k + 1] & 0xf8) == 0xd0);
     const size_t scan_room = (remain + 32 + 3) & ~size_t(3);
     const size_t need = scan_room + max_rst * sizeof(uint32_t) + 4;
     const bool lent = st.lent && need <= st.lent_cap;

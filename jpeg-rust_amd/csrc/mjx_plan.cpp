@@ -84,6 +84,15 @@ static int plan_ref_layout(ImagePlan &p)
 void replan_subsequences(ImagePlan &p, uint32_t base_bits)
 {
     if (p.role == 2 || p.seg.size() < 2 * (size_t(p.nseg) + 1)) return;        // (role 2: no scan of its own)
+    if (p.stuffed) {
+        // the exact length and the restart offsets are only known on the device: an upper bound of the subsequence count
+        // (every segment adds less than one to total / sub_bits) for the host's sizing, the subsequence length itself is final
+        base_bits = std::max<uint32_t>(uint32_t(kCpBits), std::min<uint32_t>(base_bits, uint32_t(kSubseqBits)) / uint32_t(kCpBits) * uint32_t(kCpBits));
+        p.himg.sub_bits = p.nseg == 1 ? choose_subseq_bits(p.himg.total_bits, base_bits) : base_bits;
+        p.himg.nsub = (p.himg.total_bits + p.himg.sub_bits - 1) / p.himg.sub_bits + (p.nseg > 1 ? p.nseg : 0u);
+        for (uint32_t g = 0; g <= p.nseg; g++) { p.seg[2 * size_t(g)] = g == p.nseg ? p.himg.nsub : 0u; p.seg[2 * size_t(g) + 1] = g == p.nseg ? p.himg.total_bits : 0u; }
+        return;
+    }
     base_bits = std::max<uint32_t>(uint32_t(kCpBits), std::min<uint32_t>(base_bits, uint32_t(kSubseqBits)) / uint32_t(kCpBits) * uint32_t(kCpBits));
     const uint32_t top = base_bits * 5 / 4;
     auto bit0 = [&](uint32_t g) { return p.seg[2 * size_t(g) + 1]; };
@@ -143,6 +152,7 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p, bool 
     p.layout = opts.layout;
     p.scan = d.scan;
     p.scan_len = d.scan_len;
+    p.stuffed = d.scan_is_stuffed != 0 && !gather;
     for (uint32_t c = 0; c < p.ncomp; c++) {
         const mjx_comp &k = d.comp[c];
         if (k.h < 1 || k.h > 2 || k.v < 1 || k.v > 2) return fail(MJX_ERR_UNSUPPORTED_FORMAT);   // mod.rs:275-277
@@ -266,8 +276,9 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p, bool 
         // reference panics on DRI (jpeg/mod.rs:424-428).
         if (p.layout == MJX_LAYOUT_REF_COMPAT) return fail(MJX_ERR_DRI_UNSUPPORTED);
         p.nseg = (p.nmcu + p.restart_mcus - 1) / p.restart_mcus;
-        if (d.n_restart + 1 < p.nseg) return fail(MJX_ERR_TRUNCATED);              // fewer RSTn markers than intervals
-        for (uint32_t g = 0; g <= p.nseg; g++) {
+        if (!p.stuffed && d.n_restart + 1 < p.nseg) return fail(MJX_ERR_TRUNCATED);     // fewer RSTn markers than intervals (a stuffed scan: the device counts them)
+        for (uint32_t g = 0; g <= p.nseg && p.stuffed; g++) { p.seg.push_back(0u); p.seg.push_back(0u); }      // placeholder, see replan_subsequences
+        for (uint32_t g = 0; g <= p.nseg && !p.stuffed; g++) {
             const uint64_t byte0 = g == 0 ? 0 : (g - 1 < d.n_restart ? d.restart_offsets[g - 1] : p.scan_len);
             if (byte0 > p.scan_len) return fail(MJX_ERR_INVALID_ARG);
             const uint32_t bit0 = g == p.nseg ? p.himg.total_bits : uint32_t(byte0 * 8);

@@ -30,6 +30,12 @@ struct ImagePlan {
     float qmult[3][64];                            // per component, zig-zag order: q[k] * idct prescale
     const uint8_t *scan = nullptr;
     size_t scan_len = 0;
+    // The scan still holds FF00 pairs (and RSTn markers): it is de-stuffed on the device at upload (k_destuff_*), scan_len is
+    // the stuffed length -- an upper bound; himg.total_bits, himg.nsub and the segment table are bounds and placeholders here,
+    // the device writes the exact values into the DevImage (k_destuff_prefix, k_restart_geometry).
+    bool stuffed = false;
+    uint32_t nsub_layout = 0;                      // subsequences the scan pool region is laid out for (0: himg.nsub; a batch tiled from
+                                                   // one that was de-stuffed on the device keeps the region of the bound)
     // REF_COMPAT placement (decoder.rs:239-250): replication factors per component, block grid of the image
     uint32_t ref_xf[3] = {1, 1, 1}, ref_yf[3] = {1, 1, 1};
     uint32_t nbx = 0, nby = 0;

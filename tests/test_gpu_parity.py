@@ -554,3 +554,89 @@ def test_device_side_destuffing_matches_host_destuffing(mjx, orc, gpu_ctx, data_
             ref = orc.decode(d, layout=orc.LAYOUT_STD)
             _check(ref, batch.coefs(i), batch.rgb(i), "device destuff image %d" % i)
         batch.close()
+
+
+def _hostile_stuffed_variants(mjx, data):
+    """Entropy-coded bytes that tempt a local (per-byte) de-stuffing rule: fill bytes in front of markers, a lone FF at the very
+    end, FF FF 00, markers back to back, a marker as the last two bytes."""
+    sos = data.rfind(b"\xff\xda")
+    hdr_len = int.from_bytes(data[sos + 2:sos + 4], "big")
+    head, body = data[:sos + 2 + hdr_len], data[sos + 2 + hdr_len:]
+    out = [head + body[:-2] + b"\xff", head + body[:-2] + b"\xff\xff\x00\xff\xd9", head + body[:len(body) // 2] + b"\xff",
+           head + body[:-2] + b"\xff\xd0", head + body[:-2] + b"\xff\xff\xd3\xff\xd4\xff\xd9"]
+    k = body.find(b"\xff\x00")
+    if k > 0:
+        out.append(head + body[:k] + b"\xff\xff\x00" + body[k + 2:])          # a fill byte in front of a stuffed FF
+    return out
+
+
+def test_device_side_destuffing_and_marker_scan_through_every_front_door(mjx, orc, gpu_ctx, data_dir):
+    """opts.device_destuff: the host leaves the entropy-coded bytes alone; FF00 compaction, the search for RSTn markers, the
+    scan's length and the geometry that follows from it are the device's (k_destuff_*, k_restart_geometry).  Files with and
+    without restart intervals (one marker per MCU, per row, a handful), multi-scan files (cut apart on the host as before),
+    broken files and hostile byte patterns -- through mjx_decode_batch in one group and pipelined in many, through the batch
+    API (ParsedScan), tiled from a de-stuffed base, and through the pool -- must give what the host-side path gives: the same
+    statuses, the same coefficients, the same bytes."""
+    pil = os.path.join(os.path.dirname(__file__), "golden", "pil")
+    names = sorted(n for n in os.listdir(pil) if n.startswith(("dri_", "ms", "slow_sync")) and n.endswith(".jpg"))
+    assert len([n for n in names if n.startswith("dri_")]) >= 4 and len([n for n in names if n.startswith("ms")]) >= 2
+    datas = [open(os.path.join(pil, n), "rb").read() for n in names]
+    datas += [open(os.path.join(data_dir, n), "rb").read() for n in FIXTURES]
+    datas += [mjx.synth_jpeg(w, h, s, q, seed=i) for i, (w, h, s, q) in enumerate(
+        [(1920, 1080, "420", 95), (640, 480, "444", 98), (64, 64, "gray", 100), (17, 9, "420", 99), (3840, 2160, "420", 75)])]
+    dri = open(os.path.join(pil, "dri_420_r5.jpg"), "rb").read()
+    datas += _hostile_stuffed_variants(mjx, dri) + _hostile_stuffed_variants(mjx, datas[-2])
+    datas += [b"not a jpeg", dri[:len(dri) // 2], dri[:700]]
+    host, st_host = mjx.decode_batch(gpu_ctx, datas, keep_coefs=True)
+    n_ok = sum(1 for s in st_host if s == mjx.OK)
+    assert n_ok >= len(datas) - 8
+    for env in ({}, {"MJX_GROUP_MB": "1"}):
+        os.environ.update(env)
+        try:
+            for keep in (True, False):
+                if env and keep:
+                    continue                                      # (kept coefficients: one group anyway)
+                dev, st_dev = mjx.decode_batch(gpu_ctx, datas, device_destuff=True, keep_coefs=keep, threads=3)
+                assert st_dev == st_host, [(i, a, b) for i, (a, b) in enumerate(zip(st_dev, st_host)) if a != b]
+                ok = [i for i, s in enumerate(st_host) if s == mjx.OK]
+                mx, cnt = dev.compare_rgb(ok, host, ok)
+                assert int(mx.max()) == 0, "pictures %s differ from the host-de-stuffed decode" % [ok[j] for j in np.nonzero(mx)[0][:8]]
+                if keep:
+                    for i in ok:
+                        assert np.array_equal(dev.coefs(i), host.coefs(i)), i
+                dev.close()
+        finally:
+            for k in env:
+                del os.environ[k]
+    # against the oracle (the host path is compared with it elsewhere; here: the device path directly, restart files included)
+    for i in (0, 1, len(names) + 2, len(names) + 4):
+        ref = orc.decode(datas[i], layout=orc.LAYOUT_STD, ext_dri=True, ext_multiscan=True)
+        assert np.array_equal(host.coefs(i), orc.interleave(ref)), i
+    # the batch API: stuffed scans (restart files too), a base that is tiled, REF_COMPAT geometry on a stuffed scan
+    picks = [i for i, s in enumerate(st_host) if s == mjx.OK][:12]
+    scans = [mjx.ParsedScan(datas[i], device_destuff=True) for i in picks]
+    base = mjx.Batch(gpu_ctx, scans)
+    big = base.tile(3)
+    big.decode()
+    big.wait()
+    idx = list(range(len(big)))
+    mx, cnt = big.compare_rgb(idx, host, [picks[i % len(picks)] for i in idx])
+    assert int(mx.max()) == 0
+    big.close()
+    base.close()
+    two = open(os.path.join(data_dir, "2x2-chroma.jpeg"), "rb").read()
+    (ref, coefs, rgb), = _decode_both(mjx, orc, gpu_ctx, [two], layout_std=False)
+    b2 = mjx.Batch(gpu_ctx, [mjx.ParsedScan(two, device_destuff=True)], layout=mjx.LAYOUT_REF_COMPAT)
+    b2.decode()
+    b2.wait()
+    assert b2.status(0) == mjx.OK and np.array_equal(b2.rgb(0), rgb)
+    b2.close()
+    # the pool hands the option to every slot
+    pool = mjx.Pool([0, 0])
+    res = pool.decode_batch(datas, threads_per_device=2, device_destuff=True)
+    assert res.status == st_host
+    for i in picks[:6]:
+        assert np.array_equal(res.rgb(i), host.rgb(i)), i
+    res.close()
+    pool.close()
+    host.close()
