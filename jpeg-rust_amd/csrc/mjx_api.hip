@@ -119,6 +119,7 @@ struct Chunk {
     uint64_t entries = 0, ent_base = 0;   // capacity of the chunk's stream regions; first entry (keep_coefs) or 0
     uint32_t tiles = 0, tile_base = 0;    // tile offsets (+1 sentinel per image)
     uint32_t loop_participants = 0;     // > 0: the merge rounds run as one launch (k_huff_merge_loop) with this many workgroups
+    uint32_t lut2_cap = 0;         // entries of the largest second table set (pair parts, the counting passes)
     uint32_t max_wg = 0, merge_wgs = 0, max_tiles = 0, lut_cap = 0, max_tile_blocks = 0, mode_mask = 0, max_segs = 0, bpm_mask = 0, max_restart_segs = 0;
     uint64_t plane_words = 0;      // REF_COMPAT scratch of the chunk
     uint32_t max_pixel_wgs = 0;
@@ -225,7 +226,7 @@ struct mjx_batch {
     unsigned long long *d_planes = nullptr;   // REF_COMPAT: f32 planes with write-order keys (chunk scratch)
     uint32_t *d_mismatch = nullptr;     // [chunks][kMisWords]: re-decodes of every synchronisation round; [kMaxFix]: set when the one-pass DC prediction gave up
     uint32_t *h_mismatch = nullptr;     // pinned mirror
-    size_t huff_lds = 0, idct_lds = 0;
+    size_t huff_lds = 0, huff_lds2 = 0, idct_lds = 0;      // tables + HuffImage in LDS: the plain set (write pass), the set with pair parts (counting passes)
     bool decoded_entropy = false;
     int last_chunk_resident = -1;
     bool resident_second = false;   // ... and it lives in the second scratch set
@@ -445,6 +446,7 @@ void plan_chunks(mjx_batch *b)
                 }
                 if (d.role == 2) c.has_gather = true;
                 c.lut_cap = std::max<uint32_t>(c.lut_cap, d.lut_n);
+                c.lut2_cap = std::max<uint32_t>(c.lut2_cap, d.lut2_n);
                 c.mode_mask |= 1u << d.mode;
                 c.bpm_mask |= 1u << d.bpm;
                 if (d.nseg > 1) c.max_restart_segs = std::max(c.max_restart_segs, d.nseg);
@@ -476,9 +478,10 @@ int allocate_work_buffers(mjx_batch *b, DevArena &ar)
     uint32_t max_nsub = 1;
     uint64_t max_blocks = 1, total_blocks = 0, max_entries = 4, total_entries = 0;
     uint32_t max_tiles_arr = 1, total_tiles_arr = 0;
-    uint32_t lut_cap = 8, max_tile_blocks = 1;
+    uint32_t lut_cap = 8, lut2_cap = 8, max_tile_blocks = 1;
     size_t max_segsum = 1;
     for (const Chunk &c : b->chunks) {
+        lut2_cap = std::max(lut2_cap, c.lut2_cap);
         max_segsum = std::max<size_t>(max_segsum, size_t(c.max_segs) * c.count);
         max_nsub = std::max(max_nsub, c.nsub);
         max_blocks = std::max(max_blocks, c.blocks);
@@ -566,11 +569,12 @@ int allocate_work_buffers(mjx_batch *b, DevArena &ar)
             if (sel < 0 || sel == k) HIPOK(hipMemsetAsync(bufs[k].p, v, bufs[k].n, b->ctx->upload));
     }
     b->huff_lds = huff_lds_bytes(lut_cap);
+    b->huff_lds2 = huff_lds_bytes(lut2_cap);
     b->idct_lds = idct_lds_bytes(max_tile_blocks);
     if (b->huff_lds + huff_window_bytes() + huff_stage_bytes() > 160 * 1024 || b->idct_lds > 160 * 1024) return MJX_ERR_UNSUPPORTED_FORMAT;
     {
         const size_t pad = std::max(b->ctx->spec_lds_pad, std::max(b->ctx->merge_lds_pad, b->ctx->write_lds_pad));
-        const size_t want_huff = b->huff_lds + huff_window_bytes() + huff_stage_bytes() + pad;
+        const size_t want_huff = std::max(b->huff_lds + huff_window_bytes() + huff_stage_bytes(), b->huff_lds2 + size_t(40) * 1024) + pad;
         const size_t want_idct = b->idct_lds + b->ctx->idct_lds_pad;
         if (want_huff > b->ctx->configured_huff || want_idct > b->ctx->configured_idct) {
             if (configure_kernels(std::max(want_huff, b->ctx->configured_huff), std::max(want_idct, b->ctx->configured_idct)) != 0) { (void)hipGetLastError(); return MJX_ERR_DEVICE; }
@@ -627,7 +631,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     fix_passes = std::min(fix_passes, kMaxFix);
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_SYNC)) {
         prof_begin(b, MJX_K_HUFF_SYNC, st);
-        launch_huff_spec(st, c.max_wg, nimg, b->huff_lds, b->ctx->spec_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps), b->d_segs);
+        launch_huff_spec(st, c.max_wg, nimg, b->huff_lds2, b->ctx->spec_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps), b->d_segs);
         prof_end(b, st);
     }
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_FIX)) {
@@ -635,7 +639,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         if (c.merge_wgs > 0 && c.loop_participants > 0 && fix_passes > 0) {
             // (the count of the last round run lands where the last enqueued round's would: mjx_batch_wait and k_huff_scan look there)
             prof_begin(b, MJX_K_HUFF_FIX, st);
-            launch_huff_merge_loop(st, c.merge_wgs, nimg, b->huff_lds, b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps),
+            launch_huff_merge_loop(st, c.merge_wgs, nimg, b->huff_lds2, b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps),
                                    b->d_mismatch + ci * kMisWords + fix_passes - 1, b->d_segs, b->d_loopctl + ci * 8,
                                    c.loop_participants + (b->ctx->loop_fault ? 1u : 0u), kLoopRounds, b->ctx->loop_fault ? 1u << 12 : 1u << 22);
             prof_end(b, st);
@@ -643,7 +647,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
             HIPOK(hipMemsetAsync(SCR(d_pull), 0, size_t(nimg) * std::max(fix_passes, 1) * sizeof(uint32_t), st));      // the straggler counts of every round
             for (int k = 0; k < fix_passes; k++) {
                 prof_begin(b, MJX_K_HUFF_FIX, st);
-                launch_huff_merge(st, c.merge_wgs, nimg, b->huff_lds, b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps),
+                launch_huff_merge(st, c.merge_wgs, nimg, b->huff_lds2, b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps),
                                   b->d_mismatch + ci * kMisWords + k, SCR(d_items), SCR(d_pull) + size_t(k) * nimg, b->d_segs,
                                   k > 0 ? b->d_mismatch + ci * kMisWords + k - 1 : nullptr);
                 prof_end(b, st);
@@ -852,7 +856,9 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
         d.scan_off = rep * scan_pool + scan_off[k];
         d.scan_cols = scan_region_cols(layout_nsub(p));
         d.lut_off = lut_off[k];
-        d.lut_n = lut_n[k];
+        d.lut_n = p.lut_plain_n;
+        d.lut2_off = lut_off[k] + p.lut_plain_n;
+        d.lut2_n = lut_n[k] - p.lut_plain_n;
         d.qm_off = uint32_t(k * 192);
         d.seg_off = seg_off[k];
         inf.width = p.width; inf.height = p.height; inf.bpm = p.bpm; inf.nmcu = p.nmcu;
@@ -861,11 +867,11 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
         inf.ntiles = uint32_t((inf.nblocks + d.tile_blocks - 1) / d.tile_blocks);
         // every stream entry consumes at least 2 bits of scan (1-bit code + 1 value bit) and a block holds at most 63
         // every subsequence's run of entries is rounded up to a whole 32-byte group (null entries): see k_huff_write
-        const uint64_t group_pad = uint64_t(p.himg.nsub) * 8 + 16;
-        inf.ent_cap = (std::min<uint64_t>(uint64_t(p.scan_len) * 4, inf.nblocks * 63) + group_pad) / 8 * 8;   // regions start on 32-byte sectors
+        const uint64_t group_pad = uint64_t(p.himg.nsub) * stream_group_entries() + 2 * stream_group_entries();
+        inf.ent_cap = (std::min<uint64_t>(uint64_t(p.scan_len) * 4, inf.nblocks * 63) + group_pad) / stream_group_entries() * stream_group_entries();   // regions start on whole store groups
         // with restart intervals the lanes also fill what the synchronisation passes counted after a segment's last block
         // (garbage, up to one entry per two bits of scan)
-        if (p.restart_mcus) inf.ent_cap = (uint64_t(p.scan_len) * 4 + 64 + group_pad) / 8 * 8;
+        if (p.restart_mcus) inf.ent_cap = (uint64_t(p.scan_len) * 4 + 64 + group_pad) / stream_group_entries() * stream_group_entries();
         inf.role = p.role;
         if (p.role == 2) {                     // gathered from the three scans in front of it
             if (i < p.nparts) return MJX_ERR_INVALID_ARG;
@@ -1334,7 +1340,8 @@ extern "C" int mjx_batch_tile(mjx_ctx *ctx, const mjx_batch *src, size_t times, 
         for (uint32_t c = 0; c < 3; c++) { p.ref_xf[c] = d.ref_xf[c]; p.ref_yf[c] = d.ref_yf[c]; }
         p.nbx = d.nbx;
         p.nby = d.nby;
-        p.lut.assign(d.lut_n, 0);                         // sizes only: the pool is copied device-to-device
+        p.lut.assign(size_t(d.lut_n) + d.lut2_n, 0);      // sizes only: the pool is copied device-to-device
+        p.lut_plain_n = d.lut_n;
         p.nseg = d.nseg;
         p.restart_mcus = d.restart_mcus;
         p.role = d.role;

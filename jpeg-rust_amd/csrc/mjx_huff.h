@@ -63,6 +63,11 @@ constexpr int kMaxBlocksPerMcu = 12;           // 3 components x (2x2)
 //             r  = sat_sub(r, e & kLutZincMask)      r is kept scaled by 2^16
 //             value bits = bfe(window, -e, e >> 11)  offset (32 - adv) mod 32 and width size: the low five bits
 //  link   : 1 [31] | byte offset of the sub-table from the table's base [19:4] | nbits [3:0]
+// Pair part (AC tables of an image's second table set): kLutPrimarySize more entries right behind the primary part.  Entry i
+// is the symbol that FOLLOWS the one primary entry i describes, when its code also lies wholly inside the kLutPrimaryBits
+// index bits (first symbol's code and value bits, then the second symbol's code) -- else 0.  The passes that only count
+// (no coefficient values: k_huff_spec, the merge rounds) then take two symbols per step where they can: a third of all steps
+// on photographic content.  Never behind an end-of-block, a link or a bad entry.
 typedef uint32_t LutEntry;
 constexpr uint32_t kLutLink = 0x80000000u;
 constexpr uint32_t kLutXMask = 0x0000011fu, kLutZincMask = 0x007f0000u;
@@ -104,6 +109,8 @@ struct BlockTab {
 };
 struct HuffImage {
     BlockTab btab[kMaxBlocksPerMcu];
+    uint32_t tabs_pair[kMaxBlocksPerMcu];   // BlockTab::tabs for the image's second table set (AC tables with a pair part, see
+                                         // symbol_step), which the passes that only count use
     uint32_t bpm;                        // blocks per MCU
     uint32_t total_bits;                 // scan_len * 8
     uint32_t total_blocks;               // MCUs to decode * bpm
@@ -279,14 +286,18 @@ MJX_HD void lane_begin(LaneState &st, const BitSrc &bits, const HuffImage &img, 
 
 // One Huffman symbol: table lookup, EXTEND, coefficient placement, state update, window refill.
 // Returns true when the lane moved on to the next dword of the stream (the caller then looks at lane_event).
-template <bool WRITE, class BitSrc, class Sink>
+template <bool WRITE, bool PAIR = false, class BitSrc, class Sink>
 MJX_HD bool symbol_step(LaneState &st, BitSrc &bits, const LutEntry *lut, const HuffImage &img, uint32_t &blk,
                         Sink &sink)
 {
+    static_assert(!(WRITE && PAIR), "the pair part carries no value bits: counting passes only");
     const uint32_t w = funnel(st.w0, st.w1, st.x);                                // next 32 bits of the stream
     const uint32_t ahead = bits.ahead(st.wn - 4u);                                // the dword after w1 (see LaneState)
-    const uint32_t base = st.r == kRBlock ? st.dcb : st.acb;                      // (tables are aligned: see lut_slot)
-    LutEntry e = lut_at(lut, lut_slot(base, w));
+    const bool is_dc = st.r == kRBlock;
+    const uint32_t base = is_dc ? st.dcb : st.acb;                                // (tables are aligned: see lut_slot)
+    const uint32_t slot = lut_slot(base, w);
+    LutEntry e = lut_at(lut, slot);
+    LutEntry q = PAIR ? lut_at(lut, slot + uint32_t(kLutPrimarySize * sizeof(LutEntry))) : 0u;     // (one read instruction for both: ds_read2st64_b32)
     if (lut_is_link(e)) {
         const uint32_t nb = e & 15u;
         e = lut_at(lut, base + bits_field(e, 4, 16) + bits_field(w, 32u - kLutPrimaryBits - nb, nb) * 4u);
@@ -295,6 +306,7 @@ MJX_HD bool symbol_step(LaneState &st, BitSrc &bits, const LutEntry *lut, const 
     sink.tick();
     const uint32_t r_old = st.r;
     st.r = sat_sub(st.r, e & kLutZincMask);
+
     if (WRITE) {
         // EXTEND (T.81 F.2, huffman.rs:256-268) without a comparison: g = the value bits sign-extended from their leading
         // bit; flipping everything above them gives the value itself (leading bit 1) or value - 1 (leading bit 0)
@@ -306,6 +318,16 @@ MJX_HD bool symbol_step(LaneState &st, BitSrc &bits, const LutEntry *lut, const 
         else if (e & kLutCnt) sink.ac(blk, st.r, val);
     }
     st.x -= e & kLutXMask;
+    if (PAIR) {
+        // The symbol behind it as well -- unless this one was a DC code (its table has no pair part: what was read is not
+        // one), has just ended the block (the next symbol is a DC code), or took the lane into the next dword: boundaries
+        // (checkpoints, the end of the subsequence) are looked at when a lane moves on to a new dword, and a step that takes
+        // two symbols must see them exactly where single steps would.
+        q = (is_dc || st.r == 0 || (st.x & 0xe0u) != 0) ? 0u : q;
+        st.r = sat_sub(st.r, q & kLutZincMask);
+        st.x -= q & kLutXMask;
+        if (q) sink.tick();
+    }
     if (st.r == 0) {
         st.r = kRBlock;
         st.dcb = st.nb.tabs & 0xffffu;
@@ -406,7 +428,7 @@ MJX_HD void checkpoint_fixup(CpStore &cps, uint32_t k, uint32_t n_total, uint32_
 //   WRITE            -> emit coefficients for blocks < img.total_blocks through `sink`, starting at block `blk`
 //   CP               -> 0: no checkpoints; 1: record checkpoints in `cps`; 2: record and merge with the previous
 //                       decode of this subsequence (`sub_start` = its first bit, `old_exit` = that decode's exit)
-template <bool WRITE, int CP, class BitSrc, class Sink, class CpStore>
+template <bool WRITE, int CP, bool PAIR = false, class BitSrc, class Sink, class CpStore>
 MJX_HD SubseqState decode_subseq(BitSrc bits, const LutEntry *lut, const HuffImage &img, SubseqState entry,
                                  uint32_t end_bit, uint32_t blk, Sink &sink, CpStore &cps, uint32_t sub_start,
                                  SubseqState old_exit)
@@ -418,7 +440,7 @@ MJX_HD SubseqState decode_subseq(BitSrc bits, const LutEntry *lut, const HuffIma
     events_begin<CP>(ev, sub_start, end_bit);
     bool running = !(WRITE && blk >= img.total_blocks);
     while (running) {                               // (one back edge: a second one makes the compiler split the loop)
-        const bool crossed = symbol_step<WRITE>(st, bits, lut, img, blk, sink);
+        const bool crossed = symbol_step<WRITE, PAIR>(st, bits, lut, img, blk, sink);
         bool done = WRITE && blk >= img.total_blocks;
         if (crossed) done = lane_event<CP>(st, ev, img, cps) || done;
         running = !done;
@@ -431,7 +453,8 @@ MJX_HD SubseqState decode_subseq(BitSrc bits, const LutEntry *lut, const HuffIma
 // ---- host-side table construction (mjx_lut.cpp) ---------------------------------------------------
 // Appends the two-level decode table for one DHT table to `out` (LutEntry words) and returns its size in
 // entries, or a negative MJX_ERR_* code.  `is_dc`: symbols are DC size categories (run = 0).
-int build_decode_table(const uint8_t bits[16], const uint8_t *vals, bool is_dc, LutEntry *out, int cap);
+// `pair`: with a pair part behind the primary part (AC tables of the second table set).
+int build_decode_table(const uint8_t bits[16], const uint8_t *vals, bool is_dc, LutEntry *out, int cap, bool pair = false);
 #endif
 
 }   // namespace mjx

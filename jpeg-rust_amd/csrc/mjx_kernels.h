@@ -18,8 +18,9 @@ struct DevImage {
     uint64_t rgb_off;       // bytes into the RGB pool
     uint32_t scan_cols;     // columns of the region = subsequences rounded up to 8 (a row = scan_cols 16-byte pieces);
                             // rows = sub_bits / 128 + kLookPieces
-    uint32_t lut_off;       // entries into the decode-table pool (multiple of 4)
+    uint32_t lut_off;       // entries into the decode-table pool (multiple of 4): the plain table set (write pass)
     uint32_t lut_n;         // entries (multiple of 4)
+    uint32_t lut2_off, lut2_n;   // the set with pair parts (counting passes: k_huff_spec, merge rounds), HuffImage::tabs_pair
     uint32_t sub_off;       // index of subsequence 0 in the per-subsequence arrays
     uint32_t qm_off;        // floats into the dequant-multiplier pool (3 x 64 per image)
     uint32_t width, height, mcux, mcuy, nmcu;
@@ -99,6 +100,7 @@ size_t idct_lds_bytes(uint32_t max_tile_blocks);
 int configure_kernels(size_t huff_lds, size_t idct_lds);
 size_t huff_window_bytes();     // LDS the windowed entropy kernels need on top of huff_lds_bytes()
 size_t huff_stage_bytes();      // ... and the write pass's entry rings
+uint32_t stream_group_entries();    // entries per store group of the write pass: a subsequence's run in the stream is rounded up to whole groups
 // count -> prefix (+ geometry into `images`) -> scatter (+ marker list) -> segment tables of the pictures with restart intervals;
 // segcount / segbase: two words per 16 KiB segment of every scan
 void launch_destuff(hipStream_t st, uint32_t max_seg, uint32_t nimg, bool any_restarts, const DestuffImg *imgs, const uint8_t *raw,

@@ -214,21 +214,24 @@ struct StreamSink {
 // Decode tables + per-image constants into LDS (dynamic LDS: the tables, then HuffImage).  The dynamic LDS of the
 // entropy kernels is declared with the alignment of a primary table (kLutAlign), which lut_slot relies on.
 constexpr uint32_t kLutAlign = kLutPrimarySize * sizeof(LutEntry);
+// PAIR: the image's second table set (AC tables with a pair part), for the passes that take two symbols per step.
+template <bool PAIR = false>
 __device__ __forceinline__ void stage_tables(const DevImage &im, const LutEntry *lut_pool, unsigned char *smem,
                                              const HuffImage *&himg, const LutEntry *&lut)
 {
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    const uint32_t n = PAIR ? im.lut2_n : im.lut_n;
     LutEntry *l = reinterpret_cast<LutEntry *>(smem);
-    HuffImage *h = reinterpret_cast<HuffImage *>(smem + size_t(im.lut_n) * sizeof(LutEntry));
+    HuffImage *h = reinterpret_cast<HuffImage *>(smem + size_t(n) * sizeof(LutEntry));
     for (uint32_t i = tid; i < sizeof(HuffImage) / 4; i += nthr)
         reinterpret_cast<uint32_t *>(h)[i] = reinterpret_cast<const uint32_t *>(&im.himg)[i];
-    const uint4 *lsrc = reinterpret_cast<const uint4 *>(lut_pool + im.lut_off);
+    const uint4 *lsrc = reinterpret_cast<const uint4 *>(lut_pool + (PAIR ? im.lut2_off : im.lut_off));
     uint4 *ldst = reinterpret_cast<uint4 *>(l);
-    for (uint32_t g = tid; g < im.lut_n / 4; g += nthr) ldst[g] = lsrc[g];
+    for (uint32_t g = tid; g < n / 4; g += nthr) ldst[g] = lsrc[g];
     __syncthreads();
     // table offsets -> absolute LDS addresses (see lut_at); the tables come first in the workgroup's LDS, below 64 KiB
     if (tid < uint32_t(kMaxBlocksPerMcu))
-        h->btab[tid].tabs += uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)(l))) * 0x10001u;
+        h->btab[tid].tabs = (PAIR ? h->tabs_pair[tid] : h->btab[tid].tabs) + uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)(l))) * 0x10001u;
     __syncthreads();
     himg = h;
     lut = l;
@@ -340,7 +343,7 @@ __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry,
             window_fill(my_win, g, (st.wn - 4u) & ~15u);                       // (w0, w1 are in registers; wn - 4 is read next)
             win.rp = win_addr + ((st.wn - 4u) & 15u);
         }
-        (void)symbol_step<WRITE>(st, win, lut, h, blk, sink);
+        (void)symbol_step<WRITE, !WRITE>(st, win, lut, h, blk, sink);
         // Events (checkpoints, the end of the subsequence) are due when wn -- it only moves when the lane takes a new
         // dword -- has reached a boundary.  Both are tested on wn alone, as two flat conditions: these loops are bound
         // by scalar-instruction issue (one per SIMD turn), and exec-mask bookkeeping for nested "crossed -> event ->
@@ -372,7 +375,7 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_spec(const DevImage
     if (!im.valid || blockIdx.x * kHuffWg >= im.himg.nsub) return;
     const HuffImage *h;
     const LutEntry *lut;
-    stage_tables(im, lut_pool, smem, h, lut);
+    stage_tables<true>(im, lut_pool, smem, h, lut);
     const uint32_t s = blockIdx.x * kHuffWg + threadIdx.x;
     const bool live = s < h->nsub;
     const LaneBits bits{scan_pool + im.scan_off, (live ? s : 0u) * 16u, im.scan_cols * 16u};
@@ -455,7 +458,7 @@ __device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, c
             if (more) {
                 uint32_t stop_wn = wn_after((it.k + 1) * kCpBits);
                 stop_wn = stop_wn < end_wn ? stop_wn : end_wn;
-                while (st.wn < stop_wn) (void)symbol_step<false>(st, win, lut, h, blk, sink);
+                while (st.wn < stop_wn) (void)symbol_step<false, true>(st, win, lut, h, blk, sink);
                 if (st.wn >= end_wn) {                                     // left the subsequence without merging
                     fin = true;
                     more = false;
@@ -533,7 +536,7 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
     }
     const HuffImage *h;
     const LutEntry *lut;
-    stage_tables(im, lut_pool, smem, h, lut);
+    stage_tables<true>(im, lut_pool, smem, h, lut);
     const unsigned char *bytes = scan_pool + im.scan_off;          // the image's (lane-interleaved) region
     uint32_t *my_win = s_win + tid * kMergeStride;
     for (int slice = 0;; slice++) {
@@ -599,7 +602,7 @@ extern "C" __global__ __launch_bounds__(64) void k_huff_merge_tail(const DevImag
     if (group * 64 >= count) return;
     const HuffImage *h;
     const LutEntry *lut;
-    stage_tables(im, lut_pool, smem, h, lut);
+    stage_tables<true>(im, lut_pool, smem, h, lut);
     const uint32_t j = group * 64 + threadIdx.x;
     if (j >= count) return;
     const uint32_t *slot = g_items + (size_t(im.sub_off) + j) * kItemDwords;
@@ -664,7 +667,7 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge_loop(const D
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const HuffImage *h;
     const LutEntry *lut;
-    stage_tables(im, lut_pool, smem, h, lut);
+    stage_tables<true>(im, lut_pool, smem, h, lut);
     const unsigned char *bytes = scan_pool + im.scan_off;
     uint32_t *my_win = s_win + tid * kMergeStride;
     uint32_t last = 0;
@@ -2150,6 +2153,7 @@ size_t huff_window_bytes() { return size_t(kHuffWg) * kWinStride * 4; }
 size_t huff_stage_bytes() { return size_t(kHuffWg) * (LaneRing<kAcGroup>::kRing + LaneRing<kDcGroup>::kRing) * 4; }    // the write pass's rings
 
 uint32_t tile_mcus_420() { return kTile420; }
+uint32_t stream_group_entries() { return kAcGroup; }
 size_t idct_lds_bytes(uint32_t max_tile_blocks) { return size_t(max_tile_blocks) * kPixStride * 4; }
 
 int configure_kernels(size_t huff_lds, size_t idct_lds)

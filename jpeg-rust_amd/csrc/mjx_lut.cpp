@@ -23,7 +23,7 @@ static LutEntry entry_for_symbol(unsigned len, uint8_t sym, bool is_dc)
     return lut_direct(len, r, s, true);              // includes ZRL (r = 15, s = 0) and the degenerate r/0 symbols
 }
 
-int build_decode_table(const uint8_t bits[16], const uint8_t *vals, bool is_dc, LutEntry *out, int cap)
+int build_decode_table(const uint8_t bits[16], const uint8_t *vals, bool is_dc, LutEntry *out, int cap, bool pair)
 {
     // canonical code assignment
     struct Code { uint16_t code; uint8_t len, sym; };
@@ -44,6 +44,11 @@ int build_decode_table(const uint8_t bits[16], const uint8_t *vals, bool is_dc, 
     if (cap < kLutPrimarySize) return -MJX_ERR_NOMEM;
     for (int k = 0; k < kLutPrimarySize; k++) out[k] = lut_invalid();
     int used = kLutPrimarySize;
+    if (pair) {                                           // the pair part lies right behind the primary part, filled in at the end
+        if (cap < 2 * kLutPrimarySize) return -MJX_ERR_NOMEM;
+        for (int k = 0; k < kLutPrimarySize; k++) out[kLutPrimarySize + k] = 0;
+        used = 2 * kLutPrimarySize;
+    }
 
     // longest code under each primary prefix that needs a sub-table
     uint8_t maxlen[kLutPrimarySize];
@@ -84,6 +89,19 @@ int build_decode_table(const uint8_t bits[16], const uint8_t *vals, bool is_dc, 
     out[bad_at] = lut_invalid();
     for (int k = 0; k < kLutPrimarySize; k++)
         if (out[k] == lut_invalid()) out[k] = lut_link(unsigned(bad_at), 0);
+    if (pair && !is_dc) {
+        for (unsigned i = 0; i < unsigned(kLutPrimarySize); i++) {
+            const LutEntry e1 = out[i];
+            if (lut_is_link(e1) || (e1 & kLutBad)) continue;
+            const unsigned adv1 = e1 & 31u, zinc1 = (e1 >> 16) & 0x7fu;
+            if (zinc1 >= 64u || adv1 >= unsigned(kLutPrimaryBits)) continue;     // end of block: the next symbol is a DC code; or no index bit left
+            const unsigned rem = unsigned(kLutPrimaryBits) - adv1;
+            const LutEntry e2 = out[(i << adv1) & unsigned(kLutPrimarySize - 1)];        // the bits behind the first symbol, zeros behind them
+            if (lut_is_link(e2) || (e2 & kLutBad)) continue;
+            const unsigned len2 = (e2 & 31u) - ((e2 >> 11) & 15u);
+            if (len2 <= rem) out[kLutPrimarySize + i] = e2;                  // its code is all there: the symbol is certain
+        }
+    }
     return used;
 }
 

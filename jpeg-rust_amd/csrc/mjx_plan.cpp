@@ -214,53 +214,74 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p, bool 
     int dc_base[4] = {-1, -1, -1, -1}, ac_base[4] = {-1, -1, -1, -1};
     if (!gather) {
     // decode tables: each distinct (class, slot) used by the scan is built once.  Layout: the primary tables first, each
-    // on a multiple of its size (lut_slot ORs the index into the base), then the sub-tables; a table's links are
-    // relative to its own primary table.
+    // on a multiple of its size (lut_slot ORs the index into the base) -- an AC table of the second set with its pair part
+    // right behind it --, then the sub-tables; a table's links are relative to its own primary table.
+    // Two sets: the plain one for the write pass, and one whose AC tables have a pair part for the passes that only count
+    // (mjx_huff.h); p.lut holds the first, then (from lut_plain_n on) the second.
     p.lut.clear();
-    static thread_local LutEntry tmp[kLutPrimarySize + 4096];
-    std::vector<std::vector<LutEntry>> built;
-    auto add_table = [&](const mjx_hufftab &t, bool is_dc) -> int {
-        const int n = build_decode_table(t.bits, t.vals, is_dc, tmp, int(sizeof tmp / sizeof tmp[0]));
-        if (n < 0) return n;
-        built.emplace_back(tmp, tmp + n);
-        return int(built.size() - 1) * kLutPrimarySize;
-    };
-    for (uint32_t c = 0; c < p.ncomp; c++) {
-        const mjx_comp &k = d.comp[c];
-        if (dc_base[k.td] < 0) {
-            const int b = add_table(d.dc[k.td], true);
-            if (b < 0) return fail(-b);
-            dc_base[k.td] = b;
+    static thread_local LutEntry tmp[2 * kLutPrimarySize + 4096];
+    int dc_base2[4] = {-1, -1, -1, -1}, ac_base2[4] = {-1, -1, -1, -1};
+    auto build_set = [&](bool pair, std::vector<LutEntry> &out, int *dcb, int *acb) -> int {
+        std::vector<std::vector<LutEntry>> built;
+        std::vector<int> units;                              // primary-sized slots the table takes in front (1, or 2 with a pair part)
+        int next_unit = 0;
+        auto add_table = [&](const mjx_hufftab &t, bool is_dc) -> int {
+            const bool with_pair = pair && !is_dc;
+            const int n = build_decode_table(t.bits, t.vals, is_dc, tmp, int(sizeof tmp / sizeof tmp[0]), with_pair);
+            if (n < 0) return n;
+            built.emplace_back(tmp, tmp + n);
+            units.push_back(with_pair ? 2 : 1);
+            const int base = next_unit * kLutPrimarySize;
+            next_unit += units.back();
+            return base;
+        };
+        for (uint32_t c = 0; c < p.ncomp; c++) {
+            const mjx_comp &k = d.comp[c];
+            if (dcb[k.td] < 0) {
+                const int b = add_table(d.dc[k.td], true);
+                if (b < 0) return b;
+                dcb[k.td] = b;
+            }
+            if (acb[k.ta] < 0) {
+                const int b = add_table(d.ac[k.ta], false);
+                if (b < 0) return b;
+                acb[k.ta] = b;
+            }
         }
-        if (ac_base[k.ta] < 0) {
-            const int b = add_table(d.ac[k.ta], false);
-            if (b < 0) return fail(-b);
-            ac_base[k.ta] = b;
-        }
-    }
-    {
-        size_t subs = built.size() * kLutPrimarySize;                                // where the next sub-table region goes
-        p.lut.assign(subs, 0);
+        size_t subs = size_t(next_unit) * kLutPrimarySize;                            // where the next sub-table region goes
+        out.assign(subs, 0);
+        size_t own = 0;
         for (size_t k = 0; k < built.size(); k++) {
             const std::vector<LutEntry> &t = built[k];
-            const size_t own = k * kLutPrimarySize;
-            for (int i = 0; i < kLutPrimarySize; i++) {
+            const size_t front = size_t(units[k]) * kLutPrimarySize;
+            for (size_t i = 0; i < front; i++) {
                 LutEntry e = t[i];
-                if (lut_is_link(e)) e = lut_link(unsigned(lut_link_offset(e) - kLutPrimarySize + subs - own), e & 15u);
-                p.lut[own + i] = e;
+                if (i < size_t(kLutPrimarySize) && lut_is_link(e)) e = lut_link(unsigned(lut_link_offset(e) - front + subs - own), e & 15u);
+                out[own + i] = e;
             }
-            p.lut.insert(p.lut.end(), t.begin() + kLutPrimarySize, t.end());
-            subs += t.size() - kLutPrimarySize;
+            out.insert(out.end(), t.begin() + long(front), t.end());
+            subs += t.size() - front;
+            own += front;
         }
+        // table offsets become 16-bit LDS addresses on the device; four tables of a baseline scan need < 24 KB
+        if (out.size() * sizeof(LutEntry) > 0x7fff) return -MJX_ERR_BAD_HUFFMAN;
+        while (out.size() % 4) out.push_back(0);                                      // 16-byte granules for staging
+        return 0;
+    };
+    {
+        std::vector<LutEntry> second;
+        int rc1 = build_set(false, p.lut, dc_base, ac_base);
+        if (rc1 == 0) rc1 = build_set(true, second, dc_base2, ac_base2);
+        if (rc1 < 0) return fail(-rc1);
+        p.lut_plain_n = uint32_t(p.lut.size());
+        p.lut.insert(p.lut.end(), second.begin(), second.end());
     }
-    // table offsets become 16-bit LDS addresses on the device; four tables of a baseline scan need < 24 KB
-    if (p.lut.size() * sizeof(LutEntry) > 0x7fff) return fail(MJX_ERR_BAD_HUFFMAN);
-    while (p.lut.size() % 4) p.lut.push_back(0);                                    // 16-byte granules for staging
     std::memset(&p.himg, 0, sizeof p.himg);
     for (uint32_t b = 0; b < p.bpm; b++) {
         const mjx_comp &k = d.comp[p.blk_comp[b]];
         p.himg.btab[b].tabs = uint32_t(dc_base[k.td]) * uint32_t(sizeof(LutEntry)) | (uint32_t(ac_base[k.ta]) * uint32_t(sizeof(LutEntry)) << 16);
         p.himg.btab[b].next = b + 1 == p.bpm ? 0 : b + 1;
+        p.himg.tabs_pair[b] = uint32_t(dc_base2[k.td]) * uint32_t(sizeof(LutEntry)) | (uint32_t(ac_base2[k.ta]) * uint32_t(sizeof(LutEntry)) << 16);
     }
     p.himg.bpm = p.bpm;
     p.himg.total_bits = uint32_t(p.scan_len * 8);

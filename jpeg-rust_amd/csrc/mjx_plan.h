@@ -26,7 +26,8 @@ struct ImagePlan {
     uint8_t blk_bx[kMaxBlocksPerMcu] = {0};        //                       -> block column inside the MCU
     uint8_t blk_by[kMaxBlocksPerMcu] = {0};        //                       -> block row inside the MCU
     HuffImage himg{};
-    std::vector<LutEntry> lut;                     // all decode tables of the image, concatenated
+    std::vector<LutEntry> lut;                     // all decode tables of the image, concatenated: the plain set (what the write pass
+    uint32_t lut_plain_n = 0;                      // uses), then from lut_plain_n on the set with pair parts (the counting passes)
     float qmult[3][64];                            // per component, zig-zag order: q[k] * idct prescale
     const uint8_t *scan = nullptr;
     size_t scan_len = 0;

@@ -99,6 +99,11 @@ extern "C" int emul_decode_coefs_sub(const uint8_t *jpeg, size_t len, int layout
     if (sub_base_bits) replan_subsequences(plan, sub_base_bits);
     if (plan.restart_mcus) { mjx_free_scan(&d); return MJX_ERR_DRI_UNSUPPORTED; }   // (restart intervals: GPU tests only)
     const HuffImage &img = plan.himg;
+    // the counting passes (k_huff_spec, the merge rounds) use the image's second table set: AC tables with a pair part, two
+    // symbols per step where they can (mjx_huff.h); the write pass the plain one
+    HuffImage img2 = img;
+    for (uint32_t k = 0; k < uint32_t(kMaxBlocksPerMcu); k++) img2.btab[k].tabs = img.tabs_pair[k];
+    const LutEntry *lut2 = plan.lut.data() + plan.lut_plain_n;
     const HostBits bits{plan.scan, plan.scan_len};
     const uint32_t nsub = img.nsub;
     std::vector<SubseqState> g_entry(nsub), g_exit(nsub);
@@ -115,7 +120,7 @@ extern "C" int emul_decode_coefs_sub(const uint8_t *jpeg, size_t len, int layout
         const SubseqState e = make_state(s * img.sub_bits, 0, 0);
         HostCps hc{g_cps.data() + size_t(s) * kMaxCp * 2};
         const long t0 = ns.ticks;
-        g_exit[s] = decode_subseq<false, 1>(bits, plan.lut.data(), img, e, end_of(s), 0, ns, hc, s * img.sub_bits, e);
+        g_exit[s] = decode_subseq<false, 1, true>(bits, lut2, img2, e, end_of(s), 0, ns, hc, s * img.sub_bits, e);
         g_entry[s] = e;
         iter_ticks[0].push_back(ns.ticks - t0);
     }
@@ -131,7 +136,7 @@ extern "C" int emul_decode_coefs_sub(const uint8_t *jpeg, size_t len, int layout
             g_entry[s] = e;
             HostCps hc{g_cps.data() + size_t(s) * kMaxCp * 2};
             const long t0 = ns.ticks;
-            g_exit[s] = decode_subseq<false, 2>(bits, plan.lut.data(), img, e, end_of(s), 0, ns, hc, s * img.sub_bits, g_exit[s]);
+            g_exit[s] = decode_subseq<false, 2, true>(bits, lut2, img2, e, end_of(s), 0, ns, hc, s * img.sub_bits, g_exit[s]);
             iter_ticks.back().push_back(ns.ticks - t0);
             redone++;
         }
