@@ -649,7 +649,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
                 prof_begin(b, MJX_K_HUFF_FIX, st);
                 launch_huff_merge(st, c.merge_wgs, nimg, b->huff_lds2, b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps),
                                   b->d_mismatch + ci * kMisWords + k, SCR(d_items), SCR(d_pull) + size_t(k) * nimg, b->d_segs,
-                                  k > 0 ? b->d_mismatch + ci * kMisWords + k - 1 : nullptr);
+                                  k > 0 ? b->d_mismatch + ci * kMisWords + k - 1 : nullptr, k == 0 && (phases & PH_SYNC));
                 prof_end(b, st);
             }
         }

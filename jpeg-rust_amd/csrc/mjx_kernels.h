@@ -114,7 +114,8 @@ void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tab
 void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                        const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
                        uint32_t *cps, uint32_t *mismatches, uint32_t *items, uint32_t *item_count, const uint32_t *segs,
-                       const uint32_t *prev_mismatches /* count of the round before, or null for the first */);
+                       const uint32_t *prev_mismatches /* count of the round before, or null for the first */,
+                       bool first_round /* most subsequences re-decode: the workgroups run their first slices in place */);
 // The merge rounds of a small chunk in one launch (device-wide barrier between rounds); `participants` = the workgroups (x, image)
 // with x * merge_wg_lanes() + 1 < nsub(image): all of them must be resident at once (the caller checks against merge_loop_capacity()).
 void launch_huff_merge_loop(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,

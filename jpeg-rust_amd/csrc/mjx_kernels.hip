@@ -404,13 +404,16 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_spec(const DevImage
 // window and rebuilds the decoder registers from p, z, c.
 // The slowest few per cent of the items need all sixteen slices; left in place they would hold their workgroup's
 // LDS (and with it the CU's occupancy) for a single wave's worth of work.  So k_huff_merge runs kHeadSlices slices and
-// appends what is still unfinished to a per-image list in HBM; k_huff_merge_tail picks the lists up with one-wave
-// workgroups (ten per CU) and runs every item to its end.
+// appends what is still unfinished to a per-image list in HBM; k_huff_merge_tail picks the lists up with small
+// workgroups that hold nothing but the tables and a window per lane (five of 256 lanes per CU) and runs every item to its end.
 constexpr int kMergeWin = 16, kMergeStride = kMergeWin + 1, kItemDwords = 6;    // four pieces: a slice touches < 56 bytes from a 16-byte boundary
 #ifndef MJX_HEAD_SLICES
 #define MJX_HEAD_SLICES 6
 #endif
 constexpr int kHeadSlices = MJX_HEAD_SLICES;
+#ifndef MJX_LATER_HEAD_SLICES
+#define MJX_LATER_HEAD_SLICES 0
+#endif
 struct MergeItem { uint32_t s, p, zc, n, m, k; };
 constexpr uint32_t kSliceCps = kCpBits >= 256 ? 1u : 256u / uint32_t(kCpBits);
 
@@ -502,7 +505,8 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
                                                                 const LutEntry *lut_pool, SubseqState *g_entry,
                                                                 SubseqState *g_exit, uint32_t *g_cps, uint32_t *mismatches,
                                                                 uint32_t win_off, uint32_t *g_items, uint32_t *g_item_count,
-                                                                const uint32_t *segs, const uint32_t *prev_mismatches)
+                                                                const uint32_t *segs, const uint32_t *prev_mismatches,
+                                                                uint32_t head_slices)
 {
     // A round behind one that re-decoded nothing has nothing to do either (the fixed point is reached): it leaves at
     // once, its own count stays zero, and so does every later round's.  That makes spare rounds nearly free (a launch),
@@ -534,12 +538,30 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
         if (tid == 0) atomicAdd(mismatches, any);                          // one atomic per workgroup, not per wave: all of them hit one word
         __syncthreads();                                                   // (s_cnt is written again in the slice loop)
     }
+    auto hand_over = [&](unsigned long long mask, uint32_t rank) {      // the wave's unfinished items -> k_huff_merge_tail
+        uint32_t base = 0;
+        if (lane == 0 && mask) base = atomicAdd(g_item_count + blockIdx.y, uint32_t(__popcll(mask)));
+        base = __shfl(base, 0);
+        if (active) {
+            uint32_t *slot = g_items + (size_t(im.sub_off) + base + rank) * kItemDwords;
+            slot[0] = it.s; slot[1] = it.p; slot[2] = it.zc; slot[3] = it.n; slot[4] = it.m; slot[5] = it.k;
+        }
+    };
+    // Rounds behind the first re-decode a few per cent of the subsequences: a workgroup would stage its tables and sit through
+    // its slices for a handful of lanes (the second round took 0.27 ms per 1024 pictures, over half of the first one's, for a
+    // twentieth of its items).  With head_slices == 0 the round only finds its items; k_huff_merge_tail, whose
+    // workgroups take them packed, does all the decoding.
+    if (head_slices == 0) {
+        const unsigned long long mask = __ballot(active);
+        hand_over(mask, __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u)));
+        return;
+    }
     const HuffImage *h;
     const LutEntry *lut;
     stage_tables<true>(im, lut_pool, smem, h, lut);
     const unsigned char *bytes = scan_pool + im.scan_off;          // the image's (lane-interleaved) region
     uint32_t *my_win = s_win + tid * kMergeStride;
-    for (int slice = 0;; slice++) {
+    for (uint32_t slice = 0;; slice++) {
         if (active) {
             SubseqState x;
             if (merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x, segs)) {
@@ -549,14 +571,8 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
         }
         const unsigned long long mask = __ballot(active);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
-        if (slice + 1 == kHeadSlices) {                                    // hand the stragglers to k_huff_merge_tail
-            uint32_t base = 0;
-            if (lane == 0 && mask) base = atomicAdd(g_item_count + blockIdx.y, uint32_t(__popcll(mask)));
-            base = __shfl(base, 0);
-            if (active) {
-                uint32_t *slot = g_items + (size_t(im.sub_off) + base + rank) * kItemDwords;
-                slot[0] = it.s; slot[1] = it.p; slot[2] = it.zc; slot[3] = it.n; slot[4] = it.m; slot[5] = it.k;
-            }
+        if (slice + 1 == head_slices) {                                    // hand the stragglers to k_huff_merge_tail
+            hand_over(mask, rank);
             break;
         }
         // pack the unfinished items into the lowest lanes
@@ -584,13 +600,17 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
     }
 }
 
-extern "C" __global__ __launch_bounds__(64) void k_huff_merge_tail(const DevImage *images, const uint8_t *scan_pool,
+#ifndef MJX_TAIL_WG
+#define MJX_TAIL_WG 256
+#endif
+constexpr uint32_t kTailWg = MJX_TAIL_WG;      // lanes per workgroup (measured 64 / 128 / 256: 2.50 / 2.30 / 2.20 ms of merge rounds per 2048 pictures)
+extern "C" __global__ __launch_bounds__(kTailWg) void k_huff_merge_tail(const DevImage *images, const uint8_t *scan_pool,
                                                                     const LutEntry *lut_pool, SubseqState *g_exit,
                                                                     uint32_t *g_cps, uint32_t win_off,
                                                                     const uint32_t *g_items, const uint32_t *g_item_count,
                                                                     const uint32_t *segs)
 {
-    extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, 64 windows
+    extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, a window per lane
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
     // Workgroup (image, group): the image is the fast grid dimension, so that the groups that have items -- the first
     // few of every image -- are consecutive workgroup ids and spread over all XCDs and CUs; with the group as the fast
@@ -599,11 +619,11 @@ extern "C" __global__ __launch_bounds__(64) void k_huff_merge_tail(const DevImag
     const DevImage &im = images[img];
     if (!im.valid) return;
     const uint32_t count = g_item_count[img];
-    if (group * 64 >= count) return;
+    if (group * kTailWg >= count) return;
     const HuffImage *h;
     const LutEntry *lut;
     stage_tables<true>(im, lut_pool, smem, h, lut);
-    const uint32_t j = group * 64 + threadIdx.x;
+    const uint32_t j = group * kTailWg + threadIdx.x;
     if (j >= count) return;
     const uint32_t *slot = g_items + (size_t(im.sub_off) + j) * kItemDwords;
     MergeItem it{slot[0], slot[1], slot[2], slot[3], slot[4], slot[5]};
@@ -2210,13 +2230,14 @@ void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tab
 void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                        const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
                        uint32_t *cps, uint32_t *mismatches, uint32_t *items, uint32_t *item_count, const uint32_t *segs,
-                       const uint32_t *prev_mismatches)
+                       const uint32_t *prev_mismatches, bool first_round)
 {
     // (item_count: this round's straggler counts, one per image, zeroed by the caller -- one memset for all the rounds of a chunk)
     const size_t lds = tables_lds + size_t(kMergeWg) * kMergeStride * 4 + (kMergeWg / 64) * 4 + pad_lds;
-    hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches, uint32_t(tables_lds), items, item_count, segs, prev_mismatches);
-    const size_t tail_lds = tables_lds + size_t(64) * kMergeStride * 4;
-    hipLaunchKernelGGL(k_huff_merge_tail, dim3(nimg, max_wg * (kMergeWg / 64)), dim3(64), tail_lds, st, images, scan_pool, lut_pool, exit_, cps, uint32_t(tables_lds), items, item_count, segs);
+    hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches, uint32_t(tables_lds), items, item_count, segs, prev_mismatches,
+                       first_round ? uint32_t(kHeadSlices) : uint32_t(MJX_LATER_HEAD_SLICES));
+    const size_t tail_lds = tables_lds + size_t(kTailWg) * kMergeStride * 4;
+    hipLaunchKernelGGL(k_huff_merge_tail, dim3(nimg, max_wg * (kMergeWg / kTailWg)), dim3(kTailWg), tail_lds, st, images, scan_pool, lut_pool, exit_, cps, uint32_t(tables_lds), items, item_count, segs);
 }
 
 void launch_huff_merge_loop(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,

@@ -1,8 +1,8 @@
 #!/bin/bash
 # One GPU-box call that produces everything profiles/<round>_* is built from (run through gpurun from the repo root):
-#   tools/profile_round.sh r02
-# the default bench line (two streams, parity gate, extra configs, CPU baseline), rocprofv3 kernel stats of the 4K run with one
-# and with two streams, HBM traffic counters (FETCH_SIZE / WRITE_SIZE in separate passes, one launch per kernel) and the SQ
+#   tools/profile_round.sh r03
+# the default bench line (the library's default streams: three, parity gate, extra configs, CPU baseline), rocprofv3 kernel stats of the 4K run with one
+# and with the default streams, HBM traffic counters (FETCH_SIZE / WRITE_SIZE in separate passes, one launch per kernel) and the SQ
 # counters in two passes (one stream: per-kernel counters are only meaningful without overlap).
 R=$1
 O=gpurun_out/$R; mkdir -p $O
@@ -22,9 +22,12 @@ unset MJX_STREAMS
 python3 tools/single_image_times.py > $O/single_images.txt 2>&1
 python3 tools/e2e_from_files.py 512 0 > $O/e2e_512.txt 2>&1
 python3 tools/e2e_from_files.py 2048 0 > $O/e2e_2048.txt 2>&1
+python3 tools/e2e_from_files.py 512 0 1 > $O/e2e_512_device_destuff.txt 2>&1
+python3 tools/e2e_from_files.py 2048 0 1 > $O/e2e_2048_device_destuff.txt 2>&1
+python3 tools/batch_size_sweep.py > $O/batch_size_sweep.txt 2>&1
 python3 tools/collect_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/traffic.json 256 > /dev/null
 python3 tools/pmc_summary.py $O/pmc_sqA/*counter_collection.csv $O/pmc_sqB/*counter_collection.csv > $O/pmc_sq_summary.txt 2>&1
-cp $O/stats2/*kernel_stats.csv $O/kernel_stats_2048x4K_2streams.csv 2>/dev/null
+cp $O/stats2/*kernel_stats.csv $O/kernel_stats_2048x4K_default_streams.csv 2>/dev/null
 cp $O/stats1/*kernel_stats.csv $O/kernel_stats_2048x4K_1stream.csv 2>/dev/null
 rm -rf $O/pmc_*/ $O/stats1 $O/stats2
 ls -la $O | head -30; tail -1 $O/bench_2048x4K.json | cut -c1-600
