@@ -219,7 +219,8 @@ struct mjx_batch {
     uint32_t *d_ebase = nullptr;        // per subsequence: stream entries before it
     uint32_t *d_img_entries = nullptr;  // per image: entries counted by the synchronisation passes
     uint32_t *d_img_flags = nullptr;    // per image: 1 = scan ends before all MCUs (truncated), set by k_huff_scan
-    int32_t *d_dc = nullptr;            // per block: DC difference, then (after k_dc_apply) the predicted DC
+    int32_t *d_dc = nullptr;            // per block: the predicted DC (what stage B reads)
+    int16_t *d_dcd = nullptr;           // per block: the DC difference as the write pass decoded it (what the prediction kernels read)
     uint8_t *d_rgb = nullptr;
     size_t rgb_pool_bytes = 0;
     int *d_status = nullptr;
@@ -235,6 +236,7 @@ struct mjx_batch {
         SubseqState *d_entry = nullptr, *d_exit = nullptr;
         uint32_t *d_blkbase = nullptr, *d_ebase = nullptr, *d_cps = nullptr, *d_pull = nullptr, *d_items = nullptr;
         int32_t *d_segsum = nullptr, *d_dc = nullptr;
+        int16_t *d_dcd = nullptr;
         unsigned long long *d_planes = nullptr;
         uint32_t *d_entries = nullptr, *d_tile_eoff = nullptr;
     } alt;
@@ -514,6 +516,7 @@ int allocate_work_buffers(mjx_batch *b, DevArena &ar)
     ar.take(&b->d_tile_eoff, size_t(b->opts.keep_coefs ? std::max<uint32_t>(total_tiles_arr, 1) : max_tiles_arr) * 4 + 16);
     ar.take(&b->d_ebase, size_t(max_nsub) * sizeof(uint32_t));
     ar.take(&b->d_dc, size_t(coef_blocks) * sizeof(int32_t) + 64);
+    ar.take(&b->d_dcd, size_t(coef_blocks) * sizeof(int16_t) + 64);
     ar.take(&b->d_rgb, std::max<size_t>(b->rgb_pool_bytes, 16));
     // (d_img_entries, d_img_flags, d_status: laid out by build_batch inside the block of small pools, whose upload clears them)
     const size_t mm = std::max<size_t>(b->chunks.size(), 1) * kMisWords * sizeof(uint32_t);
@@ -538,11 +541,12 @@ int allocate_work_buffers(mjx_batch *b, DevArena &ar)
         for (const Chunk &c : b->chunks) max_planes = std::max(max_planes, c.plane_words);
         if (max_planes) ar.take(&a.d_planes, size_t(max_planes) * 8);
         if (b->opts.keep_coefs) {
-            a.d_entries = b->d_entries; a.d_tile_eoff = b->d_tile_eoff; a.d_dc = b->d_dc;
+            a.d_entries = b->d_entries; a.d_tile_eoff = b->d_tile_eoff; a.d_dc = b->d_dc; a.d_dcd = b->d_dcd;
         } else {
             ar.take(&a.d_entries, size_t(max_entries) * 4 + 64);
             ar.take(&a.d_tile_eoff, size_t(max_tiles_arr) * 4 + 16);
             ar.take(&a.d_dc, size_t(coef_blocks) * sizeof(int32_t) + 64);
+            ar.take(&a.d_dcd, size_t(coef_blocks) * sizeof(int16_t) + 64);
         }
     }
     if (ar.measuring) return MJX_OK;
@@ -564,6 +568,7 @@ int allocate_work_buffers(mjx_batch *b, DevArena &ar)
             {b->d_entries, size_t(b->opts.keep_coefs ? std::max<uint64_t>(total_entries, 4) : max_entries) * 4 + 64},      // 7
             {b->d_tile_eoff, size_t(b->opts.keep_coefs ? std::max<uint32_t>(total_tiles_arr, 1) : max_tiles_arr) * 4 + 16},   // 8
             {b->d_dc, size_t(coef_blocks) * sizeof(int32_t) + 64},                // 9
+            {b->d_dcd, size_t(coef_blocks) * sizeof(int16_t) + 64},               // 10
         };
         for (int k = 0; k < int(sizeof bufs / sizeof bufs[0]); k++)
             if (sel < 0 || sel == k) HIPOK(hipMemsetAsync(bufs[k].p, v, bufs[k].n, b->ctx->upload));
@@ -667,10 +672,10 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         prof_end(b, st);
         prof_begin(b, MJX_K_HUFF_WRITE, st);
         launch_huff_write(st, c.max_wg, nimg, b->huff_lds, b->ctx->write_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_blkbase), SCR(d_ebase),
-                              SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_status, b->d_img_flags, b->d_segs, SCR(d_exit));
+                              SCR(d_entries), SCR(d_tile_eoff), SCR(d_dcd), b->d_status, b->d_img_flags, b->d_segs, SCR(d_exit));
         prof_end(b, st);
         prof_begin(b, MJX_K_DC_SCAN, st);
-        launch_dc_scan(st, c.max_segs, nimg, imgs, dcb, SCR(d_segsum), b->d_img_flags, c.bpm_mask, c.max_restart_segs,
+        launch_dc_scan(st, c.max_segs, nimg, imgs, SCR(d_dcd), dcb, SCR(d_segsum), b->d_img_flags, c.bpm_mask, c.max_restart_segs,
                        (b->ctx->dc_one_pass && !b->dc_two_pass) ? b->d_segflag[set] : nullptr, ++b->dc_gen[set],
                        b->d_mismatch + ci * kMisWords + kMaxFix, b->ctx->dc_fault ? 1u << 10 : 1u << 20, b->ctx->dc_fault);
         prof_end(b, st);

@@ -128,8 +128,8 @@ void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, con
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                        const uint8_t *scan_pool, const LutEntry *lut_pool, const SubseqState *entry,
                        const uint32_t *blkbase, const uint32_t *ebase, uint32_t *entries, uint32_t *tile_eoff,
-                       int32_t *dcbuf, int *status, const uint32_t *img_flags, const uint32_t *segs, const SubseqState *exit_);
-void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int32_t *dcbuf,
+                       int16_t *dcdiff, int *status, const uint32_t *img_flags, const uint32_t *segs, const SubseqState *exit_);
+void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, const int16_t *dcdiff, int32_t *dcbuf,
                     int32_t *segsum, const uint32_t *img_flags, uint32_t bpm_mask, uint32_t max_restart_segs,
                     uint32_t *segflag = nullptr, uint32_t gen = 0,
                     uint32_t *fail = nullptr /* device word, set when the one-pass kernel gave up waiting */, uint32_t spin_limit = 1u << 20,

@@ -159,6 +159,51 @@ struct LaneRing {
     }
 };
 
+// The DC differences leave as 16-bit words (round 3; int32 before): what EXTEND returns is an i16 in the reference as well
+// (huffman.rs:256-268).  A lane's run in the per-block array fills an eighth as fast as its run of stream entries -- a
+// 16-byte group per ~20 symbols, a 128-byte line per 160 -- so practically every group reaches HBM as a partial write of its
+// own: with no DC output at all the write pass takes 8.7 instead of 10.7 ms per 2048 pictures, with every second difference
+// dropped 9.9.  Halfwords halve the groups for the same 32 bytes of ring per lane; the prediction kernels read them and write
+// the int32 predictions stage B reads into a second array (same indexing), so a repair run finds the differences intact.
+struct DcRing16 {
+    static constexpr uint32_t kRing = 16, kGroup = 8;     // halfwords: 32 bytes of LDS per lane, 16-byte groups
+    uint16_t *ring;
+    int16_t *out;           // the image's region (aligned to kGroup halfwords)
+    uint32_t off, flushed;  // block indices: next, first not yet in HBM
+    __device__ __forceinline__ void begin(uint32_t *lds, int16_t *region, uint32_t first)
+    {
+        ring = reinterpret_cast<uint16_t *>(lds);
+        out = region;
+        off = flushed = first;
+    }
+    __device__ __forceinline__ void push(int v)
+    {
+        ring[off & (kRing - 1)] = uint16_t(v);
+        off++;
+    }
+    __device__ __forceinline__ void flush_groups()
+    {
+        while (__builtin_amdgcn_ballot_w64((flushed & (kGroup - 1)) != 0 && flushed < off)) {      // up to the first group boundary
+            if ((flushed & (kGroup - 1)) != 0 && flushed < off) {
+                out[flushed] = int16_t(ring[flushed & (kRing - 1)]);
+                flushed++;
+            }
+        }
+        while (__builtin_amdgcn_ballot_w64((flushed & (kGroup - 1)) == 0 && flushed + kGroup <= off)) {
+            if ((flushed & (kGroup - 1)) == 0 && flushed + kGroup <= off) {
+                *reinterpret_cast<uint4 *>(out + flushed) = *reinterpret_cast<const uint4 *>(ring + (flushed & (kRing - 1)));
+                flushed += kGroup;
+            }
+        }
+    }
+    __device__ __forceinline__ void flush_all()
+    {
+        flush_groups();
+        for (uint32_t i = flushed; i < off; i++) out[i] = int16_t(ring[i & (kRing - 1)]);
+        flushed = off;
+    }
+};
+
 // Sink of the write pass: the compact coefficient stream (see coef_entry), DC differences (one per block), tile
 // offsets.  A symbol adds at most one stream entry, a block takes at least two symbols: the rings below hold.
 #ifndef MJX_AC_GROUP
@@ -167,12 +212,12 @@ struct LaneRing {
 #ifndef MJX_DC_GROUP
 #define MJX_DC_GROUP 4
 #endif
-constexpr uint32_t kAcGroup = MJX_AC_GROUP, kDcGroup = MJX_DC_GROUP;                 // 32-byte sectors of entries, 16 bytes of DC differences
-static_assert(kAcGroup >= kFlushEvery && 2 * kDcGroup >= kFlushEvery, "ring capacity between two flushes");
+constexpr uint32_t kAcGroup = MJX_AC_GROUP;                                          // 32-byte sectors of entries
+static_assert(kAcGroup >= kFlushEvery && 2 * (DcRing16::kRing - DcRing16::kGroup) >= kFlushEvery, "ring capacity between two flushes (a block takes two symbols at least)");
 __device__ __forceinline__ uint32_t stream_run(uint32_t m) { return (m + kAcGroup - 1) & ~(kAcGroup - 1); }
 struct StreamSink {
     LaneRing<kAcGroup, true> ac_ring;   // index = entry index in the image's stream region; runs are whole groups
-    LaneRing<kDcGroup> dc_ring;     // index = block index in the image
+    DcRing16 dc_ring;               // index = block index in the image
     uint32_t *tile_eoff;    // the image's tile offsets (+ sentinel)
     int *status;
     uint32_t blk_bits;      // the current block's index, placed as in coef_entry (bits above the field: don't care),
@@ -181,7 +226,7 @@ struct StreamSink {
     static __device__ __forceinline__ uint32_t block_bits(uint32_t blk) { return ((blk & 0xffu) << 22) + (63u << kRShift); }
     __device__ __forceinline__ void dc(uint32_t b, int v)
     {
-        dc_ring.push(uint32_t(v));                  // (b == dc_ring.off - 1: a lane's blocks are consecutive)
+        dc_ring.push(v);                            // (b == dc_ring.off - 1: a lane's blocks are consecutive)
         if (b == next_tile_blk) {           // first block of a stage-B tile: remember where its entries start
             tile_eoff[tile_idx] = ac_ring.off;
             tile_idx++;
@@ -1053,7 +1098,7 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *im
 extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImage *images, const uint8_t *scan_pool,
                                                                 const LutEntry *lut_pool, const SubseqState *g_entry,
                                                                 const uint32_t *g_blkbase, const uint32_t *g_ebase,
-                                                                uint32_t *entries, uint32_t *tile_eoff, int32_t *dcbuf,
+                                                                uint32_t *entries, uint32_t *tile_eoff, int16_t *dcdiff,
                                                                 int *status, const uint32_t *img_flags, uint32_t win_off,
                                                                 const uint32_t *segs, const SubseqState *g_exit)
 {
@@ -1100,8 +1145,7 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
         uint32_t *rings = s_win + kHuffWg * kWinStride;
         sink.ac_ring.begin(rings + threadIdx.x * LaneRing<kAcGroup>::kRing, entries + im.ent_off, ebase);
         rings += kHuffWg * LaneRing<kAcGroup>::kRing;
-        sink.dc_ring.begin(rings + threadIdx.x * LaneRing<kDcGroup>::kRing,
-                           reinterpret_cast<uint32_t *>(dcbuf + im.coef_off), first_start);
+        sink.dc_ring.begin(rings + threadIdx.x * (DcRing16::kRing / 2), dcdiff + im.coef_off, first_start);
     }
     sink.blk_bits = StreamSink::block_bits(blk);
     sink.tile_blocks = im.tile_blocks;
@@ -1248,7 +1292,8 @@ extern "C" __global__ __launch_bounds__(256) void k_planar_copy(const DevImage *
 }
 
 // DC prediction (decoder.rs:173, 208-210: running sum per component, never reset) as a two-level prefix sum over
-// dcbuf, which holds per-block differences in decode order.  An image is cut into segments of kDcSegMcus MCUs:
+// `dcd`, which holds per-block differences (16-bit words, see DcRing16) in decode order; the predictions go to dcbuf
+// (int32, same indexing), which stage B reads.  An image is cut into segments of kDcSegMcus MCUs:
 //   k_dc_sums   one workgroup per segment: per-component sum of the segment's differences -> segsum
 //   k_dc_apply  one workgroup per segment: carry-in = sums of the preceding segments; then MCU chunks of 256 with
 //               coalesced loads into LDS, one lane per MCU, a workgroup scan, coalesced write-back of absolute DCs.
@@ -1267,7 +1312,7 @@ __device__ __forceinline__ void wg_reduce3(int32_t v[3], int32_t (*s_w)[3], int3
 }
 
 constexpr uint32_t kDcFastShapes = (1u << 1) | (1u << 3) | (1u << 4) | (1u << 6);     // blocks per MCU with a fast kernel
-extern "C" __global__ __launch_bounds__(256) void k_dc_sums(const DevImage *images, const int32_t *dcbuf,
+extern "C" __global__ __launch_bounds__(256) void k_dc_sums(const DevImage *images, const int16_t *dcd,
                                                              int32_t *segsum, uint32_t max_segs, const uint32_t *img_flags)
 {
     __shared__ int32_t s_w[4][3];
@@ -1276,7 +1321,7 @@ extern "C" __global__ __launch_bounds__(256) void k_dc_sums(const DevImage *imag
     if (!im.valid || m0 >= im.nmcu || img_flags[im.status_idx] || ((kDcFastShapes >> im.bpm) & 1u) || im.nseg > 1) return;
     const uint32_t bpm = im.bpm, tid = threadIdx.x;
     const uint32_t nv = (min(uint32_t(kDcSegMcus), im.nmcu - m0)) * bpm;
-    const int32_t *dc = dcbuf + im.coef_off + size_t(m0) * bpm;
+    const int16_t *dc = dcd + im.coef_off + size_t(m0) * bpm;
     int32_t sum[3] = {0, 0, 0};
     for (uint32_t i = tid; i < nv; i += 256) {
         const int32_t v = dc[i];
@@ -1290,7 +1335,7 @@ extern "C" __global__ __launch_bounds__(256) void k_dc_sums(const DevImage *imag
     if (tid < 3) segsum[(size_t(blockIdx.y) * max_segs + blockIdx.x) * 3 + tid] = tot[tid];
 }
 
-extern "C" __global__ __launch_bounds__(256) void k_dc_apply(const DevImage *images, int32_t *dcbuf,
+extern "C" __global__ __launch_bounds__(256) void k_dc_apply(const DevImage *images, const int16_t *dcd, int32_t *dcbuf,
                                                               const int32_t *segsum, uint32_t max_segs,
                                                               const uint32_t *img_flags)
 {
@@ -1302,6 +1347,7 @@ extern "C" __global__ __launch_bounds__(256) void k_dc_apply(const DevImage *ima
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, bpm = im.bpm;
     const uint32_t seg1 = min(im.nmcu, seg0 + kDcSegMcus);
     int32_t *dc = dcbuf + im.coef_off;
+    const int16_t *dd = dcd + im.coef_off;
     int32_t carry[3] = {0, 0, 0};
     for (uint32_t sgi = 0; sgi < blockIdx.x; sgi++) {
         const int32_t *p = segsum + (size_t(blockIdx.y) * max_segs + sgi) * 3;
@@ -1312,7 +1358,7 @@ extern "C" __global__ __launch_bounds__(256) void k_dc_apply(const DevImage *ima
     for (uint32_t j = 0; j < kMaxBlocksPerMcu; j++) comp[j] = im.blk_comp[j];
     for (uint32_t m0 = seg0; m0 < seg1; m0 += 256) {
         const uint32_t nm = min(256u, seg1 - m0), nv = nm * bpm;
-        for (uint32_t i = tid; i < nv; i += 256) s_dc[i] = dc[size_t(m0) * bpm + i];
+        for (uint32_t i = tid; i < nv; i += 256) s_dc[i] = dd[size_t(m0) * bpm + i];
         __syncthreads();
         int32_t sum[3] = {0, 0, 0};
         if (tid < nm) {
@@ -1377,28 +1423,37 @@ extern "C" __global__ __launch_bounds__(256) void k_dc_apply(const DevImage *ima
 constexpr int kDcLaneMcus = kDcSegMcus / 256;
 struct __attribute__((packed, aligned(4))) Int4 { int32_t a, b, c, d; };
 
+// The lane's differences (16-bit words: 16-byte loads of eight, the lane's run starts on a multiple of eight blocks) into v;
+// p = where its predictions go.
 template <int BPM>
-__device__ __forceinline__ uint32_t dc_lane_load(const DevImage &im, const int32_t *dcbuf, uint32_t seg0, uint32_t seg1,
+__device__ __forceinline__ uint32_t dc_lane_load(const DevImage &im, const int16_t *dcd, int32_t *dcbuf, uint32_t seg0, uint32_t seg1,
                                                  int32_t (&v)[kDcLaneMcus * BPM], int32_t *&p)
 {
+    static_assert(kDcLaneMcus % 8 == 0, "a lane's run is whole 16-byte pieces of halfwords");
     const uint32_t m_first = seg0 + threadIdx.x * kDcLaneMcus;
     const uint32_t nvalid = m_first < seg1 ? min(uint32_t(kDcLaneMcus), seg1 - m_first) : 0u;
-    p = const_cast<int32_t *>(dcbuf) + im.coef_off + size_t(m_first) * BPM;
+    p = dcbuf + im.coef_off + size_t(m_first) * BPM;
+    const int16_t *d = dcd + im.coef_off + size_t(m_first) * BPM;
     if (nvalid == kDcLaneMcus) {
 #pragma unroll
-        for (int q = 0; q < kDcLaneMcus * BPM / 4; q++) {
-            const Int4 x = reinterpret_cast<const Int4 *>(p)[q];
-            v[4 * q] = x.a; v[4 * q + 1] = x.b; v[4 * q + 2] = x.c; v[4 * q + 3] = x.d;
+        for (int q = 0; q < kDcLaneMcus * BPM / 8; q++) {
+            const uint4 x = reinterpret_cast<const uint4 *>(d)[q];
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                v[8 * q + 2 * j] = int32_t(int16_t(w[j] & 0xffffu));
+                v[8 * q + 2 * j + 1] = int32_t(w[j]) >> 16;
+            }
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < kDcLaneMcus * BPM; i++) v[i] = uint32_t(i) < nvalid * BPM ? p[i] : 0;
+        for (int i = 0; i < kDcLaneMcus * BPM; i++) v[i] = uint32_t(i) < nvalid * BPM ? int32_t(d[i]) : 0;
     }
     return nvalid;
 }
 
 template <int BPM>
-__global__ __launch_bounds__(256) void k_dc_sums_t(const DevImage *images, const int32_t *dcbuf, int32_t *segsum,
+__global__ __launch_bounds__(256) void k_dc_sums_t(const DevImage *images, const int16_t *dcd, int32_t *segsum,
                                                    uint32_t max_segs, const uint32_t *img_flags)
 {
     static_assert((kDcLaneMcus * BPM) % 4 == 0, "16-byte pieces");
@@ -1409,7 +1464,7 @@ __global__ __launch_bounds__(256) void k_dc_sums_t(const DevImage *images, const
     const uint32_t seg1 = min(im.nmcu, seg0 + kDcSegMcus);
     int32_t v[kDcLaneMcus * BPM];
     int32_t *p;
-    (void)dc_lane_load<BPM>(im, dcbuf, seg0, seg1, v, p);
+    (void)dc_lane_load<BPM>(im, dcd, nullptr, seg0, seg1, v, p);
     int32_t sum[3] = {0, 0, 0};
 #pragma unroll
     for (int j = 0; j < BPM; j++) {
@@ -1427,7 +1482,7 @@ __global__ __launch_bounds__(256) void k_dc_sums_t(const DevImage *images, const
 }
 
 template <int BPM>
-__global__ __launch_bounds__(256) void k_dc_apply_t(const DevImage *images, int32_t *dcbuf, const int32_t *segsum,
+__global__ __launch_bounds__(256) void k_dc_apply_t(const DevImage *images, const int16_t *dcd, int32_t *dcbuf, const int32_t *segsum,
                                                     uint32_t max_segs, const uint32_t *img_flags)
 {
     __shared__ int32_t s_wsum[4][3];
@@ -1438,7 +1493,7 @@ __global__ __launch_bounds__(256) void k_dc_apply_t(const DevImage *images, int3
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int32_t v[kDcLaneMcus * BPM];
     int32_t *p;
-    const uint32_t nvalid = dc_lane_load<BPM>(im, dcbuf, seg0, seg1, v, p);
+    const uint32_t nvalid = dc_lane_load<BPM>(im, dcd, dcbuf, seg0, seg1, v, p);
     int32_t carry[3] = {0, 0, 0};
     for (uint32_t sgi = 0; sgi < blockIdx.x; sgi++) {
         const int32_t *q = segsum + (size_t(blockIdx.y) * max_segs + sgi) * 3;
@@ -1513,7 +1568,7 @@ __global__ __launch_bounds__(256) void k_dc_apply_t(const DevImage *images, int3
 // image never publishes.
 constexpr uint32_t kDcPoison = 0x80000000u;
 template <int BPM>
-__global__ __launch_bounds__(256) void k_dc_scan_t(const DevImage *images, int32_t *dcbuf, uint32_t *segsum,
+__global__ __launch_bounds__(256) void k_dc_scan_t(const DevImage *images, const int16_t *dcd, int32_t *dcbuf, uint32_t *segsum,
                                                    uint32_t max_segs, const uint32_t *img_flags, uint32_t gen, uint32_t *fail,
                                                    uint32_t spin_limit, uint32_t fault)
 {
@@ -1529,7 +1584,7 @@ __global__ __launch_bounds__(256) void k_dc_scan_t(const DevImage *images, int32
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int32_t v[kDcLaneMcus * BPM];
     int32_t *p;
-    const uint32_t nvalid = dc_lane_load<BPM>(im, dcbuf, seg0, seg1, v, p);
+    const uint32_t nvalid = dc_lane_load<BPM>(im, dcd, dcbuf, seg0, seg1, v, p);
     uint32_t comp[BPM];
 #pragma unroll
     for (int j = 0; j < BPM; j++) comp[j] = im.blk_comp[j];
@@ -1615,7 +1670,7 @@ __global__ __launch_bounds__(256) void k_dc_scan_t(const DevImage *images, int32
 
 // Restart intervals: the DC predictors start again at 0 in every interval (T.81 E.2.4), so the
 // prediction is independent per interval: one lane walks the blocks of one interval.
-extern "C" __global__ __launch_bounds__(256) void k_dc_restart(const DevImage *images, int32_t *dcbuf,
+extern "C" __global__ __launch_bounds__(256) void k_dc_restart(const DevImage *images, const int16_t *dcd, int32_t *dcbuf,
                                                                 const uint32_t *img_flags)
 {
     const DevImage &im = images[blockIdx.y];
@@ -1625,12 +1680,13 @@ extern "C" __global__ __launch_bounds__(256) void k_dc_restart(const DevImage *i
     const uint32_t seg_blocks = im.restart_mcus * im.bpm, b0 = g * seg_blocks;
     const uint32_t b1 = min(b0 + seg_blocks, im.himg.total_blocks);
     int32_t *dc = dcbuf + im.coef_off;
+    const int16_t *dd = dcd + im.coef_off;
     int32_t p0 = 0, p1 = 0, p2 = 0;
     uint32_t j = 0;
     for (uint32_t b = b0; b < b1; b += 8) {                                // eight loads in flight, then the serial part
         int32_t v[8];
 #pragma unroll
-        for (uint32_t q = 0; q < 8; q++) v[q] = b + q < b1 ? dc[b + q] : 0;
+        for (uint32_t q = 0; q < 8; q++) v[q] = b + q < b1 ? int32_t(dd[b + q]) : 0;
 #pragma unroll
         for (uint32_t q = 0; q < 8; q++) {
             const uint32_t c = im.blk_comp[j];
@@ -2170,7 +2226,7 @@ extern "C" __global__ __launch_bounds__(256) void k_rgb_compare(const RgbPair *p
 // ------------------------------------------------------------------------------------------------
 size_t huff_lds_bytes(uint32_t lut_cap_entries) { return (sizeof(HuffImage) + size_t(lut_cap_entries) * sizeof(LutEntry) + 15) / 16 * 16; }
 size_t huff_window_bytes() { return size_t(kHuffWg) * kWinStride * 4; }
-size_t huff_stage_bytes() { return size_t(kHuffWg) * (LaneRing<kAcGroup>::kRing + LaneRing<kDcGroup>::kRing) * 4; }    // the write pass's rings
+size_t huff_stage_bytes() { return size_t(kHuffWg) * (LaneRing<kAcGroup>::kRing * 4 + DcRing16::kRing * 2); }    // the write pass's rings
 
 uint32_t tile_mcus_420() { return kTile420; }
 uint32_t stream_group_entries() { return kAcGroup; }
@@ -2258,35 +2314,35 @@ void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, con
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                        const uint8_t *scan_pool, const LutEntry *lut_pool, const SubseqState *entry,
                        const uint32_t *blkbase, const uint32_t *ebase, uint32_t *entries, uint32_t *tile_eoff,
-                       int32_t *dcbuf, int *status, const uint32_t *img_flags, const uint32_t *segs, const SubseqState *exit_)
+                       int16_t *dcdiff, int *status, const uint32_t *img_flags, const uint32_t *segs, const SubseqState *exit_)
 {
     const size_t lds = tables_lds + huff_window_bytes() + huff_stage_bytes() + pad_lds;
-    hipLaunchKernelGGL(k_huff_write, dim3(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, blkbase, ebase, entries, tile_eoff, dcbuf, status, img_flags, uint32_t(tables_lds), segs, exit_);
+    hipLaunchKernelGGL(k_huff_write, dim3(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, blkbase, ebase, entries, tile_eoff, dcdiff, status, img_flags, uint32_t(tables_lds), segs, exit_);
 }
 
-void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, int32_t *dcbuf,
+void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, const int16_t *dcd, int32_t *dcbuf,
                     int32_t *segsum, const uint32_t *img_flags, uint32_t bpm_mask, uint32_t max_restart_segs,
                     uint32_t *segflag, uint32_t gen, uint32_t *fail, uint32_t spin_limit, bool fault)
 {
     const dim3 grid(max_segs, nimg), wg(256);
     if (segflag) {          // the common MCU shapes in one pass (k_dc_scan_t); segflag == nullptr: two passes as before
         const dim3 grid(nimg, max_segs);
-        if (bpm_mask & (1u << 1)) hipLaunchKernelGGL(k_dc_scan_t<1>, grid, wg, 0, st, images, dcbuf, segflag, max_segs, img_flags, gen, fail, spin_limit, fault ? 1u : 0u);
-        if (bpm_mask & (1u << 3)) hipLaunchKernelGGL(k_dc_scan_t<3>, grid, wg, 0, st, images, dcbuf, segflag, max_segs, img_flags, gen, fail, spin_limit, fault ? 1u : 0u);
-        if (bpm_mask & (1u << 4)) hipLaunchKernelGGL(k_dc_scan_t<4>, grid, wg, 0, st, images, dcbuf, segflag, max_segs, img_flags, gen, fail, spin_limit, fault ? 1u : 0u);
-        if (bpm_mask & (1u << 6)) hipLaunchKernelGGL(k_dc_scan_t<6>, grid, wg, 0, st, images, dcbuf, segflag, max_segs, img_flags, gen, fail, spin_limit, fault ? 1u : 0u);
+        if (bpm_mask & (1u << 1)) hipLaunchKernelGGL(k_dc_scan_t<1>, grid, wg, 0, st, images, dcd, dcbuf, segflag, max_segs, img_flags, gen, fail, spin_limit, fault ? 1u : 0u);
+        if (bpm_mask & (1u << 3)) hipLaunchKernelGGL(k_dc_scan_t<3>, grid, wg, 0, st, images, dcd, dcbuf, segflag, max_segs, img_flags, gen, fail, spin_limit, fault ? 1u : 0u);
+        if (bpm_mask & (1u << 4)) hipLaunchKernelGGL(k_dc_scan_t<4>, grid, wg, 0, st, images, dcd, dcbuf, segflag, max_segs, img_flags, gen, fail, spin_limit, fault ? 1u : 0u);
+        if (bpm_mask & (1u << 6)) hipLaunchKernelGGL(k_dc_scan_t<6>, grid, wg, 0, st, images, dcd, dcbuf, segflag, max_segs, img_flags, gen, fail, spin_limit, fault ? 1u : 0u);
         bpm_mask &= ~kDcFastShapes;
     }
-#define MJX_DC_PASS(KERNEL)                                                                                              \
-    if (bpm_mask & (1u << 1)) hipLaunchKernelGGL(KERNEL##_t<1>, grid, wg, 0, st, images, dcbuf, segsum, max_segs, img_flags); \
-    if (bpm_mask & (1u << 3)) hipLaunchKernelGGL(KERNEL##_t<3>, grid, wg, 0, st, images, dcbuf, segsum, max_segs, img_flags); \
-    if (bpm_mask & (1u << 4)) hipLaunchKernelGGL(KERNEL##_t<4>, grid, wg, 0, st, images, dcbuf, segsum, max_segs, img_flags); \
-    if (bpm_mask & (1u << 6)) hipLaunchKernelGGL(KERNEL##_t<6>, grid, wg, 0, st, images, dcbuf, segsum, max_segs, img_flags); \
-    if (bpm_mask & ~kDcFastShapes) hipLaunchKernelGGL(KERNEL, grid, wg, 0, st, images, dcbuf, segsum, max_segs, img_flags);
-    MJX_DC_PASS(k_dc_sums)
-    MJX_DC_PASS(k_dc_apply)
+#define MJX_DC_PASS(KERNEL, ...)                                                                                           \
+    if (bpm_mask & (1u << 1)) hipLaunchKernelGGL(KERNEL##_t<1>, grid, wg, 0, st, images, __VA_ARGS__, segsum, max_segs, img_flags); \
+    if (bpm_mask & (1u << 3)) hipLaunchKernelGGL(KERNEL##_t<3>, grid, wg, 0, st, images, __VA_ARGS__, segsum, max_segs, img_flags); \
+    if (bpm_mask & (1u << 4)) hipLaunchKernelGGL(KERNEL##_t<4>, grid, wg, 0, st, images, __VA_ARGS__, segsum, max_segs, img_flags); \
+    if (bpm_mask & (1u << 6)) hipLaunchKernelGGL(KERNEL##_t<6>, grid, wg, 0, st, images, __VA_ARGS__, segsum, max_segs, img_flags); \
+    if (bpm_mask & ~kDcFastShapes) hipLaunchKernelGGL(KERNEL, grid, wg, 0, st, images, __VA_ARGS__, segsum, max_segs, img_flags);
+    MJX_DC_PASS(k_dc_sums, dcd)
+    MJX_DC_PASS(k_dc_apply, dcd, dcbuf)
 #undef MJX_DC_PASS
-    if (max_restart_segs) hipLaunchKernelGGL(k_dc_restart, dim3((max_restart_segs + 255) / 256, nimg), wg, 0, st, images, dcbuf, img_flags);
+    if (max_restart_segs) hipLaunchKernelGGL(k_dc_restart, dim3((max_restart_segs + 255) / 256, nimg), wg, 0, st, images, dcd, dcbuf, img_flags);
 }
 
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
