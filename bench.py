@@ -78,8 +78,8 @@ def algorithmic_bytes(kind, by, nsub_total, nblk):
         "huff_sync": S + state + cps,             # k_huff_spec: scan in, states + checkpoints out
         "huff_fix": S // 5 + state + cps // 5,    # k_huff_merge rounds: ~1/5 of the scan is re-read (median merge distance)
         "huff_scan": 24 * nsub_total,             # exit state in, block base + entry base out
-        "huff_write": S + 24 * nsub_total + coef, # scan + entry state + bases in, compact stream + DC out
-        "dc_scan": 8 * nblk,                      # DC differences in, predicted DC out
+        "huff_write": S + 24 * nsub_total + coef - 2 * nblk,  # scan + entry state + bases in, compact stream + 16-bit DC differences out
+        "dc_scan": 6 * nblk,                      # 16-bit DC differences in, int32 predicted DC out
         "idct_color": 128 * nblk + rgb,           # B_idct
     }[kind]
 
