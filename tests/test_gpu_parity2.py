@@ -466,7 +466,8 @@ def test_dc_prediction_that_never_hears_from_its_predecessor_gives_up_and_two_pa
         "            assert np.abs(b.rgb(i).astype(int) - ref.rgb.astype(int)).max() <= 1, (chunk, rep, i)\n"
         "    b.close()\n"
         "print('dc fault ok')\n" % (ROOT, ROOT, ROOT))
-    for extra in ({"MJX_DC_FAULT": "1", "MJX_TIMING": "1"}, {"MJX_DC_FAULT": "1", "MJX_STREAMS": "1"}, {"MJX_DC_ONE_PASS": "0"}):
+    for extra in ({"MJX_DC_FAULT": "1", "MJX_TIMING": "1", "MJX_DC_ONE_PASS": "1"},      # (pinned: the suite itself may run under MJX_DC_ONE_PASS=0)
+                      {"MJX_DC_FAULT": "1", "MJX_STREAMS": "1", "MJX_DC_ONE_PASS": "1"}, {"MJX_DC_ONE_PASS": "0"}):
         out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "dc fault ok" in out.stdout, str(extra) + out.stdout[-2000:] + out.stderr[-2000:]
         if "MJX_TIMING" in extra:
