@@ -152,6 +152,7 @@ struct NullSink {
     MJX_HD void bad_code(uint32_t) const {}
     MJX_HD void tick() const {}          // one call per decoded symbol (statistics in the CPU emulation)
     MJX_HD void flush_groups() const {}
+    MJX_HD void flush_step(uint32_t) const {}
 };
 
 // ---- checkpoints: early merge of a re-decode with the path of the previous decode ----------------------

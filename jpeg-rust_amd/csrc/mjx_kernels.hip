@@ -213,7 +213,7 @@ struct DcRing16 {
 #define MJX_DC_GROUP 4
 #endif
 constexpr uint32_t kAcGroup = MJX_AC_GROUP;                                          // 32-byte sectors of entries
-static_assert(kAcGroup >= kFlushEvery && 2 * (DcRing16::kRing - DcRing16::kGroup) >= kFlushEvery, "ring capacity between two flushes (a block takes two symbols at least)");
+static_assert(kAcGroup >= kFlushEvery && DcRing16::kGroup - 1 + kFlushEvery <= DcRing16::kRing, "ring capacity between two flushes (a block takes two symbols at least; the DC ring is flushed every second time)");
 __device__ __forceinline__ uint32_t stream_run(uint32_t m) { return (m + kAcGroup - 1) & ~(kAcGroup - 1); }
 struct StreamSink {
     LaneRing<kAcGroup, true> ac_ring;   // index = entry index in the image's stream region; runs are whole groups
@@ -241,6 +241,13 @@ struct StreamSink {
     {
         ac_ring.flush_groups();
         dc_ring.flush_groups();
+    }
+    __device__ __forceinline__ void flush_step(uint32_t it)  // wave-uniform call, every kFlushEvery symbols
+    {
+        ac_ring.flush_groups();
+        // the DC ring every second time: a block takes two symbols at least, so at most kFlushEvery differences arrive in
+        // 2 * kFlushEvery symbols on top of the < kGroup that wait for their group (9.83 -> 9.74 ms per 2048 pictures)
+        if (it % (2 * kFlushEvery) == 0) dc_ring.flush_groups();
     }
     __device__ __forceinline__ void block_done(uint32_t next_blk)
     {
@@ -397,7 +404,7 @@ __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry,
         if (CP == 1 && st.wn >= ev.next_wn && st.wn < ev.end_wn) checkpoint_record(st, ev, cps);
         running = st.wn < ev.end_wn && !(WRITE && blk >= total_blocks);
         if (WRITE) {
-            if (it % kFlushEvery == 0) sink.flush_groups();
+            if (it % kFlushEvery == 0) sink.flush_step(it);
             it++;
         }
     }
