@@ -43,6 +43,8 @@ struct LaneBits {
     const unsigned char *base;      // wave-uniform: the image's region of the pool
     uint32_t col;                   // byte offset of the lane's column inside a row: subsequence index * 16
     uint32_t row_stride;            // bytes per row: scan_cols * 16
+    // (cached loads: a 128-byte line holds the pieces of eight lanes, which ask for them at different times -- streamed past L2
+    // these loads cost the write pass 0.35 ms per step; what is streamed are the pictures and stage B's reads of the stream)
     __device__ __forceinline__ uint4 piece(uint32_t k) const { return *reinterpret_cast<const uint4 *>(base + (col + k * row_stride)); }
 };
 
@@ -1799,10 +1801,21 @@ __device__ __forceinline__ Rgb4 pack4(const Rgb p[4])
     return o;
 }
 
+// The pictures leave with non-temporal stores (round 3): 25 MB per picture that nothing reads again soon would push the
+// write pass's half-filled lines out of L2 when the two kernels share the device (30.1 -> 29.65 ms per step with the default
+// streams; 16.1 -> 16.0 ms for stage B alone).  The compiler fuses the three dword stores into one global_store_dwordx3 nt.
+__device__ __forceinline__ void store_rgb4(uint8_t *dst, const Rgb4 &v)
+{
+    uint32_t *d = reinterpret_cast<uint32_t *>(dst);
+    __builtin_nontemporal_store(v.a, d);
+    __builtin_nontemporal_store(v.b, d + 1);
+    __builtin_nontemporal_store(v.c, d + 2);
+}
+
 __device__ __forceinline__ void store4(uint8_t *dst, const Rgb4 &v, bool aligned, uint32_t npix)
 {
     if (npix >= 4) {
-        if (aligned) *reinterpret_cast<Rgb4 *>(dst) = v;
+        if (aligned) store_rgb4(dst, v);
         else *reinterpret_cast<Rgb4u *>(dst) = Rgb4u{v.a, v.b, v.c};
     } else {
         const uint32_t w[3] = {v.a, v.b, v.c};
@@ -1845,10 +1858,10 @@ __device__ __forceinline__ void tile_fetch(const uint32_t *__restrict__ src, con
 #pragma unroll
     for (int k = 0; k < kPrefetch; k++) {
         const uint32_t i = f.e0 + tid + LANES * k;
-        f.ent[k] = i < f.e1 ? src[i] : 0u;
+        f.ent[k] = i < f.e1 ? __builtin_nontemporal_load(src + i) : 0u;      // (read once: streamed past L2, like the pictures on their way out)
     }
     const uint32_t blk = tile * tile_blocks + tid;
-    f.dc = (tid < tile_blocks && blk < total_blocks) ? dc[blk] : 0;
+    f.dc = (tid < tile_blocks && blk < total_blocks) ? __builtin_nontemporal_load(dc + blk) : 0;
 }
 
 // One stream entry -> one float in the tile: find the block from the entry's block byte, multiply by the
@@ -1935,12 +1948,12 @@ __device__ __forceinline__ void pixels_420(uint32_t width, uint32_t height, uint
         p[0] = ycc_to_rgb(ya.x, c0); p[1] = ycc_to_rgb(ya.y, c0);
         p[2] = ycc_to_rgb(ya.z, c1); p[3] = ycc_to_rgb(ya.w, c1);
         uint8_t *dst = col + size_t(rp) * 2 * width * 3;
-        if (INTERIOR) *reinterpret_cast<Rgb4 *>(dst) = pack4(p);
+        if (INTERIOR) store_rgb4(dst, pack4(p));
         else store4(dst, pack4(p), aligned, npix);
         if (INTERIOR || py + 1 < height) {
             p[0] = ycc_to_rgb(yb.x, c0); p[1] = ycc_to_rgb(yb.y, c0);
             p[2] = ycc_to_rgb(yb.z, c1); p[3] = ycc_to_rgb(yb.w, c1);
-            if (INTERIOR) *reinterpret_cast<Rgb4 *>(dst + size_t(width) * 3) = pack4(p);
+            if (INTERIOR) store_rgb4(dst + size_t(width) * 3, pack4(p));
             else store4(dst + size_t(width) * 3, pack4(p), aligned, npix);
         }
     }
