@@ -11,11 +11,21 @@ global batch goes to rank i mod N.  The harness needs one barrier and one MAX-re
 gloo (host TCP) -- the north star says "no RCCL", and that holds for the harness as well as for the data path.
 
 The JSON line carries, besides the contract fields:
-  roofline      dominant kernel (by summed HIP-event time over the timed region): algorithmic bytes per launch / average
-                launch duration vs the 8 TB/s HBM3E peak; frac_physical = the same with the bytes the kernel really moves.
-                The library overlaps the entropy stages of two chunks and stage B on three streams, so these durations include contention;
-  roofline_isolated  is the same object from a one-stream pass over the same batch: the kernel's stand-alone duration
-  roofline_e2e  whole path: sum over images of (S + 3*W*H) (SURVEY.md s8(d) B_e2e) per step / wall time per step
+  roofline      what SURVEY.md s8(d) defines.  stages=all (the default, the headline): achieved = sum over the images of
+                B_e2e = S + 3*W*H (compressed bytes in, packed RGB out) per step / wall time per step of the timed region, frac =
+                that / the 8 TB/s HBM3E peak; `kernel` = the kernel class with the largest HIP-event time in the timed region,
+                whose own per-launch figures (algorithmic bytes, average launch duration, fraction of peak) are in
+                `dominant_kernel`; `traffic` = HBM bytes per step from rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, separate
+                passes, /opt/skills/guides/MI355X_MICROARCH.md) -- observed in this run when rocprofv3 is on the box
+                (`traffic_source`: "observed ..."), else scaled from the committed collection under profiles/.
+                stages=pixels (the config-4 stage-B sweep): the pixel kernel on B_idct = 128*n_blocks + 3*W*H.
+  kernel_rooflines  every kernel class on its own algorithmic bytes, from the timed region's event times
+                (the library overlaps the entropy stages of two chunks and stage B on three streams: these durations include
+                the contention); idct_color also with the bytes it physically moves (frac_physical)
+  roofline_isolated / kernel_rooflines_isolated  the same from a one-stream pass over the same batch: stand-alone durations
+  upload_side   the per-batch work outside the timed region: the pass that lays the de-stuffed scans out lane-interleaved
+                (k_scan_interleave; with --device-destuff also the de-stuffing kernels), HIP-event time for the unique pictures
+                scaled to the batch -- the timed region starts from that layout
   kernels       per kernel class: launches, total ms
   parity        the gate behind `value`: every picture of the timed batch compared on the device with its
                 unique original (bit-equal), pictures of the batch compared with the CPU oracle (coefficients equal, RGB
@@ -59,7 +69,9 @@ def parse_args():
                     "stage B of one chunk overlaps stage A of the next and per-kernel times include the contention")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU baseline (0 = every core the job may use: affinity mask capped by the cgroup quota)")
-    ap.add_argument("--no-extra", action="store_true", help="skip extra_configs and e2e_from_bytes (main line only)")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra_configs, e2e_from_bytes and the traffic passes (main line only)")
+    ap.add_argument("--no-traffic", action="store_true", help="do not run the rocprofv3 PMC passes that observe HBM traffic (roofline.traffic then comes from profiles/)")
+    ap.add_argument("--traffic-images", type=int, default=256, help="pictures per launch in the PMC passes")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle legs of the parity gate (the on-device check stays)")
     ap.add_argument("--parity-images", type=int, default=16, help="pictures of the timed batch checked against the CPU oracle (decoded in parallel on the host cores)")
     return ap.parse_args()
@@ -90,18 +102,80 @@ def algorithmic_bytes_physical(kind, by, nsub_total, nblk):
     return algorithmic_bytes(kind, by, nsub_total, nblk)
 
 
-def measured_traffic(kind, images_per_launch):
-    """HBM bytes per launch from the committed rocprofv3 PMC collection (profiles/*_traffic.json, FETCH_SIZE x 2 +
-    WRITE_SIZE, separate passes), scaled to this run's images per launch.  None if no collection is committed."""
+KERNEL_ALIAS = {"k_huff_spec": "huff_sync", "k_huff_merge": "huff_fix", "k_huff_merge_tail": "huff_fix", "k_huff_merge_loop": "huff_fix",
+                "k_huff_scan": "huff_scan", "k_huff_write": "huff_write", "k_idct_color": "idct_color", "k_ref_color": "idct_color",
+                "k_dc_sums_t": "dc_scan", "k_dc_apply_t": "dc_scan", "k_dc_scan_t": "dc_scan", "k_dc_sums": "dc_scan",
+                "k_dc_apply": "dc_scan", "k_dc_restart": "dc_scan", "k_planar_count": "gather", "k_planar_offsets": "gather",
+                "k_planar_copy": "gather"}
+
+
+def pmc_bytes_by_class(directory, counter):
+    """Sum of a rocprofv3 --pmc counter (KB) over the dispatches of each decode kernel class, in bytes."""
+    import collections, csv, glob
+    acc = collections.defaultdict(float)
+    for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = r["Kernel_Name"].split("(")[0].replace("void mjx::", "").split("<")[0].strip()
+            if k in KERNEL_ALIAS:
+                acc[KERNEL_ALIAS[k]] += float(r["Counter_Value"]) * 1024.0
+    return dict(acc)
+
+
+def observe_traffic(args):
+    """HBM bytes per kernel class of one step, observed now: two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE need separate
+    passes: TCC counter slots) over a child `bench.py` of `--traffic-images` pictures, one stream (per-kernel counters mean
+    something only without overlap), one step, no warm-up -- every decode kernel of the child runs exactly once.  FETCH_SIZE is
+    doubled (gfx950 reports half the bytes of wide coalesced reads; for the narrow reads of the entropy kernels an upper bound).
+    Returns ({class: bytes for the child's batch}, images, note) or None when rocprofv3 is missing or a pass fails."""
+    import shutil, signal, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None
+    out = {}
+    with tempfile.TemporaryDirectory(prefix="mjx_pmc_", dir="/tmp") as tmp:
+        env = dict(os.environ, MJX_STREAMS="1", TMPDIR="/tmp")
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "-d", d, "-o", "out", "--output-format", "csv", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                   "--no-cpu-baseline", "--no-extra", "--no-parity", "--steps", "1", "--warmup", "0", "--images-per-gpu", str(args.traffic_images),
+                   "--width", str(args.width), "--height", str(args.height), "--subsampling", args.subsampling, "--quality", str(args.quality),
+                   "--unique", str(min(args.unique, args.traffic_images))]
+            try:
+                p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+                try:
+                    rc = p.wait(timeout=300)
+                except subprocess.TimeoutExpired:
+                    os.killpg(p.pid, signal.SIGKILL)          # (the group this call started, nothing else)
+                    p.wait()
+                    return None
+            except OSError:
+                return None
+            if rc != 0:
+                return None
+            out[counter] = pmc_bytes_by_class(d, counter)
+    if not out["FETCH_SIZE"] or not out["WRITE_SIZE"]:
+        return None
+    classes = sorted(set(out["FETCH_SIZE"]) | set(out["WRITE_SIZE"]))
+    return ({k: {"fetch_bytes": int(2 * out["FETCH_SIZE"].get(k, 0)), "write_bytes": int(out["WRITE_SIZE"].get(k, 0)),
+                 "hbm_bytes": int(2 * out["FETCH_SIZE"].get(k, 0) + out["WRITE_SIZE"].get(k, 0))} for k in classes},
+            args.traffic_images, "observed in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH x 2), "
+            "%d pictures, one stream, one step" % args.traffic_images)
+
+
+def committed_traffic():
+    """The last PMC collection committed under profiles/ (tools/collect_traffic.py), as observe_traffic() returns it."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
     if not files:
         return None
     t = json.load(open(files[-1]))
-    k = t["kernels"].get(kind)
-    if not k:
-        return None
-    return int(k["hbm_bytes"] * images_per_launch / t["images_per_launch"]), os.path.basename(files[-1])
+    k = dict(t["kernels"])
+    if "huff_fix_tail" in k:                                   # (older collections list the straggler kernel on its own, per launch)
+        k["huff_fix"] = {f: 6 * (k["huff_fix"][f] + k["huff_fix_tail"][f]) for f in ("fetch_bytes", "write_bytes", "hbm_bytes")}
+    k = {c: v for c, v in k.items() if c in set(KERNEL_ALIAS.values())}
+    return k, t["images_per_launch"], "committed collection profiles/%s (not observed in this run)" % os.path.basename(files[-1])
 
 
 def shard_seeds(rank, world, unique):
@@ -230,6 +304,7 @@ def run_config(mjx, ctx, datas, per_gpu, stages, steps, warmup, chunk_images=0, 
                           "compressed_MB_per_file": round(sum(len(d) for d in datas) / len(datas) / 1e6, 3),
                           "note": "host marker walk + de-stuffing (threads), then planning + decode tables + H2D of the compressed "
                                   "scans and first-use allocations (mjx_batch_create) for the unique files; not part of `value`"})
+    up_ms, up_n = base.kernel_ms().get("upload", (0.0, 0))
     batch = base.tile(reps) if reps > 1 else base
     if batch is not base:
         base.close()
@@ -259,8 +334,16 @@ def run_config(mjx, ctx, datas, per_gpu, stages, steps, warmup, chunk_images=0, 
     kms = batch.kernel_ms()
     by = batch.bytes()
     kernels = {k: {"launches": v[1], "ms": round(v[0], 4)} for k, v in kms.items() if v[1]}
+    kernels.pop("upload", None)                   # (upload-time kernels of a batch that was not tiled: not part of a step)
     rec = {"elapsed": elapsed, "per_gpu": per_gpu, "period": period, "by": by, "kernels": kernels, "nsub": nsub_total, "nblk": nblk,
-           "chunks": geo["chunks"]}
+           "chunks": geo["chunks"],
+           "upload_side": {"kernels_ms_unique": round(up_ms, 4), "unique_pictures": period, "launches": int(up_n),
+                           "ms_per_batch": round(up_ms * per_gpu / max(period, 1), 4), "pictures_per_batch": per_gpu,
+                           "device_destuff": bool(device_destuff),
+                           "note": "HIP-event time of the upload-time kernels (k_scan_interleave: linear de-stuffed scan -> the lane-"
+                                   "interleaved pool the entropy kernels read; with --device-destuff also the de-stuffing kernels) for the "
+                                   "unique pictures, scaled to the batch; runs once per upload, outside the timed region, which starts "
+                                   "from that layout (the tiled batch copies the pool)"}}
     # on-device half of the parity gate: every picture of the batch equals its unique original bit for bit
     n = len(batch)
     if n > period:
@@ -273,45 +356,61 @@ def run_config(mjx, ctx, datas, per_gpu, stages, steps, warmup, chunk_images=0, 
     return rec, batch
 
 
-def rooflines(rec, steps, stages, traffic_ok, dom=None):
-    """`dom`: the dominant kernel when the caller knows it from the one-stream pass.  In the overlapped timed region the entropy
-    kernels of two chunks and stage B run side by side, so a kernel's event duration includes the time it shares the device
-    (the write pass measures 2x its stand-alone time beside the next chunk's synchronisation passes): which kernel
-    dominates the step is decided on stand-alone durations, its roofline is computed from the timed region's."""
+def rooflines(rec, steps, stages, traffic=None):
+    """The roofline objects of one timed configuration (see the module docstring).  `traffic` = (per-class bytes, images they
+    were collected on, source note) or None."""
     kernels, by, nsub_total, nblk = rec["kernels"], rec["by"], rec["nsub"], rec["nblk"]
     out = {}
     if not kernels:
         return out
-    if dom is None or dom not in kernels:
-        dom = max(kernels, key=lambda k: kernels[k]["ms"])
+    dom = max(kernels, key=lambda k: kernels[k]["ms"])          # largest event time in this timed region
     n_launch = kernels[dom]["launches"]
     avg_s = kernels[dom]["ms"] / 1e3 / n_launch
     per_launch = algorithmic_bytes(dom, by, nsub_total, nblk) * steps / n_launch
     per_launch_phys = algorithmic_bytes_physical(dom, by, nsub_total, nblk) * steps / n_launch
     ach = per_launch / avg_s / 1e9
     ach_phys = per_launch_phys / avg_s / 1e9
-    imgs_per_launch = rec["per_gpu"] * steps / n_launch * (4 if dom == "huff_fix" else 1)
-    tr = measured_traffic(dom, imgs_per_launch) if traffic_ok else None
-    out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": tr[0] if tr else None,
-                       "traffic_source": tr[1] if tr else None,
-                       "bytes_per_launch": int(per_launch), "avg_launch_ms": round(avg_s * 1e3, 5),
-                       "achieved_physical": round(ach_phys, 2), "frac_physical": round(ach_phys / HBM_PEAK_GBS, 5),
-                       "bytes_basis": "SURVEY s8(d) B_idct = 128*n_blocks + 3*W*H; *_physical: compact stream + DC + RGB, what the kernel moves"
-                       if dom == "idct_color" else "DESIGN.md s5"}
-    out["kernel_rooflines"] = {
-        k: {"GB/s": round(algorithmic_bytes(k, by, nsub_total, nblk) * steps / (v["ms"] / 1e3) / 1e9, 1),
-            "frac": round(algorithmic_bytes(k, by, nsub_total, nblk) * steps / (v["ms"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4)}
-        for k, v in kernels.items() if v["ms"] > 0}
+    scale = (rec["per_gpu"] / traffic[1]) if traffic else 0.0      # the collection's pictures -> one step of this batch
+    def tr_step(kind):
+        return int(traffic[0][kind]["hbm_bytes"] * scale) if traffic and kind in traffic[0] else None
+    dom_obj = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(ach / HBM_PEAK_GBS, 5), "bytes_per_launch": int(per_launch), "avg_launch_ms": round(avg_s * 1e3, 5),
+               "launches_per_step": round(n_launch / steps, 2), "traffic_per_step": tr_step(dom),
+               "achieved_physical": round(ach_phys, 2), "frac_physical": round(ach_phys / HBM_PEAK_GBS, 5),
+               "bytes_basis": "SURVEY s8(d) B_idct = 128*n_blocks + 3*W*H; *_physical: compact stream + DC + RGB, what the kernel moves"
+               if dom == "idct_color" else "DESIGN.md s5"}
+    out["kernel_rooflines"] = {}
+    for k, v in kernels.items():
+        if v["ms"] <= 0:
+            continue
+        gbs = algorithmic_bytes(k, by, nsub_total, nblk) * steps / (v["ms"] / 1e3) / 1e9
+        o = {"GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "ms_per_step": round(v["ms"] / steps, 4), "traffic_per_step": tr_step(k)}
+        if k == "idct_color":
+            gp = algorithmic_bytes_physical(k, by, nsub_total, nblk) * steps / (v["ms"] / 1e3) / 1e9
+            o.update({"GB/s_physical": round(gp, 1), "frac_physical": round(gp / HBM_PEAK_GBS, 4)})
+        out["kernel_rooflines"][k] = o
     tot_ms = sum(v["ms"] for v in kernels.values())
-    e2e_bytes = (by["scan"] + by["rgb"]) if stages == "all" else algorithmic_bytes("idct_color", by, nsub_total, nblk)
-    # (the timed region's wall clock, not the sum of the kernel durations: with two streams the kernels overlap)
-    e2e = e2e_bytes * steps / rec["elapsed"] / 1e9
-    out["roofline_e2e"] = {"bound": "hbm", "achieved": round(e2e, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(e2e / HBM_PEAK_GBS, 5), "bytes_per_step": int(e2e_bytes),
-                           "kernel_ms_per_step_summed": round(tot_ms / steps, 4), "wall_ms_per_step": round(rec["elapsed"] / steps * 1e3, 4),
-                           "definition": "sum(S + 3*W*H) per step / wall time per step of the timed region" if stages == "all"
-                           else "B_idct = 128*n_blocks + 3*W*H (SURVEY s8(d)) per step / wall time per step"}
+    wall_ms = rec["elapsed"] / steps * 1e3
+    if stages == "all":
+        # SURVEY s8(d): the whole path on its compulsory traffic -- compressed bytes in, packed RGB out -- over the wall clock of
+        # the timed region (not the sum of the kernel durations: the kernels of three streams overlap)
+        e2e_bytes = by["scan"] + by["rgb"]
+        e2e = e2e_bytes * steps / rec["elapsed"] / 1e9
+        tot_traffic = sum(tr_step(k) or 0 for k in kernels) if traffic else None
+        out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(e2e, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(e2e / HBM_PEAK_GBS, 5), "traffic": tot_traffic,
+                           "traffic_source": traffic[2] if traffic else None,
+                           "bytes_per_step": int(e2e_bytes), "wall_ms_per_step": round(wall_ms, 4),
+                           "kernel_ms_per_step_summed": round(tot_ms / steps, 4),
+                           "definition": "SURVEY s8(d): sum over the images of B_e2e = S + 3*W*H per step / wall time per step of the timed "
+                                         "region / 8 TB/s; `kernel` = the class with the largest HIP-event time in the timed region (its "
+                                         "own per-launch figures: dominant_kernel); traffic = HBM bytes per step, all decode kernels",
+                           "dominant_kernel": dom_obj}
+    else:
+        # the config-4 "HBM-bound IDCT sweep": stage B alone on B_idct
+        out["roofline"] = dict(dom_obj, traffic=tr_step(dom), traffic_source=traffic[2] if traffic else None,
+                               wall_ms_per_step=round(wall_ms, 4),
+                               definition="SURVEY s8(d), stage B in isolation: B_idct = 128*n_blocks + 3*W*H per launch / the kernel's average launch duration / 8 TB/s")
     return out
 
 
@@ -395,10 +494,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    import torch
+    import torch                       # (first: libmjx.so must find torch's HIP runtime already loaded, not bring its own)
     import torch.distributed as dist
     import __graft_entry__ as ge
     ge.build()
+    # ---- HBM traffic of one step, observed with rocprofv3 PMC passes in child processes (before this process touches the GPU) ----
+    traffic = None
+    if rank == 0 and world == 1 and not args.no_extra and not args.no_traffic and args.stages == "all":
+        traffic = observe_traffic(args)
+    if traffic is None and args.width == 3840 and args.height == 2160 and args.quality == 75 and args.subsampling == "420":
+        traffic = committed_traffic()            # (collected on this workload; other workloads: none)
+
     mjx = ge.load_package()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
@@ -445,7 +551,9 @@ def main():
         "kernels": kernels,
     }
     out["host_side"] = host_side
-    dom_kernel = None
+    out["upload_side"] = rec["upload_side"]
+    if rec["upload_side"]["ms_per_batch"] > 0:
+        out["upload_side"]["value_with_interleave_in_the_step"] = round(by["pixels"] * world / ((elapsed / args.steps) + rec["upload_side"]["ms_per_batch"] / 1e3) / 1e6, 2)
 
     # ---- parity gate: no number without it ----
     parity = {"tiled_images_compared_on_device": rec["tiled_compared"], "tiled_max_abs_diff": rec["tiled_max_abs_diff"],
@@ -464,30 +572,25 @@ def main():
             failures.append("coefficient stream differs from the oracle")
     batch.close()
 
+    out.update(rooflines(rec, args.steps, args.stages, traffic))
     if not args.no_extra and world == 1 and args.streams != 1:
-        # The library runs the entropy stage and stage B on two streams (overlapped), so the kernel durations of the timed
-        # region above include the contention between them.  The same workload on one stream gives every kernel's
-        # stand-alone duration: the roofline of the kernel itself, next to the overlapped one.
+        # The library runs the entropy stages of two chunks and stage B on three streams (overlapped), so the kernel durations of the
+        # timed region above include the contention between them.  The same workload on one stream gives every kernel's
+        # stand-alone duration.
         os.environ["MJX_STREAMS"] = "1"
         ctx1 = mjx.Context(device, profiling=True, throughput_plan=True)
         os.environ.pop("MJX_STREAMS")
         iso_steps = max(2, min(args.steps, 3))
         r1, b1 = run_config(mjx, ctx1, datas, args.images_per_gpu, args.stages, iso_steps, 1, args.chunk_images, args.device_destuff, sync_all)
         b1.close()
-        rl1 = rooflines(r1, iso_steps, args.stages, args.width == 3840 and args.height == 2160 and args.quality == 75)
+        rl1 = rooflines(r1, iso_steps, args.stages, traffic)
         out["roofline_isolated"] = dict(rl1["roofline"], note="same workload with MJX_STREAMS=1 (no overlap between the entropy stage and stage B): "
-                                        "the dominant kernel's stand-alone duration", steps=iso_steps,
+                                        "stand-alone kernel durations", steps=iso_steps,
                                         value_single_stream=round(r1["by"]["pixels"] * iso_steps / r1["elapsed"] / 1e6, 2))
         out["kernel_rooflines_isolated"] = rl1["kernel_rooflines"]
-        dom_kernel = rl1["roofline"]["kernel"]
         if r1["tiled_max_abs_diff"] != 0:
             failures.append("single-stream pass: tiled pictures differ from their originals")
         ctx1.close()
-    # (after the one-stream pass: the dominant kernel is the one with the largest stand-alone time, see rooflines)
-    rl = rooflines(rec, args.steps, args.stages, args.width == 3840 and args.height == 2160 and args.quality == 75, dom_kernel)
-    if dom_kernel:
-        rl["roofline"]["dominant_by"] = "stand-alone duration (one-stream pass, roofline_isolated); achieved / frac from the overlapped timed region"
-    out.update(rl)
 
     extra = []
     if not args.no_extra and world == 1 and args.stages == "all":
@@ -498,15 +601,16 @@ def main():
             d2 = datas if (w, h, q) == (args.width, args.height, args.quality) else make_inputs(mjx, w, h, "420", q, seeds)
             r2, b2 = run_config(mjx, ctx, d2, n_img, stg, small_steps, 1, sync_all=sync_all)
             b2.close()
-            rl = rooflines(r2, small_steps, stg, False)
+            rl = rooflines(r2, small_steps, stg)
             px = r2["by"]["pixels"] * small_steps
             e = {"name": name, "workload": "%d x %dx%d 4:2:0 q%d, stages=%s" % (r2["per_gpu"], w, h, q, stg),
                  "Mpixels/s": round(px / r2["elapsed"] / 1e6, 1), "ms_per_step": round(r2["elapsed"] / small_steps * 1e3, 3),
                  "steps": small_steps,
                  "entropy_Gbit_per_s": round(r2["by"]["scan"] * 8 * small_steps / r2["elapsed"] / 1e9, 2),
                  "bits_per_pixel": round(r2["by"]["scan"] * 8 / max(r2["by"]["pixels"], 1), 4),
-                 "roofline": {k: rl["roofline"][k] for k in ("kernel", "achieved", "frac", "achieved_physical", "frac_physical", "avg_launch_ms")},
-                 "roofline_e2e_frac": rl["roofline_e2e"]["frac"],
+                 "roofline": {k: rl["roofline"][k] for k in ("kernel", "achieved", "frac", "wall_ms_per_step")},
+                 "dominant_kernel": {k: (rl["roofline"]["dominant_kernel"] if stg == "all" else rl["roofline"])[k]
+                                     for k in ("kernel", "achieved", "frac", "achieved_physical", "frac_physical", "avg_launch_ms")},
                  "tiled_images_compared_on_device": r2["tiled_compared"], "tiled_max_abs_diff": r2["tiled_max_abs_diff"]}
             if r2["tiled_max_abs_diff"] != 0:
                 failures.append(name + ": tiled pictures differ from their originals")

@@ -101,6 +101,8 @@ extern "C" {
     pub fn mjx_ctx_destroy(ctx: *mut mjx_ctx);
     pub fn mjx_ctx_set_profiling(ctx: *mut mjx_ctx, enable: c_int) -> c_int;
     pub fn mjx_ctx_set_throughput_plan(ctx: *mut mjx_ctx, enable: c_int) -> c_int;
+    pub fn mjx_ctx_numa_node(ctx: *const mjx_ctx) -> c_int;
+    pub fn mjx_host_processors() -> c_uint;
     pub fn mjx_batch_create(ctx: *mut mjx_ctx, descs: *const mjx_scan_desc, n: usize, opts: *const mjx_opts,
                             out: *mut *mut mjx_batch, status: *mut c_int) -> c_int;
     pub fn mjx_batch_tile(ctx: *mut mjx_ctx, src: *const mjx_batch, times: usize, out: *mut *mut mjx_batch) -> c_int;
@@ -135,6 +137,7 @@ extern "C" {
                                  out: *mut *mut mjx_pool_result) -> c_int;
     pub fn mjx_pool_result_locate(r: *const mjx_pool_result, i: usize, slot: *mut usize, batch: *mut *mut mjx_batch,
                                   index: *mut usize) -> c_int;
+    pub fn mjx_pool_result_host(r: *const mjx_pool_result, slot: usize, threads: *mut c_uint, numa_node: *mut c_int) -> c_int;
     pub fn mjx_pool_result_free(r: *mut mjx_pool_result);
     pub fn mjx_strerror(code: c_int) -> *const c_char;
     pub fn mjx_version() -> *const c_char;

@@ -139,6 +139,10 @@ int mjx_ctx_set_profiling(mjx_ctx *ctx, int enable);
  * block and pinned buffers: expect that call to take several times as long as the ones after it (0.5 s against 50 ms for
  * 2048 4K files). */
 int mjx_ctx_set_throughput_plan(mjx_ctx *ctx, int enable);
+/* NUMA node of the context's GPU (from the PCI device's numa_node in sysfs), -1 when the platform does not say. */
+int mjx_ctx_numa_node(const mjx_ctx *ctx);
+/* Processors this process may use: the affinity mask, capped by the cgroup CPU quota. */
+unsigned mjx_host_processors(void);
 
 /* JPEGDecoder::new(..).frame_header(..).scan_header(..).dimensions(..) + table setters for n images
  * (decoder.rs:55-152): validates, builds decode tables, packs and uploads the scans; device buffers for the
@@ -196,7 +200,9 @@ enum {
     MJX_K_HUFF_WRITE = 4, /* final decode writing coefficients */
     MJX_K_DC_SCAN = 5,    /* DC prediction prefix sums */
     MJX_K_IDCT_COLOR = 6, /* dequant + IDCT + upsample + colour + RGB store */
-    MJX_K_COUNT = 7
+    MJX_K_UPLOAD = 7,     /* upload time, once per batch, not part of a decode: de-stuffing on the device (opts.device_destuff)
+                             and the pass that lays the scans out lane-interleaved (k_scan_interleave) */
+    MJX_K_COUNT = 8
 };
 int mjx_batch_kernel_ms(mjx_batch *b, double ms[MJX_K_COUNT], uint64_t launches[MJX_K_COUNT], int reset);
 
@@ -220,11 +226,15 @@ int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const size_t *le
 /* ---- multi-GPU front: one context + one host thread + one work queue per device, no collective ----------
  * Pictures are independent (decoder.rs:162-343 touches only `self`), so a list of files shards over the GPUs of a node
  * without any exchange: every slot decodes its share with the pipelined mjx_decode_batch on its own device, outputs stay
- * where they were produced.  Files are dealt to the slots by compressed bytes (each file to the slot with the fewest bytes
- * so far, the lowest slot on a tie: i mod N for a list of equal files, level queues for a skewed one) or round robin
- * (mjx_pool_set_deal).  `devices` may name a device more than once (two slots on one GPU).  One mjx_pool_decode_batch
+ * where they were produced.  Files are dealt to the slots by compressed bytes (largest file first, each to the slot with the
+ * fewest bytes so far, the lowest slot on a tie: i mod N for a list of equal files, level queues for a skewed one) or round
+ * robin (mjx_pool_set_deal).  `devices` may name a device more than once (two slots on one GPU).  One mjx_pool_decode_batch
  * call at a time per pool.  A slot whose device fails fails its own files (their status is the slot's error, the call
- * returns it); the other slots' results stay valid. */
+ * returns it); the other slots' results stay valid.
+ * Host side: the slots share the host.  With threads_per_device == 0 every slot takes max(2, P / (2 N)) parse threads, P =
+ * mjx_host_processors(), so that N slots together stay within the processors the process may use (mjx_decode_batch alone
+ * takes P / 2); and a slot's host thread -- with it the parse threads it starts and the pinned arena it allocates -- is bound
+ * to the processors of its GPU's NUMA node when the platform names one and the process may run there (MJX_POOL_NUMA=0: no). */
 typedef struct mjx_pool mjx_pool;
 typedef struct mjx_pool_result mjx_pool_result;
 int mjx_pool_create(const int *devices, size_t n_devices, mjx_pool **out);
@@ -240,6 +250,9 @@ int mjx_pool_decode_batch(mjx_pool *pool, const uint8_t *const *jpegs, const siz
 /* file i of the call -> its slot, the slot's batch and the picture's index inside it (for mjx_batch_image_info,
  * mjx_batch_copy_rgb, ...) */
 int mjx_pool_result_locate(const mjx_pool_result *r, size_t i, size_t *slot, mjx_batch **batch, size_t *index);
+/* host side of the call, per slot: parse threads the slot's mjx_decode_batch ran with (0: the slot had no file) and the NUMA
+ * node its host thread was bound to (-1: not bound) */
+int mjx_pool_result_host(const mjx_pool_result *r, size_t slot, unsigned *threads, int *numa_node);
 void mjx_pool_result_free(mjx_pool_result *r);
 
 const char *mjx_strerror(int code);

@@ -30,7 +30,7 @@ OK, ERR_TRUNCATED, ERR_UNSUPPORTED_MARKER, ERR_DRI_UNSUPPORTED, ERR_BAD_HUFFMAN,
     ERR_UNSUPPORTED_FORMAT, ERR_NO_SCAN, ERR_INVALID_ARG, ERR_NOMEM, ERR_MISSING_TABLE = range(12)
 LAYOUT_STANDARD, LAYOUT_REF_COMPAT = 0, 1
 STAGE_ENTROPY, STAGE_PIXELS, STAGE_ALL = 1, 2, 3
-KERNEL_NAMES = ["gather", "huff_sync", "huff_fix", "huff_scan", "huff_write", "dc_scan", "idct_color"]
+KERNEL_NAMES = ["gather", "huff_sync", "huff_fix", "huff_scan", "huff_write", "dc_scan", "idct_color", "upload"]
 SUBSAMPLING = {"444": 0, "422": 1, "420": 2, "gray": 3, "440": 4}
 
 
@@ -88,6 +88,8 @@ SYMBOLS = {
     "mjx_ctx_destroy": (None, [_vp]),
     "mjx_ctx_set_profiling": (_int, [_vp, _int]),
     "mjx_ctx_set_throughput_plan": (_int, [_vp, _int]),
+    "mjx_ctx_numa_node": (_int, [_vp]),
+    "mjx_host_processors": (ctypes.c_uint, []),
     "mjx_batch_create": (_int, [_vp, _P(ScanDesc), _sz, _P(Opts), _P(_vp), _P(_int)]),
     "mjx_batch_free": (None, [_vp]),
     "mjx_batch_tile": (_int, [_vp, _vp, _sz, _P(_vp)]),
@@ -111,6 +113,7 @@ SYMBOLS = {
     "mjx_pool_set_deal": (_int, [_vp, _int]),
     "mjx_pool_decode_batch": (_int, [_vp, _P(ctypes.c_char_p), _P(_sz), _sz, _P(Opts), ctypes.c_uint, _P(_int), _P(_P(ctypes.c_uint8)), _P(_int), _P(_vp)]),
     "mjx_pool_result_locate": (_int, [_vp, _sz, _P(_sz), _P(_vp), _P(_sz)]),
+    "mjx_pool_result_host": (_int, [_vp, _sz, _P(ctypes.c_uint), _P(_int)]),
     "mjx_pool_result_free": (None, [_vp]),
     "mjx_strerror": (ctypes.c_char_p, [_int]),
     "mjx_version": (ctypes.c_char_p, []),
@@ -504,7 +507,8 @@ def decode_batch(ctx, datas, strict_ref=False, layout=LAYOUT_STANDARD, threads=0
 
 class Pool:
     """mjx_pool: one context, host thread and work queue per device slot; the files of a call are dealt to the slots by
-    compressed bytes (i mod N for equal files) or round robin (set_deal)."""
+    compressed bytes (largest first; i mod N for equal files) or round robin (set_deal).  threads_per_device = 0: the slots
+    share the host's processors (max(2, P / 2N) parse threads each)."""
 
     def __init__(self, devices):
         self.h = _vp()
@@ -559,6 +563,12 @@ class PoolResult:
         slot, idx, b = _sz(), _sz(), _vp()
         _check(lib().mjx_pool_result_locate(self.h, i, ctypes.byref(slot), ctypes.byref(b), ctypes.byref(idx)))
         return slot.value, b, idx.value
+
+    def host(self, slot):
+        """-> (parse threads the slot's call ran with, NUMA node its host thread is bound to or -1)"""
+        t, node = ctypes.c_uint(), _int()
+        _check(lib().mjx_pool_result_host(self.h, slot, ctypes.byref(t), ctypes.byref(node)), "mjx_pool_result_host")
+        return int(t.value), int(node.value)
 
     def compare_rgb(self, mine, theirs):
         """On-device comparison of picture mine[k] with picture theirs[k] of this result (they may lie in different slots'

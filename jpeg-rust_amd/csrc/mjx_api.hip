@@ -4,6 +4,7 @@
 // hand-off in JPEGImage::parse (src/jpeg/mod.rs:388-417).  One context = one HIP device + one stream; a batch owns
 // every device buffer of its images; mjx_batch_decode only enqueues kernels (no allocation, no host sync).
 #include <hip/hip_runtime.h>
+#include <cctype>
 #include <sched.h>
 
 #include "mjx.h"
@@ -229,6 +230,7 @@ struct mjx_batch {
     uint32_t *h_mismatch = nullptr;     // pinned mirror
     size_t huff_lds = 0, huff_lds2 = 0, idct_lds = 0;      // tables + HuffImage in LDS: the plain set (write pass), the set with pair parts (counting passes)
     bool decoded_entropy = false;
+    unsigned last_stages = MJX_STAGE_ALL;   // what the last mjx_batch_decode was asked for: a repair in mjx_batch_wait runs the same stages
     int last_chunk_resident = -1;
     bool resident_second = false;   // ... and it lives in the second scratch set
     // second set of per-chunk scratch for the chunks that run on ctx->stream2 (null = single stream)
@@ -576,10 +578,14 @@ int allocate_work_buffers(mjx_batch *b, DevArena &ar)
     b->huff_lds = huff_lds_bytes(lut_cap);
     b->huff_lds2 = huff_lds_bytes(lut2_cap);
     b->idct_lds = idct_lds_bytes(max_tile_blocks);
-    if (b->huff_lds + huff_window_bytes() + huff_stage_bytes() > 160 * 1024 || b->idct_lds > 160 * 1024) return MJX_ERR_UNSUPPORTED_FORMAT;
+    // the largest dynamic LDS any entropy launch asks for, from the launchers' own expressions (mjx_kernels.hip): the write pass
+    // on the plain table set, the counting passes on the set with pair parts
+    const size_t lds_write = b->huff_lds + huff_window_bytes() + huff_stage_bytes();
+    const size_t lds_count = b->huff_lds2 + std::max(huff_window_bytes(), huff_merge_bytes());
+    if (std::max(lds_write, lds_count) > 160 * 1024 || b->idct_lds > 160 * 1024) return MJX_ERR_UNSUPPORTED_FORMAT;
     {
         const size_t pad = std::max(b->ctx->spec_lds_pad, std::max(b->ctx->merge_lds_pad, b->ctx->write_lds_pad));
-        const size_t want_huff = std::max(b->huff_lds + huff_window_bytes() + huff_stage_bytes(), b->huff_lds2 + size_t(40) * 1024) + pad;
+        const size_t want_huff = std::max(lds_write, lds_count) + pad;
         const size_t want_idct = b->idct_lds + b->ctx->idct_lds_pad;
         if (want_huff > b->ctx->configured_huff || want_idct > b->ctx->configured_idct) {
             if (configure_kernels(std::max(want_huff, b->ctx->configured_huff), std::max(want_idct, b->ctx->configured_idct)) != 0) { (void)hipGetLastError(); return MJX_ERR_DEVICE; }
@@ -676,7 +682,9 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         prof_end(b, st);
         prof_begin(b, MJX_K_DC_SCAN, st);
         launch_dc_scan(st, c.max_segs, nimg, imgs, SCR(d_dcd), dcb, SCR(d_segsum), b->d_img_flags, c.bpm_mask, c.max_restart_segs,
-                       (b->ctx->dc_one_pass && !b->dc_two_pass) ? b->d_segflag[set] : nullptr, ++b->dc_gen[set],
+                       // (a repair run -- force_first -- takes the two-pass kernels, which wait for nobody: nothing looks at the
+                       // "gave up" word after it, round-3 review)
+                       (b->ctx->dc_one_pass && !b->dc_two_pass && !force_first) ? b->d_segflag[set] : nullptr, ++b->dc_gen[set],
                        b->d_mismatch + ci * kMisWords + kMaxFix, b->ctx->dc_fault ? 1u << 10 : 1u << 20, b->ctx->dc_fault);
         prof_end(b, st);
         if (c.has_gather) {
@@ -1130,9 +1138,11 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
                 }
                 b->h_di = di;                                                  // (kept alive behind the asynchronous copy)
                 HIPOK(hipMemcpyAsync(b->d_di, b->h_di.data(), b->h_di.size() * sizeof(DestuffImg), hipMemcpyHostToDevice, up));
+                prof_begin(b, MJX_K_UPLOAD, up);
                 launch_destuff(up, destuff_max_seg, uint32_t(di.size()), destuff_restarts, static_cast<const DestuffImg *>(b->d_di), b->d_raw,
                                b->d_segcount, b->d_segbase, b->d_lin, b->d_rst, b->d_images, static_cast<InterleaveImg *>(b->d_ii), b->d_segs,
                                b->d_img_flags);
+                prof_end(b, up);
                 HIPOK(hipGetLastError());
             }
             if (timing && !async_upload) {
@@ -1143,8 +1153,10 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
             {   // linear -> lane-interleaved
                 if (!ii.empty()) {
                     const InterleaveImg *d_ii = static_cast<const InterleaveImg *>(b->d_ii);
+                    prof_begin(b, MJX_K_UPLOAD, up);
                     for (size_t at = 0; at < ii.size(); at += 32768)
                         launch_scan_interleave(up, max_pieces, uint32_t(std::min<size_t>(32768, ii.size() - at)), d_ii + at, b->d_images, b->d_lin, b->d_scan, b->d_segs);
+                    prof_end(b, up);
                     HIPOK(hipGetLastError());
                 }
                 if (timing && !async_upload) {
@@ -1269,6 +1281,26 @@ extern "C" int mjx_ctx_set_throughput_plan(mjx_ctx *ctx, int enable)
     ctx->throughput_plan = enable != 0;
     return MJX_OK;
 }
+
+// NUMA node of the context's GPU: /sys/bus/pci/devices/<domain:bus:device.function>/numa_node (-1 there: the platform does
+// not say, e.g. a single-node host or a VM).
+extern "C" int mjx_ctx_numa_node(const mjx_ctx *ctx)
+{
+    if (!ctx) return -1;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, int(sizeof bus) - 1, ctx->device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char *c = bus; *c; c++) *c = char(std::tolower(static_cast<unsigned char>(*c)));
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+    int node = -1;
+    if (FILE *f = std::fopen(path.c_str(), "r")) {
+        if (std::fscanf(f, "%d", &node) != 1) node = -1;
+        std::fclose(f);
+    }
+    return node;
+}
+
+namespace { unsigned usable_processors(); }
+extern "C" unsigned mjx_host_processors(void) { return usable_processors(); }
 
 // ---- batch ---------------------------------------------------------------------------------------
 extern "C" int mjx_batch_create(mjx_ctx *ctx, const mjx_scan_desc *descs, size_t n, const mjx_opts *opts,
@@ -1399,6 +1431,7 @@ extern "C" int mjx_batch_decode(mjx_batch *b, unsigned stages)
         const int rc = run_chunk(b, ci, stages, b->ctx->fix_passes);
         if (rc != MJX_OK) return rc;
     }
+    b->last_stages = stages;
     if (stages & MJX_STAGE_ENTROPY) {
         b->decoded_entropy = true;
         b->last_chunk_resident = int(b->chunks.size()) - 1;
@@ -1435,7 +1468,7 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
                 b->dc_two_pass = true;
                 first_set_rewritten = true;
                 HIPOK(hipMemsetAsync(b->d_status + c.first, 0, c.count * sizeof(int), b->ctx->stream));
-                const int rcd = run_chunk(b, ci, MJX_STAGE_ALL, std::min(b->ctx->fix_passes, kMaxFix), PH_ENTROPY_ALL, true);
+                const int rcd = run_chunk(b, ci, b->last_stages | MJX_STAGE_ENTROPY, std::min(b->ctx->fix_passes, kMaxFix), PH_ENTROPY_ALL, true);
                 if (rcd != MJX_OK) return rcd;
                 HIPOK(hipStreamSynchronize(b->ctx->stream));
                 collect_events(b);
@@ -1477,7 +1510,7 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
                 if (b->h_mismatch[ci * kMisWords + more - 1] == 0) break;
                 { const int rcg = loop_gave_up(b->h_mismatch[ci * kMisWords + more - 1]); if (rcg != MJX_OK) return rcg; }
             }
-            rc = run_chunk(b, ci, MJX_STAGE_ALL, 0, PH_TAIL, true);
+            rc = run_chunk(b, ci, b->last_stages | MJX_STAGE_ENTROPY, 0, PH_TAIL, true);
             if (rc != MJX_OK) return rc;
             HIPOK(hipStreamSynchronize(b->ctx->stream));
             collect_events(b);
@@ -1733,9 +1766,16 @@ extern "C" int mjx_batch_geometry(const mjx_batch *b, uint64_t *subsequences, ui
         return MJX_OK;
     }
     uint64_t ns = 0, nb = 0;
+    // scans de-stuffed on the device: the host planned with the stuffed length as an upper bound, the exact number of
+    // subsequences is in the device's copy of the images (k_destuff_prefix / k_restart_geometry)
+    std::vector<DevImage> dev_images;
+    if (b->has_stuffed && !b->himages.empty() && hipSetDevice(b->ctx->device) == hipSuccess && hipStreamSynchronize(b->ctx->upload) == hipSuccess) {
+        dev_images.resize(b->himages.size());
+        if (hipMemcpy(dev_images.data(), b->d_images, dev_images.size() * sizeof(DevImage), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); dev_images.clear(); }
+    }
     for (size_t i = 0; i < b->info.size(); i++) {
         if (b->info[i].status != MJX_OK) continue;
-        ns += b->himages[i].himg.nsub;
+        ns += dev_images.empty() ? b->himages[i].himg.nsub : dev_images[i].himg.nsub;
         if (b->info[i].role != 1) nb += b->info[i].nblocks;
     }
     if (subsequences) *subsequences = ns;
@@ -1842,6 +1882,7 @@ extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const
     unsigned nt = threads ? threads : std::max(4u, usable_processors() / 2);
     nt = std::max(1u, std::min(nt, 32u));
     nt = unsigned(std::min<size_t>(nt, std::max<size_t>(n, 1)));
+    if (std::getenv("MJX_TIMING")) std::fprintf(stderr, "[mjx] decode_batch on device %d: %zu files, %u parse threads\n", ctx->device, n, nt);
     // groups: small ones first so that the device has work early (12 MB, doubling), then group_bytes each.  Consecutive
     // transfers start 0.3 ms apart whatever stream they are on (measured with a copy stream of their own, and with three),
     // so long lists get larger groups: 192 MB from 1.5 GB on, 96 MB below.  Smaller groups again at the end of the list

@@ -315,8 +315,13 @@ MJX_HD bool symbol_step(LaneState &st, BitSrc &bits, const LutEntry *lut, const 
         const int32_t g = bits_field_signed(w, 0u - e, size);
         const int32_t hflip = g ^ int32_t(0xffffffffu << (size & 31u));
         const int32_t val = hflip - (hflip >> 31);
+#if defined(MJX_EXP_DCSTREAM)
+        if (r_old == kRBlock) sink.dc(blk, val);
+        if (e & kLutCnt) sink.ac(blk, st.r, val);
+#else
         if (r_old == kRBlock) sink.dc(blk, val);
         else if (e & kLutCnt) sink.ac(blk, st.r, val);
+#endif
     }
     st.x -= e & kLutXMask;
     if (PAIR) {
@@ -331,12 +336,17 @@ MJX_HD bool symbol_step(LaneState &st, BitSrc &bits, const LutEntry *lut, const 
     }
     if (st.r == 0) {
         st.r = kRBlock;
-        st.dcb = st.nb.tabs & 0xffffu;
-        st.acb = st.nb.tabs >> 16;
-        st.nb = img.btab[st.nb.next];
         st.n++;
         blk++;
         if (WRITE) sink.block_done(blk);
+        st.dcb = st.nb.tabs & 0xffffu;
+        st.acb = st.nb.tabs >> 16;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (the table entry of the block after the next one is not needed before the next block ends: the read goes straight
+        // into the lane's registers, last in this region, so that nothing in it waits for the LDS round trip)
+        asm volatile("" : "+v"(st.dcb), "+v"(st.acb));
+#endif
+        st.nb = img.btab[st.nb.next];
     }
     if ((st.x & 0xffu) > 31u) {
         st.x += 32u;                                                              // t += 32, the borrow goes back

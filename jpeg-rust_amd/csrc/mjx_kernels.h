@@ -44,6 +44,8 @@ struct DevImage {
     uint32_t restart_mcus;
     uint32_t ent_cap;       // entries the image's stream region holds
     uint32_t n_rst_found;   // scans de-stuffed on the device: RSTn markers found (k_destuff_prefix)
+    uint32_t upload_short;  // ... and their diagnosis at upload (a scan of nothing but stuffing, fewer RSTn markers than intervals): the
+                            // picture is truncated whatever the block counts of a later decode say (k_huff_scan ORs it in)
     // multi-scan files: role 1 = one scan as a picture of its own (one component in raster order, or two
     // interleaved; entropy stage only; tile = one block, so tile_eoff holds an offset per block), role 2 = the picture
     // (no scan; the k_planar_* kernels build its stream from the role-1 images: component c comes from the image
@@ -100,6 +102,7 @@ size_t idct_lds_bytes(uint32_t max_tile_blocks);
 int configure_kernels(size_t huff_lds, size_t idct_lds);
 size_t huff_window_bytes();     // LDS the windowed entropy kernels need on top of huff_lds_bytes()
 size_t huff_stage_bytes();      // ... and the write pass's entry rings
+size_t huff_merge_bytes();      // LDS the merge kernels (rounds, straggler kernel, loop kernel) need on top of huff_lds_bytes()
 uint32_t stream_group_entries();    // entries per store group of the write pass: a subsequence's run in the stream is rounded up to whole groups
 // count -> prefix (+ geometry into `images`) -> scatter (+ marker list) -> segment tables of the pictures with restart intervals;
 // segcount / segbase: two words per 16 KiB segment of every scan

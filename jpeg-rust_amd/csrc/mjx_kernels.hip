@@ -215,6 +215,10 @@ struct DcRing16 {
 #define MJX_DC_GROUP 4
 #endif
 constexpr uint32_t kAcGroup = MJX_AC_GROUP;                                          // 32-byte sectors of entries
+#ifndef MJX_RING_PAD
+#define MJX_RING_PAD 0
+#endif
+constexpr uint32_t kAcRingStride = 2 * kAcGroup + MJX_RING_PAD;                       // dwords between two lanes' rings (a multiple of 4: 16-byte reads)
 static_assert(kAcGroup >= kFlushEvery && DcRing16::kGroup - 1 + kFlushEvery <= DcRing16::kRing, "ring capacity between two flushes (a block takes two symbols at least; the DC ring is flushed every second time)");
 __device__ __forceinline__ uint32_t stream_run(uint32_t m) { return (m + kAcGroup - 1) & ~(kAcGroup - 1); }
 struct StreamSink {
@@ -228,7 +232,9 @@ struct StreamSink {
     static __device__ __forceinline__ uint32_t block_bits(uint32_t blk) { return ((blk & 0xffu) << 22) + (63u << kRShift); }
     __device__ __forceinline__ void dc(uint32_t b, int v)
     {
+#if !defined(MJX_EXP_DCSTREAM) && !defined(MJX_EXP_NODC)
         dc_ring.push(v);                            // (b == dc_ring.off - 1: a lane's blocks are consecutive)
+#endif
         if (b == next_tile_blk) {           // first block of a stage-B tile: remember where its entries start
             tile_eoff[tile_idx] = ac_ring.off;
             tile_idx++;
@@ -249,7 +255,9 @@ struct StreamSink {
         ac_ring.flush_groups();
         // the DC ring every second time: a block takes two symbols at least, so at most kFlushEvery differences arrive in
         // 2 * kFlushEvery symbols on top of the < kGroup that wait for their group (9.83 -> 9.74 ms per 2048 pictures)
+#if !defined(MJX_EXP_DCSTREAM) && !defined(MJX_EXP_NODC)
         if (it % (2 * kFlushEvery) == 0) dc_ring.flush_groups();
+#endif
     }
     __device__ __forceinline__ void block_done(uint32_t next_blk)
     {
@@ -657,6 +665,7 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
 #ifndef MJX_TAIL_WG
 #define MJX_TAIL_WG 256
 #endif
+static_assert(MJX_TAIL_WG <= MJX_MERGE_WG && MJX_MERGE_WG % MJX_TAIL_WG == 0, "the straggler kernel's grid is the merge grid times kMergeWg / kTailWg");
 constexpr uint32_t kTailWg = MJX_TAIL_WG;      // lanes per workgroup (measured 64 / 128 / 256: 2.50 / 2.30 / 2.20 ms of merge rounds per 2048 pictures)
 extern "C" __global__ __launch_bounds__(kTailWg) void k_huff_merge_tail(const DevImage *images, const uint8_t *scan_pool,
                                                                     const LutEntry *lut_pool, SubseqState *g_exit,
@@ -933,7 +942,7 @@ extern "C" __global__ __launch_bounds__(256) void k_destuff_prefix(const Destuff
         d.himg.total_bits = run * 8u;
         d.n_rst_found = run_rst;
         if (d.nseg <= 1) d.himg.nsub = (run * 8u + d.himg.sub_bits - 1) / d.himg.sub_bits;      // (else: k_restart_geometry)
-        if (run == 0) img_flags[d.status_idx] = 1u;                        // nothing but stuffing: reported as truncated
+        if (run == 0) { img_flags[d.status_idx] = 1u; d.upload_short = 1u; }   // nothing but stuffing: reported as truncated
     }
 }
 
@@ -1006,7 +1015,7 @@ extern "C" __global__ __launch_bounds__(256) void k_restart_geometry(const Destu
     if (threadIdx.x == 0) {
         sg[nseg] = make_uint2(run, total_bits);
         d.himg.nsub = run;
-        if (found + 1 < nseg) img_flags[d.status_idx] = 1u;                 // fewer RSTn markers than intervals
+        if (found + 1 < nseg) { img_flags[d.status_idx] = 1u; d.upload_short = 1u; }   // fewer RSTn markers than intervals
     }
 }
 
@@ -1100,7 +1109,7 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *im
     }
     if (tid == 0) {
         img_entries[im.status_idx] = total_m;      // upper bound of the entries the write pass produces
-        img_flags[im.status_idx] = s_short;
+        img_flags[im.status_idx] = s_short | im.upload_short;     // (a repair run comes through here again: the upload-time diagnosis stays)
     }
 }
 
@@ -1152,8 +1161,8 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
     const uint32_t first_start = blk + (e.z ? 1u : 0u);                    // first block whose DC this lane decodes
     {
         uint32_t *rings = s_win + kHuffWg * kWinStride;
-        sink.ac_ring.begin(rings + threadIdx.x * LaneRing<kAcGroup>::kRing, entries + im.ent_off, ebase);
-        rings += kHuffWg * LaneRing<kAcGroup>::kRing;
+        sink.ac_ring.begin(rings + threadIdx.x * kAcRingStride, entries + im.ent_off, ebase);
+        rings += kHuffWg * kAcRingStride;
         sink.dc_ring.begin(rings + threadIdx.x * (DcRing16::kRing / 2), dcdiff + im.coef_off, first_start);
     }
     sink.blk_bits = StreamSink::block_bits(blk);
@@ -2246,7 +2255,8 @@ extern "C" __global__ __launch_bounds__(256) void k_rgb_compare(const RgbPair *p
 // ------------------------------------------------------------------------------------------------
 size_t huff_lds_bytes(uint32_t lut_cap_entries) { return (sizeof(HuffImage) + size_t(lut_cap_entries) * sizeof(LutEntry) + 15) / 16 * 16; }
 size_t huff_window_bytes() { return size_t(kHuffWg) * kWinStride * 4; }
-size_t huff_stage_bytes() { return size_t(kHuffWg) * (LaneRing<kAcGroup>::kRing * 4 + DcRing16::kRing * 2); }    // the write pass's rings
+size_t huff_merge_bytes() { return size_t(kMergeWg) * kMergeStride * 4 + (kMergeWg / 64 + 1) * 4; }
+size_t huff_stage_bytes() { return size_t(kHuffWg) * (kAcRingStride * 4 + DcRing16::kRing * 2); }    // the write pass's rings
 
 uint32_t tile_mcus_420() { return kTile420; }
 uint32_t stream_group_entries() { return kAcGroup; }
@@ -2309,7 +2319,7 @@ void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
                        const uint32_t *prev_mismatches, bool first_round)
 {
     // (item_count: this round's straggler counts, one per image, zeroed by the caller -- one memset for all the rounds of a chunk)
-    const size_t lds = tables_lds + size_t(kMergeWg) * kMergeStride * 4 + (kMergeWg / 64) * 4 + pad_lds;
+    const size_t lds = tables_lds + huff_merge_bytes() + pad_lds;
     hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches, uint32_t(tables_lds), items, item_count, segs, prev_mismatches,
                        first_round ? uint32_t(kHeadSlices) : uint32_t(MJX_LATER_HEAD_SLICES));
     const size_t tail_lds = tables_lds + size_t(kTailWg) * kMergeStride * 4;
@@ -2321,7 +2331,7 @@ void launch_huff_merge_loop(hipStream_t st, uint32_t max_wg, uint32_t nimg, size
                             uint32_t *cps, uint32_t *verdict, const uint32_t *segs, uint32_t *ctl, uint32_t participants, uint32_t max_rounds,
                             uint32_t spin_limit)
 {
-    const size_t lds = tables_lds + size_t(kMergeWg) * kMergeStride * 4 + (kMergeWg / 64 + 1) * 4 + pad_lds;
+    const size_t lds = tables_lds + huff_merge_bytes() + pad_lds;
     hipLaunchKernelGGL(k_huff_merge_loop, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, verdict, uint32_t(tables_lds), segs, ctl, participants, max_rounds, spin_limit);
 }
 

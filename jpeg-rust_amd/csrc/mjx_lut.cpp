@@ -16,7 +16,11 @@ static LutEntry entry_for_symbol(unsigned len, uint8_t sym, bool is_dc)
 {
     if (is_dc) {
         if (sym > 15) return lut_invalid();          // read_n_bits asserts n <= 16 (huffman.rs:202); 16 is unusable
+#ifdef MJX_EXP_DCSTREAM                          // (measurement builds only: the DC difference as an entry of the stream)
+        return lut_direct(len, 0, sym, false) | kLutCnt;
+#else
         return lut_direct(len, 0, sym, false);
+#endif
     }
     const unsigned r = sym >> 4, s = sym & 15;
     if (sym == 0x00) return lut_direct(len, 63, 0, true);  // EOB

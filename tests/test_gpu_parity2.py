@@ -311,6 +311,40 @@ def test_pool_deals_a_skewed_list_by_bytes(mjx, orc):
     assert max(loads[False]) <= 1.25 * min(loads[False]), loads[False]
 
 
+def test_pool_slots_share_the_hosts_processors(mjx, orc):
+    """First contact with eight GPUs on one host (round-3 review): with threads_per_device = 0 every slot used to size its
+    parse threads as if it were alone (eight slots on a 16-processor quota: 64 threads).  The slots now share the budget --
+    max(2, P / 2N) each, P = the processors the process may use -- so eight slots together stay within P (or at two per
+    slot on a host smaller than that), a largest-first deal keeps a skewed list level even when the large files come last,
+    and the pictures equal the one-slot decode of the same list bit for bit."""
+    P = int(mjx.lib().mjx_host_processors())
+    assert P >= 1
+    big = [mjx.synth_jpeg(1280, 720, "420", 85, seed=200 + k) for k in range(8)]
+    small = [mjx.synth_jpeg(96 + 8 * (k % 3), 64, ("420", "444")[k % 2], 60, seed=k) for k in range(16)]
+    datas = [small[i % 16] for i in range(248)] + big                      # the eight large files at the very end of the list
+    one = mjx.Pool([0])
+    r1 = one.decode_batch(datas)
+    assert r1.rc == mjx.OK and all(s == mjx.OK for s in r1.status)
+    assert r1.host(0)[0] == max(2, P // 2)
+    pool = mjx.Pool([0] * 8)
+    res = pool.decode_batch(datas)                                          # threads_per_device = 0: the budgeted default
+    assert res.rc == mjx.OK and all(s == mjx.OK for s in res.status)
+    per_slot = [res.host(s)[0] for s in range(8)]
+    assert all(t == max(2, P // 16) for t in per_slot), (per_slot, P)
+    assert sum(per_slot) <= max(P, 16), (per_slot, P)
+    nodes = {res.host(s)[1] for s in range(8)}
+    assert len(nodes) == 1                                                  # eight slots on one GPU: one node (or none named: -1)
+    load = [0] * 8
+    for i, s in enumerate(res.slot_of):
+        load[s] += len(datas[i])
+    assert max(load) <= 1.25 * min(load), load                              # (dealt in list order the last slot would carry 8 large files' worth more)
+    for i in list(range(0, 248, 31)) + list(range(248, 256)):
+        assert np.array_equal(res.rgb(i), r1.rgb(i)), i
+    ref = orc.decode(datas[255], layout=orc.LAYOUT_STD)
+    assert np.abs(res.rgb(255).astype(int) - ref.rgb.astype(int)).max() <= TOL
+    res.close(); r1.close(); pool.close(); one.close()
+
+
 def test_pipelined_decode_batch_equals_the_batch_api(mjx, gpu_ctx):
     """mjx_decode_batch cuts its list into groups that are parsed, uploaded and decoded in overlap; with groups of 1 MB a list
     of 70 mixed files becomes a dozen groups.  Every picture must equal, bit for bit, what the one-batch path
@@ -466,8 +500,11 @@ def test_dc_prediction_that_never_hears_from_its_predecessor_gives_up_and_two_pa
         "            assert np.abs(b.rgb(i).astype(int) - ref.rgb.astype(int)).max() <= 1, (chunk, rep, i)\n"
         "    b.close()\n"
         "print('dc fault ok')\n" % (ROOT, ROOT, ROOT))
+    # (the third: one synchronisation round enqueued, so the chunks are also unconverged -- the repair path's own decode must
+    # not start the one-pass kernel again and leave its "gave up" word unread, round-3 review)
     for extra in ({"MJX_DC_FAULT": "1", "MJX_TIMING": "1", "MJX_DC_ONE_PASS": "1"},      # (pinned: the suite itself may run under MJX_DC_ONE_PASS=0)
-                      {"MJX_DC_FAULT": "1", "MJX_STREAMS": "1", "MJX_DC_ONE_PASS": "1"}, {"MJX_DC_ONE_PASS": "0"}):
+                      {"MJX_DC_FAULT": "1", "MJX_STREAMS": "1", "MJX_DC_ONE_PASS": "1"},
+                      {"MJX_DC_FAULT": "1", "MJX_FIX_PASSES": "1", "MJX_DC_ONE_PASS": "1", "MJX_MERGE_LOOP": "0"}, {"MJX_DC_ONE_PASS": "0"}):
         out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "dc fault ok" in out.stdout, str(extra) + out.stdout[-2000:] + out.stderr[-2000:]
         if "MJX_TIMING" in extra:

@@ -205,6 +205,20 @@ def test_no_gpu_means_loud_failure_not_fallback(mjx):
     assert e.value.code == mjx.ERR_DEVICE
 
 
+def test_host_processor_count_follows_affinity_and_quota(mjx):
+    """mjx_host_processors (what mjx_decode_batch and the pool size their parse threads on) = the affinity mask capped by the
+    cgroup CPU quota; a null context has no NUMA node."""
+    n = int(mjx.lib().mjx_host_processors())
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            assert n <= max(1, -(-int(q) // int(period)))
+    except (OSError, ValueError):
+        pass
+    assert mjx.lib().mjx_ctx_numa_node(None) == -1
+
+
 def test_ref_compat_panic_detection_matches_the_oracle(mjx, orc):
     """geometries on which the reference's placement code indexes out of bounds must be reported as
     MJX_ERR_REF_PANIC by the host plan (REF_COMPAT layout), everything else must be accepted."""
