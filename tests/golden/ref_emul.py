@@ -503,21 +503,45 @@ def coef_stream_sha256(dec):
 
 
 SAMPLES = ["huff_simple0.jpg", "lena-bw.jpeg", "lena.jpeg", "2x2-chroma.jpeg"]
+# The two geometries the headline numbers are quoted on (BASELINE configs 4 and 5): 4:2:0 with nbx = 240 and 480, both
+# = 0 (mod 4) -- where get_indices (decoder.rs:259-288) misplaces the right half of every MCU row and the MCU count
+# of 1080p is short (Q2).  Inputs come from the repo's deterministic generator (jpeg-rust_amd/synth/mjx_synth.c).
+SYNTH = {"synth_1920x1080_420_q75_seed0": (1920, 1080, "420", 75, 0), "synth_3840x2160_420_q75_seed0": (3840, 2160, "420", 75, 0)}
+
+
+def record(dec):
+    return {"width": dec.dimensions[0], "height": dec.dimensions[1], "mcus": int(dec.mcus_read), "bits_used": int(dec.bits_used),
+            "blocks": [int(c.shape[0]) for c in dec.coef_stream], "coef_sha256": coef_stream_sha256(dec),
+            "rgb_sha256": hashlib.sha256(np.ascontiguousarray(dec.rgb).tobytes()).hexdigest()}
 
 
 def decode_sample(path):
     data = open(path, "rb").read()
     dec = parse(data, skip_unknown_app=True)
-    return {"width": dec.dimensions[0], "height": dec.dimensions[1], "mcus": int(dec.mcus_read), "bits_used": int(dec.bits_used),
-            "blocks": [int(c.shape[0]) for c in dec.coef_stream], "coef_sha256": coef_stream_sha256(dec),
-            "rgb_sha256": hashlib.sha256(np.ascontiguousarray(dec.rgb).tobytes()).hexdigest()}, dec
+    return record(dec), dec
+
+
+def decode_synth(data):
+    dec = parse(data, skip_unknown_app=True)
+    rec = record(dec)
+    rec["input_sha256"] = hashlib.sha256(data).hexdigest()
+    return rec, dec
 
 
 if __name__ == "__main__":
+    import sys
     root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, root)
+    import __graft_entry__ as ge                      # (only for the synthetic generator: mjx.synth_jpeg is gcc-built C, no GPU)
+    ge._load_build().build_synth()
+    mjx = ge.load_package()
     out = {}
     for name in SAMPLES:
         rec, _ = decode_sample(os.path.join(root, "tests", "data", name))
+        out[name] = rec
+        print(name, json.dumps(rec))
+    for name, (w, h, sub, q, seed) in SYNTH.items():
+        rec, _ = decode_synth(mjx.synth_jpeg(w, h, sub, q, seed=seed))
         out[name] = rec
         print(name, json.dumps(rec))
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_emul_golden.json"), "w") as f:

@@ -175,6 +175,31 @@ def test_two_independent_restatements_agree_byte_for_byte(orc, data_dir, name):
     assert golden[name] == rec
 
 
+@pytest.mark.parametrize("name", ["synth_1920x1080_420_q75_seed0", "synth_3840x2160_420_q75_seed0"])
+def test_two_restatements_agree_at_the_headline_geometries(mjx, orc, name):
+    """One 1080p and one 4K 4:2:0 picture -- the geometries BASELINE configs 4 and 5 are quoted on, nbx = 240 and 480, both = 0
+    (mod 4): where the reference's get_indices scrambles the right half of every MCU row and, at 1080p, stops 60
+    MCUs short (Q2).  The Python restatement (run here, full size), the C oracle in faithful mode and the answers committed in
+    ref_emul_golden.json by the generator (`python tests/golden/ref_emul.py`) must agree on the coefficient stream, the bits
+    consumed, the MCU count and every byte of the bug-compatible picture."""
+    import json
+    re_ = _ref_emul()
+    golden = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_emul_golden.json")))[name]
+    w, h, sub, q, seed = re_.SYNTH[name]
+    data = mjx.synth_jpeg(w, h, sub, q, seed=seed)
+    assert hashlib.sha256(data).hexdigest() == golden["input_sha256"]              # the generator's input, reproduced
+    d = orc.decode(data, layout=orc.LAYOUT_REF, faithful_cos=True, faithful_huff=True)
+    assert (d.bits_used, d.mcus, [len(c) for c in d.coefs]) == (golden["bits_used"], golden["mcus"], golden["blocks"])
+    assert golden["mcus"] == -(-((w + 7) // 8 * ((h + 7) // 8)) // 4)                 # decoder.rs:164-166 (Q2): 8100 at 1080p, not 8160
+    assert _coef_sha(d) == golden["coef_sha256"]
+    assert hashlib.sha256(np.ascontiguousarray(d.rgb).tobytes()).hexdigest() == golden["rgb_sha256"]
+    rec, dec = re_.decode_synth(data)                                              # the second restatement, live
+    assert rec == golden
+    assert np.array_equal(dec.rgb, d.rgb)
+    std = orc.decode(data, layout=orc.LAYOUT_STD)                                  # (and the layout the throughput is quoted in differs: Q3)
+    assert std.rgb.shape == d.rgb.shape and not np.array_equal(std.rgb, d.rgb)
+
+
 def test_two_restatements_agree_on_synthetic_files_and_on_panics(mjx, orc):
     """The same comparison on files the samples do not cover: 4:2:0 / 4:4:0 / 4:2:2 geometries whose placement is wrong in
     the reference, geometries on which it panics, 16-bit quantisation tables, and semantically corrupt
