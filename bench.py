@@ -292,11 +292,13 @@ def run_config(mjx, ctx, datas, per_gpu, stages, steps, warmup, chunk_images=0, 
     assert all(s == mjx.OK for s in base.create_status), base.create_status
     if host_side is not None:
         one = {}
-        for label, dd in (("host_destuff", False), ("device_destuff", True)):       # one thread, file after file: the host leg per file
-            t1 = time.perf_counter()
-            for d in datas:
-                mjx.ParsedScan(d, device_destuff=dd).close()
-            one[label] = round(1e3 * (time.perf_counter() - t1) / len(datas), 4)
+        for rnd in range(3):                    # one thread, file after file: the host leg per file; the two modes in turn, the best of three
+            for label, dd in (("host_destuff", False), ("device_destuff", True)):    # (a single pass right after the upload measured the box, not the parser:
+                t1 = time.perf_counter()                                               # the round-3 driver run had the two the wrong way round)
+                for d in datas:
+                    mjx.ParsedScan(d, device_destuff=dd).close()
+                v = round(1e3 * (time.perf_counter() - t1) / len(datas), 4)
+                one[label] = v if label not in one else min(one[label], v)
         host_side.update({"files": len(datas), "parse_ms_per_file": round(1e3 * t_parse / len(datas), 3),
                           "parse_ms_per_file_one_thread": one,
                           "parse_threads": min(32, os.cpu_count() or 1),

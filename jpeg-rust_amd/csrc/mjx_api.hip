@@ -84,6 +84,8 @@ struct mjx_ctx {
     std::mutex batch_mu;            // mjx_decode_batch: one call at a time per context (the pinned arena is shared state)
     int nstreams = 2;
     bool profiling = false;
+    bool upload_kernels_apart = true;   // mjx_decode_batch: upload-time kernels on a decode stream, the upload stream carries transfers only (MJX_UPLOAD_APART=0: all on the upload stream)
+    bool group_alt_stream = true;       // ... and every second group's entropy stage on the third stream (MJX_GROUP_ALT=0: all on the first)
     bool throughput_plan = false;   // mjx_ctx_set_throughput_plan: never cut a batch into short subsequences (a base that will be tiled)
     // mjx_decode_batch: pinned arena the files of a call are de-stuffed into; kept between calls (fresh pages cost ~0.35 us
     // per KB to fault in and unmap again -- four times the parsing itself), released with the context
@@ -200,6 +202,8 @@ struct mjx_batch {
     bool dc_two_pass = false;           // k_dc_scan_t gave up once on this batch (a workgroup waited too long for its predecessor): two passes from now on
     hipEvent_t uploaded = nullptr;      // recorded on ctx->upload behind the last upload command; the decode streams wait for it
     bool upload_pending = false;
+    hipEvent_t copied = nullptr;        // asynchronous upload: the transfers are done (the upload-time kernels wait for it on a decode stream)
+    bool alt_entropy_stream = false;    // mjx_decode_batch, every second group: the entropy stage runs on the context's third stream
     // mjx_decode_batch decodes its files in groups (upload of one group overlaps the decode of the one before): the batch
     // handed to the caller is then only a directory of the groups' batches
     std::vector<mjx_batch *> parts;
@@ -341,6 +345,7 @@ void release(mjx_batch *b)
     for (mjx_batch *part : b->parts) release(part);
     if (b->ctx) (void)hipSetDevice(b->ctx->device);
     if (b->uploaded) (void)hipEventDestroy(b->uploaded);
+    if (b->copied) (void)hipEventDestroy(b->copied);
     for (int k = 0; k < 2; k++) {
         if (b->ev_entropy[k]) (void)hipEventDestroy(b->ev_entropy[k]);
         if (b->ev_pixels[k]) (void)hipEventDestroy(b->ev_pixels[k]);
@@ -627,6 +632,9 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     const bool second = b->dual && (ci & 1) && !force_first;
     const int set = second ? 1 : 0;
     hipStream_t st = (second && b->ctx->stream3) ? b->ctx->stream3 : b->ctx->stream;
+    // (mjx_decode_batch: the groups of a list are batches of one chunk each; every second one takes the third stream for its
+    // entropy stage, so that two groups' latency-bound kernel chains run side by side like the chunks of one batch do)
+    if (b->alt_entropy_stream && b->ctx->stream3 && !force_first && !b->dual) st = b->ctx->stream3;
     hipStream_t sp = (b->ctx->stream2 && !force_first) ? b->ctx->stream2 : b->ctx->stream;
     if (sp != st && !b->ev_entropy[0]) {
         for (int k = 0; k < 2; k++) {
@@ -752,7 +760,8 @@ struct PinnedBump {
 // `src`'s pool, `times` repetitions of its images.
 int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_opts &opts, const mjx_batch *src,
                 size_t times, mjx_batch **out, int *status, bool async_upload = false,
-                uint32_t *pinned_words = nullptr, size_t pinned_cap = 0, PinnedBump *pin = nullptr, bool latency_plan = true)
+                uint32_t *pinned_words = nullptr, size_t pinned_cap = 0, PinnedBump *pin = nullptr, bool latency_plan = true,
+                bool alt_entropy_stream = false)
 {
     // A batch too small to fill the device (one picture, a handful) is bound by the serial chain of a lane -- ~810 symbols
     // of a 512-byte subsequence per decode pass, 0.29 us each -- not by throughput: its scans are cut into shorter subsequences
@@ -1080,6 +1089,20 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
             auto now = [] { return std::chrono::steady_clock::now(); };
             auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) { return std::chrono::duration<double, std::milli>(b2 - a).count(); };
             const auto t0 = now();
+            // Asynchronous upload (mjx_decode_batch: one batch per group of files): the upload stream carries nothing but the
+            // transfers, so that the DMA engine goes from one group's bytes straight to the next group's -- with the de-stuffing
+            // and interleave kernels between them it idled 0.15 ms per group (a kernel, a small copy and two engine hand-overs).
+            // The kernels go to the decode stream the group's entropy stage runs on, behind an event that marks the copies.
+            b->alt_entropy_stream = async_upload && alt_entropy_stream && ctx->stream3 && ctx->group_alt_stream;
+            const bool apart = async_upload && ctx->upload_kernels_apart;
+            hipStream_t ks = apart ? (b->alt_entropy_stream ? ctx->stream3 : ctx->stream) : up;
+            auto kernels_behind_copies = [&]() -> int {
+                if (!apart || b->copied) return MJX_OK;
+                HIPOK(hipEventCreateWithFlags(&b->copied, hipEventDisableTiming));
+                HIPOK(hipEventRecord(b->copied, up));
+                HIPOK(hipStreamWaitEvent(ks, b->copied, 0));
+                return MJX_OK;
+            };
             LutEntry *h_lut;
             float *h_qm;
             if (meta_block) {
@@ -1138,11 +1161,12 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
                 }
                 b->h_di = di;                                                  // (kept alive behind the asynchronous copy)
                 HIPOK(hipMemcpyAsync(b->d_di, b->h_di.data(), b->h_di.size() * sizeof(DestuffImg), hipMemcpyHostToDevice, up));
-                prof_begin(b, MJX_K_UPLOAD, up);
-                launch_destuff(up, destuff_max_seg, uint32_t(di.size()), destuff_restarts, static_cast<const DestuffImg *>(b->d_di), b->d_raw,
+                { const int rck = kernels_behind_copies(); if (rck != MJX_OK) return rck; }
+                prof_begin(b, MJX_K_UPLOAD, ks);
+                launch_destuff(ks, destuff_max_seg, uint32_t(di.size()), destuff_restarts, static_cast<const DestuffImg *>(b->d_di), b->d_raw,
                                b->d_segcount, b->d_segbase, b->d_lin, b->d_rst, b->d_images, static_cast<InterleaveImg *>(b->d_ii), b->d_segs,
                                b->d_img_flags);
-                prof_end(b, up);
+                prof_end(b, ks);
                 HIPOK(hipGetLastError());
             }
             if (timing && !async_upload) {
@@ -1153,10 +1177,11 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
             {   // linear -> lane-interleaved
                 if (!ii.empty()) {
                     const InterleaveImg *d_ii = static_cast<const InterleaveImg *>(b->d_ii);
-                    prof_begin(b, MJX_K_UPLOAD, up);
+                    { const int rck = kernels_behind_copies(); if (rck != MJX_OK) return rck; }
+                    prof_begin(b, MJX_K_UPLOAD, ks);
                     for (size_t at = 0; at < ii.size(); at += 32768)
-                        launch_scan_interleave(up, max_pieces, uint32_t(std::min<size_t>(32768, ii.size() - at)), d_ii + at, b->d_images, b->d_lin, b->d_scan, b->d_segs);
-                    prof_end(b, up);
+                        launch_scan_interleave(ks, max_pieces, uint32_t(std::min<size_t>(32768, ii.size() - at)), d_ii + at, b->d_images, b->d_lin, b->d_scan, b->d_segs);
+                    prof_end(b, ks);
                     HIPOK(hipGetLastError());
                 }
                 if (timing && !async_upload) {
@@ -1169,7 +1194,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
             // the caller goes on (parsing and uploading the next group of files) while the DMA engine works; the decode
             // streams wait for this event before their first kernel (run_chunk)
             HIPOK(hipEventCreateWithFlags(&b->uploaded, hipEventDisableTiming));
-            HIPOK(hipEventRecord(b->uploaded, up));
+            HIPOK(hipEventRecord(b->uploaded, b->copied ? (b->alt_entropy_stream ? ctx->stream3 : ctx->stream) : up));
             b->upload_pending = true;
         } else {
             HIPOK(hipStreamSynchronize(up));
@@ -1222,6 +1247,8 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     if (const char *e = std::getenv("MJX_MEDIUM_NSUB")) c->medium_nsub = uint64_t(std::max(0L, std::atol(e)));
     if (const char *e = std::getenv("MJX_LATENCY_SUB_BITS")) c->latency_sub_bits = uint32_t(std::max(512L, std::min(long(kSubseqBits), std::atol(e))));
     if (const char *e = std::getenv("MJX_DC_ONE_PASS")) c->dc_one_pass = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MJX_UPLOAD_APART")) c->upload_kernels_apart = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MJX_GROUP_ALT")) c->group_alt_stream = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_LOOP_FAULT")) c->loop_fault = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_DC_FAULT")) c->dc_fault = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_MERGE_LOOP")) c->merge_loop_max = uint32_t(std::min(192L, std::max(0L, std::atol(e))));
@@ -1893,19 +1920,51 @@ extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const
     size_t group_bytes = size_t(total_bytes >= (size_t(1536) << 20) ? 192 : 96) << 20;
     if (const char *e = std::getenv("MJX_GROUP_MB")) { const long v = std::atol(e); if (v > 0) group_bytes = size_t(v) << 20; }
     const bool single = o.keep_coefs || n <= 8;
+    // Group sizes: a ramp up from `first_bytes` (times `grow` per group: the device has work early, and the host -- which must
+    // have a group parsed and planned before its transfer can start -- keeps ahead of the DMA engine while the groups are
+    // small), then `group_bytes`.  A ramp down at the end of the list (MJX_GROUP_TAPER=1: halving, so that less is left to
+    // decode when the last transfer has landed) was measured again in round 4, with the other knobs (first group 6 / 8 / 12 MB,
+    // growth 1.5 / 1.6 / 2, groups of 64 / 96 / 128 MB): 13.5 .. 14.8 ms per 512 4K files whatever the schedule -- what the
+    // call waits for is the transfer (10.5 ms beside the kernels), the first group's parse and the last group's kernel chain.
+    size_t first_bytes = std::min(group_bytes / 8, size_t(12) << 20);
+    double grow = 2.0;
+    bool taper = false;
+    if (const char *e = std::getenv("MJX_GROUP_FIRST_MB")) { const double v = std::atof(e); if (v > 0) first_bytes = size_t(v * 1048576.0); }
+    if (const char *e = std::getenv("MJX_GROUP_GROW")) { const double v = std::atof(e); if (v >= 1.0) grow = v; }
+    if (const char *e = std::getenv("MJX_GROUP_TAPER")) taper = std::atoi(e) != 0;
     std::vector<size_t> gfirst{0};
-    {
-        size_t acc = 0, target = single ? ~size_t(0) : std::min(group_bytes / 8, size_t(12) << 20);
+    if (!single) {
+        std::vector<size_t> sizes, up, down;                // target bytes per group, front to back
+        for (double t = double(first_bytes); size_t(t) < group_bytes; t *= grow) up.push_back(size_t(t));
+        if (taper) for (size_t t = group_bytes / 2; t >= first_bytes && t > 0; t /= 2) down.push_back(t);
+        size_t up_sum = 0, down_sum = 0;
+        for (size_t t : up) up_sum += t;
+        for (size_t t : down) down_sum += t;
+        if (total_bytes < up_sum + down_sum + group_bytes / 2) {       // a short list: the ramp up, as far as the bytes go
+            size_t left = total_bytes;
+            for (size_t k = 0; left > 0; k++) {
+                const size_t want = k < up.size() ? up[k] : group_bytes;
+                sizes.push_back(std::min(want, left));
+                left -= sizes.back();
+            }
+        } else {
+            sizes = up;
+            const size_t mid = total_bytes - up_sum - down_sum;
+            const size_t k = std::max<size_t>(1, (mid + group_bytes / 2) / group_bytes);   // equal groups of about group_bytes in the middle
+            for (size_t j = 0; j < k; j++) sizes.push_back(mid / k + (j + 1 == k ? mid % k : 0));
+            for (size_t t : down) sizes.push_back(t);
+        }
+        size_t acc = 0, gi = 0;
         for (size_t i = 0; i < n; i++) {
             acc += lens[i];
-            if (acc >= target && i + 1 < n) {
+            if (gi < sizes.size() && acc >= sizes[gi] && i + 1 < n) {
                 gfirst.push_back(i + 1);
                 acc = 0;
-                target = std::min(group_bytes, target * 2);
+                gi++;
             }
         }
-        gfirst.push_back(n);
     }
+    gfirst.push_back(n);
     const size_t ngroups = gfirst.size() - 1;
     // one arena for all the de-stuffed scans (a slice of len + 64 bytes per file; what does not fit -- files with many
     // restart markers, multi-scan files -- is allocated by the parser): hundreds of megabyte-sized malloc / free pairs cost
@@ -2005,7 +2064,7 @@ extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const
         }
         if (rc != MJX_OK) break;
         constexpr size_t kPinnedPerPart = 8 * kMisWords;
-        rc = build_batch(ctx, plans, o, nullptr, 1, &part, nullptr, true, dir->h_mismatch + g * kPinnedPerPart, kPinnedPerPart, &pin, ngroups == 1);
+        rc = build_batch(ctx, plans, o, nullptr, 1, &part, nullptr, true, dir->h_mismatch + g * kPinnedPerPart, kPinnedPerPart, &pin, ngroups == 1, (g & 1) != 0);
         if (rc != MJX_OK) break;
         dir->parts.push_back(part);
         if (part->visible.size() != cnt) { rc = MJX_ERR_DEVICE; break; }
