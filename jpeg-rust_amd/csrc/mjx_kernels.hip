@@ -1876,13 +1876,55 @@ __device__ __forceinline__ void tile_fetch(const uint32_t *__restrict__ src, con
 // One stream entry -> one float in the tile: find the block from the entry's block byte, multiply by the
 // dequantisation x IDCT-prescale factor of its zig-zag position, store at the natural-order position
 // (un-zigzag, decoder.rs:230-232, 425-437).
-__device__ __forceinline__ void scatter_entry(uint32_t e, uint32_t first_lo, uint32_t nblk, float *tile_f,
+//
+// The tile's entries are scattered in batches of kPrefetch per lane, without a branch (round 4).  Entry by entry behind its own
+// `if (valid)`, each one paid two LDS round trips of its own -- the block's component and the position's natural index, then
+// the multiplier -- before its store: sixteen exposed round trips per lane and tile.  Now the component of a 4:2:0 block comes
+// from arithmetic on its index (other layouts: one byte read, batched as well), so the multiplier's and the natural position's
+// addresses are known at once, all reads of a batch are in flight together, and an entry that must not land (a null entry --
+// position 0 --, a block of another tile) is sent to a word of row padding instead of being branched around.  (The tables stay
+// two small arrays: a single array of {multiplier, offset} pairs would add 0.7 KB of static LDS, and with the allocation
+// granule that is the third workgroup per CU -- measured: 17.6 instead of 15.5 ms per 2048 pictures.)
+// where a lane sends the entries that must not land: a padding word (floats 64..67 of a block row are never read) of a row of
+// its own -- rows 0..127 exist in every tile allocation (tile_mcus), and the 32 lanes of an LDS store group hit 32 banks
+__device__ __forceinline__ uint32_t dump_bytes() { return (threadIdx.x & 127u) * uint32_t(kPixStride * 4) + (64u + ((threadIdx.x >> 3) & 3u)) * 4u; }
+
+template <int MODE>
+__device__ __forceinline__ uint32_t comp_of_block(uint32_t b, const uint8_t *s_comp)
+{
+    if (MODE == 1) {                                        // Y Y Y Y Cb Cr: block b of the tile, b < 256
+        const uint32_t j = b - 6u * ((b * 171u) >> 10);     // (171 / 1024: exact quotient by 6 below 512)
+        return j < 4u ? 0u : j - 3u;
+    }
+    return s_comp[b];
+}
+
+template <int MODE, int N>
+__device__ __forceinline__ void scatter_batch(const uint32_t (&ent)[N], uint32_t first_lo, uint32_t nblk, float *tile_f,
                                               const float *s_qm, const uint8_t *s_nat, const uint8_t *s_comp)
 {
-    const uint32_t b = ((e >> 22) - first_lo) & 0xffu;
-    const uint32_t pos = (e >> 16) & 63u;
-    // pos == 0 marks a null entry (the write pass fills up its runs with them)
-    if (b < nblk && pos != 0) tile_f[b * kPixStride + s_nat[pos]] = float(int32_t(int16_t(e & 0xffffu))) * s_qm[s_comp[b] * 64 + pos];
+    uint32_t b[N], pos[N], comp[N], nat[N];
+    float qm[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        b[k] = ((ent[k] >> 22) - first_lo) & 0xffu;
+        pos[k] = (ent[k] >> 16) & 63u;
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++) comp[k] = comp_of_block<MODE>(MODE == 1 ? b[k] : (b[k] < nblk ? b[k] : 0u), s_comp);
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        qm[k] = s_qm[comp[k] * 64u + pos[k]];
+        nat[k] = s_nat[pos[k]];
+    }
+    unsigned char *base = reinterpret_cast<unsigned char *>(tile_f);
+    const uint32_t dump = dump_bytes();
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const bool ok = b[k] < nblk && pos[k] != 0;           // pos == 0 marks a null entry (the write pass fills up its runs with them)
+        const uint32_t at = ok ? b[k] * uint32_t(kPixStride * 4) + nat[k] * 4u : dump;
+        *reinterpret_cast<float *>(base + at) = float(int32_t(int16_t(ent[k] & 0xffffu))) * qm[k];
+    }
 }
 
 // One lane = one 8x8 block: 16 x ds_read_b128 of its row, 8 column + 8 row transforms in registers, back to the row.
@@ -1924,6 +1966,11 @@ __device__ __forceinline__ void load4(const float *tile, const DevImage &im, uin
     }
 }
 
+#ifndef MJX_PIX_XCHG
+#define MJX_PIX_XCHG 1
+#endif
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Phase 3 for 4:2:0 (Y 2x2, Cb 1x1, Cr 1x1): lane -> (MCU t, 4-pixel strip sx) fixed; each step handles a 4x2 pixel
 // patch that shares one pair of chroma samples per component (box replication).  INTERIOR: every pixel of the tile
 // lies inside the image and rows are 4-byte aligned, so all eight stores are unconditional 12-byte stores.
@@ -1942,26 +1989,58 @@ __device__ __forceinline__ void pixels_420(uint32_t width, uint32_t height, uint
     const float *ybase = tile + (t * 6 + (sx >> 1)) * kPixStride + (sx & 1) * 4;
     const float *cbase = tile + (t * 6 + 4) * kPixStride + sx * 2;
     uint8_t *col = out_img + (size_t(my) * 16 * width + px) * 3;
+    // all the samples the lane converts in this tile are requested first (four row pairs: 48 registers, free here -- the
+    // transform's registers are dead), so that the LDS round trips of the four steps overlap instead of each step waiting
+    // for its own
+    f32x4 ya[4], yb[4];
+    f32x2 cb[4], cr[4];
+    if (INTERIOR && MJX_PIX_XCHG) {
+        // An interior tile: every sample of the tile is read exactly once in this phase, by exactly one lane -- so the read is an
+        // exchange with zero (ds_wrxchg), and the tile is clean for the next one's coefficients without a zero-fill pass
+        // (52 KB of LDS stores and a barrier per tile).  The compiler does not track LDS operations inside asm statements:
+        // the waits are spelled out, one per row pair, in issue order.
+        const f32x2 zero = {0.0f, 0.0f};
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t rp = tid / (kTile420 * 4) + 2 * j;
+            const float *yp = ybase + (rp >> 2) * 2 * kPixStride + ((rp * 2) & 7) * 8;
+            const uint32_t ay = uint32_t(uintptr_t((const __attribute__((address_space(3))) float *)(yp)));
+            const uint32_t ac = uint32_t(uintptr_t((const __attribute__((address_space(3))) float *)(cbase + rp * 8)));
+            asm volatile("ds_wrxchg2_rtn_b64 %0, %1, %2, %2 offset1:1" : "=v"(ya[j]) : "v"(ay), "v"(zero) : "memory");
+            asm volatile("ds_wrxchg2_rtn_b64 %0, %1, %2, %2 offset0:4 offset1:5" : "=v"(yb[j]) : "v"(ay), "v"(zero) : "memory");
+            asm volatile("ds_wrxchg_rtn_b64 %0, %1, %2" : "=v"(cb[j]) : "v"(ac), "v"(zero) : "memory");
+            asm volatile("ds_wrxchg_rtn_b64 %0, %1, %2 offset:%3" : "=v"(cr[j]) : "v"(ac), "v"(zero), "n"(kPixStride * 4) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(ya[0]), "+v"(yb[0]), "+v"(cb[0]), "+v"(cr[0]) :: "memory");
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(ya[1]), "+v"(yb[1]), "+v"(cb[1]), "+v"(cr[1]) :: "memory");
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ya[2]), "+v"(yb[2]), "+v"(cb[2]), "+v"(cr[2]) :: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ya[3]), "+v"(yb[3]), "+v"(cb[3]), "+v"(cr[3]) :: "memory");
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t rp = tid / (kTile420 * 4) + 2 * j;                 // row pair 0..7 inside the MCU
+            const float *yp = ybase + (rp >> 2) * 2 * kPixStride + ((rp * 2) & 7) * 8;
+            ya[j] = *reinterpret_cast<const f32x4 *>(yp);
+            yb[j] = *reinterpret_cast<const f32x4 *>(yp + 8);
+            cb[j] = *reinterpret_cast<const f32x2 *>(cbase + rp * 8);
+            cr[j] = *reinterpret_cast<const f32x2 *>(cbase + kPixStride + rp * 8);
+        }
+    }
 #pragma unroll
     for (uint32_t j = 0; j < 4; j++) {
-        const uint32_t rp = tid / (kTile420 * 4) + 2 * j;                 // row pair 0..7 inside the MCU
+        const uint32_t rp = tid / (kTile420 * 4) + 2 * j;
         const uint32_t py = my * 16 + rp * 2;
         if (!INTERIOR && py >= height) break;
-        const float *yp = ybase + (rp >> 2) * 2 * kPixStride + ((rp * 2) & 7) * 8;
-        const float4 ya = *reinterpret_cast<const float4 *>(yp);
-        const float4 yb = *reinterpret_cast<const float4 *>(yp + 8);
-        const float2 cb = *reinterpret_cast<const float2 *>(cbase + rp * 8);
-        const float2 cr = *reinterpret_cast<const float2 *>(cbase + kPixStride + rp * 8);
-        const ChromaTerms c0 = chroma_terms(cb.x, cr.x), c1 = chroma_terms(cb.y, cr.y);
+        const ChromaTerms c0 = chroma_terms(cb[j].x, cr[j].x), c1 = chroma_terms(cb[j].y, cr[j].y);
         Rgb p[4];
-        p[0] = ycc_to_rgb(ya.x, c0); p[1] = ycc_to_rgb(ya.y, c0);
-        p[2] = ycc_to_rgb(ya.z, c1); p[3] = ycc_to_rgb(ya.w, c1);
+        p[0] = ycc_to_rgb(ya[j].x, c0); p[1] = ycc_to_rgb(ya[j].y, c0);
+        p[2] = ycc_to_rgb(ya[j].z, c1); p[3] = ycc_to_rgb(ya[j].w, c1);
         uint8_t *dst = col + size_t(rp) * 2 * width * 3;
         if (INTERIOR) store_rgb4(dst, pack4(p));
         else store4(dst, pack4(p), aligned, npix);
         if (INTERIOR || py + 1 < height) {
-            p[0] = ycc_to_rgb(yb.x, c0); p[1] = ycc_to_rgb(yb.y, c0);
-            p[2] = ycc_to_rgb(yb.z, c1); p[3] = ycc_to_rgb(yb.w, c1);
+            p[0] = ycc_to_rgb(yb[j].x, c0); p[1] = ycc_to_rgb(yb[j].y, c0);
+            p[2] = ycc_to_rgb(yb[j].z, c1); p[3] = ycc_to_rgb(yb[j].w, c1);
             if (INTERIOR) store_rgb4(dst + size_t(width) * 3, pack4(p));
             else store4(dst + size_t(width) * 3, pack4(p), aligned, npix);
         }
@@ -2147,6 +2226,10 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
         s_nat[tid] = ZZ[tid];
     }
     if (tid < tile_blocks) s_comp[tid] = im.blk_comp[tid % bpm];
+    // the lane's own block slot (tid) has the same component in every tile (a tile is whole MCUs): its DC multiplier and level shift
+    const uint32_t my_comp = im.blk_comp[tid % bpm];
+    const float my_dc_qm = qmult[im.qm_off + my_comp * 64];
+    const float my_dc_add = (MODE != 2 && my_comp == 0) ? 128.0f : 0.0f;
     float *tile_f = reinterpret_cast<float *>(smem_px);
     // (the first tile's words are settled before the loop, so that on no path into a tile iteration a load is pending
     // on them: see the settle point behind phase 2)
@@ -2154,26 +2237,32 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
     for (int k = 0; k < kPrefetch; k++) asm volatile("" : "+v"(cur.ent[k]));
     asm volatile("" : "+v"(cur.dc), "+v"(cur.e0), "+v"(cur.e1));
 
+    bool clean = false;          // the tile's sample rows are zero already (the pixel phase of an interior 4:2:0 tile clears what it reads)
     for (uint32_t tile = tile0; tile < tile1; tile++) {
         const uint32_t m0 = tile * T;
         const uint32_t nm = min(T, nmcu - m0), nblk = nm * bpm;
-        {   // phase 0
+        if (!clean) {   // phase 0
             float4 *z = reinterpret_cast<float4 *>(smem_px);
             const uint32_t nq = nblk * (kPixStride / 4);
             for (uint32_t i = tid; i < nq; i += LANES) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            __syncthreads();
         }
-        __syncthreads();
         {   // phase 1
             const uint32_t first_lo = (tile * tile_blocks) & 0xffu;
+            scatter_batch<MODE>(cur.ent, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);       // (words behind the tile's last entry were fetched as 0: null)
+            for (uint32_t i0 = cur.e0 + LANES * kPrefetch; i0 < cur.e1; i0 += LANES * 4) {     // what a dense tile has beyond the prefetched words
+                uint32_t more[4];
 #pragma unroll
-            for (int k = 0; k < kPrefetch; k++)
-                if (cur.e0 + tid + LANES * k < cur.e1) scatter_entry(cur.ent[k], first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
-            for (uint32_t i = cur.e0 + tid + LANES * kPrefetch; i < cur.e1; i += LANES)
-                scatter_entry(src[i], first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t i = i0 + tid + LANES * k;
+                    more[k] = i < cur.e1 ? src[i] : 0u;
+                }
+                scatter_batch<MODE>(more, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+            }
             // DC; luminance blocks also take the + 128 of decoder.rs:318-330 here (a constant on the DC term of the
             // prescaled transform is the same constant on all 64 samples); REF_COMPAT adds it per pixel in k_ref_color,
             // where samples no block covers must come out as 0 + 128
-            if (tid < nblk) tile_f[tid * kPixStride] = float(cur.dc) * s_qm[s_comp[tid] * 64] + ((MODE != 2 && s_comp[tid] == 0) ? 128.0f : 0.0f);
+            if (tid < nblk) tile_f[tid * kPixStride] = float(cur.dc) * my_dc_qm + my_dc_add;
         }
         TileFetch nxt = cur;
         if (tile + 1 < tile1) tile_fetch<LANES>(src, s_eoff + (tile + 1 - tile0), dcs, tile + 1, tile_blocks, total_blocks, nxt);
@@ -2192,6 +2281,7 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
             const bool interior = aligned && nm == T && mx0 + T <= mcux && (mx0 + T) * 16 <= width && (my0 + 1) * 16 <= height;
             if (interior) pixels_420<true>(width, height, mcux, tile_f, m0, nm, out_img, aligned);
             else pixels_420<false>(width, height, mcux, tile_f, m0, nm, out_img, aligned);
+            clean = interior && MJX_PIX_XCHG;
         } else if (MODE == 2) {
             place_ref(im, tile_f, tile * tile_blocks, nblk, planes);
         } else {
