@@ -145,7 +145,7 @@ def observe_traffic(args):
             try:
                 p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
                 try:
-                    rc = p.wait(timeout=300)
+                    rc = p.wait(timeout=180)
                 except subprocess.TimeoutExpired:
                     os.killpg(p.pid, signal.SIGKILL)          # (the group this call started, nothing else)
                     p.wait()
