@@ -139,7 +139,8 @@ void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevI
                     bool fault = false /* test knob: a workgroup never publishes */);
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint32_t *entries, const uint32_t *tile_eoff, const int32_t *dcbuf, const float *qmult,
-                       uint8_t *rgb, uint32_t mode_mask, unsigned long long *planes, const uint32_t *img_flags);
+                       uint8_t *rgb, uint32_t mode_mask, unsigned long long *planes, const uint32_t *img_flags,
+                       bool dense = false /* the chunk's streams are dense (many entries per tile): deeper prefetch in the 4:2:0 kernel */);
 // multi-scan pictures: component streams (raster order) -> the picture's stream in MCU order, tile offsets, DC values
 void launch_planar_gather(hipStream_t st, uint32_t max_tiles, uint32_t nimg, const DevImage *images, uint32_t *entries,
                           uint32_t *tile_eoff, int32_t *dcbuf, uint32_t *img_flags);

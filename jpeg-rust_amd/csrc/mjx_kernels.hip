@@ -1839,10 +1839,15 @@ __device__ __forceinline__ void store4(uint8_t *dst, const Rgb4 &v, bool aligned
 #ifndef MJX_PREFETCH
 #define MJX_PREFETCH 8
 #endif
+#ifndef MJX_PREFETCH_DENSE
+#define MJX_PREFETCH_DENSE 12
+#endif
 #ifndef MJX_TILES_PER_WG
 #define MJX_TILES_PER_WG 16
 #endif
-constexpr int kPrefetch = MJX_PREFETCH;         // stream entries per lane held in registers (2048 per tile; the rest is re-read)
+constexpr int kPrefetch = MJX_PREFETCH;         // stream entries per lane held in registers (2048 per tile; the rest is read when the tile is scattered)
+constexpr int kPrefetchDense = MJX_PREFETCH_DENSE;   // ... in the 4:2:0 kernel's form for dense streams (3072 per tile: quality 90 and up), chosen per chunk by the host
+static_assert(MJX_PREFETCH == 8 && MJX_PREFETCH_DENSE > 8, "scatter batches of 4, 6, 8 and the full depth");
 constexpr int kTilesPerWg = MJX_TILES_PER_WG;
 #ifndef MJX_TILE420
 #define MJX_TILE420 32
@@ -1850,22 +1855,23 @@ constexpr int kTilesPerWg = MJX_TILES_PER_WG;
 constexpr uint32_t kTile420 = MJX_TILE420;        // MCUs per tile of the 4:2:0 kernel; its workgroup has 8 lanes per MCU
 constexpr uint32_t kLanes420 = kTile420 * 8;
 
+template <int PF>
 struct TileFetch {
     uint32_t e0, e1;                 // the tile's slice of the compact stream
-    uint32_t ent[kPrefetch];
+    uint32_t ent[PF];
     int32_t dc;
 };
 
-template <uint32_t LANES>
+template <uint32_t LANES, int PF>
 __device__ __forceinline__ void tile_fetch(const uint32_t *__restrict__ src, const uint32_t *__restrict__ eoff,
                                            const int32_t *__restrict__ dc, uint32_t tile, uint32_t tile_blocks,
-                                           uint32_t total_blocks, TileFetch &f)
+                                           uint32_t total_blocks, TileFetch<PF> &f)
 {
     const uint32_t tid = threadIdx.x;
     f.e0 = eoff[0];                  // (eoff: the workgroup's copy of its tiles' offsets in LDS, see k_idct_color)
     f.e1 = eoff[1];
 #pragma unroll
-    for (int k = 0; k < kPrefetch; k++) {
+    for (int k = 0; k < PF; k++) {
         const uint32_t i = f.e0 + tid + LANES * k;
         f.ent[k] = i < f.e1 ? __builtin_nontemporal_load(src + i) : 0u;      // (read once: streamed past L2, like the pictures on their way out)
     }
@@ -1900,7 +1906,7 @@ __device__ __forceinline__ uint32_t comp_of_block(uint32_t b, const uint8_t *s_c
 }
 
 template <int MODE, int N>
-__device__ __forceinline__ void scatter_batch(const uint32_t (&ent)[N], uint32_t first_lo, uint32_t nblk, float *tile_f,
+__device__ __forceinline__ void scatter_batch(const uint32_t *ent, uint32_t first_lo, uint32_t nblk, float *tile_f,
                                               const float *s_qm, const uint8_t *s_nat, const uint8_t *s_comp)
 {
     uint32_t b[N], pos[N], comp[N], nat[N];
@@ -2179,7 +2185,7 @@ extern "C" __global__ __launch_bounds__(256) void k_ref_color(const DevImage *im
 //            then issue the loads of the next tile
 //   phase 2  one lane = one 8x8 block: float AAN inverse DCT in registers (transform.rs:55-87 up to rounding)
 //   phase 3  chroma replication + YCbCr->RGB + packed stores
-template <int MODE>
+template <int MODE, int PF = kPrefetch>
 __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__ images,
                                                      const uint32_t *__restrict__ entries,
                                                      const uint32_t *__restrict__ tile_eoff,
@@ -2216,8 +2222,8 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
     // first waiting for its offsets (two dependent round trips per tile were what paced the tile loop).
     if (tid <= tiles_per_wg) s_eoff[tid] = eoff[min(tile0 + tid, ntiles)];
     __syncthreads();
-    TileFetch cur;
-    tile_fetch<LANES>(src, s_eoff, dcs, tile0, tile_blocks, total_blocks, cur);
+    TileFetch<PF> cur;
+    tile_fetch<LANES, PF>(src, s_eoff, dcs, tile0, tile_blocks, total_blocks, cur);
     for (uint32_t i = tid; i < 192; i += LANES) s_qm[i] = qmult[im.qm_off + i];
     if (tid < 64) {
         constexpr uint8_t ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
@@ -2234,7 +2240,7 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
     // (the first tile's words are settled before the loop, so that on no path into a tile iteration a load is pending
     // on them: see the settle point behind phase 2)
 #pragma unroll
-    for (int k = 0; k < kPrefetch; k++) asm volatile("" : "+v"(cur.ent[k]));
+    for (int k = 0; k < PF; k++) asm volatile("" : "+v"(cur.ent[k]));
     asm volatile("" : "+v"(cur.dc), "+v"(cur.e0), "+v"(cur.e1));
 
     bool clean = false;          // the tile's sample rows are zero already (the pixel phase of an interior 4:2:0 tile clears what it reads)
@@ -2249,23 +2255,32 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
         }
         {   // phase 1
             const uint32_t first_lo = (tile * tile_blocks) & 0xffu;
-            scatter_batch<MODE>(cur.ent, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);       // (words behind the tile's last entry were fetched as 0: null)
-            for (uint32_t i0 = cur.e0 + LANES * kPrefetch; i0 < cur.e1; i0 += LANES * 4) {     // what a dense tile has beyond the prefetched words
+            // The prefetched words the wave really has (a tile of the bench content holds ~1500 entries, 5.9 per lane; at quality
+            // 90 twice that): the batch is cut to that many slots -- a wave-uniform choice between a few batch sizes, so the
+            // reads of a batch stay in flight together and empty slots cost nothing.  (Words behind the tile's last entry were
+            // fetched as 0: null entries.)
+            const uint32_t have = cur.e1 - cur.e0, wave0 = tid & ~63u;
+            const uint32_t slots = have > wave0 ? (have - wave0 + LANES - 1) / LANES : 0u;      // uniform over the wave
+            if (slots <= 4) scatter_batch<MODE, 4>(cur.ent, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+            else if (slots <= 6) scatter_batch<MODE, 6>(cur.ent, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+            else if (slots <= 8 || PF == 8) scatter_batch<MODE, 8>(cur.ent, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+            else if (PF > 8) scatter_batch<MODE, PF>(cur.ent, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+            for (uint32_t i0 = cur.e0 + LANES * PF; i0 < cur.e1; i0 += LANES * 4) {     // what a dense tile has beyond the prefetched words
                 uint32_t more[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const uint32_t i = i0 + tid + LANES * k;
                     more[k] = i < cur.e1 ? src[i] : 0u;
                 }
-                scatter_batch<MODE>(more, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+                scatter_batch<MODE, 4>(more, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
             }
             // DC; luminance blocks also take the + 128 of decoder.rs:318-330 here (a constant on the DC term of the
             // prescaled transform is the same constant on all 64 samples); REF_COMPAT adds it per pixel in k_ref_color,
             // where samples no block covers must come out as 0 + 128
             if (tid < nblk) tile_f[tid * kPixStride] = float(cur.dc) * my_dc_qm + my_dc_add;
         }
-        TileFetch nxt = cur;
-        if (tile + 1 < tile1) tile_fetch<LANES>(src, s_eoff + (tile + 1 - tile0), dcs, tile + 1, tile_blocks, total_blocks, nxt);
+        TileFetch<PF> nxt = cur;
+        if (tile + 1 < tile1) tile_fetch<LANES, PF>(src, s_eoff + (tile + 1 - tile0), dcs, tile + 1, tile_blocks, total_blocks, nxt);
         __syncthreads();
         if (tid < nblk) idct_row_inplace(tile_f + tid * kPixStride);      // phase 2
         __syncthreads();
@@ -2273,7 +2288,7 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
         // before this tile's pixel stores go out.  Left to the next iteration, the wait for them is a vmcnt(0) that
         // sits behind those stores -- a full store drain per tile.
 #pragma unroll
-        for (int k = 0; k < kPrefetch; k++) asm volatile("" : "+v"(nxt.ent[k]));
+        for (int k = 0; k < PF; k++) asm volatile("" : "+v"(nxt.ent[k]));
         asm volatile("" : "+v"(nxt.dc), "+v"(nxt.e0), "+v"(nxt.e1));
         if (MODE == 1) {                                                  // phase 3
             // interior tile: all 32 MCUs in one MCU row, fully inside the image, rows 4-byte aligned
@@ -2364,7 +2379,8 @@ int configure_kernels(size_t huff_lds, size_t idct_lds)
     }
     if (e == hipSuccess && idct_lds > 64 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_idct_color<0>), hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_idct_color<1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_idct_color<1, kPrefetch>), hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_idct_color<1, kPrefetchDense>), hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_idct_color<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
     }
     return e == hipSuccess ? 0 : int(e);
@@ -2467,7 +2483,7 @@ void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevI
 
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint32_t *entries, const uint32_t *tile_eoff, const int32_t *dcbuf, const float *qmult,
-                       uint8_t *rgb, uint32_t mode_mask, unsigned long long *planes, const uint32_t *img_flags)
+                       uint8_t *rgb, uint32_t mode_mask, unsigned long long *planes, const uint32_t *img_flags, bool dense)
 {
     // A workgroup walks up to kTilesPerWg consecutive tiles of its image (offsets fetched once, the next tile's loads in
     // flight during this tile's arithmetic) -- when the launch has tiles to spare: with fewer than a few rounds of 3
@@ -2478,8 +2494,13 @@ void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t
     const uint32_t gx = (max_tiles + tpw - 1) / tpw;
     if (mode_mask & 1u)
         hipLaunchKernelGGL(k_idct_color<0>, dim3(gx, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags, tpw);
-    if (mode_mask & 2u)
-        hipLaunchKernelGGL(k_idct_color<1>, dim3(gx, nimg), dim3(kLanes420), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags, tpw);
+    if (mode_mask & 2u) {
+        // (dense streams -- more than ~2048 entries per tile: quality 90 and up -- take the form that prefetches twelve words per
+        // lane instead of eight: 18.2 -> 17.2 ms per 2048 4K pictures at quality 90; at quality 75 the four extra loads per
+        // lane and tile cost 0.15 ms)
+        if (dense) hipLaunchKernelGGL((k_idct_color<1, kPrefetchDense>), dim3(gx, nimg), dim3(kLanes420), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags, tpw);
+        else hipLaunchKernelGGL((k_idct_color<1, kPrefetch>), dim3(gx, nimg), dim3(kLanes420), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags, tpw);
+    }
     if (mode_mask & 4u)
         hipLaunchKernelGGL(k_idct_color<2>, dim3(gx, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags, tpw);
 }
