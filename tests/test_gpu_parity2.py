@@ -174,6 +174,28 @@ def test_T1_per_block_samples_against_the_reference_order_idct(mjx, orc, gpu_ctx
     assert flips < 0.02 * nb * 64, flips
 
 
+def test_stage_b_forms_for_sparse_and_dense_streams(mjx, orc, gpu_ctx):
+    """Stage B scatters a tile's stream entries in batches cut to what the tile holds (4, 6, 8 or all prefetched words per
+    lane), reads interior 4:2:0 tiles with an exchange for zero instead of zero-filling them, and takes a deeper-prefetching form
+    for chunks whose streams are dense (round 4).  Pictures from nearly empty tiles (flat content, coarse quantisation) to tiles
+    that overflow the prefetched words (noise at quality 98), in batches of their own -- the form is chosen per chunk -- and
+    mixed; every geometry has interior and edge tiles.  T0 equal, RGB within 1 of the oracle."""
+    flat = np.full((496, 1040, 3), 90, np.uint8)
+    flat[200:260, 300:700] = (200, 40, 120)
+    cases = [("sparse", [mjx.encode_rgb(flat, "420", 30), mjx.synth_jpeg(1040, 496, "420", 10, seed=3, noise_sigma=1.0)]),
+             ("medium", [mjx.synth_jpeg(1040, 496, "420", 75, seed=4), mjx.synth_jpeg(1536, 272, "420", 60, seed=5)]),
+             ("dense", [mjx.synth_jpeg(1040, 496, "420", 98, seed=6, noise_sigma=40.0), mjx.synth_jpeg(1536, 272, "420", 95, seed=7, noise_sigma=25.0)])]
+    everything = [d for _, ds in cases for d in ds]
+    for name, datas in cases + [("mixed", everything)]:
+        b = _decode(mjx, gpu_ctx, datas)
+        for i, d in enumerate(datas):
+            ref = orc.decode(d, layout=orc.LAYOUT_STD)
+            assert b.status(i) == mjx.OK, (name, i)
+            assert np.array_equal(b.coefs(i), orc.interleave(ref)), (name, i)
+            assert np.abs(b.rgb(i).astype(int) - ref.rgb.astype(int)).max() <= TOL, (name, i)
+        b.close()
+
+
 # ---- the harness's N > 1 path, on one GPU ------------------------------------------------------------------------------
 def test_bench_two_ranks_over_gloo_on_one_gpu(tmp_path):
     """bench.py under torch.distributed.run with two ranks (both on GPU 0): the shards are decoded independently, the
