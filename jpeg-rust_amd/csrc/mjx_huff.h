@@ -285,11 +285,24 @@ MJX_HD void lane_begin(LaneState &st, const BitSrc &bits, const HuffImage &img, 
     st.w1 = bits.be32(st.wn - 8u);
 }
 
+// (diagnostic builds only, -DMJX_STAMP: where a wave's cycles go inside the step; the default hook is empty)
+struct NoStamp { MJX_HD void at(int) {} };
+
 // One Huffman symbol: table lookup, EXTEND, coefficient placement, state update, window refill.
 // Returns true when the lane moved on to the next dword of the stream (the caller then looks at lane_event).
+template <bool WRITE, bool PAIR = false, class BitSrc, class Sink, class Stamp>
+MJX_HD bool symbol_step(LaneState &st, BitSrc &bits, const LutEntry *lut, const HuffImage &img, uint32_t &blk,
+                        Sink &sink, Stamp &sp);
 template <bool WRITE, bool PAIR = false, class BitSrc, class Sink>
 MJX_HD bool symbol_step(LaneState &st, BitSrc &bits, const LutEntry *lut, const HuffImage &img, uint32_t &blk,
                         Sink &sink)
+{
+    NoStamp sp;
+    return symbol_step<WRITE, PAIR>(st, bits, lut, img, blk, sink, sp);
+}
+template <bool WRITE, bool PAIR, class BitSrc, class Sink, class Stamp>
+MJX_HD bool symbol_step(LaneState &st, BitSrc &bits, const LutEntry *lut, const HuffImage &img, uint32_t &blk,
+                        Sink &sink, Stamp &sp)
 {
     static_assert(!(WRITE && PAIR), "the pair part carries no value bits: counting passes only");
     const uint32_t w = funnel(st.w0, st.w1, st.x);                                // next 32 bits of the stream
@@ -299,11 +312,13 @@ MJX_HD bool symbol_step(LaneState &st, BitSrc &bits, const LutEntry *lut, const 
     const uint32_t slot = lut_slot(base, w);
     LutEntry e = lut_at(lut, slot);
     LutEntry q = PAIR ? lut_at(lut, slot + uint32_t(kLutPrimarySize * sizeof(LutEntry))) : 0u;     // (one read instruction for both: ds_read2st64_b32)
+    sp.at(1);                                                                     // the primary entry is there
     if (lut_is_link(e)) {
         const uint32_t nb = e & 15u;
         e = lut_at(lut, base + bits_field(e, 4, 16) + bits_field(w, 32u - kLutPrimaryBits - nb, nb) * 4u);
         if (WRITE && (e & kLutBad)) sink.bad_code(blk);                           // (invalid patterns always come this way)
     }
+    sp.at(2);                                                                     // ... and the second-level one
     sink.tick();
     const uint32_t r_old = st.r;
     st.r = sat_sub(st.r, e & kLutZincMask);
@@ -323,6 +338,7 @@ MJX_HD bool symbol_step(LaneState &st, BitSrc &bits, const LutEntry *lut, const 
         else if (e & kLutCnt) sink.ac(blk, st.r, val);
 #endif
     }
+    sp.at(3);                                                                     // value, output
     st.x -= e & kLutXMask;
     if (PAIR) {
         // The symbol behind it as well -- unless this one was a DC code (its table has no pair part: what was read is not
@@ -348,6 +364,7 @@ MJX_HD bool symbol_step(LaneState &st, BitSrc &bits, const LutEntry *lut, const 
 #endif
         st.nb = img.btab[st.nb.next];
     }
+    sp.at(4);                                                                     // end of block
     if ((st.x & 0xffu) > 31u) {
         st.x += 32u;                                                              // t += 32, the borrow goes back
         st.w0 = st.w1;

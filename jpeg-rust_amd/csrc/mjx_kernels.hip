@@ -369,6 +369,28 @@ __device__ __forceinline__ void window_fill(uint32_t *lds, const LaneBits &g, ui
     }
 }
 
+#ifdef MJX_STAMP
+// Diagnostic build: shader-clock stamps between the parts of a wave step of the write pass, summed per part over the launch.
+// (The stamp drains the LDS counter -- cdna guide s7 -- so the build's run time means nothing; its shares do.)
+__device__ unsigned long long g_stamp_acc[8];
+struct WaveStamp {
+    uint32_t last, acc[8];
+    __device__ __forceinline__ uint32_t now() { uint64_t t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return uint32_t(t); }
+    __device__ __forceinline__ void begin() { for (int k = 0; k < 8; k++) acc[k] = 0; last = now(); }
+    __device__ __forceinline__ void at(int k) { __builtin_amdgcn_sched_barrier(0); const uint32_t t = now(); acc[k] += t - last; last = t; __builtin_amdgcn_sched_barrier(0); }
+    __device__ __forceinline__ void end()
+    {
+        if ((threadIdx.x & 63) == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_stamp_acc[k], (unsigned long long)acc[k]);
+    }
+};
+extern "C" int mjx_debug_stamps(unsigned long long out[8], int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp_acc), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_acc), z, sizeof z) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
+
 // Decode loop over LDS windows: a plain per-lane loop.  A lane that is done (left its subsequence, merged with its
 // previous decode, or ran past the last block in the write pass) drops out of the exec mask, so its state stays put in
 // its registers; the window restage and the ring flush are uniform over the lanes still active.  (These kernels are
@@ -400,11 +422,19 @@ __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry,
     bool running = live && entry.p <= end_bit && !(WRITE && blk >= total_blocks);
     const bool started = running;
     uint32_t it = 1;
+#ifdef MJX_STAMP
+    WaveStamp sp;
+    if (WRITE) sp.begin();
+#endif
     while (running) {                                                          // per-lane loop: finished lanes are masked off
         if (__builtin_amdgcn_ballot_w64(win.rp >= win_end)) {                  // uniform over the active lanes: restage
             window_fill(my_win, g, (st.wn - 4u) & ~15u);                       // (w0, w1 are in registers; wn - 4 is read next)
             win.rp = win_addr + ((st.wn - 4u) & 15u);
         }
+#ifdef MJX_STAMP
+        if (WRITE) { sp.at(0); (void)symbol_step<WRITE, !WRITE>(st, win, lut, h, blk, sink, sp); sp.at(5); }
+        else
+#endif
         (void)symbol_step<WRITE, !WRITE>(st, win, lut, h, blk, sink);
         // Events (checkpoints, the end of the subsequence) are due when wn -- it only moves when the lane takes a new
         // dword -- has reached a boundary.  Both are tested on wn alone, as two flat conditions: these loops are bound
@@ -417,7 +447,13 @@ __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry,
             if (it % kFlushEvery == 0) sink.flush_step(it);
             it++;
         }
+#ifdef MJX_STAMP
+        if (WRITE) sp.at(6);
+#endif
     }
+#ifdef MJX_STAMP
+    if (WRITE) sp.end();
+#endif
     if (!started) return make_state(entry.p, entry.z, entry.c);
     if (CP) checkpoint_fixup(cps, ev.k, st.n, lane_m(st));
     return lane_exit(st, ev, h, old_exit);
