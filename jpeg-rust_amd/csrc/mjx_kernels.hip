@@ -259,6 +259,8 @@ struct StreamSink {
         if (it % (2 * kFlushEvery) == 0) dc_ring.flush_groups();
 #endif
     }
+    __device__ __forceinline__ void flush_entries() { ac_ring.flush_groups(); }                             // (the two halves of flush_step: diagnostic builds stamp between them)
+    __device__ __forceinline__ void flush_dc(uint32_t it) { if (it % (2 * kFlushEvery) == 0) dc_ring.flush_groups(); }
     __device__ __forceinline__ void block_done(uint32_t next_blk)
     {
         blk_bits += 1u << 22;
@@ -443,12 +445,17 @@ __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry,
         static_assert(CP == 0 || CP == 1, "the kernels record checkpoints or not; merging re-decodes go slice-wise (merge_slice)");
         if (CP == 1 && st.wn >= ev.next_wn && st.wn < ev.end_wn) checkpoint_record(st, ev, cps);
         running = st.wn < ev.end_wn && !(WRITE && blk >= total_blocks);
+#ifdef MJX_STAMP
+        if (WRITE) {
+            if (it % kFlushEvery == 0) { sink.flush_entries(); sp.at(6); sink.flush_dc(it); }
+            it++;
+            sp.at(7);
+        }
+#else
         if (WRITE) {
             if (it % kFlushEvery == 0) sink.flush_step(it);
             it++;
         }
-#ifdef MJX_STAMP
-        if (WRITE) sp.at(6);
 #endif
     }
 #ifdef MJX_STAMP

@@ -15,8 +15,8 @@ f(out, 1)
 b.decode(); b.wait()
 f(out, 0)
 v = list(out)
-names = ["restage check + restage", "slot address + table read", "second-level lookup region", "value + output push", "x update + block end", "refill", "flush + loop control"]
-tot = sum(v[:7])
+names = ["restage check + restage", "slot address + table read", "second-level lookup region", "value + output push", "x update + block end", "refill", "entry-ring flush (when due)", "DC-ring flush (when due) + loop control"]
+tot = sum(v[:8])
 for n, x in zip(names, v):
     print("%-30s %6.1f %%" % (n, 100.0 * x / tot))
 print("total shader cycles (all waves)", tot)
