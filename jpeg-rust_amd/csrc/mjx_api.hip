@@ -67,6 +67,7 @@ struct mjx_ctx {
     bool dc_fault = false;          // test knob (MJX_DC_FAULT=1): a workgroup of k_dc_scan_t never publishes its sums; the ones behind it must give up
     uint64_t latency_nsub = 32768;  // batches of at most this many 512-byte subsequences (16 MB of scans: 64 of the 1024 workgroup slots of
                                     // k_huff_spec) are cut into shorter subsequences when they fit the loop kernel (MJX_LATENCY_NSUB, 0 = never),
+    bool linear_stream = false;                                 // MJX_STREAM_LINEAR=1: the packed stream for every picture (the layout of multi-scan pictures; A/B, tests)
     uint32_t latency_sub_bits = 512;                            // ... this many bits at least (MJX_LATENCY_SUB_BITS)
     uint64_t medium_nsub = 65536;   // batches of up to this many 512-byte subsequences (32 MB of scans, ~32 4K pictures) that are too large for
                                     // the loop kernel get 256-byte subsequences with launch-per-round merges (MJX_MEDIUM_NSUB, 0 = never):
@@ -107,6 +108,7 @@ struct ImageInfo {
     uint64_t rgb_off = 0, rgb_bytes = 0;
     uint64_t coef_off = 0;         // blocks, inside the per-block arrays of its chunk (or of the batch with keep_coefs)
     uint64_t ent_off = 0, ent_cap = 0;   // region of the compact coefficient stream (entries)
+    uint32_t ent_rows = 0, ent_hdr = 0;  // > 0: quad-interleaved (DevImage::ent_rows, ent_hdr)
     uint32_t tile_off = 0, ntiles = 0, tile_blocks = 0;
     uint64_t scan_len = 0;
     uint32_t chunk = 0;
@@ -123,7 +125,7 @@ struct Chunk {
     uint32_t tiles = 0, tile_base = 0;    // tile offsets (+1 sentinel per image)
     uint32_t loop_participants = 0;     // > 0: the merge rounds run as one launch (k_huff_merge_loop) with this many workgroups
     uint32_t lut2_cap = 0;         // entries of the largest second table set (pair parts, the counting passes)
-    uint32_t max_wg = 0, merge_wgs = 0, max_tiles = 0, lut_cap = 0, max_tile_blocks = 0, mode_mask = 0, max_segs = 0, bpm_mask = 0, max_restart_segs = 0;
+    uint32_t max_wg = 0, merge_wgs = 0, max_tiles = 0, lut_cap = 0, max_tile_blocks = 0, mode_mask = 0, layout_mask = 0, max_segs = 0, bpm_mask = 0, max_restart_segs = 0;
     uint64_t plane_words = 0;      // REF_COMPAT scratch of the chunk
     uint32_t max_pixel_wgs = 0;
     bool has_gather = false;       // holds multi-scan pictures (k_planar_gather runs)
@@ -457,6 +459,7 @@ void plan_chunks(mjx_batch *b)
                 c.lut_cap = std::max<uint32_t>(c.lut_cap, d.lut_n);
                 c.lut2_cap = std::max<uint32_t>(c.lut2_cap, d.lut2_n);
                 c.mode_mask |= 1u << d.mode;
+                if (d.role != 1) c.layout_mask |= d.ent_rows ? 2u : 1u;
                 c.bpm_mask |= 1u << d.bpm;
                 if (d.nseg > 1) c.max_restart_segs = std::max(c.max_restart_segs, d.nseg);
                 if (d.mode == 2) {
@@ -714,7 +717,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         if (c.plane_words) HIPOK(hipMemsetAsync(SCR(d_planes), 0, size_t(c.plane_words) * 8, sp));
         // (dense: over ~1400 bytes of scan per stage-B tile -- more than the 2048 stream entries the kernel's default form prefetches)
         launch_idct_color(sp, c.max_tiles, nimg, b->idct_lds + b->ctx->idct_lds_pad, imgs, SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_qm, b->d_rgb, c.mode_mask, SCR(d_planes), b->d_img_flags,
-                          uint64_t(c.nsub) * 576u > uint64_t(c.tiles) * 1400u);
+                          uint64_t(c.nsub) * 576u > uint64_t(c.tiles) * 1400u, c.layout_mask);
         if (c.plane_words) launch_ref_color(sp, c.max_pixel_wgs, nimg, imgs, SCR(d_planes), b->d_rgb, b->d_img_flags);
         prof_end(b, sp);
         if (sp != st) {
@@ -896,6 +899,19 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
         // with restart intervals the lanes also fill what the synchronisation passes counted after a segment's last block
         // (garbage, up to one entry per two bits of scan)
         if (p.restart_mcus) inf.ent_cap = (uint64_t(p.scan_len) * 4 + 64 + group_pad) / stream_group_entries() * stream_group_entries();
+        // A picture of one scan gets the quad-interleaved stream: one column of fixed capacity per subsequence (mjx_kernels.h,
+        // stream_phys); tile offsets are 32-bit virtual indices into the columns.
+        if (p.role == 0 && !ctx->linear_stream) {
+            const uint32_t rows = stream_rows_for(p.himg.sub_bits);
+            const uint64_t cap = stream_quad_entries(layout_nsub(p), rows);
+            if (rows < 65536u && cap < 0xffffffffull) {
+                d.ent_rows = rows;
+                d.ent_hdr = stream_hdr_entries(layout_nsub(p));
+                inf.ent_cap = cap + d.ent_hdr;
+            }
+        }
+        inf.ent_rows = d.ent_rows;
+        inf.ent_hdr = d.ent_hdr;
         inf.role = p.role;
         if (p.role == 2) {                     // gathered from the three scans in front of it
             if (i < p.nparts) return MJX_ERR_INVALID_ARG;
@@ -903,6 +919,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
             inf.ent_cap = 8;
             for (uint32_t k = 1; k <= p.nparts; k++) inf.ent_cap += b->info[i - k].ent_cap;
         }
+        inf.ent_cap = (inf.ent_cap + 31) / 32 * 32;        // regions start on whole 128-byte lines (rows of the quad-interleaved stream)
         d.ent_cap = uint32_t(std::min<uint64_t>(inf.ent_cap, 0xffffffffu));
         inf.scan_len = p.scan_len;
         inf.rgb_off = rgb_pool;
@@ -1247,6 +1264,7 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     if (const char *e = std::getenv("MJX_STREAMS")) { c->nstreams = std::atoi(e) == 1 ? 1 : 2; third = std::atoi(e) >= 3; }
     if (const char *e = std::getenv("MJX_LATENCY_NSUB")) c->latency_nsub = uint64_t(std::max(0L, std::atol(e)));
     if (const char *e = std::getenv("MJX_MEDIUM_NSUB")) c->medium_nsub = uint64_t(std::max(0L, std::atol(e)));
+    if (const char *e = std::getenv("MJX_STREAM_LINEAR")) c->linear_stream = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_LATENCY_SUB_BITS")) c->latency_sub_bits = uint32_t(std::max(512L, std::min(long(kSubseqBits), std::atol(e))));
     if (const char *e = std::getenv("MJX_DC_ONE_PASS")) c->dc_one_pass = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_UPLOAD_APART")) c->upload_kernels_apart = std::atoi(e) != 0;
@@ -1666,19 +1684,39 @@ extern "C" int mjx_batch_copy_coefs(mjx_batch *b, size_t iu, int16_t *host_coefs
     const uint32_t *tile_eoff = sec ? b->alt.d_tile_eoff : b->d_tile_eoff, *entries = sec ? b->alt.d_entries : b->d_entries;
     const int32_t *dcs = sec ? b->alt.d_dc : b->d_dc;
     HIPOK(hipMemcpy(eoff.data(), tile_eoff + inf.tile_off, eoff.size() * 4, hipMemcpyDeviceToHost));
-    const uint32_t nent = eoff.back();
-    if (nent > inf.ent_cap) return MJX_ERR_DEVICE;
-    std::vector<uint32_t> ent(size_t(nent) + 1);
-    if (nent) HIPOK(hipMemcpy(ent.data(), entries + inf.ent_off, size_t(nent) * 4, hipMemcpyDeviceToHost));
     std::vector<int32_t> dc(size_t(inf.nblocks));
     HIPOK(hipMemcpy(dc.data(), dcs + inf.coef_off, dc.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     std::memset(host_coefs, 0, size_t(inf.nblocks) * 128);
-    for (uint32_t t = 0; t < inf.ntiles; t++) {
-        const uint32_t first = t * inf.tile_blocks;
-        for (uint32_t j = eoff[t]; j < eoff[t + 1] && j < nent; j++) {
-            const uint32_t e = ent[j];
-            const uint64_t blk = first + (((e >> 22) - first) & 0xffu);
-            if (blk < inf.nblocks) host_coefs[blk * 64 + ((e >> 16) & 63)] = int16_t(e & 0xffff);
+    auto place = [&](uint32_t first, uint32_t e) {
+        const uint64_t blk = first + (((e >> 22) - first) & 0xffu);
+        if (blk < inf.nblocks) host_coefs[blk * 64 + ((e >> 16) & 63)] = int16_t(e & 0xffff);
+    };
+    if (inf.ent_rows) {
+        // quad-interleaved: a tile runs from (subsequence, entry) of its own offset to that of the next one, through the whole
+        // runs (the 16-bit group counts at the head of the region) of the subsequences between
+        std::vector<uint32_t> ent(size_t(inf.ent_cap));
+        HIPOK(hipMemcpy(ent.data(), entries + inf.ent_off, ent.size() * 4, hipMemcpyDeviceToHost));
+        const uint16_t *runs = reinterpret_cast<const uint16_t *>(ent.data());
+        const uint32_t *col = ent.data() + inf.ent_hdr;
+        const uint32_t cap = inf.ent_rows * 8u;
+        const uint64_t ncols = (inf.ent_cap - inf.ent_hdr) / cap;
+        for (uint32_t t = 0; t < inf.ntiles; t++) {
+            const uint32_t first = t * inf.tile_blocks;
+            const uint32_t s0 = eoff[t] / cap, j0 = eoff[t] % cap, s1 = eoff[t + 1] / cap, j1 = eoff[t + 1] % cap;
+            if (s0 > s1 || s1 >= ncols) return MJX_ERR_DEVICE;
+            for (uint32_t s = s0; s <= s1; s++) {
+                const uint32_t lo = s == s0 ? j0 : 0u, hi = s == s1 ? j1 : std::min<uint32_t>(uint32_t(runs[s]) * 8u, cap);
+                for (uint32_t j = lo; j < hi; j++) place(first, col[stream_phys(s, j, inf.ent_rows)]);
+            }
+        }
+    } else {
+        const uint32_t nent = eoff.back();
+        if (nent > inf.ent_cap) return MJX_ERR_DEVICE;
+        std::vector<uint32_t> ent(size_t(nent) + 1);
+        if (nent) HIPOK(hipMemcpy(ent.data(), entries + inf.ent_off, size_t(nent) * 4, hipMemcpyDeviceToHost));
+        for (uint32_t t = 0; t < inf.ntiles; t++) {
+            const uint32_t first = t * inf.tile_blocks;
+            for (uint32_t j = eoff[t]; j < eoff[t + 1] && j < nent; j++) place(first, ent[j]);
         }
     }
     for (size_t k = 0; k < dc.size(); k++) host_coefs[k * 64] = int16_t(dc[k]);

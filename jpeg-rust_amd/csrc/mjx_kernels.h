@@ -43,6 +43,10 @@ struct DevImage {
     uint32_t nseg;          // 1 = no restart interval
     uint32_t restart_mcus;
     uint32_t ent_cap;       // entries the image's stream region holds
+    uint32_t ent_rows;      // 0: the stream is linear, the lanes' runs packed behind one another (multi-scan pictures and their scans).
+                            // > 0: quad-interleaved columns (see stream_phys): rows of 32 bytes every lane's column holds
+    uint32_t ent_hdr;       // quad-interleaved: entries (4-byte words) at the head of the region that hold the subsequences' run
+                            // lengths in groups, 16 bits each (stream_hdr_entries); the columns follow
     uint32_t n_rst_found;   // scans de-stuffed on the device: RSTn markers found (k_destuff_prefix)
     uint32_t upload_short;  // ... and their diagnosis at upload (a scan of nothing but stuffing, fewer RSTn markers than intervals): the
                             // picture is truncated whatever the block counts of a later decode say (k_huff_scan ORs it in)
@@ -55,6 +59,22 @@ struct DevImage {
     uint32_t nparts;
     uint32_t cbw[3], cbh[3];    // role 2: block grid of each component's own scan
 };
+
+// ---- compact coefficient stream, quad-interleaved (round 4) -----------------------------------------------------------
+// A write-pass lane appends 32-byte groups (8 entries) to a stream of its own.  Packed one lane's run behind the other (the linear
+// layout), every lane keeps a 128-byte line open over four flushes and a wave's flush touches 64 lines 3 KB apart: three fifths
+// of the write pass went into these stores.  Here every subsequence owns a **column** of fixed capacity -- an
+// entry takes at least 2 bits of scan, so sub_bits / 2 + 1 entries at most -- and four neighbouring columns are interleaved
+// group by group: row r of quad q is one 128-byte line holding group r of subsequences 4q .. 4q + 3.  The four lanes flush
+// within a step or two of each other, so the line is whole before it leaves L2 (k_huff_write 9.6 -> 8.05 ms per 2048 4K pictures
+// for the stores alone), and a stage-B tile -- two or three lanes' worth of entries -- still reads consecutive lines.
+//   entry j of subsequence s lies at  stream_phys(s, j, rows) = ((s >> 2) * rows + (j >> 3)) * 32 + (s & 3) * 8 + (j & 7)
+//   a tile's start is recorded as the virtual index  s * (rows * 8) + j  (tile_eoff stays one 32-bit word per tile)
+constexpr uint32_t kStreamQuad = 4;
+MJX_HD uint32_t stream_rows_for(uint32_t sub_bits) { return (sub_bits / 2u + 1u + 7u) / 8u + 1u; }
+MJX_HD uint64_t stream_quad_entries(uint32_t nsub, uint32_t rows) { return uint64_t((nsub + kStreamQuad - 1) / kStreamQuad) * rows * 8u * kStreamQuad; }
+MJX_HD uint32_t stream_hdr_entries(uint32_t nsub) { return (nsub * 2u + 127u) / 128u * 32u; }      // whole 128-byte lines
+MJX_HD uint64_t stream_phys(uint32_t s, uint32_t j, uint32_t rows) { return (uint64_t(s >> 2) * rows + (j >> 3)) * 32u + (s & 3u) * 8u + (j & 7u); }
 
 // Lane-interleaved scan pool: pieces of 16 bytes, kLookPieces of look-ahead behind every subsequence (see LaneBits).
 constexpr uint32_t kLookPieces = 4;
@@ -140,7 +160,8 @@ void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevI
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint32_t *entries, const uint32_t *tile_eoff, const int32_t *dcbuf, const float *qmult,
                        uint8_t *rgb, uint32_t mode_mask, unsigned long long *planes, const uint32_t *img_flags,
-                       bool dense = false /* the chunk's streams are dense (many entries per tile): deeper prefetch in the 4:2:0 kernel */);
+                       bool dense /* the chunk's linear streams are dense (many entries per tile): deeper prefetch in the 4:2:0 kernel */,
+                       uint32_t layout_mask /* bit 0: pictures with a linear stream, bit 1: with a quad-interleaved one */);
 // multi-scan pictures: component streams (raster order) -> the picture's stream in MCU order, tile offsets, DC values
 void launch_planar_gather(hipStream_t st, uint32_t max_tiles, uint32_t nimg, const DevImage *images, uint32_t *entries,
                           uint32_t *tile_eoff, int32_t *dcbuf, uint32_t *img_flags);

@@ -18,6 +18,7 @@
 // as well) intra-image parallelism comes from the self-synchronisation of Huffman codes: a lane that starts decoding
 // at an arbitrary bit with a guessed state converges to the true symbol boundaries; entry states are iterated to a
 // fixed point.
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include "mjx_kernels.h"
@@ -96,9 +97,11 @@ template <uint32_t GROUP, bool ALIGNED = false>
 struct LaneRing {
     static constexpr uint32_t kRing = 2 * GROUP;
     uint32_t *ring;         // the lane's kRing dwords of LDS
-    uint32_t *out;          // the image's region (aligned to GROUP dwords)
+    uint32_t *out;          // the image's region (aligned to GROUP dwords) -- or, ALIGNED with gstride != GROUP, the lane's column
     uint32_t off;           // next index
     uint32_t flushed;       // indices below this are in HBM
+    uint32_t gstride = GROUP;   // ALIGNED: dwords from one group of the run to the next (GROUP: the run is contiguous; 4 * GROUP: a
+                                // column of a quad-interleaved stream, see stream_phys)
     __device__ __forceinline__ void begin(uint32_t *lds, uint32_t *region, uint32_t first)
     {
         ring = lds;
@@ -118,7 +121,7 @@ struct LaneRing {
 #ifdef MJX_EXP_STORE_SMALL              // (measurement builds only: the same store instructions, into 8 KB per image -- they stay in L2)
             uint4 *dst = reinterpret_cast<uint4 *>(out + (flushed & 0x7f8u));
 #else
-            uint4 *dst = reinterpret_cast<uint4 *>(out + flushed);
+            uint4 *dst = reinterpret_cast<uint4 *>(ALIGNED ? out + size_t(flushed / GROUP) * gstride : out + flushed);
 #endif
             const uint4 v0 = src[0], v1 = src[GROUP / 4 - 1];
 #ifndef MJX_EXP_NOSTORE                 // (measurement builds only: what the write pass costs without its global stores)
@@ -225,6 +228,8 @@ struct StreamSink {
     LaneRing<kAcGroup, true> ac_ring;   // index = entry index in the image's stream region; runs are whole groups
     DcRing16 dc_ring;               // index = block index in the image
     uint32_t *tile_eoff;    // the image's tile offsets (+ sentinel)
+    uint32_t tile_virt;     // what a tile offset adds to the ring's index: 0 (linear stream: the index is the offset), or the
+                            // virtual index of the lane's column (quad-interleaved: subsequence * column capacity)
     int *status;
     uint32_t blk_bits;      // the current block's index, placed as in coef_entry (bits above the field: don't care),
                             // + 63 << 16: minus the scaled r = position
@@ -236,7 +241,7 @@ struct StreamSink {
         dc_ring.push(v);                            // (b == dc_ring.off - 1: a lane's blocks are consecutive)
 #endif
         if (b == next_tile_blk) {           // first block of a stage-B tile: remember where its entries start
-            tile_eoff[tile_idx] = ac_ring.off;
+            tile_eoff[tile_idx] = tile_virt + ac_ring.off;
             tile_idx++;
             next_tile_blk += tile_blocks;
         }
@@ -264,7 +269,7 @@ struct StreamSink {
     __device__ __forceinline__ void block_done(uint32_t next_blk)
     {
         blk_bits += 1u << 22;
-        if (next_blk == total_blocks) tile_eoff[ntiles] = ac_ring.off;
+        if (next_blk == total_blocks) tile_eoff[ntiles] = tile_virt + ac_ring.off;
     }
     __device__ __forceinline__ void flush()
     {
@@ -371,8 +376,9 @@ __device__ __forceinline__ void window_fill(uint32_t *lds, const LaneBits &g, ui
     }
 }
 
-#ifdef MJX_STAMP
-// Diagnostic build: shader-clock stamps between the parts of a wave step of the write pass, summed per part over the launch.
+#if defined(MJX_STAMP) || defined(MJX_STAMP_B)
+// Diagnostic build: shader-clock stamps between the parts of a wave step of the write pass (MJX_STAMP) or of a stage-B tile
+// (MJX_STAMP_B), summed per part over the launch.
 // (The stamp drains the LDS counter -- cdna guide s7 -- so the build's run time means nothing; its shares do.)
 __device__ unsigned long long g_stamp_acc[8];
 struct WaveStamp {
@@ -1197,6 +1203,7 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
         // store is a whole aligned group
         pad_to = ebase + stream_run(g_exit[im.sub_off + s].m);
         pad_to = pad_to < im.ent_cap ? pad_to : im.ent_cap;
+        if (im.ent_rows) pad_to = min(stream_run(g_exit[im.sub_off + s].m), im.ent_rows * 8u);     // quad-interleaved: the lane's column starts at 0
     }
     StreamSink sink;
     sink.tile_eoff = tile_eoff + im.tile_off;
@@ -1204,7 +1211,16 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
     const uint32_t first_start = blk + (e.z ? 1u : 0u);                    // first block whose DC this lane decodes
     {
         uint32_t *rings = s_win + kHuffWg * kWinStride;
-        sink.ac_ring.begin(rings + threadIdx.x * kAcRingStride, entries + im.ent_off, ebase);
+        if (im.ent_rows) {          // quad-interleaved stream: the lane's column (stream_phys(s, 0)), groups four groups apart
+            const uint32_t sl = live ? s : 0u;
+            sink.ac_ring.begin(rings + threadIdx.x * kAcRingStride, entries + im.ent_off + im.ent_hdr + stream_phys(sl, 0, im.ent_rows), 0u);
+            if (live) reinterpret_cast<uint16_t *>(entries + im.ent_off)[s] = uint16_t(pad_to >> 3);      // the run in groups, for stage B
+            sink.ac_ring.gstride = kAcGroup * kStreamQuad;
+            sink.tile_virt = sl * (im.ent_rows * 8u);
+        } else {
+            sink.ac_ring.begin(rings + threadIdx.x * kAcRingStride, entries + im.ent_off, ebase);
+            sink.tile_virt = 0;
+        }
         rings += kHuffWg * kAcRingStride;
         sink.dc_ring.begin(rings + threadIdx.x * (DcRing16::kRing / 2), dcdiff + im.coef_off, first_start);
     }
@@ -1769,19 +1785,21 @@ constexpr int kPixStride = 68;       // floats per IDCT output block (64 + 4)
 // 8-point inverse DCT, Arai-Agui-Nakajima factorisation on inputs pre-scaled by the AAN factors (folded into the
 // dequantisation multipliers on the host, mjx_plan.cpp).  5 multiplies, 29 additions.  Same transform as the
 // reference's direct-form DCT-III (transform.rs:55-87) up to float rounding.
-__device__ __forceinline__ void idct8(float &i0, float &i1, float &i2, float &i3, float &i4, float &i5, float &i6,
-                                      float &i7)
+// (T = float, or a pair of floats: two transforms side by side in packed instructions, see idct_row_inplace)
+typedef float float_pair __attribute__((ext_vector_type(2)));
+template <class T>
+__device__ __forceinline__ void idct8(T &i0, T &i1, T &i2, T &i3, T &i4, T &i5, T &i6, T &i7)
 {
-    const float t10 = i0 + i4, t11 = i0 - i4;
-    const float t13 = i2 + i6, t12 = (i2 - i6) * 1.414213562f - t13;
-    const float e0 = t10 + t13, e3 = t10 - t13, e1 = t11 + t12, e2 = t11 - t12;
-    const float z13 = i5 + i3, z10 = i5 - i3, z11 = i1 + i7, z12 = i1 - i7;
-    const float o7 = z11 + z13;
-    const float u11 = (z11 - z13) * 1.414213562f;
-    const float z5 = (z10 + z12) * 1.847759065f;
-    const float u10 = 1.082392200f * z12 - z5;
-    const float u12 = -2.613125930f * z10 + z5;
-    const float o6 = u12 - o7, o5 = u11 - o6, o4 = u10 + o5;
+    const T t10 = i0 + i4, t11 = i0 - i4;
+    const T t13 = i2 + i6, t12 = (i2 - i6) * 1.414213562f - t13;
+    const T e0 = t10 + t13, e3 = t10 - t13, e1 = t11 + t12, e2 = t11 - t12;
+    const T z13 = i5 + i3, z10 = i5 - i3, z11 = i1 + i7, z12 = i1 - i7;
+    const T o7 = z11 + z13;
+    const T u11 = (z11 - z13) * 1.414213562f;
+    const T z5 = (z10 + z12) * 1.847759065f;
+    const T u10 = 1.082392200f * z12 - z5;
+    const T u12 = -2.613125930f * z10 + z5;
+    const T o6 = u12 - o7, o5 = u11 - o6, o4 = u10 + o5;
     i0 = e0 + o7; i7 = e0 - o7;
     i1 = e1 + o6; i6 = e1 - o6;
     i2 = e2 + o5; i5 = e2 - o5;
@@ -1922,6 +1940,158 @@ __device__ __forceinline__ void tile_fetch(const uint32_t *__restrict__ src, con
     f.dc = (tid < tile_blocks && blk < total_blocks) ? __builtin_nontemporal_load(dc + blk) : 0;
 }
 
+// The quad-interleaved stream (mjx_kernels.h: stream_phys).  A tile's entries are store groups in the columns of a few
+// neighbouring subsequences: from the tile's own start (subsequence s0, entry j0 -- its tile offset, split by the kernel) to the
+// end of s0's run, the whole runs of the subsequences between, and the head of s1's column up to the next tile's start.  The
+// groups are numbered in that order and lane i of the workgroup takes group i (+ 256 per further round): all eight entries of
+// the 32-byte group, two 16-byte loads.  Entries of the first and the last group that belong to the neighbouring tiles are masked
+// (k_lo / k_hi).  For every tile the workgroup prepares, once, the cumulative group counts of the tile's first kQuadSegs
+// subsequences (16 bytes in LDS: one read per lane and fetch): with them a lane finds its group without a loop and without a
+// second trip to LDS -- the fetch of the next tile sits between the scatter phase and the barrier in front of the inverse DCT,
+// and a loop over the subsequences with a dependent LDS read per turn there cost 0.5 ms per 2048 pictures.  Tiles that span
+// more subsequences (beyond quality ~97) take the loop, on the run lengths at the head of the stream region.
+constexpr uint32_t kQuadSegs = 8;
+struct QuadView {
+    const uint32_t *s_sub;               // LDS: subsequence of the workgroup's tile starts ...
+    const uint16_t *s_at;                // ... and entry index in its column
+    const uint4 *s_cum;                  // LDS, per tile: cumulative groups after the tile's 1st, 2nd, ... subsequence, 16 bits each
+                                         // (the last one = the tile's groups; 0xffff in the last slot: more than kQuadSegs subsequences)
+    const uint16_t *runs;                // run lengths in groups of all the picture's subsequences: the head of its stream region
+    uint32_t rows, nsub;
+};
+struct QuadCell { uint32_t phys, k_lo, k_hi; };     // phys = 0xffffffff: no group for this lane
+// What lane t of the workgroup prepares for tile t.
+__device__ __forceinline__ uint4 quad_prepare(const QuadView &q, uint32_t k)
+{
+    const uint32_t s0 = q.s_sub[k], s1 = q.s_sub[k + 1], j0 = q.s_at[k], j1 = q.s_at[k + 1];
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (s1 < s0 || s1 >= q.nsub) return make_uint4(0, 0, 0, 0);      // (offsets of a picture that did not decode: no entries, no reads)
+    if (s1 - s0 >= kQuadSegs) return make_uint4(0, 0, 0, 0xffff0000u);
+    uint32_t c = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < kQuadSegs; i++) {
+        const uint32_t s = s0 + i;
+        if (s <= s1) {
+            const uint32_t gs = i == 0 ? j0 >> 3 : 0u;
+            const uint32_t ge = s == s1 ? (j1 + 7u) >> 3 : uint32_t(q.runs[s]);
+            c += ge > gs ? ge - gs : 0u;
+        }
+        w[i >> 1] |= min(c, 0xfffeu) << (16u * (i & 1u));
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+// Group o of tile k (of the workgroup): where it lies and which of its entries are the tile's.  Returns the tile's groups.
+__device__ __forceinline__ uint32_t quad_cell(const QuadView &q, uint32_t k, uint32_t o, QuadCell &cell)
+{
+    const uint32_t s0 = q.s_sub[k], s1 = q.s_sub[k + 1], j0 = q.s_at[k], j1 = q.s_at[k + 1];
+    const uint4 cw = q.s_cum[k];
+    cell.phys = 0xffffffffu;
+    cell.k_lo = 0;
+    cell.k_hi = 8;
+    uint32_t total, s = s0, first = j0 >> 3, before = 0;              // the group's subsequence, that one's first group, groups before it
+    if (cw.w >> 16 != 0xffffu) {
+        const uint32_t cum[kQuadSegs] = {cw.x & 0xffffu, cw.x >> 16, cw.y & 0xffffu, cw.y >> 16, cw.z & 0xffffu, cw.z >> 16, cw.w & 0xffffu, cw.w >> 16};
+        total = cum[kQuadSegs - 1];
+#pragma unroll
+        for (uint32_t i = 0; i + 1 < kQuadSegs; i++) {
+            const bool behind = o >= cum[i];                               // (cum[] stays at the total behind the tile's last subsequence)
+            s += behind ? 1u : 0u;
+            before = behind ? cum[i] : before;
+        }
+        first = o >= cum[0] ? 0u : first;
+    } else {
+        total = 0;
+        bool found = false;
+        for (uint32_t t = s0; t <= s1; t++) {
+            const uint32_t gs = t == s0 ? j0 >> 3 : 0u;
+            const uint32_t ge = t == s1 ? (j1 + 7u) >> 3 : uint32_t(q.runs[t]);
+            const uint32_t cnt = ge > gs ? ge - gs : 0u;
+            if (!found && o < total + cnt) { s = t; first = gs; before = total; found = true; }
+            total += cnt;
+        }
+    }
+    if (o < total) {
+        const uint32_t at = (first + o - before) * 8u;
+        cell.phys = uint32_t(stream_phys(s, at, q.rows));
+#ifdef MJX_EXP_QUAD_CONTIG       // (measurement builds only: the tile's groups read from consecutive addresses -- garbage out)
+        cell.phys = uint32_t(stream_phys(s0 & ~3u, 0, q.rows)) + o * 8u;
+#endif
+        cell.k_lo = (o == 0u) ? j0 & 7u : 0u;
+        cell.k_hi = (o == total - 1u && (j1 & 7u) != 0u) ? j1 & 7u : 8u;
+    }
+    return total;
+}
+
+// (MJX_QUAD_PART=4: a lane takes half a group, one 16-byte load, two neighbouring lanes the two halves of one, so that a wave's
+// load instruction touches 32 lines instead of 64 twice over -- measured: 16.1 instead of 15.8 ms per 2048 pictures in stage B.
+// With the same groups read from consecutive addresses -- MJX_EXP_QUAD_CONTIG, garbage out -- 15.1: the spread costs 0.7 ms.)
+#ifndef MJX_QUAD_PART
+#define MJX_QUAD_PART 8
+#endif
+constexpr uint32_t kQuadPart = MJX_QUAD_PART;           // entries a lane takes per round: 4 (half a group) or 8
+constexpr int kQuadRounds = 8 / kQuadPart;              // rounds that are prefetched: 256 groups (a tile of the bench content: ~190)
+constexpr uint32_t kQuadShift = kQuadPart == 4 ? 1 : 0;
+struct QuadFetch {
+    uint32_t ncells;                                    // the tile's parts (halves of groups, or groups)
+    uint32_t ent[kQuadRounds][kQuadPart];
+    uint32_t k_lo[kQuadRounds], k_hi[kQuadRounds];
+    int32_t dc;
+};
+// part `h` of the tile (kQuadPart entries): loads it and says which of its entries are the tile's; returns the tile's parts
+__device__ __forceinline__ uint32_t quad_load(const uint32_t *__restrict__ src, const QuadView &q, uint32_t k, uint32_t h,
+                                              uint32_t *ent, uint32_t &k_lo, uint32_t &k_hi)
+{
+    QuadCell cell;
+    const uint32_t total = quad_cell(q, k, h >> kQuadShift, cell);
+    const uint32_t sub = kQuadPart == 4 ? (h & 1u) * 4u : 0u;
+    uint4 a = make_uint4(0, 0, 0, 0), b = a;
+    if (cell.phys != 0xffffffffu) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(src + cell.phys + sub);
+        a = p[0];
+        if (kQuadPart == 8) b = p[1];
+    }
+    ent[0] = a.x; ent[1] = a.y; ent[2] = a.z; ent[3] = a.w;
+    if constexpr (kQuadPart == 8) { ent[4] = b.x; ent[5] = b.y; ent[6] = b.z; ent[7] = b.w; }
+    k_lo = cell.k_lo > sub ? cell.k_lo - sub : 0u;
+    k_hi = cell.k_hi > sub ? cell.k_hi - sub : 0u;
+    return total << kQuadShift;
+}
+template <uint32_t LANES>
+__device__ __forceinline__ void tile_fetch_quad(const uint32_t *__restrict__ src, const QuadView &q, uint32_t k,
+                                                const int32_t *__restrict__ dc, uint32_t tile, uint32_t tile_blocks,
+                                                uint32_t total_blocks, QuadFetch &f)
+{
+    static_assert(kAcGroup == 8, "the stream's store groups are 32 bytes");
+    const uint32_t tid = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < kQuadRounds; r++) f.ncells = quad_load(src, q, k, tid + LANES * r, f.ent[r], f.k_lo[r], f.k_hi[r]);
+    const uint32_t blk = tile * tile_blocks + tid;
+    f.dc = (tid < tile_blocks && blk < total_blocks) ? __builtin_nontemporal_load(dc + blk) : 0;
+}
+// (what pins a tile's prefetched words: an empty asm that "uses" them, so the wait for their loads is placed there)
+template <int PF>
+__device__ __forceinline__ void settle(TileFetch<PF> &f)
+{
+#pragma unroll
+    for (int k = 0; k < PF; k++) asm volatile("" : "+v"(f.ent[k]));
+    asm volatile("" : "+v"(f.dc), "+v"(f.e0), "+v"(f.e1));
+}
+__device__ __forceinline__ void settle(QuadFetch &f)
+{
+#pragma unroll
+    for (int r = 0; r < kQuadRounds; r++) {
+#pragma unroll
+        for (uint32_t k = 0; k < kQuadPart; k++) asm volatile("" : "+v"(f.ent[r][k]));
+        asm volatile("" : "+v"(f.k_lo[r]), "+v"(f.k_hi[r]));
+    }
+    asm volatile("" : "+v"(f.dc), "+v"(f.ncells));
+}
+__device__ __forceinline__ void quad_mask(uint32_t *ent, uint32_t k_lo, uint32_t k_hi)
+{
+#pragma unroll
+    for (uint32_t k = 0; k < kQuadPart; k++) ent[k] = (k >= k_lo && k < k_hi) ? ent[k] : 0u;
+}
+
 // One stream entry -> one float in the tile: find the block from the entry's block byte, multiply by the
 // dequantisation x IDCT-prescale factor of its zig-zag position, store at the natural-order position
 // (un-zigzag, decoder.rs:230-232, 425-437).
@@ -1976,24 +2146,42 @@ __device__ __forceinline__ void scatter_batch(const uint32_t *ent, uint32_t firs
     }
 }
 
-// One lane = one 8x8 block: 16 x ds_read_b128 of its row, 8 column + 8 row transforms in registers, back to the row.
+// One lane = one 8x8 block: 16 x ds_read_b128 of its row, 8 row + 8 column transforms in registers, back to the row.
+// The transforms run two at a time in packed fp32 instructions (v_pk_add_f32, v_pk_mul_f32, v_pk_fma_f32: two floats of a
+// register pair per instruction, at the rate of one plain instruction -- stage B is bound by vector-instruction issue, and the
+// inverse DCT was two thirds of its vector instructions): the row transforms on pairs of neighbouring rows, the column
+// transforms on pairs of neighbouring columns, with one transposition of the 2x2 sub-blocks between them.  For the first pass
+// the coefficients must lie in the lane's row as pairs (row 2i, row 2i+1) of one column: idct_slot() is that order, and the
+// scatter phase writes it (its table maps the zig-zag position straight to the slot); the second pass leaves the samples in
+// plain row-major order for the pixel phase.
+__device__ __host__ constexpr uint32_t idct_slot(uint32_t natural) { return (((natural >> 4) * 8u + (natural & 7u)) << 1) | ((natural >> 3) & 1u); }
 __device__ __forceinline__ void idct_row_inplace(float *rowf)
 {
-    float v[64];
+    float_pair p[4][8];                 // p[i][k] = (row 2i, row 2i+1) of column k
     float4 *row = reinterpret_cast<float4 *>(rowf);
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         const float4 t = row[q];
-        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        p[q >> 2][2 * (q & 3)] = float_pair{t.x, t.y};
+        p[q >> 2][2 * (q & 3) + 1] = float_pair{t.z, t.w};
     }
 #pragma unroll
-    for (int c8 = 0; c8 < 8; c8++)
-        idct8(v[c8], v[8 + c8], v[16 + c8], v[24 + c8], v[32 + c8], v[40 + c8], v[48 + c8], v[56 + c8]);
+    for (int i = 0; i < 4; i++) idct8(p[i][0], p[i][1], p[i][2], p[i][3], p[i][4], p[i][5], p[i][6], p[i][7]);
+    float_pair c[8][4];                 // c[r][j] = (column 2j, column 2j+1) of row r
 #pragma unroll
-    for (int r = 0; r < 8; r++)
-        idct8(v[8 * r], v[8 * r + 1], v[8 * r + 2], v[8 * r + 3], v[8 * r + 4], v[8 * r + 5], v[8 * r + 6], v[8 * r + 7]);
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int q = 0; q < 16; q++) row[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        for (int j = 0; j < 4; j++) {
+            c[2 * i][j] = __builtin_shufflevector(p[i][2 * j], p[i][2 * j + 1], 0, 2);
+            c[2 * i + 1][j] = __builtin_shufflevector(p[i][2 * j], p[i][2 * j + 1], 1, 3);
+        }
+#pragma unroll
+    for (int j = 0; j < 4; j++) idct8(c[0][j], c[1][j], c[2][j], c[3][j], c[4][j], c[5][j], c[6][j], c[7][j]);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const float_pair a = c[q >> 1][2 * (q & 1)], b = c[q >> 1][2 * (q & 1) + 1];
+        row[q] = make_float4(a.x, a.y, b.x, b.y);
+    }
 }
 
 // Reads 4 horizontally adjacent samples of one component for the pixel strip starting at MCU-local (x, y);
@@ -2228,7 +2416,7 @@ extern "C" __global__ __launch_bounds__(256) void k_ref_color(const DevImage *im
 //            then issue the loads of the next tile
 //   phase 2  one lane = one 8x8 block: float AAN inverse DCT in registers (transform.rs:55-87 up to rounding)
 //   phase 3  chroma replication + YCbCr->RGB + packed stores
-template <int MODE, int PF = kPrefetch>
+template <int MODE, int PF, bool QUAD>
 __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__ images,
                                                      const uint32_t *__restrict__ entries,
                                                      const uint32_t *__restrict__ tile_eoff,
@@ -2240,10 +2428,14 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_px[];
     __shared__ float s_qm[3 * 64];
     __shared__ uint8_t s_nat[64];
-    __shared__ uint8_t s_comp[256];
+    __shared__ uint8_t s_comp[MODE == 1 ? 4 : 256];     // (4:2:0: the component comes from arithmetic on the block index)
+    // per tile of the workgroup (+ sentinel).  Linear stream: s_eoff = the tile's first entry.  Quad-interleaved stream (QUAD):
+    // s_eoff = the subsequence and s_at = the entry in its column where the tile starts; s_cum: see quad_prepare
     __shared__ uint32_t s_eoff[kTilesPerWg + 1];
+    __shared__ uint16_t s_at[QUAD ? kTilesPerWg + 1 : 1];
+    __shared__ uint4 s_cum[QUAD ? kTilesPerWg : 1];
     const DevImage &im = images[blockIdx.y];
-    if (!im.valid || im.mode != uint32_t(MODE) || img_flags[im.status_idx]) return;
+    if (!im.valid || im.mode != uint32_t(MODE) || (im.ent_rows != 0) != QUAD || img_flags[im.status_idx]) return;
     // everything the tile loop needs from the descriptor, read once (uniform -> scalar registers)
     constexpr uint32_t LANES = MODE == 1 ? kLanes420 : 256u;
     const uint32_t T = MODE == 1 ? kTile420 : (1u << im.log2_tile);
@@ -2256,25 +2448,40 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
     if (tile0 >= ntiles) return;
     const uint32_t tile1 = min(ntiles, tile0 + tiles_per_wg);
     const uint32_t tid = threadIdx.x;
-    const uint32_t *__restrict__ src = entries + im.ent_off;
+    const uint32_t *__restrict__ src = entries + im.ent_off + im.ent_hdr;
     const uint32_t *__restrict__ eoff = tile_eoff + im.tile_off;
     const int32_t *__restrict__ dcs = dcbuf + im.coef_off;
     uint8_t *__restrict__ out_img = rgb + im.rgb_off;
     const bool aligned = ((width * 3u) & 3u) == 0 && (im.rgb_off & 3u) == 0;
     // The stream offsets of all the workgroup's tiles are fetched once: a tile's entries can then be requested without
     // first waiting for its offsets (two dependent round trips per tile were what paced the tile loop).
-    if (tid <= tiles_per_wg) s_eoff[tid] = eoff[min(tile0 + tid, ntiles)];
+    // (Quad-interleaved stream: an offset is subsequence * column capacity + entry index in the column; split here, once.)
+    if (tid <= tiles_per_wg) {
+        uint32_t v = eoff[min(tile0 + tid, ntiles)];
+        if constexpr (QUAD) {
+            const uint32_t cap = im.ent_rows * 8u, sub = v / cap;
+            s_at[tid] = uint16_t(v - sub * cap);
+            v = sub;
+        }
+        s_eoff[tid] = v;
+    }
     __syncthreads();
-    TileFetch<PF> cur;
-    tile_fetch<LANES, PF>(src, s_eoff, dcs, tile0, tile_blocks, total_blocks, cur);
+    const QuadView qv{s_eoff, s_at, s_cum, reinterpret_cast<const uint16_t *>(entries + im.ent_off), im.ent_rows, im.himg.nsub};
+    if constexpr (QUAD) {
+        if (tid < tile1 - tile0) s_cum[tid] = quad_prepare(qv, tid);
+        __syncthreads();
+    }
+    typename std::conditional<QUAD, QuadFetch, TileFetch<PF>>::type cur;
+    if constexpr (QUAD) tile_fetch_quad<LANES>(src, qv, 0, dcs, tile0, tile_blocks, total_blocks, cur);
+    else tile_fetch<LANES, PF>(src, s_eoff, dcs, tile0, tile_blocks, total_blocks, cur);
     for (uint32_t i = tid; i < 192; i += LANES) s_qm[i] = qmult[im.qm_off + i];
     if (tid < 64) {
         constexpr uint8_t ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                                     41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                     30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-        s_nat[tid] = ZZ[tid];
+        s_nat[tid] = uint8_t(idct_slot(ZZ[tid]));      // zig-zag position -> where the inverse DCT expects the coefficient
     }
-    if (tid < tile_blocks) s_comp[tid] = im.blk_comp[tid % bpm];
+    if (MODE != 1 && tid < tile_blocks) s_comp[tid] = im.blk_comp[tid % bpm];
     // the lane's own block slot (tid) has the same component in every tile (a tile is whole MCUs): its DC multiplier and level shift
     const uint32_t my_comp = im.blk_comp[tid % bpm];
     const float my_dc_qm = qmult[im.qm_off + my_comp * 64];
@@ -2282,10 +2489,15 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
     float *tile_f = reinterpret_cast<float *>(smem_px);
     // (the first tile's words are settled before the loop, so that on no path into a tile iteration a load is pending
     // on them: see the settle point behind phase 2)
-#pragma unroll
-    for (int k = 0; k < PF; k++) asm volatile("" : "+v"(cur.ent[k]));
-    asm volatile("" : "+v"(cur.dc), "+v"(cur.e0), "+v"(cur.e1));
+    settle(cur);
 
+#ifdef MJX_STAMP_B
+    WaveStamp sp;
+    sp.begin();
+#define MJX_SB(k) sp.at(k)
+#else
+#define MJX_SB(k)
+#endif
     bool clean = false;          // the tile's sample rows are zero already (the pixel phase of an interior 4:2:0 tile clears what it reads)
     for (uint32_t tile = tile0; tile < tile1; tile++) {
         const uint32_t m0 = tile * T;
@@ -2296,43 +2508,69 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
             for (uint32_t i = tid; i < nq; i += LANES) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             __syncthreads();
         }
+        MJX_SB(0);
         {   // phase 1
             const uint32_t first_lo = (tile * tile_blocks) & 0xffu;
-            // The prefetched words the wave really has (a tile of the bench content holds ~1500 entries, 5.9 per lane; at quality
-            // 90 twice that): the batch is cut to that many slots -- a wave-uniform choice between a few batch sizes, so the
-            // reads of a batch stay in flight together and empty slots cost nothing.  (Words behind the tile's last entry were
-            // fetched as 0: null entries.)
-            const uint32_t have = cur.e1 - cur.e0, wave0 = tid & ~63u;
-            const uint32_t slots = have > wave0 ? (have - wave0 + LANES - 1) / LANES : 0u;      // uniform over the wave
-            if (slots <= 4) scatter_batch<MODE, 4>(cur.ent, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
-            else if (slots <= 6) scatter_batch<MODE, 6>(cur.ent, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
-            else if (slots <= 8 || PF == 8) scatter_batch<MODE, 8>(cur.ent, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
-            else if (PF > 8) scatter_batch<MODE, PF>(cur.ent, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
-            for (uint32_t i0 = cur.e0 + LANES * PF; i0 < cur.e1; i0 += LANES * 4) {     // what a dense tile has beyond the prefetched words
-                uint32_t more[4];
+            const uint32_t wave0 = tid & ~63u;
+            if constexpr (QUAD) {
+                // the prefetched parts of the tile (see quad_load); what a tile has beyond them takes further rounds
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t i = i0 + tid + LANES * k;
-                    more[k] = i < cur.e1 ? src[i] : 0u;
+                for (int r = 0; r < kQuadRounds; r++) {
+                    if (cur.ncells > wave0 + LANES * r) {                                    // uniform over the wave
+                        quad_mask(cur.ent[r], cur.k_lo[r], cur.k_hi[r]);
+                        scatter_batch<MODE, int(kQuadPart)>(cur.ent[r], first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+                    }
                 }
-                scatter_batch<MODE, 4>(more, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+                for (uint32_t h0 = LANES * kQuadRounds; h0 < cur.ncells; h0 += LANES) {
+                    uint32_t more[kQuadPart], k_lo, k_hi;
+                    quad_load(src, qv, tile - tile0, h0 + tid, more, k_lo, k_hi);
+                    quad_mask(more, k_lo, k_hi);
+                    scatter_batch<MODE, int(kQuadPart)>(more, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+                }
+            } else {
+                // The prefetched words the wave really has (a tile of the bench content holds ~1500 entries, 5.9 per lane; at quality
+                // 90 twice that): the batch is cut to that many slots -- a wave-uniform choice between a few batch sizes, so the
+                // reads of a batch stay in flight together and empty slots cost nothing.  (Words behind the tile's last entry were
+                // fetched as 0: null entries.)
+                const uint32_t have = cur.e1 - cur.e0;
+                const uint32_t slots = have > wave0 ? (have - wave0 + LANES - 1) / LANES : 0u;      // uniform over the wave
+                if (slots <= 4) scatter_batch<MODE, 4>(cur.ent, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+                else if (slots <= 6) scatter_batch<MODE, 6>(cur.ent, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+                else if (slots <= 8 || PF == 8) scatter_batch<MODE, 8>(cur.ent, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+                else if (PF > 8) scatter_batch<MODE, PF>(cur.ent, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+                for (uint32_t i0 = cur.e0 + LANES * PF; i0 < cur.e1; i0 += LANES * 4) {     // what a dense tile has beyond the prefetched words
+                    uint32_t more[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t i = i0 + tid + LANES * k;
+                        more[k] = i < cur.e1 ? src[i] : 0u;
+                    }
+                    scatter_batch<MODE, 4>(more, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+                }
             }
             // DC; luminance blocks also take the + 128 of decoder.rs:318-330 here (a constant on the DC term of the
             // prescaled transform is the same constant on all 64 samples); REF_COMPAT adds it per pixel in k_ref_color,
             // where samples no block covers must come out as 0 + 128
+            MJX_SB(1);
             if (tid < nblk) tile_f[tid * kPixStride] = float(cur.dc) * my_dc_qm + my_dc_add;
         }
-        TileFetch<PF> nxt = cur;
-        if (tile + 1 < tile1) tile_fetch<LANES, PF>(src, s_eoff + (tile + 1 - tile0), dcs, tile + 1, tile_blocks, total_blocks, nxt);
+        auto nxt = cur;
+        if (tile + 1 < tile1) {
+            if constexpr (QUAD) tile_fetch_quad<LANES>(src, qv, tile + 1 - tile0, dcs, tile + 1, tile_blocks, total_blocks, nxt);
+            else tile_fetch<LANES, PF>(src, s_eoff + (tile + 1 - tile0), dcs, tile + 1, tile_blocks, total_blocks, nxt);
+        }
+        MJX_SB(2);
         __syncthreads();
+        MJX_SB(3);
         if (tid < nblk) idct_row_inplace(tile_f + tid * kPixStride);      // phase 2
+        MJX_SB(4);
         __syncthreads();
+        MJX_SB(3);
         // The next tile's prefetched words are made to land here, a whole IDCT phase after their loads were issued and
         // before this tile's pixel stores go out.  Left to the next iteration, the wait for them is a vmcnt(0) that
         // sits behind those stores -- a full store drain per tile.
-#pragma unroll
-        for (int k = 0; k < PF; k++) asm volatile("" : "+v"(nxt.ent[k]));
-        asm volatile("" : "+v"(nxt.dc), "+v"(nxt.e0), "+v"(nxt.e1));
+        settle(nxt);
+        MJX_SB(5);
         if (MODE == 1) {                                                  // phase 3
             // interior tile: all 32 MCUs in one MCU row, fully inside the image, rows 4-byte aligned
             const uint32_t mx0 = m0 % mcux, my0 = m0 / mcux;
@@ -2345,9 +2583,15 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
         } else {
             pixels_generic(im, tile_f, m0, nm, out_img, aligned);
         }
+        MJX_SB(6);
         __syncthreads();
+        MJX_SB(7);
         cur = nxt;
     }
+#ifdef MJX_STAMP_B
+    sp.end();
+#endif
+#undef MJX_SB
 }
 
 // ---- verification helper: byte-wise comparison of decoded pictures on the device ------------------------------
@@ -2421,10 +2665,12 @@ int configure_kernels(size_t huff_lds, size_t idct_lds)
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_write), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     }
     if (e == hipSuccess && idct_lds > 64 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_idct_color<0>), hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_idct_color<1, kPrefetch>), hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_idct_color<1, kPrefetchDense>), hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_idct_color<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
+        const void *fns[] = {reinterpret_cast<const void *>(k_idct_color<0, kPrefetch, false>), reinterpret_cast<const void *>(k_idct_color<0, kPrefetch, true>),
+                             reinterpret_cast<const void *>(k_idct_color<1, kPrefetch, false>), reinterpret_cast<const void *>(k_idct_color<1, kPrefetchDense, false>),
+                             reinterpret_cast<const void *>(k_idct_color<1, kPrefetch, true>),
+                             reinterpret_cast<const void *>(k_idct_color<2, kPrefetch, false>), reinterpret_cast<const void *>(k_idct_color<2, kPrefetch, true>)};
+        for (const void *f : fns)
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
     }
     return e == hipSuccess ? 0 : int(e);
 }
@@ -2526,7 +2772,8 @@ void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevI
 
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint32_t *entries, const uint32_t *tile_eoff, const int32_t *dcbuf, const float *qmult,
-                       uint8_t *rgb, uint32_t mode_mask, unsigned long long *planes, const uint32_t *img_flags, bool dense)
+                       uint8_t *rgb, uint32_t mode_mask, unsigned long long *planes, const uint32_t *img_flags, bool dense,
+                       uint32_t layout_mask)
 {
     // A workgroup walks up to kTilesPerWg consecutive tiles of its image (offsets fetched once, the next tile's loads in
     // flight during this tile's arithmetic) -- when the launch has tiles to spare: with fewer than a few rounds of 3
@@ -2535,17 +2782,28 @@ void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t
     const uint64_t total = uint64_t(max_tiles) * nimg;
     const uint32_t tpw = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(kTilesPerWg), total / 3072)));
     const uint32_t gx = (max_tiles + tpw - 1) / tpw;
-    if (mode_mask & 1u)
-        hipLaunchKernelGGL(k_idct_color<0>, dim3(gx, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags, tpw);
-    if (mode_mask & 2u) {
-        // (dense streams -- more than ~2048 entries per tile: quality 90 and up -- take the form that prefetches twelve words per
-        // lane instead of eight: 18.2 -> 17.2 ms per 2048 4K pictures at quality 90; at quality 75 the four extra loads per
-        // lane and tile cost 0.15 ms)
-        if (dense) hipLaunchKernelGGL((k_idct_color<1, kPrefetchDense>), dim3(gx, nimg), dim3(kLanes420), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags, tpw);
-        else hipLaunchKernelGGL((k_idct_color<1, kPrefetch>), dim3(gx, nimg), dim3(kLanes420), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags, tpw);
+    // (layout_mask: bit 0 = the chunk has pictures with a linear stream, bit 1 = with a quad-interleaved one; a kernel form
+    // leaves the other kind's pictures alone)
+#define MJX_IDCT(M, P, Q) hipLaunchKernelGGL((k_idct_color<M, P, Q>), dim3(gx, nimg), dim3(M == 1 ? kLanes420 : 256u), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags, tpw)
+    if (mode_mask & 1u) {
+        if (layout_mask & 1u) MJX_IDCT(0, kPrefetch, false);
+        if (layout_mask & 2u) MJX_IDCT(0, kPrefetch, true);
     }
-    if (mode_mask & 4u)
-        hipLaunchKernelGGL(k_idct_color<2>, dim3(gx, nimg), dim3(256), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags, tpw);
+    if (mode_mask & 2u) {
+        // (linear streams that are dense -- more than ~2048 entries per tile: quality 90 and up -- take the form that prefetches
+        // twelve words per lane instead of eight: 18.2 -> 17.2 ms per 2048 4K pictures at quality 90; at quality 75 the four
+        // extra loads per lane and tile cost 0.15 ms)
+        if (layout_mask & 1u) {
+            if (dense) MJX_IDCT(1, kPrefetchDense, false);
+            else MJX_IDCT(1, kPrefetch, false);
+        }
+        if (layout_mask & 2u) MJX_IDCT(1, kPrefetch, true);
+    }
+    if (mode_mask & 4u) {
+        if (layout_mask & 1u) MJX_IDCT(2, kPrefetch, false);
+        if (layout_mask & 2u) MJX_IDCT(2, kPrefetch, true);
+    }
+#undef MJX_IDCT
 }
 
 void launch_planar_gather(hipStream_t st, uint32_t max_tiles, uint32_t nimg, const DevImage *images, uint32_t *entries,

@@ -196,6 +196,55 @@ def test_stage_b_forms_for_sparse_and_dense_streams(mjx, orc, gpu_ctx):
         b.close()
 
 
+def test_both_stream_layouts_decode_alike(mjx, orc):
+    """The compact coefficient stream between the entropy stage and stage B has two layouts (round 4): quad-interleaved columns,
+    one per subsequence (pictures of one scan), and the packed runs (multi-scan pictures; every picture with MJX_STREAM_LINEAR=1).
+    The same files through both, several chunks (keep_coefs: stage B alone must find every chunk's stream again), with
+    restart intervals, a multi-scan file, REF_COMPAT placement, tiles that lie inside one subsequence (flat content) and tiles that
+    span more subsequences than the per-tile table of stage B holds (noise at quality 100): T0 equal to the oracle's, RGB
+    within 1, and the two layouts byte for byte the same."""
+    pil = os.path.join(ROOT, "tests", "golden", "pil")
+    flat = np.full((272, 1536, 3), 120, np.uint8)
+    datas = [mjx.synth_jpeg(1040, 496, "420", 75, seed=21), mjx.synth_jpeg(640, 480, "444", 90, seed=22),
+             mjx.encode_rgb(flat, "420", 50), mjx.synth_jpeg(1536, 272, "420", 100, seed=23, noise_sigma=60.0),
+             mjx.synth_jpeg(333, 217, "422", 85, seed=24), mjx.synth_jpeg(64, 48, "gray", 60, seed=25),
+             open(os.path.join(pil, "dri_420_r5.jpg"), "rb").read(), open(os.path.join(pil, "ms2_420_big.jpg"), "rb").read()]
+    refs = [orc.decode(d, layout=orc.LAYOUT_STD, ext_dri=True, ext_multiscan=True) for d in datas]
+    got = {}
+    old = os.environ.get("MJX_STREAM_LINEAR")
+    try:
+        for linear in (0, 1):
+            os.environ["MJX_STREAM_LINEAR"] = str(linear)
+            ctx = mjx.Context(0)
+            b = mjx.Batch(ctx, [mjx.ParsedScan(d) for d in datas], keep_coefs=True, chunk_images=3)
+            b.decode(mjx.STAGE_ENTROPY)
+            b.wait()
+            b.decode(mjx.STAGE_PIXELS)
+            b.wait()
+            for i, ref in enumerate(refs):
+                assert b.status(i) == mjx.OK, (linear, i)
+                assert np.array_equal(b.coefs(i), orc.interleave(ref)), (linear, i)
+                rgb = b.rgb(i)
+                assert np.abs(rgb.astype(int) - ref.rgb.astype(int)).max() <= TOL, (linear, i)
+                got[(linear, i)] = rgb.copy()
+            b.close()
+            b = mjx.Batch(ctx, [mjx.ParsedScan(d) for d in datas[:2]], layout=mjx.LAYOUT_REF_COMPAT)
+            b.decode()
+            b.wait()
+            for i in range(2):
+                assert b.status(i) == mjx.OK, (linear, i)
+                got[(linear, "ref", i)] = b.rgb(i).copy()
+            b.close()
+            ctx.close()
+    finally:
+        if old is None:
+            os.environ.pop("MJX_STREAM_LINEAR", None)
+        else:
+            os.environ["MJX_STREAM_LINEAR"] = old
+    for k in [k for k in got if k[0] == 0]:
+        assert np.array_equal(got[k], got[(1,) + k[1:]]), k
+
+
 # ---- the harness's N > 1 path, on one GPU ------------------------------------------------------------------------------
 def test_bench_two_ranks_over_gloo_on_one_gpu(tmp_path):
     """bench.py under torch.distributed.run with two ranks (both on GPU 0): the shards are decoded independently, the
