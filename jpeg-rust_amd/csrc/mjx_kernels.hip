@@ -452,7 +452,7 @@ __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry,
         if (CP == 1 && st.wn >= ev.next_wn && st.wn < ev.end_wn) checkpoint_record(st, ev, cps);
         running = st.wn < ev.end_wn && !(WRITE && blk >= total_blocks);
 #ifdef MJX_STAMP
-        if (WRITE) {
+        if constexpr (WRITE) {
             if (it % kFlushEvery == 0) { sink.flush_entries(); sp.at(6); sink.flush_dc(it); }
             it++;
             sp.at(7);
@@ -1967,13 +1967,15 @@ __device__ __forceinline__ uint4 quad_prepare(const QuadView &q, uint32_t k)
     uint32_t w[4] = {0, 0, 0, 0};
     if (s1 < s0 || s1 >= q.nsub) return make_uint4(0, 0, 0, 0);      // (offsets of a picture that did not decode: no entries, no reads)
     if (s1 - s0 >= kQuadSegs) return make_uint4(0, 0, 0, 0xffff0000u);
-    uint32_t c = 0;
+    uint32_t c = 0, run[kQuadSegs];
+#pragma unroll
+    for (uint32_t i = 0; i < kQuadSegs; i++) run[i] = q.runs[min(s0 + i, s1)];       // (all in flight together)
 #pragma unroll
     for (uint32_t i = 0; i < kQuadSegs; i++) {
         const uint32_t s = s0 + i;
         if (s <= s1) {
             const uint32_t gs = i == 0 ? j0 >> 3 : 0u;
-            const uint32_t ge = s == s1 ? (j1 + 7u) >> 3 : uint32_t(q.runs[s]);
+            const uint32_t ge = s == s1 ? (j1 + 7u) >> 3 : run[i];
             c += ge > gs ? ge - gs : 0u;
         }
         w[i >> 1] |= min(c, 0xfffeu) << (16u * (i & 1u));
@@ -2013,8 +2015,15 @@ __device__ __forceinline__ uint32_t quad_cell(const QuadView &q, uint32_t k, uin
     if (o < total) {
         const uint32_t at = (first + o - before) * 8u;
         cell.phys = uint32_t(stream_phys(s, at, q.rows));
-#ifdef MJX_EXP_QUAD_CONTIG       // (measurement builds only: the tile's groups read from consecutive addresses -- garbage out)
+        // (measurement builds only, garbage out: the tile's groups read from consecutive addresses; ... from the tile's own
+        // first row on, so that tiles read different addresses; from three neighbouring columns in turn, what numbering the
+        // groups across the columns would touch at best)
+#if defined(MJX_EXP_QUAD_CONTIG)
         cell.phys = uint32_t(stream_phys(s0 & ~3u, 0, q.rows)) + o * 8u;
+#elif defined(MJX_EXP_QUAD_CONTIG2)
+        cell.phys = uint32_t(stream_phys(s0 & ~3u, (j0 >> 3) * 8u, q.rows)) + o * 8u;
+#elif defined(MJX_EXP_QUAD_ZIP)
+        cell.phys = uint32_t(stream_phys((s0 & ~3u) + o % 3u, (o / 3u) * 8u, q.rows));
 #endif
         cell.k_lo = (o == 0u) ? j0 & 7u : 0u;
         cell.k_hi = (o == total - 1u && (j1 & 7u) != 0u) ? j1 & 7u : 8u;
@@ -2029,12 +2038,13 @@ __device__ __forceinline__ uint32_t quad_cell(const QuadView &q, uint32_t k, uin
 #define MJX_QUAD_PART 8
 #endif
 constexpr uint32_t kQuadPart = MJX_QUAD_PART;           // entries a lane takes per round: 4 (half a group) or 8
-constexpr int kQuadRounds = 8 / kQuadPart;              // rounds that are prefetched: 256 groups (a tile of the bench content: ~190)
+// (QuadFetch<R>: R rounds are prefetched -- 256 groups a round; a tile of the bench content has ~190, at quality 90 ~380)
 constexpr uint32_t kQuadShift = kQuadPart == 4 ? 1 : 0;
+template <int R>
 struct QuadFetch {
     uint32_t ncells;                                    // the tile's parts (halves of groups, or groups)
-    uint32_t ent[kQuadRounds][kQuadPart];
-    uint32_t k_lo[kQuadRounds], k_hi[kQuadRounds];
+    uint32_t ent[R][kQuadPart];
+    uint32_t k_lo[R], k_hi[R];
     int32_t dc;
 };
 // part `h` of the tile (kQuadPart entries): loads it and says which of its entries are the tile's; returns the tile's parts
@@ -2056,15 +2066,15 @@ __device__ __forceinline__ uint32_t quad_load(const uint32_t *__restrict__ src, 
     k_hi = cell.k_hi > sub ? cell.k_hi - sub : 0u;
     return total << kQuadShift;
 }
-template <uint32_t LANES>
+template <uint32_t LANES, int R>
 __device__ __forceinline__ void tile_fetch_quad(const uint32_t *__restrict__ src, const QuadView &q, uint32_t k,
                                                 const int32_t *__restrict__ dc, uint32_t tile, uint32_t tile_blocks,
-                                                uint32_t total_blocks, QuadFetch &f)
+                                                uint32_t total_blocks, QuadFetch<R> &f)
 {
     static_assert(kAcGroup == 8, "the stream's store groups are 32 bytes");
     const uint32_t tid = threadIdx.x;
 #pragma unroll
-    for (int r = 0; r < kQuadRounds; r++) f.ncells = quad_load(src, q, k, tid + LANES * r, f.ent[r], f.k_lo[r], f.k_hi[r]);
+    for (int r = 0; r < R; r++) f.ncells = quad_load(src, q, k, tid + LANES * r, f.ent[r], f.k_lo[r], f.k_hi[r]);
     const uint32_t blk = tile * tile_blocks + tid;
     f.dc = (tid < tile_blocks && blk < total_blocks) ? __builtin_nontemporal_load(dc + blk) : 0;
 }
@@ -2076,10 +2086,11 @@ __device__ __forceinline__ void settle(TileFetch<PF> &f)
     for (int k = 0; k < PF; k++) asm volatile("" : "+v"(f.ent[k]));
     asm volatile("" : "+v"(f.dc), "+v"(f.e0), "+v"(f.e1));
 }
-__device__ __forceinline__ void settle(QuadFetch &f)
+template <int R>
+__device__ __forceinline__ void settle(QuadFetch<R> &f)
 {
 #pragma unroll
-    for (int r = 0; r < kQuadRounds; r++) {
+    for (int r = 0; r < R; r++) {
 #pragma unroll
         for (uint32_t k = 0; k < kQuadPart; k++) asm volatile("" : "+v"(f.ent[r][k]));
         asm volatile("" : "+v"(f.k_lo[r]), "+v"(f.k_hi[r]));
@@ -2471,7 +2482,9 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
         if (tid < tile1 - tile0) s_cum[tid] = quad_prepare(qv, tid);
         __syncthreads();
     }
-    typename std::conditional<QUAD, QuadFetch, TileFetch<PF>>::type cur;
+    constexpr int QR = PF / 8;       // quad-interleaved stream: rounds that are prefetched
+    static_assert(!QUAD || (kQuadPart == 8 && PF % 8 == 0), "whole groups per lane and round");
+    typename std::conditional<QUAD, QuadFetch<QR>, TileFetch<PF>>::type cur;
     if constexpr (QUAD) tile_fetch_quad<LANES>(src, qv, 0, dcs, tile0, tile_blocks, total_blocks, cur);
     else tile_fetch<LANES, PF>(src, s_eoff, dcs, tile0, tile_blocks, total_blocks, cur);
     for (uint32_t i = tid; i < 192; i += LANES) s_qm[i] = qmult[im.qm_off + i];
@@ -2515,13 +2528,13 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
             if constexpr (QUAD) {
                 // the prefetched parts of the tile (see quad_load); what a tile has beyond them takes further rounds
 #pragma unroll
-                for (int r = 0; r < kQuadRounds; r++) {
+                for (int r = 0; r < QR; r++) {
                     if (cur.ncells > wave0 + LANES * r) {                                    // uniform over the wave
                         quad_mask(cur.ent[r], cur.k_lo[r], cur.k_hi[r]);
                         scatter_batch<MODE, int(kQuadPart)>(cur.ent[r], first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
                     }
                 }
-                for (uint32_t h0 = LANES * kQuadRounds; h0 < cur.ncells; h0 += LANES) {
+                for (uint32_t h0 = LANES * QR; h0 < cur.ncells; h0 += LANES) {
                     uint32_t more[kQuadPart], k_lo, k_hi;
                     quad_load(src, qv, tile - tile0, h0 + tid, more, k_lo, k_hi);
                     quad_mask(more, k_lo, k_hi);
@@ -2665,10 +2678,10 @@ int configure_kernels(size_t huff_lds, size_t idct_lds)
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_write), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     }
     if (e == hipSuccess && idct_lds > 64 * 1024) {
-        const void *fns[] = {reinterpret_cast<const void *>(k_idct_color<0, kPrefetch, false>), reinterpret_cast<const void *>(k_idct_color<0, kPrefetch, true>),
+        const void *fns[] = {reinterpret_cast<const void *>(k_idct_color<0, kPrefetch, false>), reinterpret_cast<const void *>(k_idct_color<0, 8, true>),
                              reinterpret_cast<const void *>(k_idct_color<1, kPrefetch, false>), reinterpret_cast<const void *>(k_idct_color<1, kPrefetchDense, false>),
-                             reinterpret_cast<const void *>(k_idct_color<1, kPrefetch, true>),
-                             reinterpret_cast<const void *>(k_idct_color<2, kPrefetch, false>), reinterpret_cast<const void *>(k_idct_color<2, kPrefetch, true>)};
+                             reinterpret_cast<const void *>(k_idct_color<1, 8, true>), reinterpret_cast<const void *>(k_idct_color<1, 16, true>),
+                             reinterpret_cast<const void *>(k_idct_color<2, kPrefetch, false>), reinterpret_cast<const void *>(k_idct_color<2, 8, true>)};
         for (const void *f : fns)
             if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
     }
@@ -2787,7 +2800,7 @@ void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t
 #define MJX_IDCT(M, P, Q) hipLaunchKernelGGL((k_idct_color<M, P, Q>), dim3(gx, nimg), dim3(M == 1 ? kLanes420 : 256u), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags, tpw)
     if (mode_mask & 1u) {
         if (layout_mask & 1u) MJX_IDCT(0, kPrefetch, false);
-        if (layout_mask & 2u) MJX_IDCT(0, kPrefetch, true);
+        if (layout_mask & 2u) MJX_IDCT(0, 8, true);
     }
     if (mode_mask & 2u) {
         // (linear streams that are dense -- more than ~2048 entries per tile: quality 90 and up -- take the form that prefetches
@@ -2797,11 +2810,15 @@ void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t
             if (dense) MJX_IDCT(1, kPrefetchDense, false);
             else MJX_IDCT(1, kPrefetch, false);
         }
-        if (layout_mask & 2u) MJX_IDCT(1, kPrefetch, true);
+        // (quad-interleaved streams: one round of 256 groups prefetched, two for dense streams -- 20.2 -> ... ms at quality 90)
+        if (layout_mask & 2u) {
+            if (dense) MJX_IDCT(1, 16, true);
+            else MJX_IDCT(1, 8, true);
+        }
     }
     if (mode_mask & 4u) {
         if (layout_mask & 1u) MJX_IDCT(2, kPrefetch, false);
-        if (layout_mask & 2u) MJX_IDCT(2, kPrefetch, true);
+        if (layout_mask & 2u) MJX_IDCT(2, 8, true);
     }
 #undef MJX_IDCT
 }

@@ -5,18 +5,21 @@ O=$1; shift
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 export MJX_STREAMS=1 MJX_BENCH_IGNORE_STATUS=1
+DEFAULT_SETS="SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
+SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VALU SQ_WAVE_CYCLES
+TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum
+TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
+# (PMC_SETS: newline-separated counter sets instead of these; MJX_STREAM_LINEAR etc. are inherited by the runs)
 Q="--no-cpu-baseline --no-extra --no-parity --steps 1 --warmup 0 --images-per-gpu 256"
 for L in "$@"; do
   n=$(basename $L .so)
   export MJX_LIB=$PWD/$L
   i=0
-  for set in "SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
-             "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VALU SQ_WAVE_CYCLES" \
-             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum" \
-             "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+  while read -r set; do
+    [ -z "$set" ] && continue
     i=$((i+1))
-    timeout 150 rocprofv3 --pmc $set -d $O/p_${n}_$i -o out --output-format csv -- python3 bench.py $Q > $O/p_${n}_$i.log 2>&1
-  done
+    timeout 150 rocprofv3 --pmc $set -d $O/p_${n}_$i -o out --output-format csv -- python3 bench.py $Q > $O/p_${n}_$i.log 2>&1 < /dev/null
+  done <<< "${PMC_SETS:-$DEFAULT_SETS}"
 done
 python3 - "$O" <<'PY'
 import csv, glob, sys, collections, os
