@@ -373,8 +373,10 @@ void fill_dev_image(const ImagePlan &p, DevImage &d)
     d.mode = (p.ncomp == 3 && p.h[0] == 2 && p.v[0] == 2 && p.h[1] == 1 && p.v[1] == 1 && p.h[2] == 1 && p.v[2] == 1) ? 1 : 0;
     uint32_t t = (d.mode == 1 && p.layout != MJX_LAYOUT_REF_COMPAT) ? tile_mcus_420() : tile_mcus(p.bpm, p.hmax), l2 = 0;
     while ((1u << (l2 + 1)) <= t) l2++;
+    if (!(d.mode == 1 && p.layout != MJX_LAYOUT_REF_COMPAT)) t = 1u << l2;      // (the generic pixel phase needs a power of two)
     d.log2_tile = l2;
-    d.tile_blocks = (1u << l2) * p.bpm;
+    d.tile_mcus = t;
+    d.tile_blocks = t * p.bpm;
     if (p.layout == MJX_LAYOUT_REF_COMPAT) {
         d.mode = 2;
         for (uint32_t c = 0; c < 3; c++) { d.ref_xf[c] = uint8_t(p.ref_xf[c]); d.ref_yf[c] = uint8_t(p.ref_yf[c]); }
@@ -385,6 +387,7 @@ void fill_dev_image(const ImagePlan &p, DevImage &d)
     if (p.role == 1) {                 // a scan of a multi-scan file: no stage B; one tile offset per block for the gather
         d.mode = 7;
         d.log2_tile = 0;
+        d.tile_mcus = 1;
         d.tile_blocks = 1;
     } else if (p.role == 2) {
         d.nparts = p.nparts;
@@ -450,7 +453,7 @@ void plan_chunks(mjx_batch *b)
                 c.max_wg = std::max<uint32_t>(c.max_wg, (d.himg.nsub + kHuffWg - 1) / kHuffWg);
                 if (d.himg.nsub > 1) c.merge_wgs = std::max<uint32_t>(c.merge_wgs, (d.himg.nsub - 1 + kMergeWg - 1) / kMergeWg);
                 if (d.himg.nsub > 1) c.loop_participants += (d.himg.nsub - 1 + kMergeWg - 1) / kMergeWg;      // workgroups x with x * kMergeWg + 1 < nsub
-                const uint32_t T = 1u << d.log2_tile;
+                const uint32_t T = d.tile_mcus;
                 if (d.role != 1) {
                     c.max_tiles = std::max<uint32_t>(c.max_tiles, (d.nmcu + T - 1) / T);
                     c.max_tile_blocks = std::max<uint32_t>(c.max_tile_blocks, T * d.bpm);

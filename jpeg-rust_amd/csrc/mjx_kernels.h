@@ -27,10 +27,11 @@ struct DevImage {
     uint32_t ncomp, bpm, hmax, vmax;
     uint32_t valid;         // 0: skip (error at plan time)
     uint32_t status_idx;    // index into the batch-wide device status array
-    uint32_t log2_tile;     // stage-B tile = 1 << log2_tile MCUs
+    uint32_t log2_tile;     // stage-B tile = 1 << log2_tile MCUs (modes 0 and 2; mode 1: floor(log2(tile_mcus)), unused)
+    uint32_t tile_mcus;     // MCUs per stage-B tile (mode 1: tile_mcus_420(), which need not be a power of two)
     uint32_t mode;          // stage-B specialisation: 0 generic, 1 = 4:2:0 (Y 2x2, Cb 1x1, Cr 1x1), 2 = REF_COMPAT placement
     uint32_t tile_off;      // index of the image's first tile offset in the tile_eoff array
-    uint32_t tile_blocks;   // blocks per stage-B tile = (1 << log2_tile) * bpm  (<= 256)
+    uint32_t tile_blocks;   // blocks per stage-B tile = tile_mcus * bpm  (<= 256)
     uint8_t blk_comp[kMaxBlocksPerMcu], blk_bx[kMaxBlocksPerMcu], blk_by[kMaxBlocksPerMcu];
     uint8_t ch[4], cv[4];   // sampling factors per component
     uint8_t cfirst[4];      // first block position of each component inside the MCU

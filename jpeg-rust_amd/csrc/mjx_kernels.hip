@@ -1255,7 +1255,7 @@ struct PlanarSlot { uint32_t s0, cnt, c, rb; bool inside, real; };
 __device__ __forceinline__ PlanarSlot planar_slot(const DevImage *images, const DevImage &im, uint32_t img, uint32_t tile,
                                                   const uint32_t *tile_eoff)
 {
-    const uint32_t T = 1u << im.log2_tile, bpm = im.bpm, tid = threadIdx.x;
+    const uint32_t T = im.tile_mcus, bpm = im.bpm, tid = threadIdx.x;
     const uint32_t m = tile * T + tid / bpm, k = tid % bpm;
     PlanarSlot p{0, 0, 0, 0, false, false};
     p.inside = tid < im.tile_blocks && m < im.nmcu;
@@ -1293,7 +1293,7 @@ extern "C" __global__ __launch_bounds__(256) void k_planar_count(const DevImage 
     __shared__ uint32_t s_tmp[4];
     const uint32_t img = blockIdx.y, tile = blockIdx.x;
     const DevImage &im = images[img];
-    const uint32_t T = 1u << im.log2_tile;
+    const uint32_t T = im.tile_mcus;
     uint32_t bad;
     if (!im.valid || im.role != 2 || tile >= (im.nmcu + T - 1) / T || planar_flags(images, im, img, img_flags, bad)) return;
     const PlanarSlot p = planar_slot(images, im, img, tile, tile_eoff);
@@ -1314,7 +1314,7 @@ extern "C" __global__ __launch_bounds__(256) void k_planar_offsets(const DevImag
         if (tid == 0) img_flags[im.status_idx] = bad;
         return;
     }
-    const uint32_t T = 1u << im.log2_tile, ntiles = (im.nmcu + T - 1) / T;
+    const uint32_t T = im.tile_mcus, ntiles = (im.nmcu + T - 1) / T;
     uint32_t *eoff = tile_eoff + im.tile_off;
     uint32_t run = 0;
     for (uint32_t t0 = 0; t0 < ntiles; t0 += kWgLanes) {           // eoff[t + 1] holds tile t's count -> the offset behind it
@@ -1341,7 +1341,7 @@ extern "C" __global__ __launch_bounds__(256) void k_planar_copy(const DevImage *
                                             // stream regions pass 2^32 entries after a few hundred multi-scan 4K pictures)
     const uint32_t img = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     const DevImage &im = images[img];
-    const uint32_t T = 1u << im.log2_tile;
+    const uint32_t T = im.tile_mcus;
     if (!im.valid || im.role != 2 || tile >= (im.nmcu + T - 1) / T || img_flags[im.status_idx]) return;
     const PlanarSlot p = planar_slot(images, im, img, tile, tile_eoff);
     uint32_t total;
@@ -2227,7 +2227,7 @@ __device__ __forceinline__ void pixels_420(uint32_t width, uint32_t height, uint
                                            uint32_t nm, uint8_t *out_img, bool aligned)
 {
     const uint32_t tid = threadIdx.x;
-    const uint32_t q = tid & (kTile420 * 4 - 1), t = q >> 2, sx = q & 3;
+    const uint32_t q = tid % (kTile420 * 4), t = q >> 2, sx = q & 3;
     if (!INTERIOR && t >= nm) return;
     const uint32_t m = m0 + t;
     const uint32_t mx = m % mcux, my = m / mcux;
