@@ -77,6 +77,102 @@ MJX_HD uint64_t stream_quad_entries(uint32_t nsub, uint32_t rows) { return uint6
 MJX_HD uint32_t stream_hdr_entries(uint32_t nsub) { return (nsub * 2u + 127u) / 128u * 32u; }      // whole 128-byte lines
 MJX_HD uint64_t stream_phys(uint32_t s, uint32_t j, uint32_t rows) { return (uint64_t(s >> 2) * rows + (j >> 3)) * 32u + (s & 3u) * 8u + (j & 7u); }
 
+// ---- reading a tile out of the quad-interleaved stream (stage B; also the host-side expansion and the CPU emulation of the tests) ----
+// A tile's entries are store groups in the columns of a few neighbouring subsequences: from the tile's own start (subsequence
+// s0, entry j0 -- its tile offset, split by the caller) to the end of s0's run, the whole runs of the subsequences between, and
+// the head of s1's column up to the next tile's start.  The groups are numbered in that order; quad_cell() finds group o.  So
+// that a lane of stage B finds its group without a loop over memory, quad_prepare() packs, once per tile, the cumulative group
+// counts of the tile's first kQuadSegs subsequences into 16 bytes; tiles that span more (beyond quality ~97) take the loop over
+// the run lengths at the head of the stream region.  (With a dependent LDS read per subsequence in the fetch -- which sits
+// between the scatter phase and the barrier in front of the inverse DCT -- stage B took 0.3 ms more per 2048 pictures.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MJX_UNROLL _Pragma("unroll")
+#else
+#define MJX_UNROLL
+#endif
+constexpr uint32_t kQuadSegs = 8;
+struct alignas(16) QuadCum { uint32_t x, y, z, w; };      // (one 16-byte LDS read)
+struct QuadView {
+    const uint32_t *s_sub;               // LDS: subsequence of the workgroup's tile starts ...
+    const uint16_t *s_at;                // ... and entry index in its column
+    const QuadCum *s_cum;                 // LDS, per tile: cumulative groups after the tile's 1st, 2nd, ... subsequence, 16 bits each
+                                         // (the last one = the tile's groups; 0xffff in the last slot: more than kQuadSegs subsequences)
+    const uint16_t *runs;                // run lengths in groups of all the picture's subsequences: the head of its stream region
+    uint32_t rows, nsub;
+};
+struct QuadCell { uint32_t phys, k_lo, k_hi; };     // phys = 0xffffffff: no group for this lane
+// What lane t of the workgroup prepares for tile t.
+MJX_HD QuadCum quad_prepare(const QuadView &q, uint32_t k)
+{
+    const uint32_t s0 = q.s_sub[k], s1 = q.s_sub[k + 1], j0 = q.s_at[k], j1 = q.s_at[k + 1];
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (s1 < s0 || s1 >= q.nsub) return QuadCum{0, 0, 0, 0};     // (offsets of a picture that did not decode: no entries, no reads)
+    if (s1 - s0 >= kQuadSegs) return QuadCum{0, 0, 0, 0xffff0000u};
+    uint32_t c = 0, run[kQuadSegs];
+MJX_UNROLL
+    for (uint32_t i = 0; i < kQuadSegs; i++) run[i] = q.runs[s0 + i < s1 ? s0 + i : s1];       // (all in flight together)
+MJX_UNROLL
+    for (uint32_t i = 0; i < kQuadSegs; i++) {
+        const uint32_t s = s0 + i;
+        if (s <= s1) {
+            const uint32_t gs = i == 0 ? j0 >> 3 : 0u;
+            const uint32_t ge = s == s1 ? (j1 + 7u) >> 3 : run[i];
+            c += ge > gs ? ge - gs : 0u;
+        }
+        w[i >> 1] |= (c < 0xfffeu ? c : 0xfffeu) << (16u * (i & 1u));
+    }
+    return QuadCum{w[0], w[1], w[2], w[3]};
+}
+// Group o of tile k (of the workgroup): where it lies and which of its entries are the tile's.  Returns the tile's groups.
+MJX_HD uint32_t quad_cell(const QuadView &q, uint32_t k, uint32_t o, QuadCell &cell)
+{
+    const uint32_t s0 = q.s_sub[k], s1 = q.s_sub[k + 1], j0 = q.s_at[k], j1 = q.s_at[k + 1];
+    const QuadCum cw = q.s_cum[k];
+    cell.phys = 0xffffffffu;
+    cell.k_lo = 0;
+    cell.k_hi = 8;
+    uint32_t total, s = s0, first = j0 >> 3, before = 0;              // the group's subsequence, that one's first group, groups before it
+    if (cw.w >> 16 != 0xffffu) {
+        const uint32_t cum[kQuadSegs] = {cw.x & 0xffffu, cw.x >> 16, cw.y & 0xffffu, cw.y >> 16, cw.z & 0xffffu, cw.z >> 16, cw.w & 0xffffu, cw.w >> 16};
+        total = cum[kQuadSegs - 1];
+MJX_UNROLL
+        for (uint32_t i = 0; i + 1 < kQuadSegs; i++) {
+            const bool behind = o >= cum[i];                               // (cum[] stays at the total behind the tile's last subsequence)
+            s += behind ? 1u : 0u;
+            before = behind ? cum[i] : before;
+        }
+        first = o >= cum[0] ? 0u : first;
+    } else {
+        total = 0;
+        bool found = false;
+        for (uint32_t t = s0; t <= s1; t++) {
+            const uint32_t gs = t == s0 ? j0 >> 3 : 0u;
+            const uint32_t ge = t == s1 ? (j1 + 7u) >> 3 : uint32_t(q.runs[t]);
+            const uint32_t cnt = ge > gs ? ge - gs : 0u;
+            if (!found && o < total + cnt) { s = t; first = gs; before = total; found = true; }
+            total += cnt;
+        }
+    }
+    if (o < total) {
+        const uint32_t at = (first + o - before) * 8u;
+        cell.phys = uint32_t(stream_phys(s, at, q.rows));
+        // (measurement builds only, garbage out: the tile's groups read from consecutive addresses; ... from the tile's own
+        // first row on, so that tiles read different addresses; from three neighbouring columns in turn, what numbering the
+        // groups across the columns would touch at best)
+#if defined(MJX_EXP_QUAD_CONTIG)
+        cell.phys = uint32_t(stream_phys(s0 & ~3u, 0, q.rows)) + o * 8u;
+#elif defined(MJX_EXP_QUAD_CONTIG2)
+        cell.phys = uint32_t(stream_phys(s0 & ~3u, (j0 >> 3) * 8u, q.rows)) + o * 8u;
+#elif defined(MJX_EXP_QUAD_ZIP)
+        cell.phys = uint32_t(stream_phys((s0 & ~3u) + o % 3u, (o / 3u) * 8u, q.rows));
+#endif
+        cell.k_lo = (o == 0u) ? j0 & 7u : 0u;
+        cell.k_hi = (o == total - 1u && (j1 & 7u) != 0u) ? j1 & 7u : 8u;
+    }
+    return total;
+}
+
+
 // Lane-interleaved scan pool: pieces of 16 bytes, kLookPieces of look-ahead behind every subsequence (see LaneBits).
 constexpr uint32_t kLookPieces = 4;
 MJX_HD uint32_t scan_region_cols(uint32_t nsub) { return nsub ? (nsub + 7u) & ~7u : 0u; }

@@ -1950,87 +1950,6 @@ __device__ __forceinline__ void tile_fetch(const uint32_t *__restrict__ src, con
 // second trip to LDS -- the fetch of the next tile sits between the scatter phase and the barrier in front of the inverse DCT,
 // and a loop over the subsequences with a dependent LDS read per turn there cost 0.5 ms per 2048 pictures.  Tiles that span
 // more subsequences (beyond quality ~97) take the loop, on the run lengths at the head of the stream region.
-constexpr uint32_t kQuadSegs = 8;
-struct QuadView {
-    const uint32_t *s_sub;               // LDS: subsequence of the workgroup's tile starts ...
-    const uint16_t *s_at;                // ... and entry index in its column
-    const uint4 *s_cum;                  // LDS, per tile: cumulative groups after the tile's 1st, 2nd, ... subsequence, 16 bits each
-                                         // (the last one = the tile's groups; 0xffff in the last slot: more than kQuadSegs subsequences)
-    const uint16_t *runs;                // run lengths in groups of all the picture's subsequences: the head of its stream region
-    uint32_t rows, nsub;
-};
-struct QuadCell { uint32_t phys, k_lo, k_hi; };     // phys = 0xffffffff: no group for this lane
-// What lane t of the workgroup prepares for tile t.
-__device__ __forceinline__ uint4 quad_prepare(const QuadView &q, uint32_t k)
-{
-    const uint32_t s0 = q.s_sub[k], s1 = q.s_sub[k + 1], j0 = q.s_at[k], j1 = q.s_at[k + 1];
-    uint32_t w[4] = {0, 0, 0, 0};
-    if (s1 < s0 || s1 >= q.nsub) return make_uint4(0, 0, 0, 0);      // (offsets of a picture that did not decode: no entries, no reads)
-    if (s1 - s0 >= kQuadSegs) return make_uint4(0, 0, 0, 0xffff0000u);
-    uint32_t c = 0, run[kQuadSegs];
-#pragma unroll
-    for (uint32_t i = 0; i < kQuadSegs; i++) run[i] = q.runs[min(s0 + i, s1)];       // (all in flight together)
-#pragma unroll
-    for (uint32_t i = 0; i < kQuadSegs; i++) {
-        const uint32_t s = s0 + i;
-        if (s <= s1) {
-            const uint32_t gs = i == 0 ? j0 >> 3 : 0u;
-            const uint32_t ge = s == s1 ? (j1 + 7u) >> 3 : run[i];
-            c += ge > gs ? ge - gs : 0u;
-        }
-        w[i >> 1] |= min(c, 0xfffeu) << (16u * (i & 1u));
-    }
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-// Group o of tile k (of the workgroup): where it lies and which of its entries are the tile's.  Returns the tile's groups.
-__device__ __forceinline__ uint32_t quad_cell(const QuadView &q, uint32_t k, uint32_t o, QuadCell &cell)
-{
-    const uint32_t s0 = q.s_sub[k], s1 = q.s_sub[k + 1], j0 = q.s_at[k], j1 = q.s_at[k + 1];
-    const uint4 cw = q.s_cum[k];
-    cell.phys = 0xffffffffu;
-    cell.k_lo = 0;
-    cell.k_hi = 8;
-    uint32_t total, s = s0, first = j0 >> 3, before = 0;              // the group's subsequence, that one's first group, groups before it
-    if (cw.w >> 16 != 0xffffu) {
-        const uint32_t cum[kQuadSegs] = {cw.x & 0xffffu, cw.x >> 16, cw.y & 0xffffu, cw.y >> 16, cw.z & 0xffffu, cw.z >> 16, cw.w & 0xffffu, cw.w >> 16};
-        total = cum[kQuadSegs - 1];
-#pragma unroll
-        for (uint32_t i = 0; i + 1 < kQuadSegs; i++) {
-            const bool behind = o >= cum[i];                               // (cum[] stays at the total behind the tile's last subsequence)
-            s += behind ? 1u : 0u;
-            before = behind ? cum[i] : before;
-        }
-        first = o >= cum[0] ? 0u : first;
-    } else {
-        total = 0;
-        bool found = false;
-        for (uint32_t t = s0; t <= s1; t++) {
-            const uint32_t gs = t == s0 ? j0 >> 3 : 0u;
-            const uint32_t ge = t == s1 ? (j1 + 7u) >> 3 : uint32_t(q.runs[t]);
-            const uint32_t cnt = ge > gs ? ge - gs : 0u;
-            if (!found && o < total + cnt) { s = t; first = gs; before = total; found = true; }
-            total += cnt;
-        }
-    }
-    if (o < total) {
-        const uint32_t at = (first + o - before) * 8u;
-        cell.phys = uint32_t(stream_phys(s, at, q.rows));
-        // (measurement builds only, garbage out: the tile's groups read from consecutive addresses; ... from the tile's own
-        // first row on, so that tiles read different addresses; from three neighbouring columns in turn, what numbering the
-        // groups across the columns would touch at best)
-#if defined(MJX_EXP_QUAD_CONTIG)
-        cell.phys = uint32_t(stream_phys(s0 & ~3u, 0, q.rows)) + o * 8u;
-#elif defined(MJX_EXP_QUAD_CONTIG2)
-        cell.phys = uint32_t(stream_phys(s0 & ~3u, (j0 >> 3) * 8u, q.rows)) + o * 8u;
-#elif defined(MJX_EXP_QUAD_ZIP)
-        cell.phys = uint32_t(stream_phys((s0 & ~3u) + o % 3u, (o / 3u) * 8u, q.rows));
-#endif
-        cell.k_lo = (o == 0u) ? j0 & 7u : 0u;
-        cell.k_hi = (o == total - 1u && (j1 & 7u) != 0u) ? j1 & 7u : 8u;
-    }
-    return total;
-}
-
 // (MJX_QUAD_PART=4: a lane takes half a group, one 16-byte load, two neighbouring lanes the two halves of one, so that a wave's
 // load instruction touches 32 lines instead of 64 twice over -- measured: 16.1 instead of 15.8 ms per 2048 pictures in stage B.
 // With the same groups read from consecutive addresses -- MJX_EXP_QUAD_CONTIG, garbage out -- 15.1: the spread costs 0.7 ms.)
@@ -2444,7 +2363,7 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
     // s_eoff = the subsequence and s_at = the entry in its column where the tile starts; s_cum: see quad_prepare
     __shared__ uint32_t s_eoff[kTilesPerWg + 1];
     __shared__ uint16_t s_at[QUAD ? kTilesPerWg + 1 : 1];
-    __shared__ uint4 s_cum[QUAD ? kTilesPerWg : 1];
+    __shared__ QuadCum s_cum[QUAD ? kTilesPerWg : 1];
     const DevImage &im = images[blockIdx.y];
     if (!im.valid || im.mode != uint32_t(MODE) || (im.ent_rows != 0) != QUAD || img_flags[im.status_idx]) return;
     // everything the tile loop needs from the descriptor, read once (uniform -> scalar registers)

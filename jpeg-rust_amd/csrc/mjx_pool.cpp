@@ -30,6 +30,7 @@ namespace {
 struct Worker {
     mjx_ctx *ctx = nullptr;
     int device = 0;
+    bool ready = false;              // the thread has placed itself (slot_affinity); under mu
     std::atomic<int> numa_node{-1};  // node the thread is bound to (-1: not bound); set by the thread when it starts
     std::thread thread;
     std::mutex mu;
@@ -81,6 +82,11 @@ void slot_affinity(Worker *w, unsigned threads_wanted)
 void worker_loop(Worker *w, unsigned threads_wanted)
 {
     slot_affinity(w, threads_wanted);
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->ready = true;                 // (mjx_pool_create waits for it: a call then finds every slot where it will stay)
+    }
+    w->cv.notify_all();
     for (;;) {
         std::function<void()> job;
         {
@@ -133,6 +139,8 @@ extern "C" int mjx_pool_create(const int *devices, size_t n_devices, mjx_pool **
             if (rc != MJX_OK) { delete w; break; }
             w->thread = std::thread(worker_loop, w, std::max(2u, mjx_host_processors() / unsigned(2 * n_devices)));
             p->workers.push_back(w);
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [&] { return w->ready; });
         }
         if (rc != MJX_OK) { mjx_pool_destroy(p); return rc; }
         if (const char *e = std::getenv("MJX_POOL_FAULT_SLOT")) p->fault_slot = std::atoi(e);

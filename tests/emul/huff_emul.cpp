@@ -56,6 +56,32 @@ struct StreamSink {
     void bad_code(uint32_t) const { *bad = 1; }
     void tick() const {}
 };
+// The same for the quad-interleaved stream (pictures of one scan on the device, mjx_kernels.h: stream_phys): the lane's entries go
+// to its own column, a tile offset is the virtual index subsequence * column capacity + entry.
+struct QuadSink {
+    uint32_t *col;          // the columns (behind the run-length head of the region)
+    int16_t *dcbuf;
+    uint32_t *tile_eoff;
+    uint32_t tile_blocks, total_blocks;
+    uint32_t s, rows, off;
+    int *bad;
+    void dc(uint32_t b, int v)
+    {
+        dcbuf[b] = int16_t(v);
+        if (b % tile_blocks == 0) tile_eoff[b / tile_blocks] = s * (rows * 8u) + off;
+    }
+    void ac(uint32_t b, uint32_t r_scaled, int v)
+    {
+        if (off >= rows * 8u) { *bad = 6; return; }                 // (a column holds any run: an entry takes two bits of scan at least)
+        col[stream_phys(s, off++, rows)] = coef_entry(v, 63u - (r_scaled >> kRShift), b);
+    }
+    void block_done(uint32_t next_blk)
+    {
+        if (next_blk == total_blocks) tile_eoff[(total_blocks + tile_blocks - 1) / tile_blocks] = s * (rows * 8u) + off;
+    }
+    void bad_code(uint32_t) const { *bad = 1; }
+    void tick() const {}
+};
 struct TickSink {
     mutable long ticks = 0;
     void dc(uint32_t, int) const {}
@@ -180,6 +206,41 @@ extern "C" int emul_decode_coefs_sub(const uint8_t *jpeg, size_t len, int layout
                 if (blk >= nb) { bad = 4; break; }
                 out[size_t(blk) * 64 + ((e >> 16) & 63)] = int16_t(e & 0xffff);
             }
+        }
+        // The write pass once more into the quad-interleaved layout, expanded the way stage B reads it (quad_prepare + quad_cell,
+        // the functions the kernel runs): every group of every tile, masked at the tile's ends -- must give the same blocks.
+        if (!bad) {
+            const uint32_t rows = stream_rows_for(img.sub_bits), cap = rows * 8u, hdr = stream_hdr_entries(nsub);
+            std::vector<uint32_t> region(size_t(hdr) + size_t(stream_quad_entries(nsub, rows)), 0xdeadbeefu), eoff2(ntiles + 1, 0xffffffffu);
+            std::vector<int16_t> dcb2(nb, 0), out2(nb * 64, 0);
+            uint16_t *runs = reinterpret_cast<uint16_t *>(region.data());
+            for (uint32_t s = 0; s < nsub; s++) {
+                QuadSink sink{region.data() + hdr, dcb2.data(), eoff2.data(), tile_blocks, uint32_t(nb), s, rows, 0u, &bad};
+                decode_subseq<true, 0>(bits, plan.lut.data(), img, g_entry[s], end_of(s), blkbase[s], sink, nocp, 0, g_exit[s]);
+                while (sink.off & 7u) region[hdr + stream_phys(s, sink.off++, rows)] = 0u;       // null entries up to the group boundary
+                runs[s] = uint16_t(sink.off >> 3);
+            }
+            for (uint32_t t = 0; t < ntiles && !bad; t++) {
+                if (eoff2[t] == 0xffffffffu || eoff2[t + 1] == 0xffffffffu) { bad = 7; break; }
+                const uint32_t sub[2] = {eoff2[t] / cap, eoff2[t + 1] / cap};
+                const uint16_t at[2] = {uint16_t(eoff2[t] % cap), uint16_t(eoff2[t + 1] % cap)};
+                QuadCum cum;
+                QuadView q{sub, at, &cum, runs, rows, nsub};
+                cum = quad_prepare(q, 0);
+                QuadCell cell;
+                const uint32_t total = quad_cell(q, 0, 0, cell);
+                for (uint32_t o = 0; o < total; o++) {
+                    if (quad_cell(q, 0, o, cell) != total || cell.phys == 0xffffffffu) { bad = 8; break; }
+                    for (uint32_t k = cell.k_lo; k < cell.k_hi; k++) {
+                        const uint32_t e = region[hdr + cell.phys + k];
+                        if (((e >> 16) & 63) == 0) continue;                                   // null entry
+                        const uint32_t blk = t * tile_blocks + (((e >> 22) - t * tile_blocks) & 0xffu);
+                        if (blk >= nb || blk / tile_blocks != t) { bad = 9; break; }
+                        out2[size_t(blk) * 64 + ((e >> 16) & 63)] = int16_t(e & 0xffff);
+                    }
+                }
+            }
+            if (!bad && (std::memcmp(out2.data(), out, nb * 64 * sizeof(int16_t)) != 0 || dcb2 != dcb)) bad = 10;
         }
         int32_t pred[3] = {0, 0, 0};
         for (size_t b = 0; b < nb; b++) {
