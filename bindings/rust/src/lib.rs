@@ -14,6 +14,9 @@ pub const MJX_OK: c_int = 0;
 pub const MJX_LAYOUT_STANDARD: u8 = 0;
 pub const MJX_LAYOUT_REF_COMPAT: u8 = 1;
 pub const MJX_STAGE_ALL: c_uint = 3;
+pub const MJX_DESTUFF_AUTO: u8 = 0;
+pub const MJX_DESTUFF_DEVICE: u8 = 1;
+pub const MJX_DESTUFF_HOST: u8 = 2;
 
 #[repr(C)]
 #[derive(Clone, Copy, Default)]

@@ -41,16 +41,25 @@ enum {
     MJX_LAYOUT_REF_COMPAT = 1 /* bug-for-bug placement of decoder.rs:239-312 */
 };
 
+enum mjx_destuff {
+    MJX_DESTUFF_AUTO = 0,
+    MJX_DESTUFF_DEVICE = 1,
+    MJX_DESTUFF_HOST = 2
+};
+
 typedef struct mjx_opts {
     uint8_t strict_ref;   /* 1: unknown / APP12 / APP14 markers are errors like the reference; 0: skip them */
     uint8_t layout;       /* MJX_LAYOUT_* */
     uint8_t keep_coefs;   /* 1: keep the whole batch's coefficient stream resident (T0 checks, stage-B-only sweeps) */
-    uint8_t device_destuff;/* 1 = the host does not touch the entropy-coded bytes: mjx_parse copies them as they are
-                             (desc.scan_is_stuffed = 1), and the FF00 -> FF compaction of jpeg/mod.rs:371-385, the search for
-                             RSTn markers and the scan's length are the GPU's at upload (mjx_batch_create, mjx_decode_batch,
-                             the pool).  The picture is the same.  Not with strict_ref (the byte pass stays, for the
-                             reference's unguarded read behind a last FF) nor for multi-scan files (their scans are cut
-                             apart on the host). */
+    uint8_t device_destuff;/* MJX_DESTUFF_*: who removes the FF00 stuffing of jpeg/mod.rs:371-385.
+                             MJX_DESTUFF_DEVICE (1): the host does not touch the entropy-coded bytes -- mjx_parse copies them as
+                             they are (desc.scan_is_stuffed = 1), and the FF00 -> FF compaction, the search for RSTn markers
+                             and the scan's length are the GPU's at upload (mjx_batch_create, mjx_decode_batch, the pool).
+                             MJX_DESTUFF_HOST (2): the byte pass on the host.  MJX_DESTUFF_AUTO (0): the host pass in
+                             mjx_parse and mjx_decode; in mjx_decode_batch and the pool the GPU for lists of 64 MB and more
+                             (MJX_AUTO_DESTUFF_MB; it is the faster of the two there), the host below.  The picture is the
+                             same.  Never on the GPU with strict_ref (the byte pass stays, for the reference's unguarded read
+                             behind a last FF) nor for multi-scan files (their scans are cut apart on the host). */
     uint32_t chunk_images;/* images per kernel chunk; 0 = library default */
 } mjx_opts;
 

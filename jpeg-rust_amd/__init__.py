@@ -148,8 +148,13 @@ def _check(rc, what=""):
         raise MjxError(rc, what)
 
 
+DESTUFF_AUTO, DESTUFF_DEVICE, DESTUFF_HOST = 0, 1, 2
+
+
 def _opts(strict_ref=False, layout=LAYOUT_STANDARD, keep_coefs=False, chunk_images=0, device_destuff=False):
-    return Opts(int(bool(strict_ref)), int(layout), int(bool(keep_coefs)), int(bool(device_destuff)), int(chunk_images))
+    """device_destuff: True = on the GPU, False = on the host, None = the library's choice (mjx.h: MJX_DESTUFF_*)."""
+    dd = DESTUFF_AUTO if device_destuff is None else (DESTUFF_DEVICE if device_destuff else DESTUFF_HOST)
+    return Opts(int(bool(strict_ref)), int(layout), int(bool(keep_coefs)), dd, int(chunk_images))
 
 
 # ---- host parse ------------------------------------------------------------------------------------
@@ -490,7 +495,7 @@ class JPEGImage:
         return self._rgb
 
 
-def decode_batch(ctx, datas, strict_ref=False, layout=LAYOUT_STANDARD, threads=0, device_destuff=False, keep_coefs=False):
+def decode_batch(ctx, datas, strict_ref=False, layout=LAYOUT_STANDARD, threads=0, device_destuff=None, keep_coefs=False):
     """mjx_decode_batch: parse (host threads) + GPU decode of a list of files -> (Batch, [status per file]).
     device_destuff: the host copies the entropy-coded bytes as they are; de-stuffing, restart markers and the scan's length
     are found on the GPU."""
@@ -524,7 +529,7 @@ class Pool:
     def set_deal(self, round_robin):
         _check(lib().mjx_pool_set_deal(self.h, 1 if round_robin else 0), "mjx_pool_set_deal")
 
-    def decode_batch(self, datas, strict_ref=False, layout=LAYOUT_STANDARD, threads_per_device=0, device_destuff=False):
+    def decode_batch(self, datas, strict_ref=False, layout=LAYOUT_STANDARD, threads_per_device=0, device_destuff=None):
         """-> PoolResult; .slot_of[i], .status[i], .rgb(i), .rc (the call's return code: a failed slot fails its own files only)"""
         n = len(datas)
         arr = (ctypes.c_char_p * max(n, 1))(*[bytes(d) for d in datas])

@@ -1960,6 +1960,13 @@ extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const
     // device-side de-stuffing take the whole list as one group (one batch, as mjx_batch_create would build it).
     size_t total_bytes = 0;
     for (size_t i = 0; i < n; i++) total_bytes += lens[i];
+    if (o.device_destuff == MJX_DESTUFF_AUTO) {
+        // who de-stuffs: on a list of this size the GPU (the host threads then only walk the markers and copy: 13.9 against
+        // 15.3 ms per 512 4K files, 45.3 against 46.6 per 2048); a few pictures are faster without the three upload kernels
+        size_t auto_mb = 64;
+        if (const char *e = std::getenv("MJX_AUTO_DESTUFF_MB")) auto_mb = size_t(std::max(0L, std::atol(e)));
+        o.device_destuff = (!o.strict_ref && total_bytes >= (auto_mb << 20)) ? MJX_DESTUFF_DEVICE : MJX_DESTUFF_HOST;
+    }
     size_t group_bytes = size_t(total_bytes >= (size_t(1536) << 20) ? 192 : 96) << 20;
     if (const char *e = std::getenv("MJX_GROUP_MB")) { const long v = std::atol(e); if (v > 0) group_bytes = size_t(v) << 20; }
     const bool single = o.keep_coefs || n <= 8;

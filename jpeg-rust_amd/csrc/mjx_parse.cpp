@@ -351,7 +351,7 @@ void walk(const uint8_t *jpeg, size_t len, const mjx_opts &opts, mjx_scan_desc *
         case Seg::SOF0: read_sof0(f, i, st, strict); break;
         case Seg::DHT: read_dht(f, i, body, out); break;
         case Seg::SOS: {
-            const size_t next = read_sos(f, i, st, strict, opts.device_destuff != 0);
+            const size_t next = read_sos(f, i, st, strict, opts.device_destuff == MJX_DESTUFF_DEVICE);
             if (!next) return;                                                    // :415-417 returns after the first scan
             i = next;
             continue;

@@ -587,16 +587,17 @@ def test_device_side_destuffing_and_marker_scan_through_every_front_door(mjx, or
     dri = open(os.path.join(pil, "dri_420_r5.jpg"), "rb").read()
     datas += _hostile_stuffed_variants(mjx, dri) + _hostile_stuffed_variants(mjx, datas[-2])
     datas += [b"not a jpeg", dri[:len(dri) // 2], dri[:700]]
-    host, st_host = mjx.decode_batch(gpu_ctx, datas, keep_coefs=True)
+    host, st_host = mjx.decode_batch(gpu_ctx, datas, keep_coefs=True, device_destuff=False)
     n_ok = sum(1 for s in st_host if s == mjx.OK)
     assert n_ok >= len(datas) - 8
-    for env in ({}, {"MJX_GROUP_MB": "1"}):
+    # (MJX_DESTUFF_AUTO, what a zeroed mjx_opts says: the GPU for lists of MJX_AUTO_DESTUFF_MB and more -- here: for any list)
+    for env in ({}, {"MJX_GROUP_MB": "1"}, {"MJX_AUTO_DESTUFF_MB": "0", "MJX_GROUP_MB": "2"}):
         os.environ.update(env)
         try:
             for keep in (True, False):
                 if env and keep:
                     continue                                      # (kept coefficients: one group anyway)
-                dev, st_dev = mjx.decode_batch(gpu_ctx, datas, device_destuff=True, keep_coefs=keep, threads=3)
+                dev, st_dev = mjx.decode_batch(gpu_ctx, datas, device_destuff=None if "MJX_AUTO_DESTUFF_MB" in env else True, keep_coefs=keep, threads=3)
                 assert st_dev == st_host, [(i, a, b) for i, (a, b) in enumerate(zip(st_dev, st_host)) if a != b]
                 ok = [i for i, s in enumerate(st_host) if s == mjx.OK]
                 mx, cnt = dev.compare_rgb(ok, host, ok)

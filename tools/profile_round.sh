@@ -22,6 +22,8 @@ unset MJX_STREAMS
 timeout 400 python3 tools/single_image_times.py > $O/single_images.txt 2>&1
 timeout 400 python3 tools/e2e_from_files.py 512 0 > $O/e2e_512.txt 2>&1
 timeout 400 python3 tools/e2e_from_files.py 2048 0 > $O/e2e_2048.txt 2>&1
+timeout 400 python3 tools/e2e_from_files.py 512 0 0 > $O/e2e_512_host_destuff.txt 2>&1
+timeout 400 python3 tools/e2e_from_files.py 2048 0 0 > $O/e2e_2048_host_destuff.txt 2>&1
 timeout 400 python3 tools/e2e_from_files.py 512 0 1 > $O/e2e_512_device_destuff.txt 2>&1
 timeout 400 python3 tools/e2e_from_files.py 2048 0 1 > $O/e2e_2048_device_destuff.txt 2>&1
 timeout 400 python3 tools/batch_size_sweep.py > $O/batch_size_sweep.txt 2>&1
