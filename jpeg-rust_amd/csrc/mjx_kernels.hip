@@ -1940,50 +1940,36 @@ __device__ __forceinline__ void tile_fetch(const uint32_t *__restrict__ src, con
     f.dc = (tid < tile_blocks && blk < total_blocks) ? __builtin_nontemporal_load(dc + blk) : 0;
 }
 
-// The quad-interleaved stream (mjx_kernels.h: stream_phys).  A tile's entries are store groups in the columns of a few
-// neighbouring subsequences: from the tile's own start (subsequence s0, entry j0 -- its tile offset, split by the kernel) to the
-// end of s0's run, the whole runs of the subsequences between, and the head of s1's column up to the next tile's start.  The
-// groups are numbered in that order and lane i of the workgroup takes group i (+ 256 per further round): all eight entries of
-// the 32-byte group, two 16-byte loads.  Entries of the first and the last group that belong to the neighbouring tiles are masked
-// (k_lo / k_hi).  For every tile the workgroup prepares, once, the cumulative group counts of the tile's first kQuadSegs
-// subsequences (16 bytes in LDS: one read per lane and fetch): with them a lane finds its group without a loop and without a
-// second trip to LDS -- the fetch of the next tile sits between the scatter phase and the barrier in front of the inverse DCT,
-// and a loop over the subsequences with a dependent LDS read per turn there cost 0.5 ms per 2048 pictures.  Tiles that span
-// more subsequences (beyond quality ~97) take the loop, on the run lengths at the head of the stream region.
-// (MJX_QUAD_PART=4: a lane takes half a group, one 16-byte load, two neighbouring lanes the two halves of one, so that a wave's
-// load instruction touches 32 lines instead of 64 twice over -- measured: 16.1 instead of 15.8 ms per 2048 pictures in stage B.
-// With the same groups read from consecutive addresses -- MJX_EXP_QUAD_CONTIG, garbage out -- 15.1: the spread costs 0.7 ms.)
-#ifndef MJX_QUAD_PART
-#define MJX_QUAD_PART 8
-#endif
-constexpr uint32_t kQuadPart = MJX_QUAD_PART;           // entries a lane takes per round: 4 (half a group) or 8
-// (QuadFetch<R>: R rounds are prefetched -- 256 groups a round; a tile of the bench content has ~190, at quality 90 ~380)
-constexpr uint32_t kQuadShift = kQuadPart == 4 ? 1 : 0;
+// A tile of the quad-interleaved stream (mjx_kernels.h: stream_phys, quad_prepare, quad_cell): lane i of the workgroup takes
+// the tile's i-th store group (+ 256 per further round) -- all eight entries of the 32-byte group, two 16-byte loads -- and
+// masks what belongs to the neighbouring tiles (k_lo / k_hi).  QuadFetch<R>: R rounds are prefetched; a tile of the bench
+// content has ~190 groups, at quality 90 ~380.  (Half a group per lane, so that a wave's load touches 32 rows instead of 64 twice
+// over: 16.1 instead of 15.8 ms per 2048 pictures in stage B.  The same groups read from consecutive addresses --
+// -DMJX_EXP_QUAD_CONTIG2, garbage out -- 14.9: the spread over rows shared with the neighbours costs 0.9 ms)
 template <int R>
 struct QuadFetch {
-    uint32_t ncells;                                    // the tile's parts (halves of groups, or groups)
-    uint32_t ent[R][kQuadPart];
+    uint32_t ncells;                                    // the tile's groups
+    uint32_t ent[R][8];
     uint32_t k_lo[R], k_hi[R];
     int32_t dc;
 };
-// part `h` of the tile (kQuadPart entries): loads it and says which of its entries are the tile's; returns the tile's parts
-__device__ __forceinline__ uint32_t quad_load(const uint32_t *__restrict__ src, const QuadView &q, uint32_t k, uint32_t h,
+// group `o` of the tile: loads it and says which of its entries are the tile's; returns the tile's groups
+__device__ __forceinline__ uint32_t quad_load(const uint32_t *__restrict__ src, const QuadView &q, uint32_t k, uint32_t o,
                                               uint32_t *ent, uint32_t &k_lo, uint32_t &k_hi)
 {
     QuadCell cell;
-    const uint32_t total = quad_cell(q, k, h >> kQuadShift, cell);
-    const uint32_t sub = kQuadPart == 4 ? (h & 1u) * 4u : 0u;
+    const uint32_t total = quad_cell(q, k, o, cell);
     uint4 a = make_uint4(0, 0, 0, 0), b = a;
     if (cell.phys != 0xffffffffu) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(src + cell.phys + sub);
+        const uint4 *p = reinterpret_cast<const uint4 *>(src + cell.phys);
         a = p[0];
-        if (kQuadPart == 8) b = p[1];
+        b = p[1];
     }
     ent[0] = a.x; ent[1] = a.y; ent[2] = a.z; ent[3] = a.w;
-    if constexpr (kQuadPart == 8) { ent[4] = b.x; ent[5] = b.y; ent[6] = b.z; ent[7] = b.w; }
-    k_lo = cell.k_lo > sub ? cell.k_lo - sub : 0u;
-    k_hi = cell.k_hi > sub ? cell.k_hi - sub : 0u;
-    return total << kQuadShift;
+    ent[4] = b.x; ent[5] = b.y; ent[6] = b.z; ent[7] = b.w;
+    k_lo = cell.k_lo;
+    k_hi = cell.k_hi;
+    return total;
 }
 template <uint32_t LANES, int R>
 __device__ __forceinline__ void tile_fetch_quad(const uint32_t *__restrict__ src, const QuadView &q, uint32_t k,
@@ -2011,7 +1997,7 @@ __device__ __forceinline__ void settle(QuadFetch<R> &f)
 #pragma unroll
     for (int r = 0; r < R; r++) {
 #pragma unroll
-        for (uint32_t k = 0; k < kQuadPart; k++) asm volatile("" : "+v"(f.ent[r][k]));
+        for (int k = 0; k < 8; k++) asm volatile("" : "+v"(f.ent[r][k]));
         asm volatile("" : "+v"(f.k_lo[r]), "+v"(f.k_hi[r]));
     }
     asm volatile("" : "+v"(f.dc), "+v"(f.ncells));
@@ -2019,7 +2005,7 @@ __device__ __forceinline__ void settle(QuadFetch<R> &f)
 __device__ __forceinline__ void quad_mask(uint32_t *ent, uint32_t k_lo, uint32_t k_hi)
 {
 #pragma unroll
-    for (uint32_t k = 0; k < kQuadPart; k++) ent[k] = (k >= k_lo && k < k_hi) ? ent[k] : 0u;
+    for (uint32_t k = 0; k < 8; k++) ent[k] = (k >= k_lo && k < k_hi) ? ent[k] : 0u;
 }
 
 // One stream entry -> one float in the tile: find the block from the entry's block byte, multiply by the
@@ -2402,7 +2388,7 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
         __syncthreads();
     }
     constexpr int QR = PF / 8;       // quad-interleaved stream: rounds that are prefetched
-    static_assert(!QUAD || (kQuadPart == 8 && PF % 8 == 0), "whole groups per lane and round");
+    static_assert(!QUAD || PF % 8 == 0, "whole groups per lane and round");
     typename std::conditional<QUAD, QuadFetch<QR>, TileFetch<PF>>::type cur;
     if constexpr (QUAD) tile_fetch_quad<LANES>(src, qv, 0, dcs, tile0, tile_blocks, total_blocks, cur);
     else tile_fetch<LANES, PF>(src, s_eoff, dcs, tile0, tile_blocks, total_blocks, cur);
@@ -2445,19 +2431,19 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
             const uint32_t first_lo = (tile * tile_blocks) & 0xffu;
             const uint32_t wave0 = tid & ~63u;
             if constexpr (QUAD) {
-                // the prefetched parts of the tile (see quad_load); what a tile has beyond them takes further rounds
+                // the prefetched groups of the tile (see quad_load); what a tile has beyond them takes further rounds
 #pragma unroll
                 for (int r = 0; r < QR; r++) {
                     if (cur.ncells > wave0 + LANES * r) {                                    // uniform over the wave
                         quad_mask(cur.ent[r], cur.k_lo[r], cur.k_hi[r]);
-                        scatter_batch<MODE, int(kQuadPart)>(cur.ent[r], first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+                        scatter_batch<MODE, 8>(cur.ent[r], first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
                     }
                 }
                 for (uint32_t h0 = LANES * QR; h0 < cur.ncells; h0 += LANES) {
-                    uint32_t more[kQuadPart], k_lo, k_hi;
+                    uint32_t more[8], k_lo, k_hi;
                     quad_load(src, qv, tile - tile0, h0 + tid, more, k_lo, k_hi);
                     quad_mask(more, k_lo, k_hi);
-                    scatter_batch<MODE, int(kQuadPart)>(more, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+                    scatter_batch<MODE, 8>(more, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
                 }
             } else {
                 // The prefetched words the wave really has (a tile of the bench content holds ~1500 entries, 5.9 per lane; at quality
