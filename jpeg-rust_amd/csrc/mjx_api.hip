@@ -119,6 +119,7 @@ struct ImageInfo {
 struct Chunk {
     size_t first = 0, count = 0;
     uint32_t nsub = 0;             // subsequences in the chunk
+    uint64_t scan_bytes = 0;       // scan bytes in the chunk (what closes it, plan_chunks)
     uint64_t blocks = 0;           // coefficient blocks in the chunk
     uint64_t coef_base = 0;        // first block of the chunk inside the per-block arrays (keep_coefs) or 0
     uint64_t entries = 0, ent_base = 0;   // capacity of the chunk's stream regions; first entry (keep_coefs) or 0
@@ -415,10 +416,15 @@ void plan_chunks(mjx_batch *b)
 {
     const size_t n = b->info.size();
     const bool keep = b->opts.keep_coefs != 0;
-    // A chunk should give every kernel several rounds of workgroups per CU: by default it is closed after ~2 M
-    // subsequences (1 GiB of scan: 1024 4K images, 4096 1080p images); opts.chunk_images fixes the image count instead.
+    // A chunk should give every kernel many rounds of workgroups per CU (the last, partly filled round of a launch is what a
+    // kernel loses: with two write workgroups per CU a launch of 2278 workgroups is 4.45 rounds): by default it is closed after
+    // 1.5 GiB of scan (MJX_CHUNK_SCAN_MB; ~1600 4K images -- where the 24 GiB of stream capacity close it first --, all of 4096
+    // 1080p images; measured with everything overlapped, 2048 4K pictures per step: 1 / 1.25 / 1.5 / 2 GiB 26.9 / 26.5 / 26.2 /
+    // 26.2 ms at quality 75, 42.0 / 41.0 / 42.1 / 42.1 at quality 90, 23.4 / 24.0 / 24.1 / 24.1 at quality 50);
+    // opts.chunk_images fixes the image count instead.
     const size_t per_chunk = std::min<size_t>(b->opts.chunk_images ? b->opts.chunk_images : 65535, 65535);
-    const uint64_t sub_target = b->opts.chunk_images ? ~uint64_t(0) : (uint64_t(1) << 21);
+    uint64_t scan_target = b->opts.chunk_images ? ~uint64_t(0) : (uint64_t(3) << 29);
+    if (const char *e = std::getenv("MJX_CHUNK_SCAN_MB")) { const long v = std::atol(e); if (v > 0 && !b->opts.chunk_images) scan_target = uint64_t(v) << 20; }
     const uint64_t kMaxChunkEntries = (uint64_t(24) << 30) / 4;          // 24 GiB of stream capacity per chunk
     b->chunks.clear();
     uint64_t coef_running = 0, ent_running = 0;
@@ -436,7 +442,7 @@ void plan_chunks(mjx_batch *b)
             // (the scans of a multi-scan file and their picture stay in one chunk: only a group's first image may open one)
             const bool head = inf.role == 0 || (inf.role == 1 && (i == 0 || b->info[i - 1].role != 1));
             if (head && c.count >= per_chunk) break;
-            if (head && c.count > 0 && (c.entries + inf.ent_cap > kMaxChunkEntries || c.nsub >= sub_target)) break;
+            if (head && c.count > 0 && (c.entries + inf.ent_cap > kMaxChunkEntries || c.scan_bytes >= scan_target || c.nsub >= (uint64_t(1) << 22))) break;
             DevImage &d = b->himages[i];
             if (inf.status == MJX_OK) {
                 d.sub_off = c.nsub;
@@ -449,6 +455,7 @@ void plan_chunks(mjx_batch *b)
                 c.entries += inf.ent_cap;
                 c.tiles += inf.ntiles + 1;
                 c.nsub += d.himg.nsub;
+                c.scan_bytes += inf.scan_len;
                 c.blocks += (inf.nblocks + 7) & ~uint64_t(7);          // regions of DC differences start on 32-byte sectors
                 c.max_wg = std::max<uint32_t>(c.max_wg, (d.himg.nsub + kHuffWg - 1) / kHuffWg);
                 if (d.himg.nsub > 1) c.merge_wgs = std::max<uint32_t>(c.merge_wgs, (d.himg.nsub - 1 + kMergeWg - 1) / kMergeWg);
@@ -824,6 +831,8 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
     std::vector<uint32_t> lut_off(nu, 0), lut_n(nu, 0), seg_off(nu, 0);
     size_t scan_pool = 0, lin_pool = 0, lut_pool = 0, raw_pool = 0;
     auto layout_nsub = [](const ImagePlan &p) { return p.nsub_layout ? p.nsub_layout : p.himg.nsub; };
+    const long skew_mod = std::getenv("MJX_SKEW") ? std::atol(std::getenv("MJX_SKEW")) : 0;      // experiment: regions of neighbouring pictures out of step
+    auto skew = [&](size_t i) -> size_t { return skew_mod > 0 ? (i * 7) % size_t(skew_mod) : 0; };
     b->has_stuffed = any_stuffed && !src;
     std::vector<char> lut_first(nu, 1);                     // 0: the image shares an earlier image's tables
     std::unordered_multimap<uint64_t, size_t> lut_seen;
@@ -831,7 +840,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
     for (size_t k = 0; k < nu; k++) {
         if (plans[k].status != MJX_OK) continue;
         scan_off[k] = scan_pool;
-        scan_pool += align_up(size_t(scan_region_bytes(layout_nsub(plans[k]), plans[k].himg.sub_bits)), 256);
+        scan_pool += align_up(size_t(scan_region_bytes(layout_nsub(plans[k]), plans[k].himg.sub_bits)), 256) + skew(k) * 256;
         lin_off[k] = lin_pool;
         lin_pool += align_up(plans[k].scan_len, 16) + 16;
         if (plans[k].stuffed && !src) {                     // raw bytes for the device-side compaction: whole 64-byte pieces + one behind
@@ -922,7 +931,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
             inf.ent_cap = 8;
             for (uint32_t k = 1; k <= p.nparts; k++) inf.ent_cap += b->info[i - k].ent_cap;
         }
-        inf.ent_cap = (inf.ent_cap + 31) / 32 * 32;        // regions start on whole 128-byte lines (rows of the quad-interleaved stream)
+        inf.ent_cap = (inf.ent_cap + 31) / 32 * 32 + skew(i) * 64;        // regions start on whole 128-byte lines (rows of the quad-interleaved stream)
         d.ent_cap = uint32_t(std::min<uint64_t>(inf.ent_cap, 0xffffffffu));
         inf.scan_len = p.scan_len;
         inf.rgb_off = rgb_pool;

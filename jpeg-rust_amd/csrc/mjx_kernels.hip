@@ -61,6 +61,18 @@ __device__ __forceinline__ uint32_t cps_byte_off(uint32_t idx)
     return (idx / kCpRow) * (kMaxCp * kCpRowBytes) + (idx % kCpRow) * 8;
 }
 
+#ifndef MJX_GRID_WG_FAST
+#define MJX_GRID_WG_FAST 0      // 1: the layout of rounds 1-3 (a picture's workgroups fast), for A/B
+#endif
+// The grid of the entropy kernels that walk (picture, workgroup of the picture): the PICTURE is the fast dimension.  Workgroups go
+// to the eight XCDs round robin in launch order; with the picture's workgroups fast and a grid of 4 x pictures, the fourth
+// workgroup of every picture -- the short one, or an empty one when another picture of the chunk needs four -- always met the
+// same two XCDs, which then idled: the write pass of 2048 4K pictures took 9.3 instead of 7.2 ms at 640-byte subsequences
+// (three full workgroups + an empty slot per picture), and which subsequence lengths were "good" was an artefact of that.
+__device__ __forceinline__ uint32_t entropy_grid_image() { return MJX_GRID_WG_FAST ? blockIdx.y : blockIdx.x; }
+__device__ __forceinline__ uint32_t entropy_grid_wg() { return MJX_GRID_WG_FAST ? blockIdx.x : blockIdx.y; }
+inline dim3 entropy_grid(uint32_t max_wg, uint32_t nimg) { return MJX_GRID_WG_FAST ? dim3(max_wg, nimg) : dim3(nimg, max_wg); }
+
 struct GlobalCps {
     unsigned char *base;    // the chunk's checkpoint array (wave-uniform)
     uint32_t off;           // cps_byte_off(subsequence index in the chunk)
@@ -482,12 +494,13 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_spec(const DevImage
 {
     extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, windows
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
-    const DevImage &im = images[blockIdx.y];
-    if (!im.valid || blockIdx.x * kHuffWg >= im.himg.nsub) return;
+    const uint32_t img = entropy_grid_image(), wgi = entropy_grid_wg();
+    const DevImage &im = images[img];
+    if (!im.valid || wgi * kHuffWg >= im.himg.nsub) return;
     const HuffImage *h;
     const LutEntry *lut;
     stage_tables<true>(im, lut_pool, smem, h, lut);
-    const uint32_t s = blockIdx.x * kHuffWg + threadIdx.x;
+    const uint32_t s = wgi * kHuffWg + threadIdx.x;
     const bool live = s < h->nsub;
     const LaneBits bits{scan_pool + im.scan_off, (live ? s : 0u) * 16u, im.scan_cols * 16u};
     const SubLoc loc = locate_sub(im, *h, segs, live ? s : 0u);
@@ -626,10 +639,11 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
     extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, windows (= item exchange), wave counts
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
     uint32_t *s_cnt = s_win + kMergeWg * kMergeStride;                     // (no static LDS: it would be padded to the dynamic part's alignment)
-    const DevImage &im = images[blockIdx.y];
-    if (!im.valid || blockIdx.x * kMergeWg + 1 >= im.himg.nsub) return;
+    const uint32_t img = entropy_grid_image(), wgi = entropy_grid_wg();
+    const DevImage &im = images[img];
+    if (!im.valid || wgi * kMergeWg + 1 >= im.himg.nsub) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    MergeItem it{blockIdx.x * kMergeWg + tid + 1, 0, 0, 0, 0, 0};
+    MergeItem it{wgi * kMergeWg + tid + 1, 0, 0, 0, 0, 0};
     bool active = false;
     if (it.s < im.himg.nsub) {
         const SubseqState prev = g_exit[im.sub_off + it.s - 1];
@@ -651,7 +665,7 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
     }
     auto hand_over = [&](unsigned long long mask, uint32_t rank) {      // the wave's unfinished items -> k_huff_merge_tail
         uint32_t base = 0;
-        if (lane == 0 && mask) base = atomicAdd(g_item_count + blockIdx.y, uint32_t(__popcll(mask)));
+        if (lane == 0 && mask) base = atomicAdd(g_item_count + img, uint32_t(__popcll(mask)));
         base = __shfl(base, 0);
         if (active) {
             uint32_t *slot = g_items + (size_t(im.sub_off) + base + rank) * kItemDwords;
@@ -1171,12 +1185,13 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
 {
     extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, windows, rings
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
-    const DevImage &im = images[blockIdx.y];
-    if (!im.valid || blockIdx.x * kHuffWg >= im.himg.nsub || img_flags[im.status_idx]) return;
+    const uint32_t img = entropy_grid_image(), wgi = entropy_grid_wg();
+    const DevImage &im = images[img];
+    if (!im.valid || wgi * kHuffWg >= im.himg.nsub || img_flags[im.status_idx]) return;
     const HuffImage *h;
     const LutEntry *lut;
     stage_tables(im, lut_pool, smem, h, lut);
-    const uint32_t s = blockIdx.x * kHuffWg + threadIdx.x;
+    const uint32_t s = wgi * kHuffWg + threadIdx.x;
     const bool live = s < h->nsub;
     const LaneBits gbits{scan_pool + im.scan_off, (live ? s : 0u) * 16u, im.scan_cols * 16u};
     SubseqState e = make_state(0, 0, 0);
@@ -2623,7 +2638,7 @@ void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tab
                       uint32_t *cps, const uint32_t *segs)
 {
     const size_t lds = tables_lds + huff_window_bytes() + pad_lds;
-    hipLaunchKernelGGL(k_huff_spec, dim3(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, uint32_t(tables_lds), segs);
+    hipLaunchKernelGGL(k_huff_spec, entropy_grid(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, uint32_t(tables_lds), segs);
 }
 
 void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
@@ -2633,7 +2648,7 @@ void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
 {
     // (item_count: this round's straggler counts, one per image, zeroed by the caller -- one memset for all the rounds of a chunk)
     const size_t lds = tables_lds + huff_merge_bytes() + pad_lds;
-    hipLaunchKernelGGL(k_huff_merge, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches, uint32_t(tables_lds), items, item_count, segs, prev_mismatches,
+    hipLaunchKernelGGL(k_huff_merge, entropy_grid(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches, uint32_t(tables_lds), items, item_count, segs, prev_mismatches,
                        first_round ? uint32_t(kHeadSlices) : uint32_t(MJX_LATER_HEAD_SLICES));
     const size_t tail_lds = tables_lds + size_t(kTailWg) * kMergeStride * 4;
     hipLaunchKernelGGL(k_huff_merge_tail, dim3(nimg, max_wg * (kMergeWg / kTailWg)), dim3(kTailWg), tail_lds, st, images, scan_pool, lut_pool, exit_, cps, uint32_t(tables_lds), items, item_count, segs);
@@ -2660,7 +2675,7 @@ void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
                        int16_t *dcdiff, int *status, const uint32_t *img_flags, const uint32_t *segs, const SubseqState *exit_)
 {
     const size_t lds = tables_lds + huff_window_bytes() + huff_stage_bytes() + pad_lds;
-    hipLaunchKernelGGL(k_huff_write, dim3(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, blkbase, ebase, entries, tile_eoff, dcdiff, status, img_flags, uint32_t(tables_lds), segs, exit_);
+    hipLaunchKernelGGL(k_huff_write, entropy_grid(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, blkbase, ebase, entries, tile_eoff, dcdiff, status, img_flags, uint32_t(tables_lds), segs, exit_);
 }
 
 void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, const int16_t *dcd, int32_t *dcbuf,

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace mjx {
@@ -84,19 +85,26 @@ static int plan_ref_layout(ImagePlan &p)
 void replan_subsequences(ImagePlan &p, uint32_t base_bits)
 {
     if (p.role == 2 || p.seg.size() < 2 * (size_t(p.nseg) + 1)) return;        // (role 2: no scan of its own)
+    // long scans without restart intervals: long subsequences (mjx_huff.h: kLongSubseqBits), unless the caller asks for short ones
+    if (base_bits == uint32_t(kSubseqBits) && p.nseg == 1 && p.restart_mcus == 0 && (long long)p.himg.total_bits >= kLongScanBits)
+        base_bits = uint32_t(kLongSubseqBits);
     if (p.stuffed) {
         // the exact length and the restart offsets are only known on the device: an upper bound of the subsequence count
         // (every segment adds less than one to total / sub_bits) for the host's sizing, the subsequence length itself is final
-        base_bits = std::max<uint32_t>(uint32_t(kCpBits), std::min<uint32_t>(base_bits, uint32_t(kSubseqBits)) / uint32_t(kCpBits) * uint32_t(kCpBits));
+        base_bits = std::max<uint32_t>(uint32_t(kCpBits), std::min<uint32_t>(base_bits, uint32_t(kLongSubseqBits)) / uint32_t(kCpBits) * uint32_t(kCpBits));
         p.himg.sub_bits = p.nseg == 1 ? choose_subseq_bits(p.himg.total_bits, base_bits) : base_bits;
         p.himg.nsub = (p.himg.total_bits + p.himg.sub_bits - 1) / p.himg.sub_bits + (p.nseg > 1 ? p.nseg : 0u);
         for (uint32_t g = 0; g <= p.nseg; g++) { p.seg[2 * size_t(g)] = g == p.nseg ? p.himg.nsub : 0u; p.seg[2 * size_t(g) + 1] = g == p.nseg ? p.himg.total_bits : 0u; }
         return;
     }
-    base_bits = std::max<uint32_t>(uint32_t(kCpBits), std::min<uint32_t>(base_bits, uint32_t(kSubseqBits)) / uint32_t(kCpBits) * uint32_t(kCpBits));
+    base_bits = std::max<uint32_t>(uint32_t(kCpBits), std::min<uint32_t>(base_bits, uint32_t(kLongSubseqBits)) / uint32_t(kCpBits) * uint32_t(kCpBits));
     const uint32_t top = base_bits * 5 / 4;
     auto bit0 = [&](uint32_t g) { return p.seg[2 * size_t(g) + 1]; };
     p.himg.sub_bits = choose_subseq_bits(p.himg.total_bits, base_bits);
+    if (const char *e = std::getenv("MJX_SUB_BITS")) {           // experiment (tools/sub_bits_sweep.sh): this length for every picture
+        const long v = std::atol(e) / kCpBits * kCpBits;
+        if (v >= kCpBits && v <= kMaxSubseqBits) p.himg.sub_bits = uint32_t(v);
+    }
     if (p.nseg == 1 && p.restart_mcus == 0) {
         p.himg.nsub = (p.himg.total_bits + p.himg.sub_bits - 1) / p.himg.sub_bits;
         p.seg[0] = 0;

@@ -1,0 +1,8 @@
+#!/bin/bash
+# One pass of tools/abv.sh (one stream and default streams per build): tools/abv1.sh "lib1 lib2 ..." [bench args]
+LIBS=$1; shift
+show() { grep '^{' | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], sys.argv[2], round(d['value']), d['ms_per_step'], d['config'].get('chunks_per_step'), {k:round(v['ms']/d['steps'],2) for k,v in d['kernels'].items()})" $1 $2; }
+for L in $LIBS; do
+  MJX_STREAMS=1 MJX_BENCH_IGNORE_STATUS=1 MJX_LIB=$PWD/$L timeout 600 python3 bench.py --no-cpu-baseline --no-extra --no-parity "$@" 2>/dev/null | show $L one-stream
+  MJX_BENCH_IGNORE_STATUS=1 MJX_LIB=$PWD/$L timeout 600 python3 bench.py --no-cpu-baseline --no-extra --no-parity "$@" 2>/dev/null | show $L default
+done

@@ -10,7 +10,7 @@ SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VALU SQ_WAVE_CYCLES
 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum
 TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
 # (PMC_SETS: newline-separated counter sets instead of these; MJX_STREAM_LINEAR etc. are inherited by the runs)
-Q="--no-cpu-baseline --no-extra --no-parity --steps 1 --warmup 0 --images-per-gpu 256"
+Q="--no-cpu-baseline --no-extra --no-parity --steps 1 --warmup 0 --images-per-gpu ${PMC_IMAGES:-256}"
 for L in "$@"; do
   n=$(basename $L .so)
   export MJX_LIB=$PWD/$L
