@@ -131,6 +131,24 @@ def emul(mjx):
     return run
 
 
+def test_subsequence_length_follows_the_scans_size(mjx, orc, emul):
+    """Planning rule of round 4 (mjx_huff.h: kLongScanBits; mjx_plan.cpp: replan_subsequences): scans of at least 1.5 workgroups'
+    worth of 1024-byte subsequences (0.79 MB) are cut into subsequences of 1024 .. 1280 bytes, shorter scans into 512 .. 640.
+    Both sides of the rule through the emulated entropy stage -- which also walks the quad-interleaved stream of such a picture
+    the way stage B does -- against the oracle's coefficients."""
+    for (w, h, q, noise), (lo, hi) in ((((3840, 2160, 75, 6.0)), (1024, 1280)), ((1920, 1080, 75, 6.0), (512, 640)),
+                                       ((2048, 1536, 97, 30.0), (1024, 1280))):
+        data = mjx.synth_jpeg(w, h, "420", q, seed=9, noise_sigma=noise)
+        rc, coefs, st = emul(data, 0)
+        assert rc == 0, (w, h, q)
+        scan = mjx.ParsedScan(data)
+        per_lane = scan.desc.scan_len / st[0]
+        scan.close()
+        assert lo * 0.99 <= per_lane <= hi, (w, h, q, per_lane, st[0])
+        ref = orc.decode(data, layout=orc.LAYOUT_STD)
+        assert np.array_equal(coefs, orc.interleave(ref)), (w, h, q)
+
+
 @pytest.mark.parametrize("name", sorted(FIXTURES))
 @pytest.mark.parametrize("layout", [0, 1])
 def test_emulated_parallel_decode_equals_oracle_T0(mjx, orc, emul, name, layout):
