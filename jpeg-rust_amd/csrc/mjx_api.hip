@@ -840,8 +840,6 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
     std::vector<uint32_t> lut_off(nu, 0), lut_n(nu, 0), seg_off(nu, 0);
     size_t scan_pool = 0, lin_pool = 0, lut_pool = 0, raw_pool = 0;
     auto layout_nsub = [](const ImagePlan &p) { return p.nsub_layout ? p.nsub_layout : p.himg.nsub; };
-    const long skew_mod = std::getenv("MJX_SKEW") ? std::atol(std::getenv("MJX_SKEW")) : 0;      // experiment: regions of neighbouring pictures out of step
-    auto skew = [&](size_t i) -> size_t { return skew_mod > 0 ? (i * 7) % size_t(skew_mod) : 0; };
     b->has_stuffed = any_stuffed && !src;
     std::vector<char> lut_first(nu, 1);                     // 0: the image shares an earlier image's tables
     std::unordered_multimap<uint64_t, size_t> lut_seen;
@@ -849,7 +847,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
     for (size_t k = 0; k < nu; k++) {
         if (plans[k].status != MJX_OK) continue;
         scan_off[k] = scan_pool;
-        scan_pool += align_up(size_t(scan_region_bytes(layout_nsub(plans[k]), plans[k].himg.sub_bits)), 256) + skew(k) * 256;
+        scan_pool += align_up(size_t(scan_region_bytes(layout_nsub(plans[k]), plans[k].himg.sub_bits)), 256);
         lin_off[k] = lin_pool;
         lin_pool += align_up(plans[k].scan_len, 16) + 16;
         if (plans[k].stuffed && !src) {                     // raw bytes for the device-side compaction: whole 64-byte pieces + one behind
@@ -940,7 +938,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
             inf.ent_cap = 8;
             for (uint32_t k = 1; k <= p.nparts; k++) inf.ent_cap += b->info[i - k].ent_cap;
         }
-        inf.ent_cap = (inf.ent_cap + 31) / 32 * 32 + skew(i) * 64;        // regions start on whole 128-byte lines (rows of the quad-interleaved stream)
+        inf.ent_cap = (inf.ent_cap + 31) / 32 * 32;        // regions start on whole 128-byte lines (rows of the quad-interleaved stream)
         d.ent_cap = uint32_t(std::min<uint64_t>(inf.ent_cap, 0xffffffffu));
         inf.scan_len = p.scan_len;
         inf.rgb_off = rgb_pool;

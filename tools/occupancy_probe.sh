@@ -1,3 +1,7 @@
+#!/bin/bash
+# What the entropy kernels lose when LDS padding leaves them fewer workgroups per CU (run through gpurun): one stream, per-kernel ms.
+# (Round 4: the write pass takes 7.88 instead of 7.84 ms with one workgroup per CU instead of two; the counting pass 3.25 / 3.25 / 3.55 ms
+# at four / three / two.)
 show() { grep '^{' | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], round(d['value']), d['ms_per_step'], {k:round(v['ms']/d['steps'],2) for k,v in d['kernels'].items()})" "$1"; }
 Q="--no-cpu-baseline --no-extra --no-parity --no-traffic"
 export MJX_STREAMS=1
