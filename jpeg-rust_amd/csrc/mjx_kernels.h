@@ -71,11 +71,14 @@ struct DevImage {
 // for the stores alone), and a stage-B tile -- two or three lanes' worth of entries -- still reads consecutive lines.
 //   entry j of subsequence s lies at  stream_phys(s, j, rows) = ((s >> 2) * rows + (j >> 3)) * 32 + (s & 3) * 8 + (j & 7)
 //   a tile's start is recorded as the virtual index  s * (rows * 8) + j  (tile_eoff stays one 32-bit word per tile)
-constexpr uint32_t kStreamQuad = 4;
+#ifndef MJX_STREAM_QUAD
+#define MJX_STREAM_QUAD 4
+#endif
+constexpr uint32_t kStreamQuad = MJX_STREAM_QUAD;      // columns interleaved per row (a power of two; 4: a row is one 128-byte line)
 MJX_HD uint32_t stream_rows_for(uint32_t sub_bits) { return (sub_bits / 2u + 1u + 7u) / 8u + 1u; }
 MJX_HD uint64_t stream_quad_entries(uint32_t nsub, uint32_t rows) { return uint64_t((nsub + kStreamQuad - 1) / kStreamQuad) * rows * 8u * kStreamQuad; }
 MJX_HD uint32_t stream_hdr_entries(uint32_t nsub) { return (nsub * 2u + 127u) / 128u * 32u; }      // whole 128-byte lines
-MJX_HD uint64_t stream_phys(uint32_t s, uint32_t j, uint32_t rows) { return (uint64_t(s >> 2) * rows + (j >> 3)) * 32u + (s & 3u) * 8u + (j & 7u); }
+MJX_HD uint64_t stream_phys(uint32_t s, uint32_t j, uint32_t rows) { return (uint64_t(s / kStreamQuad) * rows + (j >> 3)) * (8u * kStreamQuad) + (s % kStreamQuad) * 8u + (j & 7u); }
 
 // ---- reading a tile out of the quad-interleaved stream (stage B; also the host-side expansion and the CPU emulation of the tests) ----
 // A tile's entries are store groups in the columns of a few neighbouring subsequences: from the tile's own start (subsequence
