@@ -7,5 +7,7 @@ for r in 1 2; do
   MJX_STREAMS=2 timeout 300 python3 bench.py $Q 2>/dev/null | show "streams=2,pixels-high"
   MJX_STREAMS=2 MJX_HIGH_PRIO=entropy timeout 300 python3 bench.py $Q 2>/dev/null | show "streams=2,entropy-high"
   MJX_STREAMS=2 MJX_HIGH_PRIO=none timeout 300 python3 bench.py $Q 2>/dev/null | show "streams=2,none"
+  MJX_HIGH_PRIO=pixels timeout 300 python3 bench.py $Q 2>/dev/null | show "default(3),pixels-high"
+  MJX_HIGH_PRIO=entropy timeout 300 python3 bench.py $Q 2>/dev/null | show "default(3),entropy(even chunks)-high"
   MJX_STREAMS=1 timeout 300 python3 bench.py $Q 2>/dev/null | show "streams=1"
 done
