@@ -69,7 +69,7 @@ struct mjx_ctx {
                                     // k_huff_spec) are cut into shorter subsequences when they fit the loop kernel (MJX_LATENCY_NSUB, 0 = never),
     bool linear_stream = false;                                 // MJX_STREAM_LINEAR=1: the packed stream for every picture (the layout of multi-scan pictures; A/B, tests)
     uint32_t latency_sub_bits = 512;                            // ... this many bits at least (MJX_LATENCY_SUB_BITS)
-    uint64_t medium_nsub = 65536;   // batches of up to this many 512-byte subsequences (32 MB of scans, ~32 4K pictures) that are too large for
+    uint64_t medium_nsub = 73728;   // batches of up to this many 512-byte subsequences' worth of scan (36 MB, ~32 4K pictures) that are too large for
                                     // the loop kernel get 256-byte subsequences with launch-per-round merges (MJX_MEDIUM_NSUB, 0 = never):
                                     // 12 / 16 / 24 / 32 4K pictures 1.34 / 1.39 / 1.47 / 1.55 -> 1.08 / 1.12 / 1.20 / 1.33 ms; 64 pictures: no gain
     hipStream_t upload = nullptr;   // H2D of the compressed scans + the upload-time kernels (de-stuffing, interleaving): a stream of
@@ -432,7 +432,7 @@ void plan_chunks(mjx_batch *b)
     if (!b->opts.chunk_images) {
         uint64_t total_scan = 0;
         for (size_t k = 0; k < n; k++) total_scan += b->info[k].scan_len;
-        if (total_scan >= (uint64_t(128) << 20)) scan_target = std::min(scan_target, total_scan - total_scan / 4);
+        if (total_scan >= (uint64_t(256) << 20)) scan_target = std::min(scan_target, total_scan - total_scan / 4);      // (128 4K pictures, 138 MB: 2.34 ms in one chunk, 2.43 in two)
     }
     const uint64_t kMaxChunkEntries = (uint64_t(24) << 30) / 4;          // 24 GiB of stream capacity per chunk
     b->chunks.clear();
@@ -773,6 +773,8 @@ void collect_events(mjx_batch *b)
 // Pinned host memory lent to build_batch for the host mirrors of its small pools (mjx_decode_batch: an asynchronous copy from
 // pageable memory is staged by the runtime and waits for the stream's earlier transfers -- the host thread would stall behind
 // the previous group's DMA).
+constexpr uint64_t kLongBatchSubs = uint64_t(1) << 19;      // short subsequences' worth of scan (256 MiB) below which a batch keeps them (build_batch)
+
 struct PinnedBump {
     uint8_t *base = nullptr;
     size_t cap = 0, used = 0;
@@ -800,7 +802,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
     for (const ImagePlan &p : plans_in) any_stuffed = any_stuffed || (p.status == MJX_OK && p.stuffed);
     if (!src && latency_plan && !any_stuffed && !ctx->throughput_plan && ctx->latency_nsub > 0 && ctx->merge_loop_max > 0) {       // (not for the groups of a pipelined list: they overlap, throughput counts)
         uint64_t total = 0;
-        for (const ImagePlan &p : plans_in) if (p.status == MJX_OK) total += p.himg.nsub;
+        for (const ImagePlan &p : plans_in) if (p.status == MJX_OK) total += (uint64_t(p.himg.total_bits) + uint64_t(kSubseqBits) - 1) / uint64_t(kSubseqBits);    // in short subsequences, whatever length the picture got
         if (total > 0 && total <= ctx->latency_nsub) {
             for (uint32_t bits = std::max<uint32_t>(ctx->latency_sub_bits, total <= 1024 ? 512u : 1024u); bits < uint32_t(kSubseqBits); bits *= 2) {
                 std::vector<ImagePlan> cut = plans_in;
@@ -819,6 +821,17 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
             replanned = plans_in;
             for (ImagePlan &p : replanned) if (p.status == MJX_OK) replan_subsequences(p, uint32_t(kSubseqBits) / 2);
             use = &replanned;
+        }
+        // not enough pictures to fill the device with long subsequences (half the lanes per picture): the short ones, as before
+        // round 4 -- 32 4K pictures 1.15 instead of 1.77 ms, 128 pictures 2.3 instead of 2.7; from ~256 pictures on the long ones win
+        if (use == &plans_in && total > 0 && total < kLongBatchSubs) {
+            bool any_long = false;
+            for (const ImagePlan &p : plans_in) any_long = any_long || (p.status == MJX_OK && p.himg.sub_bits > uint32_t(kSubseqBits) * 5 / 4);
+            if (any_long) {
+                replanned = plans_in;
+                for (ImagePlan &p : replanned) if (p.status == MJX_OK && p.himg.sub_bits > uint32_t(kSubseqBits) * 5 / 4) replan_subsequences(p, uint32_t(kSubseqBits), false);
+                use = &replanned;
+            }
         }
     }
     const std::vector<ImagePlan> &plans = *use;

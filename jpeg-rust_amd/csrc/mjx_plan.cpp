@@ -82,11 +82,11 @@ static int plan_ref_layout(ImagePlan &p)
 
 // Cuts the scan of a planned picture into subsequences of about `base_bits` bits: p.seg holds the first bit of every
 // segment (one segment without restart intervals); sets himg.sub_bits, himg.nsub and the first subsequence of every segment.
-void replan_subsequences(ImagePlan &p, uint32_t base_bits)
+void replan_subsequences(ImagePlan &p, uint32_t base_bits, bool allow_long)
 {
     if (p.role == 2 || p.seg.size() < 2 * (size_t(p.nseg) + 1)) return;        // (role 2: no scan of its own)
     // long scans without restart intervals: long subsequences (mjx_huff.h: kLongSubseqBits), unless the caller asks for short ones
-    if (base_bits == uint32_t(kSubseqBits) && p.nseg == 1 && p.restart_mcus == 0 && (long long)p.himg.total_bits >= kLongScanBits)
+    if (allow_long && base_bits == uint32_t(kSubseqBits) && p.nseg == 1 && p.restart_mcus == 0 && (long long)p.himg.total_bits >= kLongScanBits)
         base_bits = uint32_t(kLongSubseqBits);
     if (p.stuffed) {
         // the exact length and the restart offsets are only known on the device: an upper bound of the subsequence count

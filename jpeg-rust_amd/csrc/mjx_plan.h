@@ -66,7 +66,7 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &plan, bo
 
 // Re-cuts a planned picture's scan into subsequences of about `base_bits` bits (at most kSubseqBits; plan_image uses
 // kSubseqBits).  Batches too small to fill the device are re-planned with shorter subsequences (mjx_api.hip).
-void replan_subsequences(ImagePlan &plan, uint32_t base_bits);
+void replan_subsequences(ImagePlan &plan, uint32_t base_bits, bool allow_long = true);     // allow_long: kLongSubseqBits for long scans (base_bits == kSubseqBits only)
 
 // The plans of one input: `plan_image` for an ordinary file; for a multi-scan file one role-1 plan per scan (in file
 // order) followed by the role-2 plan of the picture.  The last plan appended is the picture's.
