@@ -101,10 +101,6 @@ void replan_subsequences(ImagePlan &p, uint32_t base_bits, bool allow_long)
     const uint32_t top = base_bits * 5 / 4;
     auto bit0 = [&](uint32_t g) { return p.seg[2 * size_t(g) + 1]; };
     p.himg.sub_bits = choose_subseq_bits(p.himg.total_bits, base_bits);
-    if (const char *e = std::getenv("MJX_SUB_BITS")) {           // experiment (tools/sub_bits_sweep.sh): this length for every picture
-        const long v = std::atol(e) / kCpBits * kCpBits;
-        if (v >= kCpBits && v <= kMaxSubseqBits) p.himg.sub_bits = uint32_t(v);
-    }
     if (p.nseg == 1 && p.restart_mcus == 0) {
         p.himg.nsub = (p.himg.total_bits + p.himg.sub_bits - 1) / p.himg.sub_bits;
         p.seg[0] = 0;
