@@ -141,6 +141,7 @@ extern "C" {
     pub fn mjx_pool_result_locate(r: *const mjx_pool_result, i: usize, slot: *mut usize, batch: *mut *mut mjx_batch,
                                   index: *mut usize) -> c_int;
     pub fn mjx_pool_result_host(r: *const mjx_pool_result, slot: usize, threads: *mut c_uint, numa_node: *mut c_int) -> c_int;
+    pub fn mjx_pool_result_slot_ms(r: *const mjx_pool_result, slot: usize, ms: *mut c_double) -> c_int;
     pub fn mjx_pool_result_free(r: *mut mjx_pool_result);
     pub fn mjx_strerror(code: c_int) -> *const c_char;
     pub fn mjx_version() -> *const c_char;

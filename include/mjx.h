@@ -262,6 +262,9 @@ int mjx_pool_result_locate(const mjx_pool_result *r, size_t i, size_t *slot, mjx
 /* host side of the call, per slot: parse threads the slot's mjx_decode_batch ran with (0: the slot had no file) and the NUMA
  * node its host thread was bound to (-1: not bound) */
 int mjx_pool_result_host(const mjx_pool_result *r, size_t slot, unsigned *threads, int *numa_node);
+/* ... and the wall clock of the slot's own mjx_decode_batch (host parse + uploads + kernels, in milliseconds; 0: no file): which
+ * queue the call waited for */
+int mjx_pool_result_slot_ms(const mjx_pool_result *r, size_t slot, double *ms);
 void mjx_pool_result_free(mjx_pool_result *r);
 
 const char *mjx_strerror(int code);

@@ -114,6 +114,7 @@ SYMBOLS = {
     "mjx_pool_decode_batch": (_int, [_vp, _P(ctypes.c_char_p), _P(_sz), _sz, _P(Opts), ctypes.c_uint, _P(_int), _P(_P(ctypes.c_uint8)), _P(_int), _P(_vp)]),
     "mjx_pool_result_locate": (_int, [_vp, _sz, _P(_sz), _P(_vp), _P(_sz)]),
     "mjx_pool_result_host": (_int, [_vp, _sz, _P(ctypes.c_uint), _P(_int)]),
+    "mjx_pool_result_slot_ms": (_int, [_vp, _sz, _P(ctypes.c_double)]),
     "mjx_pool_result_free": (None, [_vp]),
     "mjx_strerror": (ctypes.c_char_p, [_int]),
     "mjx_version": (ctypes.c_char_p, []),
@@ -574,6 +575,12 @@ class PoolResult:
         t, node = ctypes.c_uint(), _int()
         _check(lib().mjx_pool_result_host(self.h, slot, ctypes.byref(t), ctypes.byref(node)), "mjx_pool_result_host")
         return int(t.value), int(node.value)
+
+    def slot_ms(self, slot):
+        """-> wall clock (ms) of the slot's own mjx_decode_batch in this call (0.0: the slot had no file)"""
+        ms = ctypes.c_double()
+        _check(lib().mjx_pool_result_slot_ms(self.h, slot, ctypes.byref(ms)), "mjx_pool_result_slot_ms")
+        return float(ms.value)
 
     def compare_rgb(self, mine, theirs):
         """On-device comparison of picture mine[k] with picture theirs[k] of this result (they may lie in different slots'

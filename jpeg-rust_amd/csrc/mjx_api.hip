@@ -1868,7 +1868,11 @@ extern "C" int mjx_batch_geometry(const mjx_batch *b, uint64_t *subsequences, ui
     // scans de-stuffed on the device: the host planned with the stuffed length as an upper bound, the exact number of
     // subsequences is in the device's copy of the images (k_destuff_prefix / k_restart_geometry)
     std::vector<DevImage> dev_images;
-    if (b->has_stuffed && !b->himages.empty() && hipSetDevice(b->ctx->device) == hipSuccess && hipStreamSynchronize(b->ctx->upload) == hipSuccess) {
+    // (the upload-time kernels run on the upload stream or -- groups of a pipelined list, upload_kernels_apart -- on a decode
+    // stream behind the copies; b->uploaded is recorded behind them on whichever stream ran them)
+    const bool upload_done = b->has_stuffed && !b->himages.empty() && hipSetDevice(b->ctx->device) == hipSuccess &&
+                             (b->uploaded ? hipEventSynchronize(b->uploaded) : hipStreamSynchronize(b->ctx->upload)) == hipSuccess;
+    if (upload_done) {
         dev_images.resize(b->himages.size());
         if (hipMemcpy(dev_images.data(), b->d_images, dev_images.size() * sizeof(DevImage), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); dev_images.clear(); }
     }
@@ -1985,8 +1989,9 @@ extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const
     // groups: small ones first so that the device has work early (12 MB, doubling), then group_bytes each.  Consecutive
     // transfers start 0.3 ms apart whatever stream they are on (measured with a copy stream of their own, and with three),
     // so long lists get larger groups: 192 MB from 1.5 GB on, 96 MB below.  Smaller groups again at the end of the list
-    // (so that less is left to decode when the last transfer has landed) were tried: no gain.  Kept coefficients and
-    // device-side de-stuffing take the whole list as one group (one batch, as mjx_batch_create would build it).
+    // (so that less is left to decode when the last transfer has landed) were tried: no gain.  Kept coefficients (and lists
+    // of up to eight files) take the whole list as one group (one batch, as mjx_batch_create would build it); lists de-stuffed on
+    // the device are cut into groups like the others.
     size_t total_bytes = 0;
     for (size_t i = 0; i < n; i++) total_bytes += lens[i];
     if (o.device_destuff == MJX_DESTUFF_AUTO) {
@@ -2010,11 +2015,14 @@ extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const
     bool taper = false;
     if (const char *e = std::getenv("MJX_GROUP_FIRST_MB")) { const double v = std::atof(e); if (v > 0) first_bytes = size_t(v * 1048576.0); }
     if (const char *e = std::getenv("MJX_GROUP_GROW")) { const double v = std::atof(e); if (v >= 1.0) grow = v; }
+    // (the ramp below must end: a growth of 1.0 or a first group that rounds down to nothing would push sizes for ever)
+    grow = std::max(grow, 1.05);
+    first_bytes = std::max(first_bytes, size_t(1) << 20);
     if (const char *e = std::getenv("MJX_GROUP_TAPER")) taper = std::atoi(e) != 0;
     std::vector<size_t> gfirst{0};
     if (!single) {
         std::vector<size_t> sizes, up, down;                // target bytes per group, front to back
-        for (double t = double(first_bytes); size_t(t) < group_bytes; t *= grow) up.push_back(size_t(t));
+        for (double t = double(first_bytes); size_t(t) < group_bytes && up.size() < 64; t *= grow) up.push_back(size_t(t));
         if (taper) for (size_t t = group_bytes / 2; t >= first_bytes && t > 0; t /= 2) down.push_back(t);
         size_t up_sum = 0, down_sum = 0;
         for (size_t t : up) up_sum += t;

@@ -2165,24 +2165,41 @@ __device__ __forceinline__ void pixels_420(uint32_t width, uint32_t height, uint
     if (INTERIOR && MJX_PIX_XCHG) {
         // An interior tile: every sample of the tile is read exactly once in this phase, by exactly one lane -- so the read is an
         // exchange with zero (ds_wrxchg), and the tile is clean for the next one's coefficients without a zero-fill pass
-        // (52 KB of LDS stores and a barrier per tile).  The compiler does not track LDS operations inside asm statements:
-        // the waits are spelled out, one per row pair, in issue order.
+        // (52 KB of LDS stores and a barrier per tile).  The compiler does not track LDS operations inside asm statements, so
+        // the sixteen exchanges and the wait for them are ONE statement: its outputs are defined when it ends, whatever the
+        // register allocator or the scheduler place around it (round 4 had a statement per exchange and hand-counted staged
+        // waits between them -- correct only as long as no copy of a result was placed in front of its wait).
         const f32x2 zero = {0.0f, 0.0f};
+        uint32_t ay[4], ac[4];
 #pragma unroll
         for (uint32_t j = 0; j < 4; j++) {
             const uint32_t rp = tid / (kTile420 * 4) + 2 * j;
             const float *yp = ybase + (rp >> 2) * 2 * kPixStride + ((rp * 2) & 7) * 8;
-            const uint32_t ay = uint32_t(uintptr_t((const __attribute__((address_space(3))) float *)(yp)));
-            const uint32_t ac = uint32_t(uintptr_t((const __attribute__((address_space(3))) float *)(cbase + rp * 8)));
-            asm volatile("ds_wrxchg2_rtn_b64 %0, %1, %2, %2 offset1:1" : "=v"(ya[j]) : "v"(ay), "v"(zero) : "memory");
-            asm volatile("ds_wrxchg2_rtn_b64 %0, %1, %2, %2 offset0:4 offset1:5" : "=v"(yb[j]) : "v"(ay), "v"(zero) : "memory");
-            asm volatile("ds_wrxchg_rtn_b64 %0, %1, %2" : "=v"(cb[j]) : "v"(ac), "v"(zero) : "memory");
-            asm volatile("ds_wrxchg_rtn_b64 %0, %1, %2 offset:%3" : "=v"(cr[j]) : "v"(ac), "v"(zero), "n"(kPixStride * 4) : "memory");
+            ay[j] = uint32_t(uintptr_t((const __attribute__((address_space(3))) float *)(yp)));
+            ac[j] = uint32_t(uintptr_t((const __attribute__((address_space(3))) float *)(cbase + rp * 8)));
         }
-        asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(ya[0]), "+v"(yb[0]), "+v"(cb[0]), "+v"(cr[0]) :: "memory");
-        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(ya[1]), "+v"(yb[1]), "+v"(cb[1]), "+v"(cr[1]) :: "memory");
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ya[2]), "+v"(yb[2]), "+v"(cb[2]), "+v"(cr[2]) :: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ya[3]), "+v"(yb[3]), "+v"(cb[3]), "+v"(cr[3]) :: "memory");
+        asm volatile(
+            "ds_wrxchg2_rtn_b64 %0, %16, %24, %24 offset1:1\n\t"
+            "ds_wrxchg2_rtn_b64 %1, %16, %24, %24 offset0:4 offset1:5\n\t"
+            "ds_wrxchg_rtn_b64 %2, %20, %24\n\t"
+            "ds_wrxchg_rtn_b64 %3, %20, %24 offset:%25\n\t"
+            "ds_wrxchg2_rtn_b64 %4, %17, %24, %24 offset1:1\n\t"
+            "ds_wrxchg2_rtn_b64 %5, %17, %24, %24 offset0:4 offset1:5\n\t"
+            "ds_wrxchg_rtn_b64 %6, %21, %24\n\t"
+            "ds_wrxchg_rtn_b64 %7, %21, %24 offset:%25\n\t"
+            "ds_wrxchg2_rtn_b64 %8, %18, %24, %24 offset1:1\n\t"
+            "ds_wrxchg2_rtn_b64 %9, %18, %24, %24 offset0:4 offset1:5\n\t"
+            "ds_wrxchg_rtn_b64 %10, %22, %24\n\t"
+            "ds_wrxchg_rtn_b64 %11, %22, %24 offset:%25\n\t"
+            "ds_wrxchg2_rtn_b64 %12, %19, %24, %24 offset1:1\n\t"
+            "ds_wrxchg2_rtn_b64 %13, %19, %24, %24 offset0:4 offset1:5\n\t"
+            "ds_wrxchg_rtn_b64 %14, %23, %24\n\t"
+            "ds_wrxchg_rtn_b64 %15, %23, %24 offset:%25\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(ya[0]), "=&v"(yb[0]), "=&v"(cb[0]), "=&v"(cr[0]), "=&v"(ya[1]), "=&v"(yb[1]), "=&v"(cb[1]), "=&v"(cr[1]),
+              "=&v"(ya[2]), "=&v"(yb[2]), "=&v"(cb[2]), "=&v"(cr[2]), "=&v"(ya[3]), "=&v"(yb[3]), "=&v"(cb[3]), "=&v"(cr[3])
+            : "v"(ay[0]), "v"(ay[1]), "v"(ay[2]), "v"(ay[3]), "v"(ac[0]), "v"(ac[1]), "v"(ac[2]), "v"(ac[3]), "v"(zero), "n"(kPixStride * 4)
+            : "memory");
     } else {
 #pragma unroll
         for (uint32_t j = 0; j < 4; j++) {

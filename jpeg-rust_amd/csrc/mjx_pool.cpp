@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -122,6 +123,7 @@ struct mjx_pool_result {
     std::vector<int> slot_rc;                         // per slot: return code of its mjx_decode_batch
     std::vector<unsigned> slot_threads;               // per slot: parse threads of its call (0: no file)
     std::vector<int> slot_node;                       // per slot: NUMA node its host thread is bound to (-1: not bound)
+    std::vector<double> slot_ms;                      // per slot: wall clock of its mjx_decode_batch (0: no file)
     std::vector<uint32_t> slot_of, index_in_slot;     // per file
 };
 
@@ -218,6 +220,7 @@ extern "C" int mjx_pool_decode_batch(mjx_pool *pool, const uint8_t *const *jpegs
         r.slot_rc.assign(N, MJX_OK);
         r.slot_threads.assign(N, 0);
         r.slot_node.assign(N, -1);
+        r.slot_ms.assign(N, 0.0);
         r.slot_of.resize(n);
         r.index_in_slot.resize(n);
         call->ptrs.resize(N);
@@ -268,8 +271,10 @@ extern "C" int mjx_pool_decode_batch(mjx_pool *pool, const uint8_t *const *jpegs
             std::lock_guard<std::mutex> lk(w->mu);
             w->job = [call, s, w, opts, threads, fault_slot] {
                 if (int(s) == fault_slot) return;            // this slot's device has "failed": MJX_ERR_DEVICE stands
+                const auto t0 = std::chrono::steady_clock::now();
                 call->res.slot_rc[s] = mjx_decode_batch(w->ctx, call->ptrs[s].data(), call->sizes[s].data(), call->ptrs[s].size(), opts,
                                                         threads, call->rgb[s].data(), call->st[s].data(), &call->res.batches[s]);
+                call->res.slot_ms[s] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             };
             w->done = false;
             w->has_job = true;
@@ -325,6 +330,13 @@ extern "C" int mjx_pool_result_host(const mjx_pool_result *r, size_t slot, unsig
     if (!r || slot >= r->slot_threads.size()) return MJX_ERR_INVALID_ARG;
     if (threads) *threads = r->slot_threads[slot];
     if (numa_node) *numa_node = r->slot_node[slot];
+    return MJX_OK;
+}
+
+extern "C" int mjx_pool_result_slot_ms(const mjx_pool_result *r, size_t slot, double *ms)
+{
+    if (!r || slot >= r->slot_ms.size() || !ms) return MJX_ERR_INVALID_ARG;
+    *ms = r->slot_ms[slot];
     return MJX_OK;
 }
 

@@ -262,6 +262,28 @@ def test_bench_two_ranks_over_gloo_on_one_gpu(tmp_path):
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["parity"]["ok"] and rec["parity"]["tiled_max_abs_diff"] == 0
     assert rec["parity"]["t0_equal"] and rec["parity"]["max_abs_diff"] <= 1
+    # the N > 1 line is as complete as the N = 1 line (round-4 review, next #5): the CPU baseline timed in the same run on rank 0,
+    # rooflines from the MAX over the ranks of every kernel class's time, the stand-alone pass and the from-bytes leg on every rank
+    assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["cores"] >= 1 and rec["cpu_baseline"]["kind"] == "port"
+    assert 0 < rec["roofline"]["frac"] < 1 and rec["roofline"]["bound"] == "hbm"
+    assert rec["kernel_rooflines"]["idct_color"]["ms_per_step"] > 0 and "roofline_isolated" in rec
+    assert rec["e2e_from_bytes"]["files"] == 1024 and rec["e2e_from_bytes"]["Mpixels/s"] > 0
+    assert rec["parity"]["ref_compat_max_abs_diff"] <= 1
+
+
+def test_bench_line_has_a_pool_leg_at_one_gpu():
+    """The N = 1 line times the library's own multi-GPU front (mjx_pool_decode_batch over every visible device; one here), so the
+    driver's run on an 8-GPU node measures it without a flag."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--images-per-gpu", "64", "--width", "640",
+           "--height", "480", "--unique", "16", "--no-cpu-baseline", "--no-traffic"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    pool = rec["e2e_from_bytes_pool"]
+    assert pool["devices"] >= 1 and pool["files"] == 512 * pool["devices"] and pool["Mpixels/s"] > 0
+    assert len(pool["slots"]) == pool["devices"] and all(s["ms"] > 0 and s["files"] > 0 and s["parse_threads"] >= 1 for s in pool["slots"])
 
 
 # ---- multi-GPU front: per-device work queues, no collective (SURVEY s8(e)) -------------------------------------------------

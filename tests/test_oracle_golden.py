@@ -226,3 +226,35 @@ def test_two_restatements_agree_on_synthetic_files_and_on_panics(mjx, orc):
         assert dec.bits_used == d.bits_used and np.array_equal(dec.rgb, d.rgb), k
         agreed += 1
     assert agreed >= 10 and panics == 3
+
+
+def test_pin_recipe_compares_a_reference_ppm_with_the_committed_answers_and_the_oracle(tmp_path):
+    """tests/golden/pin_with_cargo.sh needs a Rust toolchain (absent here); its comparing half (pin_compare.py) is exercised with a
+    stand-in for the reference binary's output: the P3 text src/main.rs:35-39 would write, produced from the second restatement's
+    committed answer route (the oracle's REF picture).  A picture that is off by one in one byte must be reported as DIFFERENT."""
+    import importlib.util
+    import oracle_binding as orc
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pin_compare", os.path.join(ROOT, "tests", "golden", "pin_compare.py"))
+    pc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pc)
+    jpeg = os.path.join(ROOT, "tests", "data", "lena-bw.jpeg")
+    img = orc.decode(open(jpeg, "rb").read(), layout=orc.LAYOUT_REF, faithful_cos=True, faithful_huff=True)
+    h, w, _ = img.rgb.shape
+
+    def write_p3(path, rgb):          # main.rs:35-39
+        with open(path, "w") as f:
+            f.write("P3\n%d %d\n255\n" % (w, h))
+            f.write("".join("%d %d %d\n" % tuple(p) for p in rgb.reshape(-1, 3)))
+    good, bad = str(tmp_path / "good.ppm"), str(tmp_path / "bad.ppm")
+    write_p3(good, img.rgb)
+    off = img.rgb.copy()
+    off[h // 2, w // 2, 1] ^= 1
+    write_p3(bad, off)
+    log = []
+    assert pc.compare(good, jpeg, "lena-bw.jpeg", out=log.append), log
+    assert sum("EQUAL" in l for l in log) == 2, log
+    log = []
+    assert not pc.compare(bad, jpeg, "lena-bw.jpeg", out=log.append)
+    assert all("DIFFERENT" in l for l in log), log
+    assert os.access(os.path.join(ROOT, "tests", "golden", "pin_with_cargo.sh"), os.X_OK)

@@ -1,8 +1,9 @@
 // The decode algorithm itself (tests/emul: the per-lane routine of the kernels, run on the CPU) under AddressSanitizer /
 // UBSan over files with mutated Huffman tables and scan bytes: table lookups, links and stream writes must stay in bounds.
 //   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -Iinclude -Ijpeg-rust_amd/csrc \
-//       tools/asan_emul_fuzz.cpp tests/emul/huff_emul.cpp jpeg-rust_amd/csrc/mjx_parse.cpp jpeg-rust_amd/csrc/mjx_plan.cpp \
-//       jpeg-rust_amd/csrc/mjx_lut.cpp -o /tmp/asan_emul_fuzz && /tmp/asan_emul_fuzz tests/golden/pil/opt_*.jpg tests/data/*.jp*
+//       tools/sanitize/asan_emul_fuzz.cpp tests/emul/huff_emul.cpp jpeg-rust_amd/csrc/mjx_parse.cpp jpeg-rust_amd/csrc/mjx_plan.cpp \
+//       jpeg-rust_amd/csrc/mjx_lut.cpp -o /tmp/asan_emul_fuzz && /tmp/asan_emul_fuzz 60 tests/golden/pil/opt_*.jpg tests/data/*.jp*
+// (first argument: mutations per file; built and run by tests/test_sanitizers.py)
 #include "mjx.h"
 #include <cstdio>
 #include <cstdlib>
@@ -15,7 +16,8 @@ int main(int argc, char **argv)
     std::mt19937_64 rng(777);
     long runs = 0, ok = 0;
     std::vector<int16_t> out(size_t(200000) * 64);
-    for (int a = 1; a < argc; a++) {
+    const int per_file = argc > 1 ? std::atoi(argv[1]) : 60;
+    for (int a = 2; a < argc; a++) {
         FILE *f = std::fopen(argv[a], "rb");
         if (!f) continue;
         std::vector<uint8_t> base; uint8_t buf[65536]; size_t n;
@@ -31,7 +33,7 @@ int main(int argc, char **argv)
             if (m == 0xda) break;
             i += 2 + ln;
         }
-        for (int k = 0; k < 60; k++) {
+        for (int k = 0; k < per_file; k++) {
             std::vector<uint8_t> b = base;
             const int muts = 1 + int(rng() % 4);
             for (int m = 0; m < muts; m++) {

@@ -1,7 +1,8 @@
 // Host-side hardening run (CPU only): mjx_parse + mjx_validate over mutated fixtures under AddressSanitizer / UBSan.
 //   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -Iinclude -Ijpeg-rust_amd/csrc \
-//       tools/asan_parse_fuzz.cpp jpeg-rust_amd/csrc/mjx_parse.cpp jpeg-rust_amd/csrc/mjx_plan.cpp \
-//       jpeg-rust_amd/csrc/mjx_lut.cpp -o /tmp/asan_parse_fuzz && /tmp/asan_parse_fuzz tests/golden/pil/*.jpg tests/data/*
+//       tools/sanitize/asan_parse_fuzz.cpp jpeg-rust_amd/csrc/mjx_parse.cpp jpeg-rust_amd/csrc/mjx_plan.cpp \
+//       jpeg-rust_amd/csrc/mjx_lut.cpp -o /tmp/asan_parse_fuzz && /tmp/asan_parse_fuzz 400 tests/golden/pil/*.jpg tests/data/*
+// (first argument: mutations per file; built and run by tests/test_sanitizers.py)
 #include "mjx.h"
 #include "mjx_plan.h"
 
@@ -25,7 +26,8 @@ int main(int argc, char **argv)
 {
     std::mt19937_64 rng(12345);
     long runs = 0, ok = 0;
-    for (int a = 1; a < argc; a++) {
+    const int per_file = argc > 1 ? std::atoi(argv[1]) : 400;
+    for (int a = 2; a < argc; a++) {
         FILE *f = std::fopen(argv[a], "rb");
         if (!f) continue;
         std::vector<uint8_t> base;
@@ -34,7 +36,7 @@ int main(int argc, char **argv)
         while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) base.insert(base.end(), buf, buf + n);
         std::fclose(f);
         if (base.size() < 4 || base.size() > (1u << 20)) continue;
-        for (int k = 0; k < 400; k++) {
+        for (int k = 0; k < per_file; k++) {
             std::vector<uint8_t> b = base;
             const int muts = int(rng() % 8);
             for (int m = 0; m < muts; m++) {
