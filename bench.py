@@ -23,9 +23,9 @@ The JSON line carries, besides the contract fields:
                 (the library overlaps the entropy stages of two chunks and stage B on three streams: these durations include
                 the contention); idct_color also with the bytes it physically moves (frac_physical)
   roofline_isolated / kernel_rooflines_isolated  the same from a one-stream pass over the same batch: stand-alone durations
-  upload_side   the per-batch work outside the timed region: the pass that lays the de-stuffed scans out lane-interleaved
-                (k_scan_interleave; with --device-destuff also the de-stuffing kernels), HIP-event time for the unique pictures
-                scaled to the batch -- the timed region starts from that layout
+  upload_side   GPU work of the upload, outside the timed region (HIP-event time for the unique pictures scaled to the batch): 0
+                since round 5 -- the host writes the lane-interleaved scan pool while it packs the scans for the transfer; with
+                --device-destuff the de-stuffing kernels and k_scan_interleave
   kernels       per kernel class: launches, total ms
   parity        the gate behind `value`: every picture of the timed batch compared on the device with its
                 unique original (bit-equal), pictures of the batch compared with the CPU oracle (coefficients equal, RGB
@@ -378,10 +378,11 @@ def run_config(mjx, ctx, datas, per_gpu, stages, steps, warmup, chunk_images=0, 
            "upload_side": {"kernels_ms_unique": round(up_ms, 4), "unique_pictures": period, "launches": int(up_n),
                            "ms_per_batch": round(up_ms * per_gpu / max(period, 1), 4), "pictures_per_batch": per_gpu,
                            "device_destuff": bool(device_destuff),
-                           "note": "HIP-event time of the upload-time kernels (k_scan_interleave: linear de-stuffed scan -> the lane-"
-                                   "interleaved pool the entropy kernels read; with --device-destuff also the de-stuffing kernels) for the "
-                                   "unique pictures, scaled to the batch; runs once per upload, outside the timed region, which starts "
-                                   "from that layout (the tiled batch copies the pool)"}}
+                           "note": "HIP-event time of upload-time kernels for the unique pictures, scaled to the batch.  Since round 5 "
+                                   "mjx_batch_create lays the de-stuffed scans out lane-interleaved on the host while it packs them for the "
+                                   "transfer (build_batch / host_interleave_columns), so no kernel runs at upload and this is 0; with "
+                                   "--device-destuff the de-stuffing kernels and k_scan_interleave run here (MJX_HOST_INTERLEAVE=0: "
+                                   "k_scan_interleave for every scan, as before round 5)"}}
     # on-device half of the parity gate: every picture of the batch equals its unique original bit for bit
     n = len(batch)
     if n > period:

@@ -80,6 +80,12 @@ struct mjx_ctx {
     std::mutex cache_mu;
     std::vector<std::pair<uint8_t *, size_t>> cache;
     size_t cache_bytes = 0, cache_limit = size_t(96) << 30;
+    // mjx_batch_create: the host lays the de-stuffed scans out lane-interleaved in these two pinned blocks, alternately, and each
+    // goes up as one transfer into the scan pool (build_batch, host_interleave); kept between calls
+    uint8_t *stage_pin[2] = {nullptr, nullptr};
+    size_t stage_pin_cap[2] = {0, 0};
+    hipEvent_t stage_done[2] = {nullptr, nullptr};
+    bool host_interleave = true;    // MJX_HOST_INTERLEAVE=0: linear upload + k_scan_interleave, as the groups of mjx_decode_batch do
     uint8_t *pin_small = nullptr;   // pinned block for the host mirrors of the groups' small pools (mjx_decode_batch)
     size_t pin_small_cap = 0;
     std::mutex batch_mu;            // mjx_decode_batch: one call at a time per context (the pinned arena is shared state)
@@ -775,6 +781,38 @@ void collect_events(mjx_batch *b)
 // the previous group's DMA).
 constexpr uint64_t kLongBatchSubs = uint64_t(1) << 19;      // short subsequences' worth of scan (256 MiB) below which a batch keeps them (build_batch)
 
+unsigned usable_processors();
+
+// The lane-interleaved region of one scan (LaneBits in mjx_kernels.hip: piece k of subsequence s at (k * cols + s) * 16, the
+// pieces behind a subsequence's own continuing with the bytes that follow it in the scan, 0xAA past the end of the scan --
+// huffman.rs:236-246 -- and in the padding columns), written by the host from the linear de-stuffed scan the caller handed over
+// (jpeg/mod.rs:371-385 keeps it as one Vec<u8>; the decoder borrows it, decoder.rs:55).  What k_scan_interleave does on the
+// device for the scans that are de-stuffed there; for scans that arrive de-stuffed the layout is part of packing them for the
+// upload, and the device starts from the pool as it will read it.  Columns [s0, s1).
+void host_interleave_columns(const ImagePlan &p, uint32_t nsub, uint32_t cols, uint32_t rows, uint8_t *dst, uint32_t s0, uint32_t s1)
+{
+    const uint8_t *src = p.scan;
+    const size_t len = p.scan_len;
+    const uint32_t sub_bytes = p.himg.sub_bits / 8u;
+    uint32_t g = 0;                                                            // segment of subsequence s (restart intervals)
+    for (uint32_t s = s0; s < s1; s++) {
+        if (s >= nsub) continue;                                               // (padding column: stays 0xAA)
+        size_t at;
+        if (p.nseg <= 1 || p.seg.size() < 4) at = size_t(s) * sub_bytes;
+        else {
+            while (g + 1 < p.nseg && p.seg[2 * (g + 1)] <= s) g++;
+            while (g > 0 && p.seg[2 * g] > s) g--;
+            at = size_t(p.seg[2 * g + 1] >> 3) + size_t(s - p.seg[2 * g]) * sub_bytes;
+        }
+        uint8_t *col = dst + size_t(s) * 16u;
+        for (uint32_t k = 0; k < rows; k++, at += 16) {
+            uint8_t *d = col + size_t(k) * cols * 16u;
+            if (at + 16 <= len) std::memcpy(d, src + at, 16);
+            else if (at < len) std::memcpy(d, src + at, len - at);             // (the rest of the piece stays 0xAA)
+        }
+    }
+}
+
 struct PinnedBump {
     uint8_t *base = nullptr;
     size_t cap = 0, used = 0;
@@ -1006,7 +1044,12 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
             }
             return sp;
         };
-        const Span lin_span = find_span(false, 16), raw_span = any_stuffed ? find_span(true, 64) : Span{};
+        // Scans that arrive de-stuffed through mjx_batch_create are laid out lane-interleaved by the host while it packs them for
+        // the upload (host_interleave_columns): the device starts from the pool as its kernels read it, no upload-time kernel
+        // runs.  The groups of mjx_decode_batch (async_upload) keep the linear transfer + k_scan_interleave: there the host's
+        // threads are busy parsing the next group and the kernel hides behind the transfers.
+        const bool host_il = !src && !async_upload && ctx->host_interleave;
+        const Span lin_span = host_il ? Span{} : find_span(false, 16), raw_span = any_stuffed ? find_span(true, 64) : Span{};
         const bool one_copy = lin_span.one;
         if (lin_span.one) {
             // (the stuffed scans' compacted copies follow the span in the linear buffer)
@@ -1052,6 +1095,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
                     destuff_restarts = destuff_restarts || x.restarts;
                     di.push_back(x);
                 }
+                if (host_il && !p.stuffed) continue;                                            // (laid out by the host, below)
                 ii.push_back(InterleaveImg{0, uint32_t(p.scan_len), uint32_t(k)});              // (lin_off is filled in below)
                 max_pieces = std::max<uint32_t>(max_pieces, scan_region_cols(layout_nsub(p)) * scan_region_rows(p.himg.sub_bits));
             }
@@ -1191,7 +1235,75 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
                 b->h_ii.assign(reinterpret_cast<const unsigned char *>(ii.data()), reinterpret_cast<const unsigned char *>(ii.data() + ii.size()));
                 HIPOK(hipMemcpyAsync(b->d_ii, b->h_ii.data(), b->h_ii.size(), hipMemcpyHostToDevice, up));
             }
-            if (one_copy) {
+            if (host_il) {
+                // groups of scans whose regions fill a staging block: the host's threads write block A while block B is on the link
+                const size_t kStage = size_t(64) << 20;
+                size_t k0 = 0;
+                int which = 0;
+                const unsigned nthr = std::max(1u, std::min(16u, usable_processors()));
+                while (k0 < nu) {
+                    size_t k1 = k0, first = nu, last = nu;
+                    size_t span_lo = 0, span_hi = 0;
+                    for (; k1 < nu; k1++) {
+                        const ImagePlan &p = plans[k1];
+                        if (p.status != MJX_OK || p.stuffed || p.himg.nsub == 0) continue;
+                        const size_t lo = scan_off[k1], hi = lo + size_t(scan_region_bytes(layout_nsub(p), p.himg.sub_bits));
+                        if (first != nu && hi - span_lo > kStage) break;
+                        if (first == nu) { first = k1; span_lo = lo; }
+                        last = k1;
+                        span_hi = hi;
+                    }
+                    if (first == nu) break;
+                    const size_t bytes = span_hi - span_lo;
+                    if (ctx->stage_pin_cap[which] < bytes) {
+                        if (ctx->stage_done[which]) HIPOK(hipEventSynchronize(ctx->stage_done[which]));
+                        if (ctx->stage_pin[which]) (void)hipHostFree(ctx->stage_pin[which]);
+                        ctx->stage_pin[which] = nullptr;
+                        ctx->stage_pin_cap[which] = 0;
+                        void *hp = nullptr;
+                        if (hipHostMalloc(&hp, std::max(bytes, kStage), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return MJX_ERR_NOMEM; }
+                        ctx->stage_pin[which] = static_cast<uint8_t *>(hp);
+                        ctx->stage_pin_cap[which] = std::max(bytes, kStage);
+                    }
+                    if (!ctx->stage_done[which]) HIPOK(hipEventCreateWithFlags(&ctx->stage_done[which], hipEventDisableTiming));
+                    else HIPOK(hipEventSynchronize(ctx->stage_done[which]));           // the block's previous transfer has left it
+                    uint8_t *blk = ctx->stage_pin[which];
+                    // work items: (scan, range of columns); the threads take them in turn
+                    struct Item { size_t k; uint32_t s0, s1; };
+                    std::vector<Item> items;
+                    for (size_t k = first; k <= last; k++) {
+                        const ImagePlan &p = plans[k];
+                        if (p.status != MJX_OK || p.stuffed || p.himg.nsub == 0) continue;
+                        const uint32_t cols = scan_region_cols(layout_nsub(p));
+                        for (uint32_t c0 = 0; c0 < cols; c0 += 256) items.push_back(Item{k, c0, std::min(cols, c0 + 256)});
+                    }
+                    std::atomic<size_t> next{0};
+                    auto work = [&] {
+                        for (;;) {
+                            const size_t j = next.fetch_add(1);
+                            if (j >= items.size()) return;
+                            const ImagePlan &p = plans[items[j].k];
+                            const uint32_t cols = scan_region_cols(layout_nsub(p)), rows = scan_region_rows(p.himg.sub_bits);
+                            uint8_t *dst = blk + (scan_off[items[j].k] - span_lo);
+                            for (uint32_t k = 0; k < rows; k++)                      // 0xAA first: past the end of the scan, padding columns
+                                std::memset(dst + (size_t(k) * cols + items[j].s0) * 16u, 0xaa, size_t(items[j].s1 - items[j].s0) * 16u);
+                            host_interleave_columns(p, p.himg.nsub, cols, rows, dst, items[j].s0, items[j].s1);
+                        }
+                    };
+                    {
+                        const unsigned t = unsigned(std::min<size_t>(nthr, items.size()));
+                        std::vector<std::thread> pool;
+                        for (unsigned q = 1; q < t; q++) pool.emplace_back(work);
+                        work();
+                        for (std::thread &th : pool) th.join();
+                    }
+                    // (alignment gaps between the regions of a block go up as they are: nobody reads them)
+                    HIPOK(hipMemcpyAsync(b->d_scan + span_lo, blk, bytes, hipMemcpyHostToDevice, up));
+                    HIPOK(hipEventRecord(ctx->stage_done[which], up));
+                    which ^= 1;
+                    k0 = last + 1;
+                }
+            } else if (one_copy) {
                 HIPOK(hipMemcpyAsync(b->d_lin, lin_span.p0, lin_span.bytes, hipMemcpyHostToDevice, up));
             } else {
                 for (size_t k = 0; k < nu; k++) {
@@ -1297,6 +1409,7 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     if (const char *e = std::getenv("MJX_LATENCY_NSUB")) c->latency_nsub = uint64_t(std::max(0L, std::atol(e)));
     if (const char *e = std::getenv("MJX_MEDIUM_NSUB")) c->medium_nsub = uint64_t(std::max(0L, std::atol(e)));
     if (const char *e = std::getenv("MJX_STREAM_LINEAR")) c->linear_stream = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MJX_HOST_INTERLEAVE")) c->host_interleave = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_LATENCY_SUB_BITS")) c->latency_sub_bits = uint32_t(std::max(512L, std::min(long(kSubseqBits), std::atol(e))));
     if (const char *e = std::getenv("MJX_DC_ONE_PASS")) c->dc_one_pass = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_UPLOAD_APART")) c->upload_kernels_apart = std::atoi(e) != 0;
@@ -1342,6 +1455,10 @@ extern "C" void mjx_ctx_destroy(mjx_ctx *ctx)
     if (ctx->upload) { (void)hipStreamSynchronize(ctx->upload); (void)hipStreamDestroy(ctx->upload); }
     if (ctx->parse_arena) (void)hipHostFree(ctx->parse_arena);
     if (ctx->pin_small) (void)hipHostFree(ctx->pin_small);
+    for (int k = 0; k < 2; k++) {
+        if (ctx->stage_pin[k]) (void)hipHostFree(ctx->stage_pin[k]);
+        if (ctx->stage_done[k]) (void)hipEventDestroy(ctx->stage_done[k]);
+    }
     for (auto &blk : ctx->cache) (void)hipFree(blk.first);
     for (auto &blk : ctx->pinned_cache) (void)hipHostFree(blk.first);
     delete ctx;
@@ -1378,7 +1495,6 @@ extern "C" int mjx_ctx_numa_node(const mjx_ctx *ctx)
     return node;
 }
 
-namespace { unsigned usable_processors(); }
 extern "C" unsigned mjx_host_processors(void) { return usable_processors(); }
 
 // ---- batch ---------------------------------------------------------------------------------------
@@ -2017,7 +2133,7 @@ extern "C" int mjx_decode_batch(mjx_ctx *ctx, const uint8_t *const *jpegs, const
     if (const char *e = std::getenv("MJX_GROUP_GROW")) { const double v = std::atof(e); if (v >= 1.0) grow = v; }
     // (the ramp below must end: a growth of 1.0 or a first group that rounds down to nothing would push sizes for ever)
     grow = std::max(grow, 1.05);
-    first_bytes = std::max(first_bytes, size_t(1) << 20);
+    first_bytes = std::max(first_bytes, size_t(4096));        // (and the ramp itself is capped at 64 steps)
     if (const char *e = std::getenv("MJX_GROUP_TAPER")) taper = std::atoi(e) != 0;
     std::vector<size_t> gfirst{0};
     if (!single) {

@@ -503,11 +503,12 @@ def test_small_batches_with_short_subsequences_equal_the_long_ones(mjx, orc, tmp
         "    print(100 + i, b.geometry()['subsequences'], hashlib.sha256(b.coefs(j).tobytes()).hexdigest(), hashlib.sha256(b.rgb(j).tobytes()).hexdigest())\n"
         "b.close()\n" % (ROOT, ROOT))
     outs = []
-    switches = ("MJX_LATENCY_NSUB", "MJX_MEDIUM_NSUB", "MJX_MERGE_LOOP", "MJX_LATENCY_SUB_BITS", "MJX_DC_ONE_PASS", "MJX_STREAMS")
+    switches = ("MJX_LATENCY_NSUB", "MJX_MEDIUM_NSUB", "MJX_MERGE_LOOP", "MJX_LATENCY_SUB_BITS", "MJX_DC_ONE_PASS", "MJX_STREAMS", "MJX_HOST_INTERLEAVE")
     base_env = {k: v for k, v in os.environ.items() if k not in switches}
     # every runtime switch of the small-batch path and of the DC prediction: the bytes must not depend on any of them
     variants = ({}, {"MJX_LATENCY_NSUB": "0", "MJX_MEDIUM_NSUB": "0"}, {"MJX_MERGE_LOOP": "0"}, {"MJX_DC_ONE_PASS": "0"},
-                {"MJX_LATENCY_SUB_BITS": "1024"}, {"MJX_STREAMS": "1"})
+                {"MJX_LATENCY_SUB_BITS": "1024"}, {"MJX_STREAMS": "1"},
+                {"MJX_HOST_INTERLEAVE": "0"})       # (the scan pool laid out by k_scan_interleave instead of by the host: the same bytes)
     for env_extra in variants:
         out = subprocess.run([sys.executable, str(script)], env=dict(base_env, **env_extra), capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, str(env_extra) + out.stdout[-2000:] + out.stderr[-2000:]
