@@ -91,6 +91,11 @@ def algorithmic_bytes(kind, by, nsub_total, nblk):
         "huff_fix": S // 5 + state + cps // 5,    # k_huff_merge rounds: ~1/5 of the scan is re-read (median merge distance)
         "huff_scan": 24 * nsub_total,             # exit state in, block base + entry base out
         "huff_write": S + 24 * nsub_total + coef - 2 * nblk,  # scan + entry state + bases in, compact stream + 16-bit DC differences out
+        # single decode (round 5): the emitting first decode reads the scan once plus the warm-up (an eighth of a subsequence more at
+        # 1024 of 8192 bits), writes states, checkpoints at a quarter of the old density, the compact stream and one word per block
+        "huff_emit": S + S // 8 + state + cps // 4 + coef,
+        # ... the prefixes of the lanes whose entry was wrong (~5 % of the scan's symbols), then block words in, DC differences out
+        "huff_prefix": S // 16 + state + 6 * nblk,
         "dc_scan": 6 * nblk,                      # 16-bit DC differences in, int32 predicted DC out
         "idct_color": 128 * nblk + rgb,           # B_idct
     }[kind]
@@ -106,7 +111,7 @@ KERNEL_ALIAS = {"k_huff_spec": "huff_sync", "k_huff_merge": "huff_fix", "k_huff_
                 "k_huff_scan": "huff_scan", "k_huff_write": "huff_write", "k_idct_color": "idct_color", "k_ref_color": "idct_color",
                 "k_dc_sums_t": "dc_scan", "k_dc_apply_t": "dc_scan", "k_dc_scan_t": "dc_scan", "k_dc_sums": "dc_scan",
                 "k_dc_apply": "dc_scan", "k_dc_restart": "dc_scan", "k_planar_count": "gather", "k_planar_offsets": "gather",
-                "k_planar_copy": "gather"}
+                "k_planar_copy": "gather", "k_huff_emit": "huff_emit", "k_huff_prefix": "huff_prefix", "k_block_gather": "huff_prefix"}
 
 
 def pmc_bytes_by_class(directory, counter):
@@ -218,7 +223,7 @@ def reduce_elapsed(elapsed, world):
     return float(t.item())
 
 
-KERNEL_CLASSES = ["gather", "huff_sync", "huff_fix", "huff_scan", "huff_write", "dc_scan", "idct_color"]
+KERNEL_CLASSES = ["gather", "huff_sync", "huff_fix", "huff_scan", "huff_write", "dc_scan", "idct_color", "huff_emit", "huff_prefix"]
 
 
 def reduce_record(rec, world):

@@ -211,7 +211,10 @@ enum {
     MJX_K_IDCT_COLOR = 6, /* dequant + IDCT + upsample + colour + RGB store */
     MJX_K_UPLOAD = 7,     /* upload time, once per batch, not part of a decode: de-stuffing on the device (opts.device_destuff)
                              and the pass that lays the scans out lane-interleaved (k_scan_interleave) */
-    MJX_K_COUNT = 8
+    MJX_K_HUFF_EMIT = 8,  /* single decode (pictures of one scan without restart intervals): the first decode, which emits -- instead of
+                             MJX_K_HUFF_SYNC and the decode of MJX_K_HUFF_WRITE */
+    MJX_K_HUFF_PREFIX = 9,/* ... the prefixes of the subsequences whose entry state was wrong, and block words -> DC differences + tile offsets */
+    MJX_K_COUNT = 10
 };
 int mjx_batch_kernel_ms(mjx_batch *b, double ms[MJX_K_COUNT], uint64_t launches[MJX_K_COUNT], int reset);
 

@@ -30,7 +30,7 @@ OK, ERR_TRUNCATED, ERR_UNSUPPORTED_MARKER, ERR_DRI_UNSUPPORTED, ERR_BAD_HUFFMAN,
     ERR_UNSUPPORTED_FORMAT, ERR_NO_SCAN, ERR_INVALID_ARG, ERR_NOMEM, ERR_MISSING_TABLE = range(12)
 LAYOUT_STANDARD, LAYOUT_REF_COMPAT = 0, 1
 STAGE_ENTROPY, STAGE_PIXELS, STAGE_ALL = 1, 2, 3
-KERNEL_NAMES = ["gather", "huff_sync", "huff_fix", "huff_scan", "huff_write", "dc_scan", "idct_color", "upload"]
+KERNEL_NAMES = ["gather", "huff_sync", "huff_fix", "huff_scan", "huff_write", "dc_scan", "idct_color", "upload", "huff_emit", "huff_prefix"]
 SUBSAMPLING = {"444": 0, "422": 1, "420": 2, "gray": 3, "440": 4}
 
 

@@ -86,6 +86,13 @@ struct mjx_ctx {
     size_t stage_pin_cap[2] = {0, 0};
     hipEvent_t stage_done[2] = {nullptr, nullptr};
     bool host_interleave = true;    // MJX_HOST_INTERLEAVE=0: linear upload + k_scan_interleave, as the groups of mjx_decode_batch do
+    // Single decode (round 5, DESIGN s3.1): pictures of one scan without restart intervals, cut into subsequences of at least
+    // emit_min_sub_bits bits, are decoded ONCE by an emitting pass (k_huff_emit) whose lanes warm up over the last emit_warm_bits
+    // bits of the subsequence in front of their own and record a checkpoint every emit_cp_bits bits; MJX_SINGLE_DECODE=0: every
+    // picture takes the two-pass kernels (k_huff_spec ... k_huff_write).
+    bool single_decode = true;
+    bool emit_merge_listed = true;  // MJX_EMIT_MERGE_LISTED=0: the first merge round of such pictures runs its head slices in place, as for the others
+    uint32_t emit_cp_bits = 1024, emit_warm_bits = 2048, emit_min_sub_bits = 4096, emit_head = kEmitHeadGroups;
     uint8_t *pin_small = nullptr;   // pinned block for the host mirrors of the groups' small pools (mjx_decode_batch)
     size_t pin_small_cap = 0;
     std::mutex batch_mu;            // mjx_decode_batch: one call at a time per context (the pinned arena is shared state)
@@ -115,6 +122,8 @@ struct ImageInfo {
     uint64_t coef_off = 0;         // blocks, inside the per-block arrays of its chunk (or of the batch with keep_coefs)
     uint64_t ent_off = 0, ent_cap = 0;   // region of the compact coefficient stream (entries)
     uint32_t ent_rows = 0, ent_hdr = 0;  // > 0: quad-interleaved (DevImage::ent_rows, ent_hdr)
+    bool emit = false;             // single decode: the picture's first decode emits (DevImage::emit)
+    uint32_t emit_head = 0;
     uint32_t tile_off = 0, ntiles = 0, tile_blocks = 0;
     uint64_t scan_len = 0;
     uint32_t chunk = 0;
@@ -136,6 +145,7 @@ struct Chunk {
     uint64_t plane_words = 0;      // REF_COMPAT scratch of the chunk
     uint32_t max_pixel_wgs = 0;
     bool has_gather = false;       // holds multi-scan pictures (k_planar_gather runs)
+    bool has_emit = false, has_spec = false;   // holds pictures whose first decode emits (k_huff_emit ...) / pictures of the two-pass path
 };
 
 // All device buffers of a batch come out of ONE allocation: the layout code runs twice, first measuring, then handing out
@@ -224,6 +234,7 @@ struct mjx_batch {
     SubseqState *d_entry = nullptr, *d_exit = nullptr;
     uint32_t *d_blkbase = nullptr;
     uint32_t *d_cps = nullptr;          // [chunk subsequences / 256][kMaxCp][256] checkpoints (two words each)
+    EmitSub *d_esub = nullptr;          // per subsequence of the chunk: what the emitting first decode left behind (single decode)
     uint32_t *d_pull = nullptr;         // [chunk images] straggler counts of k_huff_merge (per round)
     uint32_t *d_items = nullptr;        // [max_nsub][6] stragglers handed from k_huff_merge to k_huff_merge_tail
     uint32_t max_nsub = 1, max_chunk_images = 1;
@@ -250,6 +261,7 @@ struct mjx_batch {
     struct Alt {
         SubseqState *d_entry = nullptr, *d_exit = nullptr;
         uint32_t *d_blkbase = nullptr, *d_ebase = nullptr, *d_cps = nullptr, *d_pull = nullptr, *d_items = nullptr;
+        EmitSub *d_esub = nullptr;
         int32_t *d_segsum = nullptr, *d_dc = nullptr;
         int16_t *d_dcd = nullptr;
         unsigned long long *d_planes = nullptr;
@@ -440,7 +452,7 @@ void plan_chunks(mjx_batch *b)
         for (size_t k = 0; k < n; k++) total_scan += b->info[k].scan_len;
         if (total_scan >= (uint64_t(256) << 20)) scan_target = std::min(scan_target, total_scan - total_scan / 4);      // (128 4K pictures, 138 MB: 2.34 ms in one chunk, 2.43 in two)
     }
-    const uint64_t kMaxChunkEntries = (uint64_t(24) << 30) / 4;          // 24 GiB of stream capacity per chunk
+    const uint64_t kMaxChunkEntries = (uint64_t(32) << 30) / 4;          // 32 GiB of stream capacity per chunk (24 before the columns got their head room, round 5)
     b->chunks.clear();
     uint64_t coef_running = 0, ent_running = 0;
     uint32_t tile_running = 0;
@@ -481,6 +493,7 @@ void plan_chunks(mjx_batch *b)
                     c.max_tile_blocks = std::max<uint32_t>(c.max_tile_blocks, T * d.bpm);
                 }
                 if (d.role == 2) c.has_gather = true;
+                if (d.emit) c.has_emit = true; else if (d.role != 2) c.has_spec = true;
                 c.lut_cap = std::max<uint32_t>(c.lut_cap, d.lut_n);
                 c.lut2_cap = std::max<uint32_t>(c.lut2_cap, d.lut2_n);
                 c.mode_mask |= 1u << d.mode;
@@ -535,6 +548,7 @@ int allocate_work_buffers(mjx_batch *b, DevArena &ar)
     ar.take(&b->d_exit, size_t(max_nsub) * sizeof(SubseqState));
     ar.take(&b->d_blkbase, size_t(max_nsub) * sizeof(uint32_t));
     ar.take(&b->d_cps, (size_t(max_nsub) + 256) / 256 * 256 * kMaxCp * 2 * sizeof(uint32_t));
+    ar.take(&b->d_esub, size_t(max_nsub) * sizeof(EmitSub));
     size_t max_imgs = 1;
     for (const Chunk &c : b->chunks) max_imgs = std::max(max_imgs, c.count);
     b->max_nsub = max_nsub;
@@ -569,6 +583,7 @@ int allocate_work_buffers(mjx_batch *b, DevArena &ar)
         ar.take(&a.d_blkbase, size_t(max_nsub) * sizeof(uint32_t));
         ar.take(&a.d_ebase, size_t(max_nsub) * sizeof(uint32_t));
         ar.take(&a.d_cps, (size_t(max_nsub) + 256) / 256 * 256 * kMaxCp * 2 * sizeof(uint32_t));
+        ar.take(&a.d_esub, size_t(max_nsub) * sizeof(EmitSub));
         ar.take(&a.d_pull, max_imgs * kMaxFix * sizeof(uint32_t));
         ar.take(&a.d_items, size_t(max_nsub) * 6 * sizeof(uint32_t));
         ar.take(&a.d_segsum, max_segsum * 3 * sizeof(int32_t));
@@ -604,6 +619,7 @@ int allocate_work_buffers(mjx_batch *b, DevArena &ar)
             {b->d_tile_eoff, size_t(b->opts.keep_coefs ? std::max<uint32_t>(total_tiles_arr, 1) : max_tiles_arr) * 4 + 16},   // 8
             {b->d_dc, size_t(coef_blocks) * sizeof(int32_t) + 64},                // 9
             {b->d_dcd, size_t(coef_blocks) * sizeof(int16_t) + 64},               // 10
+            {b->d_esub, size_t(max_nsub) * sizeof(EmitSub)},                      // 11
         };
         for (int k = 0; k < int(sizeof bufs / sizeof bufs[0]); k++)
             if (sel < 0 || sel == k) HIPOK(hipMemsetAsync(bufs[k].p, v, bufs[k].n, b->ctx->upload));
@@ -614,7 +630,7 @@ int allocate_work_buffers(mjx_batch *b, DevArena &ar)
     // the largest dynamic LDS any entropy launch asks for, from the launchers' own expressions (mjx_kernels.hip): the write pass
     // on the plain table set, the counting passes on the set with pair parts
     const size_t lds_write = b->huff_lds + huff_window_bytes() + huff_stage_bytes();
-    const size_t lds_count = b->huff_lds2 + std::max(huff_window_bytes(), huff_merge_bytes());
+    const size_t lds_count = std::max(b->huff_lds2 + std::max(huff_window_bytes(), huff_merge_bytes()), b->huff_lds + huff_prefix_bytes());
     if (std::max(lds_write, lds_count) > 160 * 1024 || b->idct_lds > 160 * 1024) return MJX_ERR_UNSUPPORTED_FORMAT;
     {
         const size_t pad = std::max(b->ctx->spec_lds_pad, std::max(b->ctx->merge_lds_pad, b->ctx->write_lds_pad));
@@ -677,9 +693,16 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     int32_t *dcb = SCR(d_dc);              // image offsets already include the chunk base
     fix_passes = std::min(fix_passes, kMaxFix);
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_SYNC)) {
-        prof_begin(b, MJX_K_HUFF_SYNC, st);
-        launch_huff_spec(st, c.max_wg, nimg, b->huff_lds2, b->ctx->spec_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps), b->d_segs);
-        prof_end(b, st);
+        if (c.has_spec) {
+            prof_begin(b, MJX_K_HUFF_SYNC, st);
+            launch_huff_spec(st, c.max_wg, nimg, b->huff_lds2, b->ctx->spec_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps), b->d_segs);
+            prof_end(b, st);
+        }
+        if (c.has_emit) {       // single decode: these pictures' first decode emits (LDS as the write pass: plain tables, windows, rings)
+            prof_begin(b, MJX_K_HUFF_EMIT, st);
+            launch_huff_emit(st, c.max_wg, nimg, b->huff_lds, b->ctx->write_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps), SCR(d_esub), SCR(d_entries));
+            prof_end(b, st);
+        }
     }
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_FIX)) {
         HIPOK(hipMemsetAsync(b->d_mismatch + ci * kMisWords, 0, kMisWords * sizeof(uint32_t), st));
@@ -688,7 +711,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
             prof_begin(b, MJX_K_HUFF_FIX, st);
             launch_huff_merge_loop(st, c.merge_wgs, nimg, b->huff_lds2, b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps),
                                    b->d_mismatch + ci * kMisWords + fix_passes - 1, b->d_segs, b->d_loopctl + ci * 8,
-                                   c.loop_participants + (b->ctx->loop_fault ? 1u : 0u), kLoopRounds, b->ctx->loop_fault ? 1u << 12 : 1u << 22);
+                                   c.loop_participants + (b->ctx->loop_fault ? 1u : 0u), kLoopRounds, b->ctx->loop_fault ? 1u << 12 : 1u << 22, SCR(d_esub));
             prof_end(b, st);
         } else if (c.merge_wgs > 0) {
             HIPOK(hipMemsetAsync(SCR(d_pull), 0, size_t(nimg) * std::max(fix_passes, 1) * sizeof(uint32_t), st));      // the straggler counts of every round
@@ -696,7 +719,10 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
                 prof_begin(b, MJX_K_HUFF_FIX, st);
                 launch_huff_merge(st, c.merge_wgs, nimg, b->huff_lds2, b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps),
                                   b->d_mismatch + ci * kMisWords + k, SCR(d_items), SCR(d_pull) + size_t(k) * nimg, b->d_segs,
-                                  k > 0 ? b->d_mismatch + ci * kMisWords + k - 1 : nullptr, k == 0 && (phases & PH_SYNC));
+                                  k > 0 ? b->d_mismatch + ci * kMisWords + k - 1 : nullptr,
+                                  // (a chunk of pictures whose lanes warmed up: a fifth of the subsequences re-decode, not all of them --
+                                  // the first round, too, only lists its items and the straggler kernel decodes them packed)
+                                  k == 0 && (phases & PH_SYNC) && !(c.has_emit && !c.has_spec && b->ctx->emit_merge_listed), SCR(d_esub));
                 prof_end(b, st);
             }
         }
@@ -710,12 +736,22 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
             const int last = (phases & PH_FIX) ? fix_passes - 1 : kMaxFix - 1;
             if (last >= 0) verdict = b->d_mismatch + ci * kMisWords + last;
         }
-        launch_huff_scan(st, nimg, imgs, SCR(d_exit), SCR(d_blkbase), SCR(d_ebase), b->d_img_entries, b->d_img_flags, b->d_segs, verdict);
+        // (the merge rounds are over: their straggler lists and counts are free, the scan lists the prefix pass's subsequences there)
+        launch_huff_scan(st, nimg, imgs, SCR(d_exit), SCR(d_blkbase), SCR(d_ebase), b->d_img_entries, b->d_img_flags, b->d_segs, verdict,
+                         SCR(d_esub), SCR(d_items), SCR(d_pull), b->d_mismatch + ci * kMisWords + kMaxFix + 1);
         prof_end(b, st);
-        prof_begin(b, MJX_K_HUFF_WRITE, st);
-        launch_huff_write(st, c.max_wg, nimg, b->huff_lds, b->ctx->write_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_blkbase), SCR(d_ebase),
-                              SCR(d_entries), SCR(d_tile_eoff), SCR(d_dcd), b->d_status, b->d_img_flags, b->d_segs, SCR(d_exit));
-        prof_end(b, st);
+        if (c.has_spec) {
+            prof_begin(b, MJX_K_HUFF_WRITE, st);
+            launch_huff_write(st, c.max_wg, nimg, b->huff_lds, b->ctx->write_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_blkbase), SCR(d_ebase),
+                                  SCR(d_entries), SCR(d_tile_eoff), SCR(d_dcd), b->d_status, b->d_img_flags, b->d_segs, SCR(d_exit), SCR(d_cps));
+            prof_end(b, st);
+        }
+        if (c.has_emit) {       // the prefixes of the lanes whose entry was wrong; block words -> DC differences + tile offsets
+            prof_begin(b, MJX_K_HUFF_PREFIX, st);
+            launch_huff_prefix(st, c.max_wg, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps), SCR(d_esub), SCR(d_blkbase),
+                               SCR(d_entries), b->d_status, b->d_img_flags, b->d_mismatch + ci * kMisWords + kMaxFix + 1, SCR(d_dcd), SCR(d_tile_eoff), SCR(d_items), SCR(d_pull));
+            prof_end(b, st);
+        }
         prof_begin(b, MJX_K_DC_SCAN, st);
         launch_dc_scan(st, c.max_segs, nimg, imgs, SCR(d_dcd), dcb, SCR(d_segsum), b->d_img_flags, c.bpm_mask, c.max_restart_segs,
                        // (a repair run -- force_first -- takes the two-pass kernels, which wait for nobody: nothing looks at the
@@ -980,6 +1016,16 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
                 inf.ent_cap = cap + d.ent_hdr;
             }
         }
+        // single decode: the picture's first decode emits (one scan, no restart intervals, quad-interleaved stream, subsequences long
+        // enough that the warm-up is a small share of them -- the short cuts of small batches keep the two-pass kernels)
+        if (ctx->single_decode && d.ent_rows && p.role == 0 && p.nseg <= 1 && p.restart_mcus == 0 && p.himg.sub_bits >= ctx->emit_min_sub_bits) {
+            d.emit = 1;
+            d.emit_head = ctx->emit_head;
+            d.himg.cp_bits = p.himg.sub_bits >= 2 * ctx->emit_cp_bits ? ctx->emit_cp_bits : uint32_t(kCpBits);
+            d.himg.warm_bits = std::min(ctx->emit_warm_bits, p.himg.sub_bits / 32u * 32u);
+        }
+        inf.emit = d.emit != 0;
+        inf.emit_head = d.emit_head;
         inf.ent_rows = d.ent_rows;
         inf.ent_hdr = d.ent_hdr;
         inf.role = p.role;
@@ -1410,6 +1456,12 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     if (const char *e = std::getenv("MJX_MEDIUM_NSUB")) c->medium_nsub = uint64_t(std::max(0L, std::atol(e)));
     if (const char *e = std::getenv("MJX_STREAM_LINEAR")) c->linear_stream = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_HOST_INTERLEAVE")) c->host_interleave = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MJX_SINGLE_DECODE")) c->single_decode = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MJX_EMIT_MERGE_LISTED")) c->emit_merge_listed = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MJX_EMIT_CP_BITS")) c->emit_cp_bits = uint32_t(std::max(long(kCpBits), std::atol(e))) / uint32_t(kCpBits) * uint32_t(kCpBits);
+    if (const char *e = std::getenv("MJX_EMIT_WARM_BITS")) c->emit_warm_bits = uint32_t(std::max(0L, std::atol(e))) / 32u * 32u;
+    if (const char *e = std::getenv("MJX_EMIT_MIN_SUB_BITS")) c->emit_min_sub_bits = uint32_t(std::max(long(kCpBits), std::atol(e)));
+    if (const char *e = std::getenv("MJX_EMIT_HEAD")) c->emit_head = uint32_t(std::max(0L, std::min(long(kEmitHeadGroups), std::atol(e))));      // (tests: no head room = every prefix that grows falls back)
     if (const char *e = std::getenv("MJX_LATENCY_SUB_BITS")) c->latency_sub_bits = uint32_t(std::max(512L, std::min(long(kSubseqBits), std::atol(e))));
     if (const char *e = std::getenv("MJX_DC_ONE_PASS")) c->dc_one_pass = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_UPLOAD_APART")) c->upload_kernels_apart = std::atoi(e) != 0;
@@ -1652,6 +1704,7 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
     // more passes until a pass counts zero.
     if (b->decoded_entropy) {
         bool first_set_rewritten = false;
+        int attempts = 0;
         for (size_t ci = 0; ci < b->chunks.size(); ci++) {
             const Chunk &c = b->chunks[ci];
             // The one-pass DC prediction hands running sums from workgroup to workgroup; a workgroup that waited too long for
@@ -1670,6 +1723,48 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
                 b->last_chunk_resident = int(ci);
                 b->resident_second = false;
             }
+            // Single decode: a lane's prefix found no head room in front of its first decode's entries (k_huff_prefix; or the counts did
+            // not fit together).  The chunk's pictures are handed to the two-pass kernels, now and in later decodes of this batch.
+            bool fell_back = false;
+            auto emit_fallback = [&]() -> int {
+                if (b->h_mismatch[ci * kMisWords + kMaxFix + 1] == 0) return MJX_OK;
+                fell_back = true;
+                if (std::getenv("MJX_TIMING")) std::fprintf(stderr, "[mjx] chunk %zu: single decode fell back (reason bits %u, see k_huff_prefix), decoding the chunk again with the two-pass kernels\n", ci, b->h_mismatch[ci * kMisWords + kMaxFix + 1]);
+                Chunk &cc = b->chunks[ci];
+                // the pictures the kernels gave up on (flag 2: k_huff_scan -- more items than its list holds --, k_huff_prefix) leave the
+                // single-decode path, here and on the device (patched in place, not uploaded again: the DevImages of scans that were
+                // de-stuffed on the device hold geometry only the device knows); the chunk is decoded again, the others as before
+                std::vector<uint32_t> fl(cc.count);
+                HIPOK(hipMemcpy(fl.data(), b->d_img_flags + cc.first, cc.count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                bool left = false;
+                for (size_t i = cc.first; i < cc.first + cc.count; i++) {
+                    DevImage &d = b->himages[i];
+                    if (!d.emit) continue;
+                    if (fl[i - cc.first] != 2u) { left = true; continue; }
+                    d.emit = 0;
+                    d.himg.cp_bits = uint32_t(kCpBits);
+                    d.himg.warm_bits = 0;
+                    b->info[i].emit = false;
+                }
+                cc.has_emit = left;
+                cc.has_spec = true;
+                first_set_rewritten = true;
+                launch_emit_off(b->ctx->stream, b->d_images + cc.first, uint32_t(cc.count), b->d_img_flags);
+                HIPOK(hipMemsetAsync(b->d_status + cc.first, 0, cc.count * sizeof(int), b->ctx->stream));
+                HIPOK(hipMemsetAsync(b->d_img_flags + cc.first, 0, cc.count * sizeof(uint32_t), b->ctx->stream));
+                const int rcf = run_chunk(b, ci, b->last_stages | MJX_STAGE_ENTROPY, std::min(b->ctx->fix_passes, kMaxFix), PH_ENTROPY_ALL, true);
+                if (rcf != MJX_OK) return rcf;
+                HIPOK(hipStreamSynchronize(b->ctx->stream));
+                collect_events(b);
+                b->last_chunk_resident = int(ci);
+                b->resident_second = false;
+                return MJX_OK;
+            };
+            { const int rcf = emit_fallback(); if (rcf != MJX_OK) return rcf; }
+            // (the chunk has just been decoded again, with some of its pictures on the other path: it is looked at again from the top --
+            // that decode may need more rounds than were enqueued, or may have lost further pictures; every fall-back takes at least
+            // one picture off the single-decode path, so this ends)
+            if (fell_back && ++attempts < 64) { ci--; continue; }
             if (c.merge_wgs == 0) continue;
             const int passes = std::min(b->ctx->fix_passes, kMaxFix);
             if (b->h_mismatch[ci * kMisWords + passes - 1] == 0) continue;
@@ -1711,6 +1806,8 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
             collect_events(b);
             b->last_chunk_resident = int(ci);
             b->resident_second = false;
+            { const int rcf = emit_fallback(); if (rcf != MJX_OK) return rcf; }      // (the prefix pass ran for the first time just now)
+            if (fell_back && ++attempts < 64) { ci--; continue; }
         }
     }
     std::vector<int> dev(b->info.size());
@@ -1844,7 +1941,7 @@ extern "C" int mjx_batch_copy_coefs(mjx_batch *b, size_t iu, int16_t *host_coefs
         // runs (the 16-bit group counts at the head of the region) of the subsequences between
         std::vector<uint32_t> ent(size_t(inf.ent_cap));
         HIPOK(hipMemcpy(ent.data(), entries + inf.ent_off, ent.size() * 4, hipMemcpyDeviceToHost));
-        const uint16_t *runs = reinterpret_cast<const uint16_t *>(ent.data());
+        const uint32_t *runs = ent.data();                   // one run word per subsequence: first group, end group, label offset (mjx_kernels.h)
         const uint32_t *col = ent.data() + inf.ent_hdr;
         const uint32_t cap = inf.ent_rows * 8u;
         const uint64_t ncols = (inf.ent_cap - inf.ent_hdr) / cap;
@@ -1853,8 +1950,12 @@ extern "C" int mjx_batch_copy_coefs(mjx_batch *b, size_t iu, int16_t *host_coefs
             const uint32_t s0 = eoff[t] / cap, j0 = eoff[t] % cap, s1 = eoff[t + 1] / cap, j1 = eoff[t + 1] % cap;
             if (s0 > s1 || s1 >= ncols) return MJX_ERR_DEVICE;
             for (uint32_t s = s0; s <= s1; s++) {
-                const uint32_t lo = s == s0 ? j0 : 0u, hi = s == s1 ? j1 : std::min<uint32_t>(uint32_t(runs[s]) * 8u, cap);
-                for (uint32_t j = lo; j < hi; j++) place(first, col[stream_phys(s, j, inf.ent_rows)]);
+                const uint32_t lo = s == s0 ? j0 : run_first(runs[s]) * 8u, hi = s == s1 ? j1 : std::min<uint32_t>(run_end(runs[s]) * 8u, cap);
+                const uint32_t label = run_label(runs[s]) << 22;
+                for (uint32_t j = lo; j < hi; j++) {
+                    const uint32_t e = col[stream_phys(s, j, inf.ent_rows)];
+                    if ((e >> 16) & 63u) place(first, e + label);      // (position 0: a null entry)
+                }
             }
         }
     } else {

@@ -122,7 +122,11 @@ struct HuffImage {
     uint32_t total_blocks;               // MCUs to decode * bpm
     uint32_t nsub;                       // ceil(total_bits / sub_bits)
     uint32_t sub_bits;                   // bits per subsequence: a multiple of kCpBits, at most kMaxSubseqBits (kSubseqBits .. 5/4 of it, or kLongSubseqBits .. 5/4 of that; less in small batches)
-    uint32_t pad_[3];
+    uint32_t cp_bits;                    // bits between two checkpoints of a subsequence: kCpBits, or a multiple of it for pictures whose
+                                         // first decode emits (round 5, k_huff_emit: there every checkpoint recorded costs the emitting
+                                         // pass, and only the few lanes whose entry was wrong ever use them)
+    uint32_t warm_bits;                  // k_huff_emit: bits in front of its subsequence over which a lane warms up (a multiple of 32)
+    uint32_t pad_[1];
 };
 
 // Subsequence length of an image.  512 bytes per lane is the sweet spot, but a workgroup's LDS (tables, windows,
@@ -155,7 +159,7 @@ struct NullSink {
     MJX_HD void dc(uint32_t, int) const {}                       // (block, value)
     MJX_HD void ac(uint32_t, uint32_t, int) const {}             // (block, r after the symbol -- scaled, see LaneState --, value)
     MJX_HD void block_done(uint32_t) const {}
-    MJX_HD void bad_code(uint32_t) const {}
+    MJX_HD void bad_code(uint32_t, uint32_t) const {}        // (block, bit position of the symbol no code matches)
     MJX_HD void tick() const {}          // one call per decoded symbol (statistics in the CPU emulation)
     MJX_HD void flush_groups() const {}
     MJX_HD void flush_step(uint32_t) const {}
@@ -322,7 +326,7 @@ MJX_HD bool symbol_step(LaneState &st, BitSrc &bits, const LutEntry *lut, const 
     if (lut_is_link(e)) {
         const uint32_t nb = e & 15u;
         e = lut_at(lut, base + bits_field(e, 4, 16) + bits_field(w, 32u - kLutPrimaryBits - nb, nb) * 4u);
-        if (WRITE && (e & kLutBad)) sink.bad_code(blk);                           // (invalid patterns always come this way)
+        if (WRITE && (e & kLutBad)) sink.bad_code(blk, lane_pos(st));             // (invalid patterns always come this way)
     }
     sp.at(2);                                                                     // ... and the second-level one
     sink.tick();
@@ -388,14 +392,16 @@ struct LaneEvents {
     uint32_t end_wn;        // ... at/after which the lane has left its subsequence
     uint32_t k;             // index of the next checkpoint
     bool merged;            // the re-decode met the previous decode's path: the exit is the previous exit
+    uint32_t cp_bytes;      // bytes of stream between two checkpoints (HuffImage::cp_bits / 8)
 };
 template <int CP>
-MJX_HD void events_begin(LaneEvents &ev, uint32_t sub_start, uint32_t end_bit)
+MJX_HD void events_begin(LaneEvents &ev, uint32_t sub_start, uint32_t end_bit, uint32_t cp_bits = uint32_t(kCpBits))
 {
     ev.end_wn = wn_after(end_bit);
     ev.k = 0;
     ev.merged = false;
-    ev.next_wn = CP ? wn_after(sub_start + kCpBits) : ev.end_wn;
+    ev.cp_bytes = cp_bits / 8u;
+    ev.next_wn = CP ? wn_after(sub_start + cp_bits) : ev.end_wn;
     if (ev.next_wn > ev.end_wn) ev.next_wn = ev.end_wn;
 }
 // Returns true when the lane is finished.  Otherwise (a checkpoint boundary was crossed): compares with the state the
@@ -420,7 +426,7 @@ MJX_HD bool lane_event(LaneState &st, LaneEvents &ev, const HuffImage &img, CpSt
         }
         cps.set(ev.k, state | (st.n << 16), lane_m(st));
         ev.k++;
-        ev.next_wn += kCpBits / 8;
+        ev.next_wn += ev.cp_bytes;
         if (ev.next_wn > ev.end_wn) ev.next_wn = ev.end_wn;
     }
     return false;
@@ -432,7 +438,7 @@ MJX_HD void checkpoint_record(const LaneState &st, LaneEvents &ev, CpStore &cps)
 {
     cps.set(ev.k, cp_state_word(st) | (st.n << 16), lane_m(st));
     ev.k++;
-    ev.next_wn += kCpBits / 8;
+    ev.next_wn += ev.cp_bytes;
     if (ev.next_wn > ev.end_wn) ev.next_wn = ev.end_wn;
 }
 MJX_HD SubseqState lane_exit(const LaneState &st, const LaneEvents &ev, const HuffImage &img, const SubseqState &old_exit)
@@ -471,7 +477,7 @@ MJX_HD SubseqState decode_subseq(BitSrc bits, const LutEntry *lut, const HuffIma
     LaneState st;
     LaneEvents ev;
     lane_begin(st, bits, img, entry);
-    events_begin<CP>(ev, sub_start, end_bit);
+    events_begin<CP>(ev, sub_start, end_bit, img.cp_bits);
     bool running = !(WRITE && blk >= img.total_blocks);
     while (running) {                               // (one back edge: a second one makes the compiler split the loop)
         const bool crossed = symbol_step<WRITE, PAIR>(st, bits, lut, img, blk, sink);

@@ -59,6 +59,10 @@ struct DevImage {
     uint32_t src_back[3], src_comp[3];
     uint32_t nparts;
     uint32_t cbw[3], cbh[3];    // role 2: block grid of each component's own scan
+    // single decode (round 5): 1 = the picture's first decode emits (k_huff_emit, then k_huff_prefix + k_block_gather instead of
+    // k_huff_spec ... k_huff_write): pictures of one scan without restart intervals, quad-interleaved stream
+    uint32_t emit;
+    uint32_t emit_head;         // groups of head room in front of the first decode's entries (kEmitHeadGroups; tests shrink it)
 };
 
 // ---- compact coefficient stream, quad-interleaved (round 4) -----------------------------------------------------------
@@ -75,9 +79,41 @@ struct DevImage {
 #define MJX_STREAM_QUAD 4
 #endif
 constexpr uint32_t kStreamQuad = MJX_STREAM_QUAD;      // columns interleaved per row (a power of two; 4: a row is one 128-byte line)
-MJX_HD uint32_t stream_rows_for(uint32_t sub_bits) { return (sub_bits / 2u + 1u + 7u) / 8u + 1u; }
+// Single decode (round 5, k_huff_emit): a column also holds one word per block -- {DC difference, column index where the block's
+// entries begin} -- filled from its top downwards (block word i at column index cap - 4 - 4 * (i >> 2) + (i & 3): 16-byte groups).
+// A block takes at least two bits of scan and every entry two more, so entries and block words together are at most
+// sub_bits / 2 + 2 words and never meet.  kEmitHeadGroups rows of head room on top of that: the first decode of a subsequence starts
+// its entries at index kEmitHeadGroups * 8 (its block words at kEmitHeadWords), so that a prefix that is decoded again
+// from the true entry state can be written RIGHT-ALIGNED against the part of the first decode that stays valid, whatever the
+// difference between the two prefixes' counts (photographic content: <= 24 entries, <= 33 blocks; flat content, whose blocks take
+// a handful of bits, reaches a hundred and more blocks per 1024 bits of prefix; more than the head room = the picture falls back
+// to the two-pass kernels).
+constexpr uint32_t kEmitHeadGroups = 64;                       // entries: 512 of head room
+constexpr uint32_t kEmitHeadWords = kEmitHeadGroups * 4u;      // block words of head room: 256 (DevImage::emit_head scales both)
+constexpr uint32_t kEmitExtraRows = kEmitHeadGroups + kEmitHeadWords / 8u + 2u;
+MJX_HD uint32_t stream_rows_for(uint32_t sub_bits) { return (sub_bits / 2u + 1u + 7u) / 8u + 1u + kEmitExtraRows; }
 MJX_HD uint64_t stream_quad_entries(uint32_t nsub, uint32_t rows) { return uint64_t((nsub + kStreamQuad - 1) / kStreamQuad) * rows * 8u * kStreamQuad; }
-MJX_HD uint32_t stream_hdr_entries(uint32_t nsub) { return (nsub * 2u + 127u) / 128u * 32u; }      // whole 128-byte lines
+// Head of a picture's stream region: one 32-bit word per subsequence -- the run of its entries in the column, in store groups,
+// and what is added to its entries' block labels:   first group [11:0] | end group [23:12] | label offset [31:24]
+// (k_huff_write: first group 0, offset 0 -- its entries carry the block's index in the picture; k_huff_emit / k_huff_prefix: the
+// labels count the blocks the lane has completed, and the offset is the low byte of what turns that into the block's index).
+MJX_HD uint32_t stream_hdr_entries(uint32_t nsub) { return (nsub * 4u + 127u) / 128u * 32u; }      // whole 128-byte lines
+MJX_HD constexpr uint32_t run_word(uint32_t g0, uint32_t g1, uint32_t label_off) { return (g0 & 0xfffu) | ((g1 & 0xfffu) << 12) | (label_off << 24); }
+MJX_HD constexpr uint32_t run_first(uint32_t w) { return w & 0xfffu; }
+MJX_HD constexpr uint32_t run_end(uint32_t w) { return (w >> 12) & 0xfffu; }
+MJX_HD constexpr uint32_t run_label(uint32_t w) { return w >> 24; }
+// column index of block word i (see above)
+MJX_HD uint32_t block_word_index(uint32_t i, uint32_t rows) { return rows * 8u - 4u - 4u * (i >> 2) + (i & 3u); }
+// per-subsequence record of the emitting decode (chunk array, index sub_off + s)
+struct alignas(16) EmitSub {
+    uint32_t d0n, d0m;      // blocks completed / entries produced by the first decode (k_huff_emit)
+    uint32_t kfix;          // 0: its entry state was right; k + 1: the true path meets it at checkpoint k; kEmitAll: nowhere inside
+    uint32_t bad;           // bit position (inside the subsequence) of the first symbol of the first decode that no code matches, or 0xffffffff
+    uint32_t bad_lbl;       // ... and the label of its block
+    int32_t lbl;            // label of the first decode's block at the merge point minus the true path's (k_huff_prefix)
+    uint32_t pad_[2];
+};
+constexpr uint32_t kEmitAll = 0xffffu;
 MJX_HD uint64_t stream_phys(uint32_t s, uint32_t j, uint32_t rows) { return (uint64_t(s / kStreamQuad) * rows + (j >> 3)) * (8u * kStreamQuad) + (s % kStreamQuad) * 8u + (j & 7u); }
 
 // ---- reading a tile out of the quad-interleaved stream (stage B; also the host-side expansion and the CPU emulation of the tests) ----
@@ -94,23 +130,32 @@ MJX_HD uint64_t stream_phys(uint32_t s, uint32_t j, uint32_t rows) { return (uin
 #define MJX_UNROLL
 #endif
 constexpr uint32_t kQuadSegs = 8;
-struct alignas(16) QuadCum { uint32_t x, y, z, w; };      // (one 16-byte LDS read)
+// What the workgroup prepares per tile (32 bytes of LDS, two 16-byte reads): one word per subsequence of the tile, in order --
+//   cumulative groups of the tile after this subsequence [13:0] | first group of the subsequence's run [23:14] | label offset [31:24]
+// (the cumulative count of the last slot = the tile's groups; all ones there: more than kQuadSegs subsequences, the loop over the
+// run words).  Round 5: the first group and the label offset are new -- a run no longer starts at row 0 of its column and its
+// entries no longer carry the block's index in the picture (see run_word); packed here, once per tile, a lane still finds its
+// group without a dependent read.
+struct alignas(16) QuadCum { uint32_t w[kQuadSegs]; };
+constexpr uint32_t kQuadCumMask = 0x3fffu, kQuadMany = 0x3fffu;
+static_assert((kMaxSubseqBits / 2 + 8) / 8 + 1 + kEmitExtraRows < 1024, "a run's first group must fit ten bits (stream_rows_for(kMaxSubseqBits) < 1024)");
 struct QuadView {
     const uint32_t *s_sub;               // LDS: subsequence of the workgroup's tile starts ...
     const uint16_t *s_at;                // ... and entry index in its column
-    const QuadCum *s_cum;                 // LDS, per tile: cumulative groups after the tile's 1st, 2nd, ... subsequence, 16 bits each
-                                         // (the last one = the tile's groups; 0xffff in the last slot: more than kQuadSegs subsequences)
-    const uint16_t *runs;                // run lengths in groups of all the picture's subsequences: the head of its stream region
+    const QuadCum *s_cum;                 // LDS, per tile: see QuadCum
+    const uint32_t *runs;                // the runs of all the picture's subsequences (run_word): the head of its stream region
     uint32_t rows, nsub;
 };
-struct QuadCell { uint32_t phys, k_lo, k_hi; };     // phys = 0xffffffff: no group for this lane
+struct QuadCell { uint32_t phys, k_lo, k_hi, label; };     // phys = 0xffffffff: no group for this lane; label: run_label of the group's subsequence
 // What lane t of the workgroup prepares for tile t.
 MJX_HD QuadCum quad_prepare(const QuadView &q, uint32_t k)
 {
     const uint32_t s0 = q.s_sub[k], s1 = q.s_sub[k + 1], j0 = q.s_at[k], j1 = q.s_at[k + 1];
-    uint32_t w[4] = {0, 0, 0, 0};
-    if (s1 < s0 || s1 >= q.nsub) return QuadCum{0, 0, 0, 0};     // (offsets of a picture that did not decode: no entries, no reads)
-    if (s1 - s0 >= kQuadSegs) return QuadCum{0, 0, 0, 0xffff0000u};
+    QuadCum out;
+MJX_UNROLL
+    for (uint32_t i = 0; i < kQuadSegs; i++) out.w[i] = 0;
+    if (s1 < s0 || s1 >= q.nsub) return out;                      // (offsets of a picture that did not decode: no entries, no reads)
+    if (s1 - s0 >= kQuadSegs) { out.w[kQuadSegs - 1] = kQuadMany; return out; }
     uint32_t c = 0, run[kQuadSegs];
 MJX_UNROLL
     for (uint32_t i = 0; i < kQuadSegs; i++) run[i] = q.runs[s0 + i < s1 ? s0 + i : s1];       // (all in flight together)
@@ -118,13 +163,13 @@ MJX_UNROLL
     for (uint32_t i = 0; i < kQuadSegs; i++) {
         const uint32_t s = s0 + i;
         if (s <= s1) {
-            const uint32_t gs = i == 0 ? j0 >> 3 : 0u;
-            const uint32_t ge = s == s1 ? (j1 + 7u) >> 3 : run[i];
+            const uint32_t gs = i == 0 ? j0 >> 3 : run_first(run[i]);
+            const uint32_t ge = s == s1 ? (j1 + 7u) >> 3 : run_end(run[i]);
             c += ge > gs ? ge - gs : 0u;
         }
-        w[i >> 1] |= (c < 0xfffeu ? c : 0xfffeu) << (16u * (i & 1u));
+        out.w[i] = (c < kQuadCumMask - 1u ? c : kQuadCumMask - 1u) | ((run_first(run[i]) & 0x3ffu) << 14) | (run_label(run[i]) << 24);
     }
-    return QuadCum{w[0], w[1], w[2], w[3]};
+    return out;
 }
 // Group o of tile k (of the workgroup): where it lies and which of its entries are the tile's.  Returns the tile's groups.
 MJX_HD uint32_t quad_cell(const QuadView &q, uint32_t k, uint32_t o, QuadCell &cell)
@@ -134,25 +179,32 @@ MJX_HD uint32_t quad_cell(const QuadView &q, uint32_t k, uint32_t o, QuadCell &c
     cell.phys = 0xffffffffu;
     cell.k_lo = 0;
     cell.k_hi = 8;
+    cell.label = 0;
     uint32_t total, s = s0, first = j0 >> 3, before = 0;              // the group's subsequence, that one's first group, groups before it
-    if (cw.w >> 16 != 0xffffu) {
-        const uint32_t cum[kQuadSegs] = {cw.x & 0xffffu, cw.x >> 16, cw.y & 0xffffu, cw.y >> 16, cw.z & 0xffffu, cw.z >> 16, cw.w & 0xffffu, cw.w >> 16};
-        total = cum[kQuadSegs - 1];
+    if ((cw.w[kQuadSegs - 1] & kQuadCumMask) != kQuadMany) {
+        total = cw.w[kQuadSegs - 1] & kQuadCumMask;
+        uint32_t sel = cw.w[0];
+        bool own = true;                                                   // the group lies in the tile's first subsequence: it starts at j0
 MJX_UNROLL
         for (uint32_t i = 0; i + 1 < kQuadSegs; i++) {
-            const bool behind = o >= cum[i];                               // (cum[] stays at the total behind the tile's last subsequence)
+            const uint32_t ci = cw.w[i] & kQuadCumMask;
+            const bool behind = o >= ci;                                   // (the counts stay at the total behind the tile's last subsequence)
             s += behind ? 1u : 0u;
-            before = behind ? cum[i] : before;
+            before = behind ? ci : before;
+            sel = behind ? cw.w[i + 1] : sel;
+            own = own && !behind;
         }
-        first = o >= cum[0] ? 0u : first;
+        first = own ? first : (sel >> 14) & 0x3ffu;
+        cell.label = sel >> 24;
     } else {
         total = 0;
         bool found = false;
         for (uint32_t t = s0; t <= s1; t++) {
-            const uint32_t gs = t == s0 ? j0 >> 3 : 0u;
-            const uint32_t ge = t == s1 ? (j1 + 7u) >> 3 : uint32_t(q.runs[t]);
+            const uint32_t rw = q.runs[t];
+            const uint32_t gs = t == s0 ? j0 >> 3 : run_first(rw);
+            const uint32_t ge = t == s1 ? (j1 + 7u) >> 3 : run_end(rw);
             const uint32_t cnt = ge > gs ? ge - gs : 0u;
-            if (!found && o < total + cnt) { s = t; first = gs; before = total; found = true; }
+            if (!found && o < total + cnt) { s = t; first = gs; before = total; found = true; cell.label = run_label(rw); }
             total += cnt;
         }
     }
@@ -238,20 +290,37 @@ void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
                        const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
                        uint32_t *cps, uint32_t *mismatches, uint32_t *items, uint32_t *item_count, const uint32_t *segs,
                        const uint32_t *prev_mismatches /* count of the round before, or null for the first */,
-                       bool first_round /* most subsequences re-decode: the workgroups run their first slices in place */);
+                       bool first_round /* most subsequences re-decode: the workgroups run their first slices in place */,
+                       EmitSub *esub /* pictures whose first decode emits: the merge depth is kept here */);
 // The merge rounds of a small chunk in one launch (device-wide barrier between rounds); `participants` = the workgroups (x, image)
 // with x * merge_wg_lanes() + 1 < nsub(image): all of them must be resident at once (the caller checks against merge_loop_capacity()).
 void launch_huff_merge_loop(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                             const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
                             uint32_t *cps, uint32_t *verdict, const uint32_t *segs, uint32_t *ctl, uint32_t participants, uint32_t max_rounds,
-                            uint32_t spin_limit);      // spin_limit: polls of a barrier (~1.5 us each) before a workgroup gives up
+                            uint32_t spin_limit,       // spin_limit: polls of a barrier (~1.5 us each) before a workgroup gives up
+                            EmitSub *esub);
+// single decode (round 5): the first decode of a picture emits (k_huff_emit); after the merge rounds and the scan, k_huff_prefix
+// re-decodes what lay in front of the merge point for the lanes whose entry was wrong and k_block_gather makes dcdiff / tile offsets
+size_t huff_prefix_bytes();
+void launch_emit_off(hipStream_t st, DevImage *images, uint32_t nimg, const uint32_t *img_flags);     // fall-back: the flagged pictures leave the single-decode path (device copies patched in place)
+void launch_huff_emit(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
+                      const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_, uint32_t *cps,
+                      EmitSub *esub, uint32_t *entries);
+void launch_huff_prefix(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, const DevImage *images,
+                        const uint8_t *scan_pool, const LutEntry *lut_pool, const SubseqState *entry, const SubseqState *exit_,
+                        const uint32_t *cps, EmitSub *esub, const uint32_t *blkbase, uint32_t *entries, int *status, uint32_t *img_flags,
+                        uint32_t *fallback /* device word: a picture had no head room for its prefix */, int16_t *dcdiff, uint32_t *tile_eoff,
+                        const uint32_t *items, const uint32_t *item_count /* as written by k_huff_scan */);
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,
                       uint32_t *ebase, uint32_t *img_entries, uint32_t *img_flags, const uint32_t *segs,
-                      const uint32_t *verdict /* device word: re-decodes of the last synchronisation round, or null */);
+                      const uint32_t *verdict /* device word: re-decodes of the last synchronisation round, or null */,
+                      const EmitSub *esub, uint32_t *items /* [chunk subsequences][6]: per picture the (subsequence, checkpoint interval) pieces k_huff_prefix decodes again */,
+                      uint32_t *item_count /* [chunk images] */, uint32_t *fallback /* device word: a picture goes to the two-pass kernels */);
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                        const uint8_t *scan_pool, const LutEntry *lut_pool, const SubseqState *entry,
                        const uint32_t *blkbase, const uint32_t *ebase, uint32_t *entries, uint32_t *tile_eoff,
-                       int16_t *dcdiff, int *status, const uint32_t *img_flags, const uint32_t *segs, const SubseqState *exit_);
+                       int16_t *dcdiff, int *status, const uint32_t *img_flags, const uint32_t *segs, const SubseqState *exit_,
+                       uint32_t *cps /* measurement builds only */);
 void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, const int16_t *dcdiff, int32_t *dcbuf,
                     int32_t *segsum, const uint32_t *img_flags, uint32_t bpm_mask, uint32_t max_restart_segs,
                     uint32_t *segflag = nullptr, uint32_t gen = 0,

@@ -288,7 +288,7 @@ struct StreamSink {
         ac_ring.flush_groups();             // (the caller padded the run to a whole group)
         dc_ring.flush_all();
     }
-    __device__ __forceinline__ void bad_code(uint32_t) const { atomicOr(status, 1); }
+    __device__ __forceinline__ void bad_code(uint32_t, uint32_t) const { atomicOr(status, 1); }
     __device__ __forceinline__ void tick() const {}
 };
 
@@ -418,7 +418,8 @@ extern "C" int mjx_debug_stamps(unsigned long long out[8], int reset)
 // matters: an `if (running)` body inside a wave-uniform loop made the compiler copy the lane state in and out of
 // temporaries, 20 of 57 vector instructions per step.)
 //   WRITE  emit coefficients through `sink`      CP  0: none, 1: record checkpoints, 2: record + merge (see mjx_huff.h)
-template <bool WRITE, int CP, class Sink, class CpStore>
+//   PAIRSTEP  two symbols per step where the table's pair part allows (counting passes on the second table set)
+template <bool WRITE, int CP, bool PAIRSTEP = !WRITE, class Sink, class CpStore>
 __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry, uint32_t end_bit, uint32_t blk,
                                                    uint32_t blk_limit, const LaneBits &g, uint32_t *my_win, const LutEntry *lut,
                                                    const HuffImage &h, Sink &sink, CpStore &cps, uint32_t sub_start,
@@ -436,7 +437,7 @@ __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry,
         lane_begin(st, win, h, entry);
         win.rp = win_addr + (st.wn - 4u - win.wbase);
     }
-    events_begin<CP>(ev, sub_start, end_bit);
+    events_begin<CP>(ev, sub_start, end_bit, h.cp_bits);
     const uint32_t win_end = win_addr + 4u * kWinDwords;
     const uint32_t total_blocks = blk_limit;                               // (write pass: first block the lane must not write)
     bool running = live && entry.p <= end_bit && !(WRITE && blk >= total_blocks);
@@ -452,10 +453,10 @@ __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry,
             win.rp = win_addr + ((st.wn - 4u) & 15u);
         }
 #ifdef MJX_STAMP
-        if (WRITE) { sp.at(0); (void)symbol_step<WRITE, !WRITE>(st, win, lut, h, blk, sink, sp); sp.at(5); }
+        if (WRITE) { sp.at(0); (void)symbol_step<WRITE, PAIRSTEP>(st, win, lut, h, blk, sink, sp); sp.at(5); }
         else
 #endif
-        (void)symbol_step<WRITE, !WRITE>(st, win, lut, h, blk, sink);
+        (void)symbol_step<WRITE, PAIRSTEP>(st, win, lut, h, blk, sink);
         // Events (checkpoints, the end of the subsequence) are due when wn -- it only moves when the lane takes a new
         // dword -- has reached a boundary.  Both are tested on wn alone, as two flat conditions: these loops are bound
         // by scalar-instruction issue (one per SIMD turn), and exec-mask bookkeeping for nested "crossed -> event ->
@@ -496,7 +497,7 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_spec(const DevImage
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
     const uint32_t img = entropy_grid_image(), wgi = entropy_grid_wg();
     const DevImage &im = images[img];
-    if (!im.valid || wgi * kHuffWg >= im.himg.nsub) return;
+    if (!im.valid || im.emit || wgi * kHuffWg >= im.himg.nsub) return;      // (emit: the picture's first decode is k_huff_emit's)
     const HuffImage *h;
     const LutEntry *lut;
     stage_tables<true>(im, lut_pool, smem, h, lut);
@@ -539,22 +540,30 @@ constexpr int kHeadSlices = MJX_HEAD_SLICES;
 #define MJX_LATER_HEAD_SLICES 0
 #endif
 struct MergeItem { uint32_t s, p, zc, n, m, k; };
-constexpr uint32_t kSliceCps = kCpBits >= 256 ? 1u : 256u / uint32_t(kCpBits);
+static_assert(kCpBits == 256, "a merge slice is one interval of kCpBits = 256 bits (window of four pieces); a picture's checkpoints lie every HuffImage::cp_bits, a multiple of it");
 
 // One slice of one item: decode from (p, z, c) to the next checkpoint boundary (or the end of the subsequence).
 // Returns true when the item is finished (its exit and checkpoints are final), false when `it` holds the progress.
+// `depth` (when the item finishes): kEmitAll if the re-decode left the subsequence without meeting the previous decode's path,
+// else 1 + the index of the checkpoint where it met it.
 __device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, const HuffImage &h, const LutEntry *lut,
                                             const unsigned char *region, uint32_t *my_win, const SubseqState *g_exit,
-                                            uint32_t *g_cps, SubseqState &x, const uint32_t *segs)
+                                            uint32_t *g_cps, SubseqState &x, const uint32_t *segs, uint32_t &depth)
 {
     const SubLoc loc = locate_sub(im, h, segs, it.s);
     const uint32_t sub_start = loc.start, end_bit = loc.end - loc.start;       // (the lane works relative to its subsequence)
     const GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + it.s), 0};
     bool fin = false;
+    depth = kEmitAll;
     x = make_state(it.p, it.zc & 0xffu, it.zc >> 8, it.n, it.m);
     const uint32_t pl = it.p - sub_start;
     if (it.p >= sub_start && pl <= end_bit) {                      // (else nothing starts inside s)
-        const uint32_t old_word = it.k < uint32_t(kMaxCp) ? cps.get_w(it.k) : 0u;   // requested early
+        // it.k counts slices (intervals of kCpBits); a checkpoint lies at the end of slice it.k when that boundary is a multiple of the
+        // picture's cp_bits (every slice for the pictures of the two-pass path, every fourth or so for those whose first decode emits)
+        const uint32_t per = h.cp_bits / uint32_t(kCpBits);
+        const bool at_cp = (it.k + 1u) % per == 0u;
+        const uint32_t ck = (it.k + 1u) / per - 1u;                // index of that checkpoint
+        const uint32_t old_word = (at_cp && ck < uint32_t(kMaxCp)) ? cps.get_w(ck) : 0u;   // requested early
         const uint32_t wi1 = (pl + 31u) >> 5, wbase = (wi1 ? 4u * wi1 - 4u : 0u) & ~15u;
         const LaneBits bits{region, it.s * 16u, im.scan_cols * 16u};
 #pragma unroll
@@ -574,35 +583,22 @@ __device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, c
         const uint32_t end_wn = wn_after(end_bit);
         uint32_t blk = 0;
         NullSink sink;
-        // a slice = kSliceCps checkpoint intervals (256 bits, ~50 symbols, whatever the checkpoint spacing)
-        uint32_t old_words[kSliceCps];
-        old_words[0] = old_word;
-#pragma unroll
-        for (uint32_t q = 1; q < kSliceCps; q++) old_words[q] = it.k + q < uint32_t(kMaxCp) ? cps.get_w(it.k + q) : 0u;
-        bool more = true;
-#pragma unroll
-        for (uint32_t q = 0; q < kSliceCps; q++) {
-            if (more) {
-                uint32_t stop_wn = wn_after((it.k + 1) * kCpBits);
-                stop_wn = stop_wn < end_wn ? stop_wn : end_wn;
-                while (st.wn < stop_wn) (void)symbol_step<false, true>(st, win, lut, h, blk, sink);
-                if (st.wn >= end_wn) {                                     // left the subsequence without merging
-                    fin = true;
-                    more = false;
-                    x = make_state(lane_pos(st) + sub_start, lane_z(st), lane_c(st, h), st.n, lane_m(st));
-                } else {
-                    const uint32_t state = cp_state_word(st);
-                    if ((old_words[q] & kCpStateMask) == state) {          // met the previous decode's path
-                        const SubseqState old_exit = g_exit[im.sub_off + it.s];
-                        fin = true;
-                        more = false;
-                        x = make_state(old_exit.p, old_exit.z, old_exit.c, st.n + ((old_words[q] >> 16) & 0x7fffu),
-                                       lane_m(st) + cps.get_m(it.k));
-                    } else {
-                        cps.set(it.k, state | (st.n << 16), lane_m(st));
-                        it.k++;
-                    }
-                }
+        uint32_t stop_wn = wn_after((it.k + 1) * kCpBits);
+        stop_wn = stop_wn < end_wn ? stop_wn : end_wn;
+        while (st.wn < stop_wn) (void)symbol_step<false, true>(st, win, lut, h, blk, sink);
+        if (st.wn >= end_wn) {                                     // left the subsequence without merging
+            fin = true;
+            x = make_state(lane_pos(st) + sub_start, lane_z(st), lane_c(st, h), st.n, lane_m(st));
+        } else {
+            const uint32_t state = cp_state_word(st);
+            if (at_cp && (old_word & kCpStateMask) == state) {     // met the previous decode's path
+                const SubseqState old_exit = g_exit[im.sub_off + it.s];
+                fin = true;
+                depth = ck + 1u;
+                x = make_state(old_exit.p, old_exit.z, old_exit.c, st.n + ((old_word >> 16) & 0x7fffu), lane_m(st) + cps.get_m(ck));
+            } else {
+                if (at_cp) cps.set(ck, state | (st.n << 16), lane_m(st));
+                it.k++;
             }
         }
         if (!fin) {
@@ -616,13 +612,19 @@ __device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, c
     }
     return fin;
 }
-// A finished item: its exit, and the counts of the checkpoints it recorded turned from "so far" into "to the end".
+// A finished item: its exit, and the counts of the checkpoints it recorded turned from "so far" into "to the end".  Pictures whose
+// first decode emitted keep, per subsequence, the deepest point at which any of its re-decodes met the recorded path: from there on
+// the first decode's entries are the true ones (k_huff_prefix writes what lies in front of it).
 __device__ __forceinline__ void merge_finish(const MergeItem &it, const DevImage &im, const SubseqState &x,
-                                             SubseqState *g_exit, uint32_t *g_cps)
+                                             SubseqState *g_exit, uint32_t *g_cps, EmitSub *g_esub, uint32_t depth)
 {
     const GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + it.s), 0};
-    checkpoint_fixup(cps, it.k, x.n, x.m);
+    checkpoint_fixup(cps, it.k / (im.himg.cp_bits / uint32_t(kCpBits)), x.n, x.m);
     g_exit[im.sub_off + it.s] = x;
+    if (im.emit) {
+        uint32_t &kf = g_esub[im.sub_off + it.s].kfix;             // (one lane per subsequence and round: no race)
+        kf = kf > depth ? kf : depth;
+    }
 }
 
 extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevImage *images, const uint8_t *scan_pool,
@@ -630,7 +632,7 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
                                                                 SubseqState *g_exit, uint32_t *g_cps, uint32_t *mismatches,
                                                                 uint32_t win_off, uint32_t *g_items, uint32_t *g_item_count,
                                                                 const uint32_t *segs, const uint32_t *prev_mismatches,
-                                                                uint32_t head_slices)
+                                                                uint32_t head_slices, EmitSub *g_esub)
 {
     // A round behind one that re-decoded nothing has nothing to do either (the fixed point is reached): it leaves at
     // once, its own count stays zero, and so does every later round's.  That makes spare rounds nearly free (a launch),
@@ -689,8 +691,9 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
     for (uint32_t slice = 0;; slice++) {
         if (active) {
             SubseqState x;
-            if (merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x, segs)) {
-                merge_finish(it, im, x, g_exit, g_cps);
+            uint32_t depth;
+            if (merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x, segs, depth)) {
+                merge_finish(it, im, x, g_exit, g_cps, g_esub, depth);
                 active = false;
             }
         }
@@ -734,7 +737,7 @@ extern "C" __global__ __launch_bounds__(kTailWg) void k_huff_merge_tail(const De
                                                                     const LutEntry *lut_pool, SubseqState *g_exit,
                                                                     uint32_t *g_cps, uint32_t win_off,
                                                                     const uint32_t *g_items, const uint32_t *g_item_count,
-                                                                    const uint32_t *segs)
+                                                                    const uint32_t *segs, EmitSub *g_esub)
 {
     extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, a window per lane
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
@@ -758,8 +761,9 @@ extern "C" __global__ __launch_bounds__(kTailWg) void k_huff_merge_tail(const De
     // every lane runs its item to the end first; the read-modify-write of the recorded checkpoints then happens once
     // for the whole wave instead of after every slice for the lanes that happen to finish there
     SubseqState x;
-    while (!merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x, segs)) {}
-    merge_finish(it, im, x, g_exit, g_cps);
+    uint32_t depth;
+    while (!merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x, segs, depth)) {}
+    merge_finish(it, im, x, g_exit, g_cps, g_esub, depth);
 }
 
 // ---- the merge rounds of a small batch in one launch ------------------------------------------------------------------
@@ -803,7 +807,8 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge_loop(const D
                                                                      const LutEntry *lut_pool, SubseqState *g_entry,
                                                                      SubseqState *g_exit, uint32_t *g_cps, uint32_t *verdict,
                                                                      uint32_t win_off, const uint32_t *segs, uint32_t *ctl,
-                                                                     uint32_t participants, uint32_t max_rounds, uint32_t spin_limit)
+                                                                     uint32_t participants, uint32_t max_rounds, uint32_t spin_limit,
+                                                                     EmitSub *g_esub)
 {
     extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, windows (= item exchange), wave counts
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
@@ -838,8 +843,9 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge_loop(const D
         for (;;) {
             if (active) {
                 SubseqState x;
-                if (merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x, segs)) {
-                    merge_finish(it, im, x, g_exit, g_cps);
+                uint32_t depth;
+                if (merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x, segs, depth)) {
+                    merge_finish(it, im, x, g_exit, g_cps, g_esub, depth);
                     active = false;
                 }
             }
@@ -1117,10 +1123,23 @@ extern "C" __global__ __launch_bounds__(256) void k_scan_interleave(const Interl
 
 // blkbase[s] / ebase[s] = blocks completed / stream entries produced before subsequence s (one workgroup per image).
 // A subsequence's run of stream entries is rounded up to whole store groups (the write pass fills up with null entries).
+// Pictures whose first decode emits: what k_huff_prefix decodes again is listed here -- one item per checkpoint interval of the
+// prefix of every subsequence whose entry was wrong: (subsequence, interval).  The merge rounds have left the true path's state
+// and counts at every checkpoint in front of the merge point, so the intervals of one prefix are independent pieces of work of the
+// same length (~200 symbols at 1024 bits): no lane of the prefix pass waits for a neighbour that decodes a whole subsequence.
+constexpr uint32_t kItemShift = 20;           // item = subsequence | interval << kItemShift
+__device__ __forceinline__ uint32_t prefix_intervals(const DevImage &im, uint32_t s, uint32_t kfix)
+{
+    if (kfix != kEmitAll) return kfix;
+    const uint32_t L = im.himg.sub_bits, start = s * L, len = min(start + L, im.himg.total_bits) - start;
+    return max(1u, (len + im.himg.cp_bits - 1u) / im.himg.cp_bits);
+}
 extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *images, const SubseqState *g_exit,
                                                                uint32_t *g_blkbase, uint32_t *g_ebase,
                                                                uint32_t *img_entries, uint32_t *img_flags,
-                                                               const uint32_t *segs, const uint32_t *verdict)
+                                                               const uint32_t *segs, const uint32_t *verdict,
+                                                               const EmitSub *g_esub, uint32_t *g_items, uint32_t *g_item_count,
+                                                               uint32_t *fallback)
 {
     __shared__ uint32_t s_tmp[4];
     const DevImage &im = images[blockIdx.x];
@@ -1174,6 +1193,29 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *im
         img_entries[im.status_idx] = total_m;      // upper bound of the entries the write pass produces
         img_flags[im.status_idx] = s_short | im.upload_short;     // (a repair run comes through here again: the upload-time diagnosis stays)
     }
+    if (im.emit) {
+        uint32_t cnt = 0;
+        for (uint32_t s = a; s < b; s++) {
+            const uint32_t kf = g_esub[im.sub_off + s].kfix;
+            if (kf) cnt += prefix_intervals(im, s, kf);
+        }
+        uint32_t total;
+        uint32_t at = wg_exclusive_scan(cnt, s_tmp, &total);
+        // the list has room for kItemDwords items per subsequence (the merge rounds' straggler list); a picture that needs more -- most
+        // of its lanes decode most of their subsequence again: noise at quality 99 -- is better off with the two-pass kernels anyway
+        if (total > nsub * uint32_t(kItemDwords) || nsub >= (1u << kItemShift)) {
+            if (tid == 0) { img_flags[im.status_idx] = 2u; atomicOr(fallback, 64u); g_item_count[blockIdx.x] = 0; }
+            return;
+        }
+        uint32_t *items = g_items + size_t(im.sub_off) * kItemDwords;
+        for (uint32_t s = a; s < b; s++) {
+            const uint32_t kf = g_esub[im.sub_off + s].kfix;
+            if (!kf) continue;
+            const uint32_t n = prefix_intervals(im, s, kf);
+            for (uint32_t k = 0; k < n; k++) items[at++] = s | (k << kItemShift);
+        }
+        if (tid == 0) g_item_count[blockIdx.x] = total;
+    }
 }
 
 extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImage *images, const uint8_t *scan_pool,
@@ -1181,13 +1223,13 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
                                                                 const uint32_t *g_blkbase, const uint32_t *g_ebase,
                                                                 uint32_t *entries, uint32_t *tile_eoff, int16_t *dcdiff,
                                                                 int *status, const uint32_t *img_flags, uint32_t win_off,
-                                                                const uint32_t *segs, const SubseqState *g_exit)
+                                                                const uint32_t *segs, const SubseqState *g_exit, uint32_t *g_cps)
 {
     extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, windows, rings
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
     const uint32_t img = entropy_grid_image(), wgi = entropy_grid_wg();
     const DevImage &im = images[img];
-    if (!im.valid || wgi * kHuffWg >= im.himg.nsub || img_flags[im.status_idx]) return;
+    if (!im.valid || im.emit || wgi * kHuffWg >= im.himg.nsub || img_flags[im.status_idx]) return;
     const HuffImage *h;
     const LutEntry *lut;
     stage_tables(im, lut_pool, smem, h, lut);
@@ -1229,7 +1271,7 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
         if (im.ent_rows) {          // quad-interleaved stream: the lane's column (stream_phys(s, 0)), groups four groups apart
             const uint32_t sl = live ? s : 0u;
             sink.ac_ring.begin(rings + threadIdx.x * kAcRingStride, entries + im.ent_off + im.ent_hdr + stream_phys(sl, 0, im.ent_rows), 0u);
-            if (live) reinterpret_cast<uint16_t *>(entries + im.ent_off)[s] = uint16_t(pad_to >> 3);      // the run in groups, for stage B
+            if (live) (entries + im.ent_off)[s] = run_word(0u, pad_to >> 3, 0u);      // the run in groups, for stage B (labels = block indices: no offset)
             sink.ac_ring.gstride = kAcGroup * kStreamQuad;
             sink.tile_virt = sl * (im.ent_rows * 8u);
         } else {
@@ -1247,14 +1289,446 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
         sink.tile_idx = (first_start + im.tile_blocks - 1) / im.tile_blocks;
         sink.next_tile_blk = sink.tile_idx * im.tile_blocks;
     }
+#ifdef MJX_EXP_WRITE_CP      // (measurement build: what an emitting pass pays for recording checkpoints as the counting pass does)
+    GlobalCps cpw{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + (live ? s : 0u)), 0};
+    wave_decode<true, 1>(live && live_entry, e, end_bit, blk, blk_limit, gbits, s_win + threadIdx.x * kWinStride, lut, *h, sink, cpw, 0, e);
+#else
+    (void)g_cps;
     NoCheckpoints nocp;
     wave_decode<true, 0>(live && live_entry, e, end_bit, blk, blk_limit, gbits, s_win + threadIdx.x * kWinStride, lut, *h, sink, nocp, 0, e);
+#endif
     sink.flush_groups();                                                   // (the rings hold one flush period, no more)
     for (uint32_t it = 1; __builtin_amdgcn_ballot_w64(sink.ac_ring.off < pad_to); it++) {
         if (sink.ac_ring.off < pad_to) sink.ac_ring.push(0u);              // null entry
         if (it % kFlushEvery == 0) sink.flush_groups();
     }
     sink.flush();
+}
+
+// ---- single decode (round 5): the first decode emits -----------------------------------------------------------------------
+// The reference decodes every symbol once (huffman.rs:146-195).  The two-pass path above decodes every symbol twice -- k_huff_spec
+// to find where the subsequences begin, k_huff_write to emit from there -- because an emitting lane needs to know which block of
+// the picture it is in, and that is only known once all the subsequences before it have been counted.  Here the first decode
+// emits without knowing:
+//   k_huff_emit    A lane first WARMS UP: it decodes the last warm_bits bits of the subsequence in front of its own from the guess
+//                  "a block starts here", counting only; Huffman codes self-synchronise, so at its own subsequence's start it
+//                  is on the true path with probability ~0.8 (1024 bits) .. 0.94 (2048).  Then it decodes its subsequence ONCE,
+//                  emitting: entries into its column from index H on, labelled with the number of blocks the lane has completed
+//                  (coef_entry's block field); one word per block -- {DC difference, column index where its entries begin} -- into
+//                  the top of the column, downwards (block_word_index), from index Hb + label on; checkpoints every cp_bits.
+//   merge rounds   as before (counting): the true entry state of every subsequence; per subsequence the deepest checkpoint at which
+//                  a re-decode met the recorded path (EmitSub::kfix) -- from there on what k_huff_emit wrote is the true decode.
+//   k_huff_scan    blocks completed before every subsequence.
+//   k_huff_prefix  the lanes whose entry was wrong (a fifth at 1024 bits of warm-up) decode from the true entry up to that
+//                  checkpoint, emitting RIGHT-ALIGNED against the first valid entry / block word of the first decode, with labels
+//                  that continue into that decode's: the subsequence's run in the column stays one contiguous run.  Every
+//                  subsequence's run word (first group, end group, label offset) goes to the head of the stream region.
+//   k_block_gather block words -> dcdiff[] (what the DC prediction kernels read) and the tile offsets stage B starts from.
+// Stage B adds the run's label offset to its entries' labels; nothing else changes for it.
+struct BlkRing {
+    static constexpr uint32_t kRing = 8, kGroup = 4;      // words: 32 bytes of LDS per lane, 16-byte groups
+    uint32_t *ring;
+    uint32_t *col;          // the lane's column: word j of it lies at col[(j >> 3) * 8 * kStreamQuad + (j & 7)]
+    uint32_t quads;         // column capacity / 4 (block word group g lies at column index 4 * (quads - 1 - g))
+    uint32_t off, flushed;  // block word indices: next, first not yet in HBM
+    __device__ __forceinline__ void begin(uint32_t *lds, uint32_t *column, uint32_t rows, uint32_t first)
+    {
+        ring = lds;
+        col = column;
+        quads = rows * 2u;
+        off = flushed = first;
+    }
+    __device__ __forceinline__ uint32_t *group_at(uint32_t i) const
+    {
+        const uint32_t t = quads - 1u - (i >> 2);
+        return col + (t >> 1) * (8u * kStreamQuad) + (t & 1u) * 4u;
+    }
+    __device__ __forceinline__ void push(uint32_t v)
+    {
+        ring[off & (kRing - 1)] = v;
+        off++;
+    }
+    __device__ __forceinline__ void flush_groups()
+    {
+        while (__builtin_amdgcn_ballot_w64((flushed & (kGroup - 1)) != 0 && flushed < off)) {      // up to the first group boundary
+            if ((flushed & (kGroup - 1)) != 0 && flushed < off) {
+                group_at(flushed)[flushed & 3u] = ring[flushed & (kRing - 1)];
+                flushed++;
+            }
+        }
+        while (__builtin_amdgcn_ballot_w64((flushed & (kGroup - 1)) == 0 && flushed + kGroup <= off)) {
+            if ((flushed & (kGroup - 1)) == 0 && flushed + kGroup <= off) {
+                *reinterpret_cast<uint4 *>(group_at(flushed)) = *reinterpret_cast<const uint4 *>(ring + (flushed & (kRing - 1)));
+                flushed += kGroup;
+            }
+        }
+    }
+    __device__ __forceinline__ void flush_all()
+    {
+        flush_groups();
+        for (uint32_t i = flushed; i < off; i++) group_at(i)[i & 3u] = ring[i & (kRing - 1)];
+        flushed = off;
+    }
+};
+static_assert(BlkRing::kGroup - 1 + kFlushEvery / 2 <= BlkRing::kRing, "block ring: a block takes two symbols at least, the ring is flushed every kFlushEvery symbols");
+
+struct EmitSink {
+    LaneRing<kAcGroup, true> ac_ring;   // index = entry index in the lane's column
+    BlkRing blk_ring;                   // index = head room + label of the block
+    uint32_t blk_bits;                  // the current block's label, placed as in coef_entry, + 63 << 16 (see StreamSink)
+    uint32_t bad_pos, bad_lbl;
+    __device__ __forceinline__ void dc(uint32_t, int v) { blk_ring.push((uint32_t(v) & 0xffffu) | (ac_ring.off << 16)); }
+    __device__ __forceinline__ void ac(uint32_t, uint32_t r_scaled, int v) { ac_ring.push((uint32_t(v) & 0xffffu) | (blk_bits - r_scaled)); }
+    __device__ __forceinline__ void block_done(uint32_t) { blk_bits += 1u << 22; }
+    __device__ __forceinline__ void bad_code(uint32_t b, uint32_t pos) { if (bad_pos == 0xffffffffu) { bad_pos = pos; bad_lbl = b; } }
+    __device__ __forceinline__ void tick() const {}
+    __device__ __forceinline__ void flush_groups() { ac_ring.flush_groups(); blk_ring.flush_groups(); }
+    __device__ __forceinline__ void flush_step(uint32_t) { ac_ring.flush_groups(); blk_ring.flush_groups(); }
+    __device__ __forceinline__ void flush_entries() { ac_ring.flush_groups(); }
+    __device__ __forceinline__ void flush_dc(uint32_t) { blk_ring.flush_groups(); }
+    __device__ __forceinline__ void flush() { ac_ring.flush_groups(); blk_ring.flush_all(); }
+};
+
+extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_emit(const DevImage *images, const uint8_t *scan_pool,
+                                                               const LutEntry *lut_pool, SubseqState *g_entry, SubseqState *g_exit,
+                                                               uint32_t *g_cps, EmitSub *g_esub, uint32_t *entries, uint32_t win_off)
+{
+    extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, windows, rings
+    uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
+    const uint32_t img = entropy_grid_image(), wgi = entropy_grid_wg();
+    const DevImage &im = images[img];
+    if (!im.valid || !im.emit || wgi * kHuffWg >= im.himg.nsub) return;
+    const HuffImage *h;
+    const LutEntry *lut;
+    stage_tables(im, lut_pool, smem, h, lut);
+    const uint32_t s = wgi * kHuffWg + threadIdx.x;
+    const bool live = s < h->nsub;
+    const uint32_t sl = live ? s : 0u, L = h->sub_bits;
+    const uint32_t start = sl * L, end = min(start + L, h->total_bits);
+    uint32_t *my_win = s_win + threadIdx.x * kWinStride;
+    // ---- warm-up over the end of the subsequence in front (its column of the pool), counting only
+    SubseqState e0 = make_state(0, 0, 0);
+    const uint32_t W = h->warm_bits;
+    if (W) {                                                                        // (uniform over the launch)
+        const bool warm = live && s > 0;
+        const LaneBits prev{scan_pool + im.scan_off, (warm ? s - 1u : 0u) * 16u, im.scan_cols * 16u};
+        NullSink ns;
+        NoCheckpoints nocp;
+        const SubseqState w0 = make_state(L - W, 0, 0);
+        const SubseqState x = wave_decode<false, 0, false>(warm, w0, L, 0, 0xffffffffu, prev, my_win, lut, *h, ns, nocp, 0u, w0);
+        if (warm) e0 = make_state(x.p - L, x.z, x.c);
+    }
+    // ---- the subsequence itself, once, emitting
+    const LaneBits gbits{scan_pool + im.scan_off, sl * 16u, im.scan_cols * 16u};
+    const uint32_t H = im.emit_head * 8u, Hb = im.emit_head * 4u;
+    uint32_t *column = entries + im.ent_off + im.ent_hdr + stream_phys(sl, 0, im.ent_rows);
+    EmitSink sink;
+    {
+        uint32_t *rings = s_win + kHuffWg * kWinStride;
+        sink.ac_ring.begin(rings + threadIdx.x * kAcRingStride, column, H);
+        sink.ac_ring.gstride = kAcGroup * kStreamQuad;
+        rings += kHuffWg * kAcRingStride;
+        sink.blk_ring.begin(rings + threadIdx.x * BlkRing::kRing, column, im.ent_rows, Hb + (e0.z ? 1u : 0u));
+    }
+    sink.blk_bits = StreamSink::block_bits(0);
+    sink.bad_pos = sink.bad_lbl = 0xffffffffu;
+    GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + sl), 0};
+    SubseqState x = wave_decode<true, 1, false>(live, e0, end - start, 0, 0xffffffffu, gbits, my_win, lut, *h, sink, cps, 0u, e0);
+    sink.flush_groups();                                                   // (the rings hold one flush period, no more)
+    const uint32_t pad_to = live ? min(stream_run(sink.ac_ring.off), im.ent_rows * 8u) : 0u;
+    for (uint32_t it = 1; __builtin_amdgcn_ballot_w64(sink.ac_ring.off < pad_to); it++) {
+        if (sink.ac_ring.off < pad_to) sink.ac_ring.push(0u);              // null entries up to the group boundary
+        if (it % kFlushEvery == 0) sink.flush_groups();
+    }
+    sink.flush();
+    if (!live) return;
+    g_entry[im.sub_off + s] = make_state(e0.p + start, e0.z, e0.c);
+    x.p += start;
+    g_exit[im.sub_off + s] = x;
+    EmitSub es;
+    es.d0n = x.n; es.d0m = x.m; es.kfix = 0; es.bad = sink.bad_pos; es.bad_lbl = sink.bad_lbl; es.lbl = 0; es.pad_[0] = es.pad_[1] = 0;
+    g_esub[im.sub_off + s] = es;
+}
+
+// Fall-back: the pictures of a chunk that the single-decode kernels gave up on (flag 2) go to the two-pass kernels.  On the device, field by field: the DevImages of scans that were
+// de-stuffed there hold geometry only the device knows (k_destuff_prefix, k_restart_geometry) -- the host's copies must not
+// overwrite them.
+extern "C" __global__ void k_emit_off(DevImage *images, uint32_t nimg, const uint32_t *img_flags)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nimg || !images[i].emit || img_flags[images[i].status_idx] != 2u) return;      // (2: the picture k_huff_scan / k_huff_prefix gave up on)
+    images[i].emit = 0;
+    images[i].himg.cp_bits = uint32_t(kCpBits);
+    images[i].himg.warm_bits = 0;
+}
+
+// Direct sink of k_huff_prefix: few lanes, short runs -- dword stores.
+struct PrefixSink {
+    uint32_t *column;
+    uint32_t rows, eoff, e_hi;   // next entry index; the prefix must end exactly at e_hi
+    uint32_t blk_bits;           // label of the current block as in coef_entry + 63 << 16
+    uint32_t bword0;             // block word index of label 0 of this decode
+    uint32_t blk0, total_blocks; // the decode's first block in the picture
+    int *status;
+    bool over;
+    __device__ __forceinline__ uint32_t *at(uint32_t j) const { return column + (j >> 3) * (8u * kStreamQuad) + (j & 7u); }
+    __device__ __forceinline__ void dc(uint32_t b, int v) { *at(block_word_index(bword0 + b, rows)) = (uint32_t(v) & 0xffffu) | (eoff << 16); }
+    __device__ __forceinline__ void ac(uint32_t, uint32_t r_scaled, int v)
+    {
+        if (eoff < e_hi) *at(eoff) = (uint32_t(v) & 0xffffu) | (blk_bits - r_scaled);
+        else over = true;
+        eoff++;
+    }
+    __device__ __forceinline__ void block_done(uint32_t) { blk_bits += 1u << 22; }
+    __device__ __forceinline__ void bad_code(uint32_t b, uint32_t) const { if (blk0 + b < total_blocks) atomicOr(status, 1); }
+    __device__ __forceinline__ void tick() const {}
+};
+
+constexpr uint32_t kPrefixWg = 64;           // one wave: it holds the tables and a window per lane, and leaves when its own items are done
+extern "C" __global__ __launch_bounds__(kPrefixWg) void k_huff_prefix(const DevImage *images, const uint8_t *scan_pool,
+                                                                    const LutEntry *lut_pool, const SubseqState *g_entry,
+                                                                    const SubseqState *g_exit, const uint32_t *g_cps, EmitSub *g_esub,
+                                                                    const uint32_t *g_blkbase, uint32_t *entries, int *status,
+                                                                    uint32_t *img_flags, uint32_t *fallback, uint32_t win_off,
+                                                                    const uint32_t *g_items, const uint32_t *g_item_count)
+{
+    extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, a window per lane
+    uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
+    const uint32_t img = blockIdx.x, group = blockIdx.y;
+    const DevImage &im = images[img];
+    if (!im.valid || !im.emit || img_flags[im.status_idx]) return;
+    const uint32_t count = g_item_count[img];
+    if (group * kPrefixWg >= count) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t L = im.himg.sub_bits, total_blocks = im.himg.total_blocks, cpb = im.himg.cp_bits;
+    const uint32_t H = im.emit_head * 8u, Hb = im.emit_head * 4u, rows = im.ent_rows;
+    uint32_t *runs = entries + im.ent_off;
+    uint32_t *columns = entries + im.ent_off + im.ent_hdr;
+    const bool need = group * kPrefixWg + tid < count;
+    const uint32_t item = need ? (g_items + size_t(im.sub_off) * kItemDwords)[group * kPrefixWg + tid] : 0u;
+    const uint32_t s = item & ((1u << kItemShift) - 1u), k = item >> kItemShift;
+    const HuffImage *h;
+    const LutEntry *lut;
+    stage_tables(im, lut_pool, smem, h, lut);                              // (barriers inside: every lane of the workgroup comes here)
+    if (!need) return;
+    const EmitSub es = g_esub[im.sub_off + s];
+    const SubseqState e = g_entry[im.sub_off + s], x = g_exit[im.sub_off + s];
+    const uint32_t B = g_blkbase[im.sub_off + s];
+    const uint32_t sub_start = s * L, end_rel = min(sub_start + L, h->total_bits) - sub_start;
+    const GlobalCps cps{reinterpret_cast<unsigned char *>(const_cast<uint32_t *>(g_cps)), cps_byte_off(im.sub_off + s), 0};
+    // the subsequence's prefix: where it ends (the merge point) and what the first decode had counted there
+    const uint32_t nint = prefix_intervals(im, s, es.kfix);
+    uint32_t n0r = 0, m0r = 0, recK = 0;
+    if (es.kfix != kEmitAll) {
+        const CpPair cp = cps.get_pair(es.kfix - 1u);                      // the first decode's record there: still its own (see merge_finish)
+        recK = cp.w;
+        n0r = (cp.w >> 16) & 0x7fffu;
+        m0r = cp.m;
+    }
+    const uint32_t n0K = es.d0n - n0r, j0K = es.d0m - m0r, n_p = x.n - n0r, m_p = x.m - m0r;
+    // head room: the prefix ends where the valid part of the first decode begins
+    // (why a picture fell back, for MJX_TIMING: 1 no head room, 2 counts of the first decode / the merge rounds do not fit together,
+    // 4 a record of the true path is missing, 8 the item did not end in the recorded state, 16 ... with the recorded counts,
+    // 32 it ran past the prefix's end; k_huff_scan: 64 more items than the list holds)
+    uint32_t why = 0;
+    if (m_p > H + j0K || n_p > Hb + n0K) why |= 1u;
+    if (x.n < n0r || x.m < m0r || es.d0n < n0r || es.d0m < m0r || k >= nint) why |= 2u;
+    bool failed = why != 0;
+    const uint32_t off_e = H + j0K - m_p;
+    const int32_t lbl = int32_t(n0K) - int32_t(n_p);
+    uint32_t *column = columns + stream_phys(s, 0, rows);
+    // this item: the true path from checkpoint k - 1 (the entry for k == 0) to checkpoint k (the merge point / the end for the last one)
+    uint32_t p, zc, n_start = 0, m_start = 0;
+    if (k == 0) {
+        p = e.p - sub_start;
+        zc = e.z | (uint32_t(e.c) << 8);
+        if (e.p < sub_start) { failed = true; why |= 2u; }
+    } else {
+        const CpPair cp = cps.get_pair(k - 1u);                            // recorded by the merge rounds on the true path, counts to the end of the subsequence
+        const uint32_t nbn = (cp.w >> 12) & 0xfu, c1 = (nbn ? nbn : h->bpm) - 1u;
+        p = 8u * (wn_after(k * cpb) - 8u) - (cp.w & 31u);
+        zc = (64u - ((cp.w >> 5) & 0x7fu)) | (((c1 ? c1 : h->bpm) - 1u) << 8);
+        n_start = x.n - ((cp.w >> 16) & 0x7fffu);
+        m_start = x.m - cp.m;
+        if (!(cp.w & kCpValid) || ((cp.w >> 16) & 0x7fffu) > x.n || cp.m > x.m) { failed = true; why |= 4u; }
+    }
+    const bool last = k + 1u == nint;
+    const uint32_t stop_rel = last ? (es.kfix == kEmitAll ? end_rel : es.kfix * cpb) : (k + 1u) * cpb;
+    if (!failed) {
+        PrefixSink sink;
+        sink.column = column;
+        sink.rows = rows;
+        sink.eoff = off_e + m_start;
+        sink.e_hi = H + j0K;
+        sink.blk_bits = StreamSink::block_bits(uint32_t(lbl) + n_start);
+        sink.bword0 = uint32_t(int32_t(Hb) + lbl);
+        sink.blk0 = B;
+        sink.total_blocks = total_blocks;
+        sink.status = status + im.status_idx;
+        sink.over = false;
+        if (k == 0) for (uint32_t j = off_e & ~7u; j < off_e; j++) *sink.at(j) = 0u;   // null entries in front of the run's first entry
+        uint32_t n = n_start;
+        uint32_t matched_word = 0;
+        if (p <= end_rel) {
+            const uint32_t end_wn = wn_after(end_rel), last_wn = min(wn_after(stop_rel), end_wn);
+            uint32_t *my_win = s_win + tid * kMergeStride;
+            const LaneBits bits{scan_pool + im.scan_off, s * 16u, im.scan_cols * 16u};
+            for (uint32_t q = p / uint32_t(kCpBits);; q++) {                // slices of kCpBits bits, a window of four pieces each (as merge_slice)
+                const uint32_t wi1 = (p + 31u) >> 5, wbase = (wi1 ? 4u * wi1 - 4u : 0u) & ~15u;
+#pragma unroll
+                for (int i = 0; i < kMergeWin / 4; i++) {
+                    const uint4 v = bits.piece((wbase >> 4) + i);
+                    my_win[4 * i] = __builtin_bswap32(v.x);
+                    my_win[4 * i + 1] = __builtin_bswap32(v.y);
+                    my_win[4 * i + 2] = __builtin_bswap32(v.z);
+                    my_win[4 * i + 3] = __builtin_bswap32(v.w);
+                }
+                LdsWindow win{reinterpret_cast<const unsigned char *>(my_win), wbase, 0u};
+                LaneState st;
+                lane_begin(st, win, *h, make_state(p, zc & 0xffu, zc >> 8));
+                win.rp = uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)(my_win))) + (st.wn - 4u - wbase);
+                st.n = n;
+                uint32_t blk = n;
+                const uint32_t stop_wn = min(wn_after((q + 1u) * uint32_t(kCpBits)), last_wn);
+                while (st.wn < stop_wn) (void)symbol_step<true, false>(st, win, lut, *h, blk, sink);
+                n = st.n;
+                p = lane_pos(st);
+                zc = lane_z(st) | (lane_c(st, *h) << 8);
+                if (st.wn >= last_wn) {
+                    matched_word = cp_state_word(st);
+                    break;
+                }
+            }
+        }
+        // the item must end where the records say the true path is: at an inner checkpoint the merge rounds' record, at the merge
+        // point the first decode's -- state and counts
+        if (last && es.kfix == kEmitAll) {
+            if (sink.eoff != H + j0K || n != n_p) why |= 16u;
+        } else {
+            const CpPair want = last ? CpPair{recK, m0r} : cps.get_pair(k);
+            if ((want.w & kCpStateMask) != matched_word) why |= 8u;
+            if (n != x.n - ((want.w >> 16) & 0x7fffu) || sink.eoff != off_e + (x.m - want.m)) why |= 16u;
+        }
+        if (sink.over) why |= 32u;
+        failed = why != 0;
+    }
+    if (failed) {
+        // no room in front of the first decode's entries (or an inconsistency): the picture is decoded by the two-pass kernels instead
+        img_flags[im.status_idx] = 2u;
+        atomicOr(fallback, why ? why : 128u);
+        return;
+    }
+    if (k != 0) return;
+    // (the subsequence's first item also leaves its run word, its label offset, and the verdict on what the first decode could not decode)
+    runs[s] = run_word(off_e >> 3, (H + es.d0m + 7u) >> 3, (B - uint32_t(lbl)) & 0xffu);
+    g_esub[im.sub_off + s].lbl = lbl;
+    if (es.bad != 0xffffffffu && es.kfix != kEmitAll) {
+        // an invalid bit pattern the first decode met: it counts if it lies on the part of that decode that stays (at or behind the merge point)
+        const uint32_t pK = 8u * (wn_after(es.kfix * cpb) - 8u) - (recK & 31u);
+        if (es.bad >= pK && int64_t(B) + int64_t(es.bad_lbl) - lbl < int64_t(total_blocks)) atomicOr(status + im.status_idx, 1);
+    }
+}
+
+// The block words of every subsequence's run -> DC differences in the picture's block order, and the offsets of the stage-B tiles
+// whose first block starts in it.  A workgroup takes kGatherSubs consecutive subsequences: their records are staged in LDS with
+// coalesced loads (a wave that fetched its own subsequence's records one dependent load after the other spent its time waiting:
+// 1.6 ms per 2048 4K pictures), then every wave walks its share -- one block word per lane and step.
+constexpr uint32_t kGatherSubs = 64;
+extern "C" __global__ __launch_bounds__(256) void k_block_gather(const DevImage *images, const SubseqState *g_entry, const SubseqState *g_exit,
+                                                                  const EmitSub *g_esub, const uint32_t *g_blkbase, uint32_t *entries,
+                                                                  int16_t *dcdiff, uint32_t *tile_eoff, const uint32_t *img_flags, int *status)
+{
+    __shared__ uint32_t s_B[kGatherSubs], s_n[kGatherSubs], s_d0m[kGatherSubs];
+    __shared__ int32_t s_lbl[kGatherSubs];
+    __shared__ uint8_t s_fs[kGatherSubs + 1], s_exz[kGatherSubs];
+    const uint32_t img = blockIdx.x;
+    const DevImage &im = images[img];
+    const uint32_t s0 = blockIdx.y * kGatherSubs, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (!im.valid || !im.emit || s0 >= im.himg.nsub || img_flags[im.status_idx]) return;
+    const uint32_t nsub = im.himg.nsub, total_blocks = im.himg.total_blocks, rows = im.ent_rows, cap = rows * 8u;
+    const uint32_t Hb = im.emit_head * 4u, H = im.emit_head * 8u;
+    if (tid <= kGatherSubs && s0 + tid < nsub) s_fs[tid] = g_entry[im.sub_off + s0 + tid].z ? 1 : 0;
+    if (tid < kGatherSubs && s0 + tid < nsub) {
+        const uint32_t s = s0 + tid;
+        const SubseqState ex = g_exit[im.sub_off + s];
+        const EmitSub es = g_esub[im.sub_off + s];
+        const uint32_t B0 = g_blkbase[im.sub_off + s];
+        s_B[tid] = B0;
+        s_n[tid] = ex.n;
+        s_exz[tid] = ex.z ? 1 : 0;
+        s_lbl[tid] = es.lbl;
+        s_d0m[tid] = es.d0m;
+        if (es.kfix == 0) {
+            // the lane's entry was right: its run is what k_huff_emit wrote, its labels count from the first block of the subsequence
+            // (the others' run words: k_huff_prefix)
+            (entries + im.ent_off)[s] = run_word(H >> 3, (H + es.d0m + 7u) >> 3, B0 & 0xffu);
+            if (es.bad != 0xffffffffu && B0 + es.bad_lbl < total_blocks) atomicOr(status + im.status_idx, 1);
+        }
+    }
+    __syncthreads();
+    int16_t *dc = dcdiff + im.coef_off;
+    uint32_t *eoff = tile_eoff + im.tile_off;
+    const uint32_t tb = im.tile_blocks, ntiles = (total_blocks + tb - 1) / tb;
+    const uint32_t tb_inv = uint32_t(0xffffffffu / tb) + 1u;                 // a / tb == mulhi(a, tb_inv) while a * tb < 2^32
+    const bool exact_inv = uint64_t(total_blocks + 1u) * tb < (uint64_t(1) << 32) && tb > 1u;
+    constexpr uint32_t per_wave = kGatherSubs / 4;
+    // Software pipeline over the wave's subsequences: the block words of subsequence i + 1 are requested before those of
+    // subsequence i are stored (four words per lane each: a subsequence of the bench holds ~210 blocks, one round of 256; longer
+    // ones take further rounds in place), so that a wave does not sit out a memory round trip per subsequence.
+    struct Sub { uint32_t s, B0, a_end, first; int32_t lbl; const uint32_t *column; bool live; };
+    auto describe = [&](uint32_t i) {
+        Sub d;
+        const uint32_t t = wave * per_wave + i;
+        d.s = s0 + t;
+        d.live = i < per_wave && d.s < nsub;
+        const uint32_t tt = d.live ? t : 0u;
+        d.B0 = s_B[tt];
+        const uint32_t B1 = d.B0 + s_n[tt], fs1 = d.s + 1 < nsub ? s_fs[tt + 1] : s_exz[tt];
+        d.first = d.B0 + s_fs[tt];
+        d.a_end = d.live ? min(B1 + fs1, total_blocks + 1u) : 0u;
+        d.lbl = s_lbl[tt];
+        d.column = entries + im.ent_off + im.ent_hdr + stream_phys(d.live ? d.s : 0u, 0, rows);
+        // the scan ends with the picture's last block: the last tile ends where the last subsequence's run does
+        if (d.live && d.s == nsub - 1 && lane == 0 && B1 + fs1 <= total_blocks) eoff[ntiles] = d.s * cap + H + s_d0m[tt];
+        return d;
+    };
+    auto fetch = [&](const Sub &d, uint32_t a0, uint32_t w[4]) {
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            const uint32_t a = a0 + 64u * q;
+            const uint32_t j = block_word_index(uint32_t(int32_t(Hb + (a - d.B0)) + d.lbl), rows);
+            w[q] = a < d.a_end ? d.column[(j >> 3) * (8u * kStreamQuad) + (j & 7u)] : 0u;
+        }
+    };
+    auto place = [&](const Sub &d, uint32_t a0, const uint32_t w[4]) {
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            const uint32_t a = a0 + 64u * q;
+            if (a >= d.a_end) continue;
+            if (a < total_blocks) dc[a] = int16_t(w[q] & 0xffffu);
+            const uint32_t tl = exact_inv ? __umulhi(a, tb_inv) : a / tb;      // (exact while block index x tile size < 2^32)
+            if (a == total_blocks) eoff[ntiles] = d.s * cap + (w[q] >> 16);
+            else if (tl * tb == a) eoff[tl] = d.s * cap + (w[q] >> 16);
+        }
+    };
+    Sub cur = describe(0);
+    uint32_t wc[4];
+    fetch(cur, cur.first + lane, wc);
+    for (uint32_t i = 0; i < per_wave; i++) {
+        if (!cur.live) break;
+        const Sub nxt = describe(i + 1);
+        uint32_t wn[4];
+        fetch(nxt, nxt.first + lane, wn);
+        place(cur, cur.first + lane, wc);
+        for (uint32_t a0 = cur.first + lane + 256u; a0 < cur.a_end; a0 += 256u) {      // (a subsequence of more than 256 blocks)
+            uint32_t wm[4];
+            fetch(cur, a0, wm);
+            place(cur, a0, wm);
+        }
+        cur = nxt;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) wc[q] = wn[q];
+    }
 }
 
 // Multi-scan pictures (beyond the reference, which stops after the first scan).  Every scan went through
@@ -1966,11 +2440,12 @@ struct QuadFetch {
     uint32_t ncells;                                    // the tile's groups
     uint32_t ent[R][8];
     uint32_t k_lo[R], k_hi[R];
+    uint32_t lab[R];                                    // label offset of the group's subsequence (run_label)
     int32_t dc;
 };
 // group `o` of the tile: loads it and says which of its entries are the tile's; returns the tile's groups
 __device__ __forceinline__ uint32_t quad_load(const uint32_t *__restrict__ src, const QuadView &q, uint32_t k, uint32_t o,
-                                              uint32_t *ent, uint32_t &k_lo, uint32_t &k_hi)
+                                              uint32_t *ent, uint32_t &k_lo, uint32_t &k_hi, uint32_t &lab)
 {
     QuadCell cell;
     const uint32_t total = quad_cell(q, k, o, cell);
@@ -1984,6 +2459,7 @@ __device__ __forceinline__ uint32_t quad_load(const uint32_t *__restrict__ src, 
     ent[4] = b.x; ent[5] = b.y; ent[6] = b.z; ent[7] = b.w;
     k_lo = cell.k_lo;
     k_hi = cell.k_hi;
+    lab = cell.label;
     return total;
 }
 template <uint32_t LANES, int R>
@@ -1994,7 +2470,7 @@ __device__ __forceinline__ void tile_fetch_quad(const uint32_t *__restrict__ src
     static_assert(kAcGroup == 8, "the stream's store groups are 32 bytes");
     const uint32_t tid = threadIdx.x;
 #pragma unroll
-    for (int r = 0; r < R; r++) f.ncells = quad_load(src, q, k, tid + LANES * r, f.ent[r], f.k_lo[r], f.k_hi[r]);
+    for (int r = 0; r < R; r++) f.ncells = quad_load(src, q, k, tid + LANES * r, f.ent[r], f.k_lo[r], f.k_hi[r], f.lab[r]);
     const uint32_t blk = tile * tile_blocks + tid;
     f.dc = (tid < tile_blocks && blk < total_blocks) ? __builtin_nontemporal_load(dc + blk) : 0;
 }
@@ -2013,7 +2489,7 @@ __device__ __forceinline__ void settle(QuadFetch<R> &f)
     for (int r = 0; r < R; r++) {
 #pragma unroll
         for (int k = 0; k < 8; k++) asm volatile("" : "+v"(f.ent[r][k]));
-        asm volatile("" : "+v"(f.k_lo[r]), "+v"(f.k_hi[r]));
+        asm volatile("" : "+v"(f.k_lo[r]), "+v"(f.k_hi[r]), "+v"(f.lab[r]));
     }
     asm volatile("" : "+v"(f.dc), "+v"(f.ncells));
 }
@@ -2414,7 +2890,7 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
         s_eoff[tid] = v;
     }
     __syncthreads();
-    const QuadView qv{s_eoff, s_at, s_cum, reinterpret_cast<const uint16_t *>(entries + im.ent_off), im.ent_rows, im.himg.nsub};
+    const QuadView qv{s_eoff, s_at, s_cum, entries + im.ent_off, im.ent_rows, im.himg.nsub};
     if constexpr (QUAD) {
         if (tid < tile1 - tile0) s_cum[tid] = quad_prepare(qv, tid);
         __syncthreads();
@@ -2468,14 +2944,15 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
                 for (int r = 0; r < QR; r++) {
                     if (cur.ncells > wave0 + LANES * r) {                                    // uniform over the wave
                         quad_mask(cur.ent[r], cur.k_lo[r], cur.k_hi[r]);
-                        scatter_batch<MODE, 8>(cur.ent[r], first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+                        // (the labels of the group's entries + its subsequence's label offset = the blocks' indices in the picture, mod 256)
+                        scatter_batch<MODE, 8>(cur.ent[r], first_lo - cur.lab[r], nblk, tile_f, s_qm, s_nat, s_comp);
                     }
                 }
                 for (uint32_t h0 = LANES * QR; h0 < cur.ncells; h0 += LANES) {
-                    uint32_t more[8], k_lo, k_hi;
-                    quad_load(src, qv, tile - tile0, h0 + tid, more, k_lo, k_hi);
+                    uint32_t more[8], k_lo, k_hi, lab;
+                    quad_load(src, qv, tile - tile0, h0 + tid, more, k_lo, k_hi, lab);
                     quad_mask(more, k_lo, k_hi);
-                    scatter_batch<MODE, 8>(more, first_lo, nblk, tile_f, s_qm, s_nat, s_comp);
+                    scatter_batch<MODE, 8>(more, first_lo - lab, nblk, tile_f, s_qm, s_nat, s_comp);
                 }
             } else {
                 // The prefetched words the wave really has (a tile of the bench content holds ~1500 entries, 5.9 per lane; at quality
@@ -2613,6 +3090,8 @@ int configure_kernels(size_t huff_lds, size_t idct_lds)
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_merge), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_merge_loop), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_write), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_emit), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_prefix), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     }
     if (e == hipSuccess && idct_lds > 64 * 1024) {
         const void *fns[] = {reinterpret_cast<const void *>(k_idct_color<0, kPrefetch, false>), reinterpret_cast<const void *>(k_idct_color<0, 8, true>),
@@ -2661,38 +3140,68 @@ void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tab
 void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                        const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
                        uint32_t *cps, uint32_t *mismatches, uint32_t *items, uint32_t *item_count, const uint32_t *segs,
-                       const uint32_t *prev_mismatches, bool first_round)
+                       const uint32_t *prev_mismatches, bool first_round, EmitSub *esub)
 {
     // (item_count: this round's straggler counts, one per image, zeroed by the caller -- one memset for all the rounds of a chunk)
     const size_t lds = tables_lds + huff_merge_bytes() + pad_lds;
     hipLaunchKernelGGL(k_huff_merge, entropy_grid(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches, uint32_t(tables_lds), items, item_count, segs, prev_mismatches,
-                       first_round ? uint32_t(kHeadSlices) : uint32_t(MJX_LATER_HEAD_SLICES));
+                       first_round ? uint32_t(kHeadSlices) : uint32_t(MJX_LATER_HEAD_SLICES), esub);
     const size_t tail_lds = tables_lds + size_t(kTailWg) * kMergeStride * 4;
-    hipLaunchKernelGGL(k_huff_merge_tail, dim3(nimg, max_wg * (kMergeWg / kTailWg)), dim3(kTailWg), tail_lds, st, images, scan_pool, lut_pool, exit_, cps, uint32_t(tables_lds), items, item_count, segs);
+    hipLaunchKernelGGL(k_huff_merge_tail, dim3(nimg, max_wg * (kMergeWg / kTailWg)), dim3(kTailWg), tail_lds, st, images, scan_pool, lut_pool, exit_, cps, uint32_t(tables_lds), items, item_count, segs, esub);
 }
 
 void launch_huff_merge_loop(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                             const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
                             uint32_t *cps, uint32_t *verdict, const uint32_t *segs, uint32_t *ctl, uint32_t participants, uint32_t max_rounds,
-                            uint32_t spin_limit)
+                            uint32_t spin_limit, EmitSub *esub)
 {
     const size_t lds = tables_lds + huff_merge_bytes() + pad_lds;
-    hipLaunchKernelGGL(k_huff_merge_loop, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, verdict, uint32_t(tables_lds), segs, ctl, participants, max_rounds, spin_limit);
+    hipLaunchKernelGGL(k_huff_merge_loop, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, verdict, uint32_t(tables_lds), segs, ctl, participants, max_rounds, spin_limit, esub);
+}
+
+void launch_emit_off(hipStream_t st, DevImage *images, uint32_t nimg, const uint32_t *img_flags)
+{
+    if (nimg) hipLaunchKernelGGL(k_emit_off, dim3((nimg + 255) / 256), dim3(256), 0, st, images, nimg, img_flags);
+}
+
+size_t huff_prefix_bytes() { return size_t(kPrefixWg) * kMergeStride * 4; }     // k_huff_prefix: a window per lane
+
+void launch_huff_emit(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
+                      const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_, uint32_t *cps,
+                      EmitSub *esub, uint32_t *entries)
+{
+    const size_t lds = tables_lds + huff_window_bytes() + huff_stage_bytes() + pad_lds;
+    hipLaunchKernelGGL(k_huff_emit, entropy_grid(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, esub, entries, uint32_t(tables_lds));
+}
+
+void launch_huff_prefix(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, const DevImage *images,
+                        const uint8_t *scan_pool, const LutEntry *lut_pool, const SubseqState *entry, const SubseqState *exit_,
+                        const uint32_t *cps, EmitSub *esub, const uint32_t *blkbase, uint32_t *entries, int *status, uint32_t *img_flags,
+                        uint32_t *fallback, int16_t *dcdiff, uint32_t *tile_eoff, const uint32_t *items, const uint32_t *item_count)
+{
+    // (the picture is the fast grid dimension, as in the other entropy kernels; a wave per 64 listed items -- the grid is sized for
+    // the list's capacity, the waves beyond a picture's count leave at once)
+    const uint32_t groups = max_wg * (kHuffWg / kPrefixWg) * kItemDwords;     // (the list's capacity; a picture of the bench has ~270 items: five waves)
+    hipLaunchKernelGGL(k_huff_prefix, dim3(nimg, groups), dim3(kPrefixWg), tables_lds + huff_prefix_bytes(), st, images, scan_pool, lut_pool, entry, exit_, cps, esub,
+                       blkbase, entries, status, img_flags, fallback, uint32_t(tables_lds), items, item_count);
+    hipLaunchKernelGGL(k_block_gather, dim3(nimg, (max_wg * kHuffWg + kGatherSubs - 1) / kGatherSubs), dim3(256), 0, st, images, entry, exit_, esub, blkbase,
+                       const_cast<uint32_t *>(entries), dcdiff, tile_eoff, img_flags, status);
 }
 
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,
-                      uint32_t *ebase, uint32_t *img_entries, uint32_t *img_flags, const uint32_t *segs, const uint32_t *verdict)
+                      uint32_t *ebase, uint32_t *img_entries, uint32_t *img_flags, const uint32_t *segs, const uint32_t *verdict,
+                      const EmitSub *esub, uint32_t *items, uint32_t *item_count, uint32_t *fallback)
 {
-    hipLaunchKernelGGL(k_huff_scan, dim3(nimg), dim3(kWgLanes), 0, st, images, exit_, blkbase, ebase, img_entries, img_flags, segs, verdict);
+    hipLaunchKernelGGL(k_huff_scan, dim3(nimg), dim3(kWgLanes), 0, st, images, exit_, blkbase, ebase, img_entries, img_flags, segs, verdict, esub, items, item_count, fallback);
 }
 
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                        const uint8_t *scan_pool, const LutEntry *lut_pool, const SubseqState *entry,
                        const uint32_t *blkbase, const uint32_t *ebase, uint32_t *entries, uint32_t *tile_eoff,
-                       int16_t *dcdiff, int *status, const uint32_t *img_flags, const uint32_t *segs, const SubseqState *exit_)
+                       int16_t *dcdiff, int *status, const uint32_t *img_flags, const uint32_t *segs, const SubseqState *exit_, uint32_t *cps)
 {
     const size_t lds = tables_lds + huff_window_bytes() + huff_stage_bytes() + pad_lds;
-    hipLaunchKernelGGL(k_huff_write, entropy_grid(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, blkbase, ebase, entries, tile_eoff, dcdiff, status, img_flags, uint32_t(tables_lds), segs, exit_);
+    hipLaunchKernelGGL(k_huff_write, entropy_grid(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, blkbase, ebase, entries, tile_eoff, dcdiff, status, img_flags, uint32_t(tables_lds), segs, exit_, cps);
 }
 
 void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, const int16_t *dcd, int32_t *dcbuf,

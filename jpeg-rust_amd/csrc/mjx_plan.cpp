@@ -208,6 +208,7 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p, bool 
         p.himg.bpm = p.bpm;
         p.himg.total_blocks = p.nmcu * p.bpm;
         p.himg.sub_bits = kSubseqBits;
+        p.himg.cp_bits = uint32_t(kCpBits);
         p.nseg = 1;
         p.seg = {0u, 0u, 0u, 0u};
         for (uint32_t c = 0; c < p.ncomp; c++) {
@@ -288,6 +289,8 @@ int plan_image(const mjx_scan_desc &d, const mjx_opts &opts, ImagePlan &p, bool 
         p.himg.tabs_pair[b] = uint32_t(dc_base2[k.td]) * uint32_t(sizeof(LutEntry)) | (uint32_t(ac_base2[k.ta]) * uint32_t(sizeof(LutEntry)) << 16);
     }
     p.himg.bpm = p.bpm;
+    p.himg.cp_bits = uint32_t(kCpBits);            // (build_batch widens it for the pictures whose first decode emits)
+    p.himg.warm_bits = 0;
     p.himg.total_bits = uint32_t(p.scan_len * 8);
     p.himg.total_blocks = p.nmcu * p.bpm;
     p.restart_mcus = d.restart_interval;

@@ -503,12 +503,18 @@ def test_small_batches_with_short_subsequences_equal_the_long_ones(mjx, orc, tmp
         "    print(100 + i, b.geometry()['subsequences'], hashlib.sha256(b.coefs(j).tobytes()).hexdigest(), hashlib.sha256(b.rgb(j).tobytes()).hexdigest())\n"
         "b.close()\n" % (ROOT, ROOT))
     outs = []
-    switches = ("MJX_LATENCY_NSUB", "MJX_MEDIUM_NSUB", "MJX_MERGE_LOOP", "MJX_LATENCY_SUB_BITS", "MJX_DC_ONE_PASS", "MJX_STREAMS", "MJX_HOST_INTERLEAVE")
+    switches = ("MJX_LATENCY_NSUB", "MJX_MEDIUM_NSUB", "MJX_MERGE_LOOP", "MJX_LATENCY_SUB_BITS", "MJX_DC_ONE_PASS", "MJX_STREAMS", "MJX_HOST_INTERLEAVE",
+                "MJX_SINGLE_DECODE", "MJX_EMIT_MIN_SUB_BITS", "MJX_EMIT_HEAD", "MJX_EMIT_WARM_BITS", "MJX_EMIT_CP_BITS")
     base_env = {k: v for k, v in os.environ.items() if k not in switches}
     # every runtime switch of the small-batch path and of the DC prediction: the bytes must not depend on any of them
     variants = ({}, {"MJX_LATENCY_NSUB": "0", "MJX_MEDIUM_NSUB": "0"}, {"MJX_MERGE_LOOP": "0"}, {"MJX_DC_ONE_PASS": "0"},
                 {"MJX_LATENCY_SUB_BITS": "1024"}, {"MJX_STREAMS": "1"},
-                {"MJX_HOST_INTERLEAVE": "0"})       # (the scan pool laid out by k_scan_interleave instead of by the host: the same bytes)
+                {"MJX_HOST_INTERLEAVE": "0"},       # (the scan pool laid out by k_scan_interleave instead of by the host: the same bytes)
+                # single decode (round 5): off; for every picture of one scan, whatever its subsequences' length; the same with no
+                # warm-up, a checkpoint every 256 bits and NO head room -- prefixes that grow hand their pictures to the two-pass kernels
+                {"MJX_SINGLE_DECODE": "0"}, {"MJX_EMIT_MIN_SUB_BITS": "256"},
+                {"MJX_EMIT_MIN_SUB_BITS": "256", "MJX_EMIT_WARM_BITS": "0", "MJX_EMIT_CP_BITS": "256", "MJX_EMIT_HEAD": "0"},
+                {"MJX_LATENCY_NSUB": "0", "MJX_MEDIUM_NSUB": "0", "MJX_EMIT_WARM_BITS": "512", "MJX_EMIT_CP_BITS": "2048"})
     for env_extra in variants:
         out = subprocess.run([sys.executable, str(script)], env=dict(base_env, **env_extra), capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, str(env_extra) + out.stdout[-2000:] + out.stderr[-2000:]
@@ -603,3 +609,49 @@ def test_dc_prediction_that_never_hears_from_its_predecessor_gives_up_and_two_pa
         assert out.returncode == 0 and "dc fault ok" in out.stdout, str(extra) + out.stdout[-2000:] + out.stderr[-2000:]
         if "MJX_TIMING" in extra:
             assert "one-pass DC prediction gave up" in out.stderr, out.stderr[-2000:]
+
+
+def test_single_decode_beside_restart_pictures_and_device_destuffing(mjx, orc, tmp_path):
+    """Round-5 fuzz find (tests/golden/fuzz_r05): seven small files -- three with restart intervals, which keep the two-pass kernels,
+    beside pictures whose first decode emits -- de-stuffed on the device.  Flat pictures' prefixes out-grew the head room, and the
+    fall-back then uploaded the host's DevImages over the geometry only the device knew (lengths, restart segments): a memory fault.
+    Now the flagged pictures alone leave the single-decode path, patched on the device.  With and without head room, host- and
+    device-side de-stuffing: every picture OK, coefficients the oracle's, RGB within 1."""
+    import glob
+    import subprocess
+    files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "fuzz_r05", "mix_*.jpg")))
+    assert len(files) == 7
+    script = tmp_path / "mix.py"
+    script.write_text(
+        "import os, sys, hashlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge\n"
+        "mjx = ge.load_package()\n"
+        "ctx = mjx.Context(0)\n"
+        "files = %r\n"
+        "for dd in (True, False):\n"
+        "    scans = [mjx.ParsedScan(open(f, 'rb').read(), device_destuff=dd) for f in files]\n"
+        "    for rep in range(2):\n"
+        "        b = mjx.Batch(ctx, scans, keep_coefs=True, chunk_images=11)\n"
+        "        b.decode(); b.wait(); b.decode(); b.wait()\n"
+        "        print(int(dd), rep, [b.status(i) for i in range(len(files))], ' '.join(hashlib.sha256(b.coefs(i).tobytes() + b.rgb(i).tobytes()).hexdigest()[:16] for i in range(len(files))))\n"
+        "        b.close()\n" % (ROOT, files))
+    outs = []
+    for env_extra in ({}, {"MJX_EMIT_HEAD": "0"}, {"MJX_SINGLE_DECODE": "0"}, {"MJX_EMIT_MIN_SUB_BITS": "256", "MJX_EMIT_HEAD": "1"}):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("MJX_EMIT") and k != "MJX_SINGLE_DECODE"}
+        out = subprocess.run([sys.executable, str(script)], env=dict(env, **env_extra), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, str(env_extra) + out.stdout[-2000:] + out.stderr[-3000:]
+        lines = out.stdout.strip().splitlines()
+        assert len(lines) == 4 and all("[0, 0, 0, 0, 0, 0, 0]" in l for l in lines), (env_extra, lines)
+        outs.append([l.split("]")[1] for l in lines])
+    assert all(o == outs[0] for o in outs) and len(set(outs[0])) == 1          # the same bytes whatever the path
+    ctx = mjx.Context(0)
+    scans = [mjx.ParsedScan(open(f, "rb").read(), device_destuff=True) for f in files]
+    b = mjx.Batch(ctx, scans, keep_coefs=True)
+    b.decode(); b.wait()
+    for i, f in enumerate(files):
+        ref = orc.decode(open(f, "rb").read(), layout=orc.LAYOUT_STD, ext_dri=True, ext_1bit=True)
+        assert b.status(i) == mjx.OK and np.array_equal(b.coefs(i), orc.interleave(ref)), f
+        assert np.abs(b.rgb(i).astype(int) - ref.rgb.astype(int)).max() <= TOL, f
+    b.close()
+    ctx.close()

@@ -499,3 +499,50 @@ def test_pool_without_a_gpu_fails_loudly(mjx):
     with pytest.raises(mjx.MjxError) as e:
         mjx.Pool([0, 0])
     assert e.value.code == mjx.ERR_DEVICE
+
+
+# ---- single decode (round 5): the first decode emits ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def emul_single(mjx):
+    lib = ctypes.CDLL(os.path.join(ROOT, "tests", "emul", "libhuff_emul.so"))
+    lib.emul_single_decode_cp.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint,
+                                          ctypes.c_uint, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]
+
+    def run(data, layout=0, mode=0, sub_bits=0, warm=1024, head=32, cp_bits=1024):
+        cap = 400000
+        out = np.zeros((cap, 64), np.int16)
+        nb, st = ctypes.c_size_t(), (ctypes.c_int * 8)()
+        rc = lib.emul_single_decode_cp(data, len(data), layout, mode, sub_bits, warm, head, cp_bits, out.ctypes.data, cap, ctypes.byref(nb), st)
+        return rc, out[: nb.value].copy(), list(st)
+    return run
+
+
+@pytest.mark.parametrize("warm,cp_bits", [(0, 256), (1024, 1024), (2048, 512), (512, 2048)])
+def test_emulated_single_decode_equals_the_oracle(mjx, orc, emul_single, warm, cp_bits):
+    """The kernel sequence of the single-decode path (k_huff_emit with its warm-up, counting merge rounds that keep the merge depth,
+    k_huff_prefix right-aligning the re-decoded prefixes, k_block_gather, stage B's walk over run words with label offsets) on the
+    CPU emulation, against the oracle's coefficients: the reference's samples, synthetic pictures of every sampling, noisy content
+    that synchronises slowly, and short subsequences (sub_bits) where a warm-up spans a whole subsequence."""
+    cases = [(_read(n), 0) for n in sorted(FIXTURES)]
+    cases += [(mjx.synth_jpeg(w, h, sub, q, seed=w + h), sb) for w, h, sub, q, sb in
+              [(64, 48, "444", 75, 0), (61, 45, "420", 95, 0), (100, 60, "gray", 75, 0), (750, 595, "420", 50, 0), (1920, 1080, "420", 75, 0),
+               (1280, 720, "420", 92, 2048), (333, 217, "444", 85, 1024), (2560, 1440, "420", 60, 0)]]
+    cases.append((open(os.path.join(ROOT, "tests", "golden", "pil", "slow_sync_444_q99.jpg"), "rb").read(), 0))
+    for data, sb in cases:
+        ref = orc.interleave(orc.decode(data, layout=orc.LAYOUT_STD))
+        for mode in (0, 1):
+            rc, coefs, st = emul_single(data, 0, mode, sb, min(warm, sb) if sb else warm, 32, cp_bits)
+            assert rc == 0 and np.array_equal(coefs, ref), (len(data), sb, mode, st)
+
+
+def test_emulated_single_decode_reports_a_prefix_without_head_room(mjx, orc, emul_single):
+    """With no head room in front of the first decode's entries a prefix that has more entries than the wrong one it replaces
+    cannot be written: the emulation must say so (the device hands such a picture to the two-pass kernels), never write out of
+    its run."""
+    data = mjx.synth_jpeg(1920, 1080, "420", 75, seed=5)
+    ref = orc.interleave(orc.decode(data, layout=orc.LAYOUT_STD))
+    rc, coefs, st = emul_single(data, warm=0, head=0, cp_bits=256)
+    assert (rc == 0 and np.array_equal(coefs, ref)) or st[6] == 14, st
+    assert st[5] > 0 and st[6] == 14, st          # (some prefix of this picture does grow: the case is exercised)
+    rc, coefs, st = emul_single(data, warm=0, head=32, cp_bits=256)
+    assert rc == 0 and np.array_equal(coefs, ref) and st[5] <= 32 * 8

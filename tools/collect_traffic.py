@@ -12,10 +12,10 @@ With W H the script checks idct_color.write_bytes against 3*W*H*images (+-1 %) a
 import collections, csv, glob, json, sys
 
 ALIAS = {"k_huff_spec": "huff_sync", "k_huff_merge": "huff_fix", "k_huff_merge_tail": "huff_fix", "k_huff_merge_loop": "huff_fix",
-         "k_huff_scan": "huff_scan", "k_huff_write": "huff_write", "k_huff_emit": "huff_sync", "k_huff_prefix": "huff_fix",
+         "k_huff_scan": "huff_scan", "k_huff_write": "huff_write", "k_huff_emit": "huff_emit", "k_huff_prefix": "huff_prefix", "k_block_gather": "huff_prefix",
          "k_idct_color": "idct_color", "k_ref_color": "idct_color",
          "k_dc_sums_t": "dc_scan", "k_dc_apply_t": "dc_scan", "k_dc_scan_t": "dc_scan", "k_dc_sums": "dc_scan", "k_dc_apply": "dc_scan",
-         "k_dc_restart": "dc_scan", "k_dc_gather": "dc_scan", "k_planar_count": "gather", "k_planar_offsets": "gather", "k_planar_copy": "gather",
+         "k_dc_restart": "dc_scan", "k_planar_count": "gather", "k_planar_offsets": "gather", "k_planar_copy": "gather",
          "k_scan_interleave": "upload", "k_destuff_count": "upload", "k_destuff_prefix": "upload", "k_destuff_scatter": "upload",
          "k_restart_geometry": "upload"}
 

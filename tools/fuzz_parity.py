@@ -92,7 +92,7 @@ while done < total:
             os.remove(os.path.join(dump, f))
         for k, (d, what) in enumerate(items):
             open(os.path.join(dump, "%03d.jpg" % k), "wb").write(d)
-        open(os.path.join(dump, "batch.txt"), "w").write("seed %d chunk_images %d\n" % (seed, chunk) + "\n".join(str(w[:3]) for _, w in items))
+        open(os.path.join(dump, "batch.txt"), "w").write("seed %d stuffed %d chunk_images %d\n" % (seed, int(stuffed), chunk) + "\n".join(str(w[:3]) for _, w in items))
     batch = mjx.Batch(ctx, scans, keep_coefs=True, chunk_images=chunk,
                       layout=mjx.LAYOUT_REF_COMPAT if ref_layout else mjx.LAYOUT_STANDARD)
     batch.decode(); batch.wait()
