@@ -87,12 +87,15 @@ struct mjx_ctx {
     hipEvent_t stage_done[2] = {nullptr, nullptr};
     bool host_interleave = true;    // MJX_HOST_INTERLEAVE=0: linear upload + k_scan_interleave, as the groups of mjx_decode_batch do
     // Single decode (round 5, DESIGN s3.1): pictures of one scan without restart intervals, cut into subsequences of at least
-    // emit_min_sub_bits bits, are decoded ONCE by an emitting pass (k_huff_emit) whose lanes warm up over the last emit_warm_bits
+    // emit_min_sub_bits bits (the long ones), are decoded ONCE by an emitting pass (k_huff_emit) whose lanes warm up over the last emit_warm_bits
     // bits of the subsequence in front of their own and record a checkpoint every emit_cp_bits bits; MJX_SINGLE_DECODE=0: every
     // picture takes the two-pass kernels (k_huff_spec ... k_huff_write).
     bool single_decode = true;
     bool emit_merge_listed = true;  // MJX_EMIT_MERGE_LISTED=0: the first merge round of such pictures runs its head slices in place, as for the others
-    uint32_t emit_cp_bits = 1024, emit_warm_bits = 2048, emit_min_sub_bits = 4096, emit_head = kEmitHeadGroups;
+    // (emit_min_sub_bits = the long subsequences of scans of 0.79 MB and more, mjx_huff.h: with the 4096 .. 5120-bit subsequences of
+    // shorter scans the warm-up is half a subsequence -- 4096 x 1080p 15.3-16.4 ms per step at 2048 / 1024 / 512 bits of warm-up
+    // against 14.9-15.1 on the two-pass kernels, 2048 x 4K at quality 50 24.1-24.7 against 23.8 --, so those keep the two passes)
+    uint32_t emit_cp_bits = 1024, emit_warm_bits = 2048, emit_min_sub_bits = uint32_t(kLongSubseqBits), emit_head = kEmitHeadGroups;
     uint8_t *pin_small = nullptr;   // pinned block for the host mirrors of the groups' small pools (mjx_decode_batch)
     size_t pin_small_cap = 0;
     std::mutex batch_mu;            // mjx_decode_batch: one call at a time per context (the pinned arena is shared state)

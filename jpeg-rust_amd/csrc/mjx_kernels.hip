@@ -2365,6 +2365,10 @@ __device__ __forceinline__ Rgb4 pack4(const Rgb p[4])
 // streams; 16.1 -> 16.0 ms for stage B alone).  The compiler fuses the three dword stores into one global_store_dwordx3 nt.
 __device__ __forceinline__ void store_rgb4(uint8_t *dst, const Rgb4 &v)
 {
+#if defined(MJX_EXP_NO_RGB_STORE)      // (measurement build: stage B without its picture stores -- the in-CU work alone)
+    asm volatile("" :: "v"(v.a), "v"(v.b), "v"(v.c), "v"(dst));
+    return;
+#endif
     uint32_t *d = reinterpret_cast<uint32_t *>(dst);
     __builtin_nontemporal_store(v.a, d);
     __builtin_nontemporal_store(v.b, d + 1);
@@ -2549,7 +2553,11 @@ __device__ __forceinline__ void scatter_batch(const uint32_t *ent, uint32_t firs
     for (int k = 0; k < N; k++) {
         const bool ok = b[k] < nblk && pos[k] != 0;           // pos == 0 marks a null entry (the write pass fills up its runs with them)
         const uint32_t at = ok ? b[k] * uint32_t(kPixStride * 4) + nat[k] * 4u : dump;
+#if defined(MJX_EXP_NO_SCATTER_STORE)  // (measurement build, garbage out: the scatter phase without its LDS stores)
+        asm volatile("" :: "v"(at), "v"(float(int32_t(int16_t(ent[k] & 0xffffu))) * qm[k]));
+#else
         *reinterpret_cast<float *>(base + at) = float(int32_t(int16_t(ent[k] & 0xffffu))) * qm[k];
+#endif
     }
 }
 
@@ -2584,11 +2592,16 @@ __device__ __forceinline__ void idct_row_inplace(float *rowf)
         }
 #pragma unroll
     for (int j = 0; j < 4; j++) idct8(c[0][j], c[1][j], c[2][j], c[3][j], c[4][j], c[5][j], c[6][j], c[7][j]);
+#if defined(MJX_EXP_NO_WRITEBACK)      // (measurement build, garbage out: what the 16 ds_write_b128 of a block's samples cost -- the results stay "used")
+#pragma unroll
+    for (int q = 0; q < 16; q++) asm volatile("" :: "v"(c[q >> 1][2 * (q & 1)].x), "v"(c[q >> 1][2 * (q & 1)].y), "v"(c[q >> 1][2 * (q & 1) + 1].x), "v"(c[q >> 1][2 * (q & 1) + 1].y));
+#else
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         const float_pair a = c[q >> 1][2 * (q & 1)], b = c[q >> 1][2 * (q & 1) + 1];
         row[q] = make_float4(a.x, a.y, b.x, b.y);
     }
+#endif
 }
 
 // Reads 4 horizontally adjacent samples of one component for the pixel strip starting at MCU-local (x, y);
@@ -2638,7 +2651,11 @@ __device__ __forceinline__ void pixels_420(uint32_t width, uint32_t height, uint
     // for its own
     f32x4 ya[4], yb[4];
     f32x2 cb[4], cr[4];
+#if defined(MJX_EXP_PLAIN_READS)       // (measurement build, garbage out: plain reads where the exchanges with zero are, no zero-fill pass either)
+    if (false) {
+#else
     if (INTERIOR && MJX_PIX_XCHG) {
+#endif
         // An interior tile: every sample of the tile is read exactly once in this phase, by exactly one lane -- so the read is an
         // exchange with zero (ds_wrxchg), and the tile is clean for the next one's coefficients without a zero-fill pass
         // (52 KB of LDS stores and a barrier per tile).  The compiler does not track LDS operations inside asm statements, so
