@@ -1340,7 +1340,8 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
                         }
                     };
                     {
-                        const unsigned t = unsigned(std::min<size_t>(nthr, items.size()));
+                        // (a picture or a handful: one thread -- starting and joining helpers costs more than laying out 100 KB)
+                        const unsigned t = bytes < (size_t(4) << 20) ? 1u : unsigned(std::min<size_t>(nthr, items.size()));
                         std::vector<std::thread> pool;
                         for (unsigned q = 1; q < t; q++) pool.emplace_back(work);
                         work();
