@@ -1732,6 +1732,7 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
             bool fell_back = false;
             auto emit_fallback = [&]() -> int {
                 if (b->h_mismatch[ci * kMisWords + kMaxFix + 1] == 0) return MJX_OK;
+                if (std::getenv("MJX_EXP_NO_FALLBACK")) return MJX_OK;      // (measurement builds that emit garbage: time the kernels, keep the path)
                 fell_back = true;
                 if (std::getenv("MJX_TIMING")) std::fprintf(stderr, "[mjx] chunk %zu: single decode fell back (reason bits %u, see k_huff_prefix), decoding the chunk again with the two-pass kernels\n", ci, b->h_mismatch[ci * kMisWords + kMaxFix + 1]);
                 Chunk &cc = b->chunks[ci];

@@ -1331,12 +1331,16 @@ struct BlkRing {
     uint32_t *col;          // the lane's column: word j of it lies at col[(j >> 3) * 8 * kStreamQuad + (j & 7)]
     uint32_t quads;         // column capacity / 4 (block word group g lies at column index 4 * (quads - 1 - g))
     uint32_t off, flushed;  // block word indices: next, first not yet in HBM
+    // first: index of the first word that will be pushed.  The run starts on the group boundary at or below it: a word in front of
+    // `first` in that group (the slot of a block whose DC symbol lay in the subsequence before) leaves with the group as whatever the
+    // ring holds -- nobody reads it --, and the flush needs no word-by-word lead-in to the first boundary.
     __device__ __forceinline__ void begin(uint32_t *lds, uint32_t *column, uint32_t rows, uint32_t first)
     {
         ring = lds;
         col = column;
         quads = rows * 2u;
-        off = flushed = first;
+        off = first;
+        flushed = first & ~(kGroup - 1);
     }
     __device__ __forceinline__ uint32_t *group_at(uint32_t i) const
     {
@@ -1348,16 +1352,11 @@ struct BlkRing {
         ring[off & (kRing - 1)] = v;
         off++;
     }
+    // (called every kFlushEvery symbols: at most kFlushEvery / 2 words have arrived on top of the < kGroup that waited -- one group at most)
     __device__ __forceinline__ void flush_groups()
     {
-        while (__builtin_amdgcn_ballot_w64((flushed & (kGroup - 1)) != 0 && flushed < off)) {      // up to the first group boundary
-            if ((flushed & (kGroup - 1)) != 0 && flushed < off) {
-                group_at(flushed)[flushed & 3u] = ring[flushed & (kRing - 1)];
-                flushed++;
-            }
-        }
-        while (__builtin_amdgcn_ballot_w64((flushed & (kGroup - 1)) == 0 && flushed + kGroup <= off)) {
-            if ((flushed & (kGroup - 1)) == 0 && flushed + kGroup <= off) {
+        if (__builtin_amdgcn_ballot_w64(flushed + kGroup <= off)) {
+            if (flushed + kGroup <= off) {
                 *reinterpret_cast<uint4 *>(group_at(flushed)) = *reinterpret_cast<const uint4 *>(ring + (flushed & (kRing - 1)));
                 flushed += kGroup;
             }
@@ -1366,24 +1365,33 @@ struct BlkRing {
     __device__ __forceinline__ void flush_all()
     {
         flush_groups();
+        flush_groups();
         for (uint32_t i = flushed; i < off; i++) group_at(i)[i & 3u] = ring[i & (kRing - 1)];
         flushed = off;
     }
 };
-static_assert(BlkRing::kGroup - 1 + kFlushEvery / 2 <= BlkRing::kRing, "block ring: a block takes two symbols at least, the ring is flushed every kFlushEvery symbols");
+static_assert(BlkRing::kGroup - 1 + kFlushEvery / 2 < 2 * BlkRing::kGroup && 2 * BlkRing::kGroup <= BlkRing::kRing, "block ring: a block takes two symbols at least, the ring is flushed every kFlushEvery symbols");
 
 struct EmitSink {
     LaneRing<kAcGroup, true> ac_ring;   // index = entry index in the lane's column
     BlkRing blk_ring;                   // index = head room + label of the block
     uint32_t blk_bits;                  // the current block's label, placed as in coef_entry, + 63 << 16 (see StreamSink)
     uint32_t bad_pos, bad_lbl;
+#if defined(MJX_EXP_EMIT_NOBLK)        // (measurement build, garbage out: the emitting pass without its block words)
+    __device__ __forceinline__ void dc(uint32_t, int v) { asm volatile("" :: "v"(v)); }
+#else
     __device__ __forceinline__ void dc(uint32_t, int v) { blk_ring.push((uint32_t(v) & 0xffffu) | (ac_ring.off << 16)); }
+#endif
     __device__ __forceinline__ void ac(uint32_t, uint32_t r_scaled, int v) { ac_ring.push((uint32_t(v) & 0xffffu) | (blk_bits - r_scaled)); }
     __device__ __forceinline__ void block_done(uint32_t) { blk_bits += 1u << 22; }
     __device__ __forceinline__ void bad_code(uint32_t b, uint32_t pos) { if (bad_pos == 0xffffffffu) { bad_pos = pos; bad_lbl = b; } }
     __device__ __forceinline__ void tick() const {}
     __device__ __forceinline__ void flush_groups() { ac_ring.flush_groups(); blk_ring.flush_groups(); }
+#if defined(MJX_EXP_EMIT_NOBLK)
+    __device__ __forceinline__ void flush_step(uint32_t) { ac_ring.flush_groups(); }
+#else
     __device__ __forceinline__ void flush_step(uint32_t) { ac_ring.flush_groups(); blk_ring.flush_groups(); }
+#endif
     __device__ __forceinline__ void flush_entries() { ac_ring.flush_groups(); }
     __device__ __forceinline__ void flush_dc(uint32_t) { blk_ring.flush_groups(); }
     __device__ __forceinline__ void flush() { ac_ring.flush_groups(); blk_ring.flush_all(); }
@@ -1433,7 +1441,13 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_emit(const DevImage
     sink.blk_bits = StreamSink::block_bits(0);
     sink.bad_pos = sink.bad_lbl = 0xffffffffu;
     GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + sl), 0};
+#if defined(MJX_EXP_EMIT_NOCP)         // (measurement build, garbage out: the emitting pass without recording checkpoints)
+    NoCheckpoints nocp2;
+    (void)cps;
+    SubseqState x = wave_decode<true, 0, false>(live, e0, end - start, 0, 0xffffffffu, gbits, my_win, lut, *h, sink, nocp2, 0u, e0);
+#else
     SubseqState x = wave_decode<true, 1, false>(live, e0, end - start, 0, 0xffffffffu, gbits, my_win, lut, *h, sink, cps, 0u, e0);
+#endif
     sink.flush_groups();                                                   // (the rings hold one flush period, no more)
     const uint32_t pad_to = live ? min(stream_run(sink.ac_ring.off), im.ent_rows * 8u) : 0u;
     for (uint32_t it = 1; __builtin_amdgcn_ballot_w64(sink.ac_ring.off < pad_to); it++) {
@@ -1673,9 +1687,11 @@ extern "C" __global__ __launch_bounds__(256) void k_block_gather(const DevImage 
     const bool exact_inv = uint64_t(total_blocks + 1u) * tb < (uint64_t(1) << 32) && tb > 1u;
     constexpr uint32_t per_wave = kGatherSubs / 4;
     // Software pipeline over the wave's subsequences: the block words of subsequence i + 1 are requested before those of
-    // subsequence i are stored (four words per lane each: a subsequence of the bench holds ~210 blocks, one round of 256; longer
-    // ones take further rounds in place), so that a wave does not sit out a memory round trip per subsequence.
-    struct Sub { uint32_t s, B0, a_end, first; int32_t lbl; const uint32_t *column; bool live; };
+    // subsequence i are stored, so that a wave does not sit out a memory round trip per subsequence.  A lane takes a whole 16-byte
+    // group of four block words (a subsequence of the bench holds ~210 blocks = 53 groups: one load instruction per subsequence
+    // and wave; longer ones take further rounds in place); words of the group that lie outside the subsequence's own range --
+    // in front of its first block, behind its last -- are skipped.
+    struct Sub { uint32_t s, B0, i0, i_end, shift; const uint32_t *column; bool live; };
     auto describe = [&](uint32_t i) {
         Sub d;
         const uint32_t t = wave * per_wave + i;
@@ -1684,27 +1700,31 @@ extern "C" __global__ __launch_bounds__(256) void k_block_gather(const DevImage 
         const uint32_t tt = d.live ? t : 0u;
         d.B0 = s_B[tt];
         const uint32_t B1 = d.B0 + s_n[tt], fs1 = d.s + 1 < nsub ? s_fs[tt + 1] : s_exz[tt];
-        d.first = d.B0 + s_fs[tt];
-        d.a_end = d.live ? min(B1 + fs1, total_blocks + 1u) : 0u;
-        d.lbl = s_lbl[tt];
+        const uint32_t a_end = d.live ? min(B1 + fs1, total_blocks + 1u) : 0u, a0 = d.B0 + s_fs[tt];
+        d.shift = uint32_t(int32_t(Hb) + s_lbl[tt]);                    // block word index = block - B0 + shift
+        d.i0 = a0 - d.B0 + d.shift;
+        d.i_end = a_end > a0 ? a_end - d.B0 + d.shift : d.i0;
         d.column = entries + im.ent_off + im.ent_hdr + stream_phys(d.live ? d.s : 0u, 0, rows);
         // the scan ends with the picture's last block: the last tile ends where the last subsequence's run does
         if (d.live && d.s == nsub - 1 && lane == 0 && B1 + fs1 <= total_blocks) eoff[ntiles] = d.s * cap + H + s_d0m[tt];
         return d;
     };
-    auto fetch = [&](const Sub &d, uint32_t a0, uint32_t w[4]) {
-#pragma unroll
-        for (uint32_t q = 0; q < 4; q++) {
-            const uint32_t a = a0 + 64u * q;
-            const uint32_t j = block_word_index(uint32_t(int32_t(Hb + (a - d.B0)) + d.lbl), rows);
-            w[q] = a < d.a_end ? d.column[(j >> 3) * (8u * kStreamQuad) + (j & 7u)] : 0u;
+    const uint32_t quads = rows * 2u;
+    auto fetch = [&](const Sub &d, uint32_t g) {                          // group g of the column's block words (see BlkRing::group_at)
+        uint4 w = make_uint4(0, 0, 0, 0);
+        if (4u * g < d.i_end && g < quads) {
+            const uint32_t t = quads - 1u - g;
+            w = *reinterpret_cast<const uint4 *>(d.column + (t >> 1) * (8u * kStreamQuad) + (t & 1u) * 4u);
         }
+        return w;
     };
-    auto place = [&](const Sub &d, uint32_t a0, const uint32_t w[4]) {
+    auto place = [&](const Sub &d, uint32_t g, const uint4 &w4) {
+        const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
         for (uint32_t q = 0; q < 4; q++) {
-            const uint32_t a = a0 + 64u * q;
-            if (a >= d.a_end) continue;
+            const uint32_t i = 4u * g + q;
+            if (i < d.i0 || i >= d.i_end) continue;
+            const uint32_t a = d.B0 + i - d.shift;
             if (a < total_blocks) dc[a] = int16_t(w[q] & 0xffffu);
             const uint32_t tl = exact_inv ? __umulhi(a, tb_inv) : a / tb;      // (exact while block index x tile size < 2^32)
             if (a == total_blocks) eoff[ntiles] = d.s * cap + (w[q] >> 16);
@@ -1712,22 +1732,15 @@ extern "C" __global__ __launch_bounds__(256) void k_block_gather(const DevImage 
         }
     };
     Sub cur = describe(0);
-    uint32_t wc[4];
-    fetch(cur, cur.first + lane, wc);
+    uint4 wc = fetch(cur, (cur.i0 >> 2) + lane);
     for (uint32_t i = 0; i < per_wave; i++) {
         if (!cur.live) break;
         const Sub nxt = describe(i + 1);
-        uint32_t wn[4];
-        fetch(nxt, nxt.first + lane, wn);
-        place(cur, cur.first + lane, wc);
-        for (uint32_t a0 = cur.first + lane + 256u; a0 < cur.a_end; a0 += 256u) {      // (a subsequence of more than 256 blocks)
-            uint32_t wm[4];
-            fetch(cur, a0, wm);
-            place(cur, a0, wm);
-        }
+        const uint4 wn = fetch(nxt, (nxt.i0 >> 2) + lane);
+        place(cur, (cur.i0 >> 2) + lane, wc);
+        for (uint32_t g = (cur.i0 >> 2) + lane + 64u; 4u * g < cur.i_end; g += 64u) place(cur, g, fetch(cur, g));      // (more than 256 blocks)
         cur = nxt;
-#pragma unroll
-        for (uint32_t q = 0; q < 4; q++) wc[q] = wn[q];
+        wc = wn;
     }
 }
 
