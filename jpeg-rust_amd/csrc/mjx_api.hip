@@ -85,6 +85,8 @@ struct mjx_ctx {
     uint8_t *stage_pin[2] = {nullptr, nullptr};
     size_t stage_pin_cap[2] = {0, 0};
     hipEvent_t stage_done[2] = {nullptr, nullptr};
+    bool destuff_direct = true;     // scans de-stuffed on the device (no restart intervals): the compaction writes the lane-interleaved region
+                                    // itself (MJX_DESTUFF_DIRECT=0: a linear copy + k_scan_interleave)
     bool host_interleave = true;    // MJX_HOST_INTERLEAVE=0: linear upload + k_scan_interleave, as the groups of mjx_decode_batch do
     // Single decode (round 5, DESIGN s3.1): pictures of one scan without restart intervals, cut into subsequences of at least
     // emit_min_sub_bits bits (the long ones), are decoded ONCE by an emitting pass (k_huff_emit) whose lanes warm up over the last emit_warm_bits
@@ -1118,7 +1120,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
         // stuffed scans: what the device-side compaction needs per scan (k_destuff_*)
         std::vector<DestuffImg> di;
         uint32_t destuff_segs = 0, destuff_max_seg = 0, rst_words = 0;
-        bool destuff_restarts = false;
+        bool destuff_restarts = false, any_direct = false;
         // the images that have a scan of their own to interleave
         std::vector<InterleaveImg> ii;
         uint32_t max_pieces = 0;
@@ -1138,11 +1140,15 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
                     x.restarts = p.restart_mcus ? 1u : 0u;
                     x.rst0 = rst_words;
                     x.rst_cap = p.restart_mcus ? p.nseg + 8u : 0u;
+                    // (round 5) without restart intervals the compaction writes the lane-interleaved region itself
+                    x.direct = (ctx->destuff_direct && !p.restart_mcus && p.nseg <= 1) ? 1u : 0u;
+                    any_direct = any_direct || x.direct;
                     rst_words += x.rst_cap;
                     destuff_segs += x.nseg;
                     destuff_max_seg = std::max(destuff_max_seg, x.nseg);
                     destuff_restarts = destuff_restarts || x.restarts;
                     di.push_back(x);
+                    if (x.direct) continue;                                                      // (no linear copy to lay out)
                 }
                 if (host_il && !p.stuffed) continue;                                            // (laid out by the host, below)
                 ii.push_back(InterleaveImg{0, uint32_t(p.scan_len), uint32_t(k)});              // (lin_off is filled in below)
@@ -1284,6 +1290,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
                 b->h_ii.assign(reinterpret_cast<const unsigned char *>(ii.data()), reinterpret_cast<const unsigned char *>(ii.data() + ii.size()));
                 HIPOK(hipMemcpyAsync(b->d_ii, b->h_ii.data(), b->h_ii.size(), hipMemcpyHostToDevice, up));
             }
+            if (any_direct) HIPOK(hipMemsetAsync(b->d_scan, 0xaa, b->scan_pool_bytes, up));      // (what the direct compaction does not write: past a scan's end, padding columns)
             if (host_il) {
                 // groups of scans whose regions fill a staging block: the host's threads write block A while block B is on the link
                 const size_t kStage = size_t(64) << 20;
@@ -1378,7 +1385,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
                 prof_begin(b, MJX_K_UPLOAD, ks);
                 launch_destuff(ks, destuff_max_seg, uint32_t(di.size()), destuff_restarts, static_cast<const DestuffImg *>(b->d_di), b->d_raw,
                                b->d_segcount, b->d_segbase, b->d_lin, b->d_rst, b->d_images, static_cast<InterleaveImg *>(b->d_ii), b->d_segs,
-                               b->d_img_flags);
+                               b->d_img_flags, b->d_scan);
                 prof_end(b, ks);
                 HIPOK(hipGetLastError());
             }
@@ -1460,6 +1467,7 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     if (const char *e = std::getenv("MJX_MEDIUM_NSUB")) c->medium_nsub = uint64_t(std::max(0L, std::atol(e)));
     if (const char *e = std::getenv("MJX_STREAM_LINEAR")) c->linear_stream = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_HOST_INTERLEAVE")) c->host_interleave = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MJX_DESTUFF_DIRECT")) c->destuff_direct = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_SINGLE_DECODE")) c->single_decode = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_EMIT_MERGE_LISTED")) c->emit_merge_listed = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_EMIT_CP_BITS")) c->emit_cp_bits = uint32_t(std::max(long(kCpBits), std::atol(e))) / uint32_t(kCpBits) * uint32_t(kCpBits);

@@ -250,6 +250,9 @@ struct DestuffImg {
     uint32_t ii_index;                   // its InterleaveImg (receives the de-stuffed length)
     uint32_t restarts;                   // 1: the picture has restart intervals -- RSTn markers leave the stream and are listed
     uint32_t rst0, rst_cap;              // the scan's slots in the marker list
+    uint32_t direct;                     // 1: k_destuff_scatter writes the lane-interleaved region itself (scans without restart intervals,
+                                         // round 5: no linear copy, no k_scan_interleave; the region was filled with 0xAA before); ii_index unused
+    uint32_t pad_;
 };
 
 // mjx_batch_compare_rgb: one pair of pictures (device pointers: the pictures may live in different pools)
@@ -280,7 +283,7 @@ uint32_t stream_group_entries();    // entries per store group of the write pass
 // segcount / segbase: two words per 16 KiB segment of every scan
 void launch_destuff(hipStream_t st, uint32_t max_seg, uint32_t nimg, bool any_restarts, const DestuffImg *imgs, const uint8_t *raw,
                     uint32_t *segcount, uint32_t *segbase, uint8_t *pool, uint32_t *rst_off, DevImage *images, InterleaveImg *ii,
-                    uint32_t *segs, uint32_t *img_flags);
+                    uint32_t *segs, uint32_t *img_flags, uint8_t *scan_pool /* the lane-interleaved pool: DestuffImg::direct scans go straight there */);
 void launch_scan_interleave(hipStream_t st, uint32_t max_pieces, uint32_t nimg, const InterleaveImg *imgs, const DevImage *images,
                             const uint8_t *linear, uint8_t *pool, const uint32_t *segs);
 void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,

@@ -1007,7 +1007,7 @@ extern "C" __global__ __launch_bounds__(256) void k_destuff_prefix(const Destuff
     }
     if (threadIdx.x == 0) {
         DevImage &d = images[im.image];
-        ii[im.ii_index].lin_len = run;
+        if (!im.direct) ii[im.ii_index].lin_len = run;
         d.himg.total_bits = run * 8u;
         d.n_rst_found = run_rst;
         if (d.nseg <= 1) d.himg.nsub = (run * 8u + d.himg.sub_bits - 1) / d.himg.sub_bits;      // (else: k_restart_geometry)
@@ -1017,8 +1017,13 @@ extern "C" __global__ __launch_bounds__(256) void k_destuff_prefix(const Destuff
 
 // The workgroup compacts its 16 KiB segment into LDS (each lane drops its kept bytes at its scan offset), then writes
 // the compacted bytes out in lane order, so a wave stores 64 consecutive bytes per instruction.
+// DestuffImg::direct (round 5): the kept bytes go straight to their places in the picture's lane-interleaved region -- byte r of
+// subsequence s at piece (r >> 4) of column s, and the first kLookPieces pieces of a subsequence once more behind the column in
+// front of it (LaneBits) -- instead of into a linear copy that k_scan_interleave would read again; the region was filled with
+// 0xAA (huffman.rs:236-246) before the launch.
 extern "C" __global__ __launch_bounds__(256) void k_destuff_scatter(const DestuffImg *imgs, const uint8_t *raw,
-                                                                     const uint2 *segbase, uint8_t *pool, uint32_t *rst_off)
+                                                                     const uint2 *segbase, uint8_t *pool, uint32_t *rst_off,
+                                                                     const DevImage *images, uint8_t *scan_pool)
 {
     __shared__ uint32_t s_tmp[4];
     __shared__ uint8_t s_out[kDestuffSeg];
@@ -1047,6 +1052,18 @@ extern "C" __global__ __launch_bounds__(256) void k_destuff_scatter(const Destuf
             if ((mask >> (k * 16 + j)) & 1) s_out[o++] = uint8_t(w[j >> 2] >> ((j & 3) * 8));
     }
     __syncthreads();
+    if (im.direct) {
+        const DevImage &d = images[im.image];
+        const uint32_t sub_bytes = d.himg.sub_bits >> 3, cols = d.scan_cols, own_rows = d.himg.sub_bits >> 7;
+        uint8_t *region = scan_pool + d.scan_off;
+        for (uint32_t i = threadIdx.x; i < total; i += 256) {
+            const uint32_t g = base.x + i, s = g / sub_bytes, r = g - s * sub_bytes;
+            const uint8_t v = s_out[i];
+            region[(size_t(r >> 4) * cols + s) * 16u + (r & 15u)] = v;
+            if (s > 0 && r < kLookPieces * 16u) region[(size_t(own_rows + (r >> 4)) * cols + (s - 1u)) * 16u + (r & 15u)] = v;
+        }
+        return;
+    }
     uint8_t *dst = pool + im.out_off + base.x;
     for (uint32_t i = threadIdx.x; i < total; i += 256) dst[i] = s_out[i];
 }
@@ -3136,7 +3153,7 @@ int configure_kernels(size_t huff_lds, size_t idct_lds)
 
 void launch_destuff(hipStream_t st, uint32_t max_seg, uint32_t nimg, bool any_restarts, const DestuffImg *imgs, const uint8_t *raw,
                     uint32_t *segcount, uint32_t *segbase, uint8_t *pool, uint32_t *rst_off, DevImage *images, InterleaveImg *ii,
-                    uint32_t *segs, uint32_t *img_flags)
+                    uint32_t *segs, uint32_t *img_flags, uint8_t *scan_pool)
 {
     if (nimg == 0) return;
     for (uint32_t at = 0; at < nimg; at += 32768) {                          // (a grid's y dimension holds 65 535 images)
@@ -3147,7 +3164,7 @@ void launch_destuff(hipStream_t st, uint32_t max_seg, uint32_t nimg, bool any_re
                        images, ii, img_flags);
     for (uint32_t at = 0; at < nimg; at += 32768) {
         const uint32_t cnt = std::min<uint32_t>(32768, nimg - at);
-        hipLaunchKernelGGL(k_destuff_scatter, dim3(max_seg, cnt), dim3(256), 0, st, imgs + at, raw, reinterpret_cast<const uint2 *>(segbase), pool, rst_off);
+        hipLaunchKernelGGL(k_destuff_scatter, dim3(max_seg, cnt), dim3(256), 0, st, imgs + at, raw, reinterpret_cast<const uint2 *>(segbase), pool, rst_off, images, scan_pool);
     }
     if (any_restarts) hipLaunchKernelGGL(k_restart_geometry, dim3(nimg), dim3(256), 0, st, imgs, images, rst_off, segs, img_flags);
 }

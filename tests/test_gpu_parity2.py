@@ -637,8 +637,11 @@ def test_single_decode_beside_restart_pictures_and_device_destuffing(mjx, orc, t
         "        print(int(dd), rep, [b.status(i) for i in range(len(files))], ' '.join(hashlib.sha256(b.coefs(i).tobytes() + b.rgb(i).tobytes()).hexdigest()[:16] for i in range(len(files))))\n"
         "        b.close()\n" % (ROOT, files))
     outs = []
-    for env_extra in ({}, {"MJX_EMIT_HEAD": "0"}, {"MJX_SINGLE_DECODE": "0"}, {"MJX_EMIT_MIN_SUB_BITS": "256", "MJX_EMIT_HEAD": "1"}):
-        env = {k: v for k, v in os.environ.items() if not k.startswith("MJX_EMIT") and k != "MJX_SINGLE_DECODE"}
+    # (MJX_DESTUFF_DIRECT=0: the device-side de-stuffing through a linear copy + k_scan_interleave instead of straight into the
+    # lane-interleaved region)
+    for env_extra in ({}, {"MJX_EMIT_HEAD": "0"}, {"MJX_SINGLE_DECODE": "0"}, {"MJX_EMIT_MIN_SUB_BITS": "256", "MJX_EMIT_HEAD": "1"},
+                      {"MJX_DESTUFF_DIRECT": "0"}, {"MJX_DESTUFF_DIRECT": "0", "MJX_EMIT_MIN_SUB_BITS": "256"}):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("MJX_EMIT") and k not in ("MJX_SINGLE_DECODE", "MJX_DESTUFF_DIRECT")}
         out = subprocess.run([sys.executable, str(script)], env=dict(env, **env_extra), capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, str(env_extra) + out.stdout[-2000:] + out.stderr[-3000:]
         lines = out.stdout.strip().splitlines()
