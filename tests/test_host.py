@@ -546,3 +546,48 @@ def test_emulated_single_decode_reports_a_prefix_without_head_room(mjx, orc, emu
     assert st[5] > 0 and st[6] == 14, st          # (some prefix of this picture does grow: the case is exercised)
     rc, coefs, st = emul_single(data, warm=0, head=32, cp_bits=256)
     assert rc == 0 and np.array_equal(coefs, ref) and st[5] <= 32 * 8
+
+
+# ---- measurement tooling (round-4 review, weak #7) ----------------------------------------------------------------------------------
+def test_traffic_collection_sums_per_step_and_bench_refuses_per_launch_files(tmp_path):
+    """tools/collect_traffic.py must SUM a counter over the step's dispatches of a kernel class (a batch of two chunks launches every
+    kernel twice; averaging per launch under 'images_per_launch = the batch' halved every kernel's bytes in round 4) and check the
+    pixel kernel's writes against 3*W*H*images; bench.py's committed_traffic() must accept only such per-step files."""
+    import json
+    import subprocess
+    import sys as _sys
+
+    def csv(path, counter, rows):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write('"Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"\n')
+            for did, name, val in rows:
+                f.write('%d,"%s","%s",%f\n' % (did, name, counter, val))
+    w, h, n = 64, 32, 10
+    rgb_kb = 3 * w * h * n / 1024.0
+    idct = "void mjx::k_idct_color<1, 8, true>(mjx::DevImage const*, unsigned int const*)"
+    fetch_rows = [(1, "k_huff_emit", 100.0), (2, "k_huff_emit", 50.0), (3, idct, 10.0), (4, idct, 30.0), (5, "__amd_rocclr_copyBuffer", 999.0)]
+    write_rows = [(1, "k_huff_emit", 7.0), (2, "k_huff_emit", 3.0), (3, idct, rgb_kb * 0.75), (4, idct, rgb_kb * 0.25), (5, "__amd_rocclr_copyBuffer", 999.0)]
+    csv(str(tmp_path / "f" / "x" / "out_counter_collection.csv"), "FETCH_SIZE", fetch_rows)
+    csv(str(tmp_path / "w" / "x" / "out_counter_collection.csv"), "WRITE_SIZE", write_rows)
+    out = str(tmp_path / "t.json")
+    tool = os.path.join(ROOT, "tools", "collect_traffic.py")
+    r = subprocess.run([_sys.executable, tool, str(tmp_path / "f"), str(tmp_path / "w"), out, str(n), str(w), str(h)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    t = json.load(open(out))
+    assert t["basis"] == "per_step" and t["images_per_step"] == n
+    assert t["kernels"]["huff_emit"] == {"fetch_bytes": int(2 * 150 * 1024), "write_bytes": int(10 * 1024), "hbm_bytes": int(2 * 150 * 1024 + 10 * 1024), "launches": 2}
+    assert t["kernels"]["idct_color"]["launches"] == 2 and abs(t["check"]["ratio"] - 1.0) < 1e-6
+    assert "upload" not in t["kernels"]                       # (runtime copy kernels are not a decode class)
+    # a collection that holds two steps (every class launched twice as often, the pictures written twice) must be refused
+    csv(str(tmp_path / "w2" / "x" / "out_counter_collection.csv"), "WRITE_SIZE", write_rows + [(6, idct, rgb_kb)])
+    csv(str(tmp_path / "f2" / "x" / "out_counter_collection.csv"), "FETCH_SIZE", fetch_rows + [(6, idct, 1.0)])
+    r = subprocess.run([_sys.executable, tool, str(tmp_path / "f2"), str(tmp_path / "w2"), str(tmp_path / "t2.json"), str(n), str(w), str(h)], capture_output=True, text=True)
+    assert r.returncode != 0 and "does not cover exactly one step" in (r.stdout + r.stderr)
+    # bench.py: the newest committed collection is per step; a per-launch file (round 4's format) is not accepted
+    import bench
+    got = bench.committed_traffic()
+    assert got is not None and got[1] == 256 and "idct_color" in got[0]
+    assert abs(got[0]["idct_color"]["write_bytes"] / (3 * 3840 * 2160 * 256) - 1.0) < 0.01
+    old = json.load(open(os.path.join(ROOT, "profiles", "r04h_traffic.json")))
+    assert old.get("basis") != "per_step"                     # (what committed_traffic() would have scaled to half the real traffic)
