@@ -45,7 +45,10 @@ constexpr int kCpBits = MJX_CP_BITS;           // bits between two checkpoints o
 #define MJX_MERGE_WG 512
 #endif
 constexpr int kMergeWg = MJX_MERGE_WG;                          // ... per k_huff_merge workgroup
-constexpr long long kLongScanBits = 3ll * MJX_HUFF_WG * kLongSubseqBits / 2;
+#ifndef MJX_LONG_SCAN_HALF_WGS
+#define MJX_LONG_SCAN_HALF_WGS 3      // scans of at least this many half workgroups' worth of long subsequences are cut into long ones
+#endif
+constexpr long long kLongScanBits = (long long)(MJX_LONG_SCAN_HALF_WGS) * MJX_HUFF_WG * kLongSubseqBits / 2;
 constexpr int kHuffWg = MJX_HUFF_WG;                            // lanes (= subsequences) per k_huff_spec / merge / write workgroup:
                                                                 // the decode tables in LDS are shared by kHuffWg / 64 waves
 
