@@ -69,7 +69,20 @@ __device__ __forceinline__ uint32_t cps_byte_off(uint32_t idx)
 // workgroup of every picture -- the short one, or an empty one when another picture of the chunk needs four -- always met the
 // same two XCDs, which then idled: the write pass of 2048 4K pictures took 9.3 instead of 7.2 ms at 640-byte subsequences
 // (three full workgroups + an empty slot per picture), and which subsequence lengths were "good" was an artefact of that.
-__device__ __forceinline__ uint32_t entropy_grid_image() { return MJX_GRID_WG_FAST ? blockIdx.y : blockIdx.x; }
+// Round 5: ... and within every whole run of eight pictures the order is rotated by a hash of the run's index.  A chunk whose
+// pictures alternate with a period of 2, 4 or 8 -- the [Y, Cb, Cr, picture] images of three-scan files are the case that showed
+// it -- put all the long pictures' second and third workgroups onto the same two XCDs (1024 three-scan 4K files, one stream:
+// counting pass 3.9 ms, write pass 13.0; the same bits as luma + interleaved chroma, three images per file: 1.65 and 6.6).
+// (picture_of_slot: for every kernel whose fast grid dimension is the picture)
+#ifndef MJX_GRID_ROTATE
+#define MJX_GRID_ROTATE 1
+#endif
+__device__ __forceinline__ uint32_t picture_of_slot(uint32_t x, uint32_t n)
+{
+    if (!MJX_GRID_ROTATE || x >= (n & ~7u)) return x;                       // (the last, partial run keeps its order)
+    return (x & ~7u) | ((x + (((x >> 3) * 0x9E3779B1u) >> 29)) & 7u);
+}
+__device__ __forceinline__ uint32_t entropy_grid_image() { return MJX_GRID_WG_FAST ? blockIdx.y : picture_of_slot(blockIdx.x, gridDim.x); }
 __device__ __forceinline__ uint32_t entropy_grid_wg() { return MJX_GRID_WG_FAST ? blockIdx.x : blockIdx.y; }
 inline dim3 entropy_grid(uint32_t max_wg, uint32_t nimg) { return MJX_GRID_WG_FAST ? dim3(max_wg, nimg) : dim3(nimg, max_wg); }
 
@@ -744,7 +757,7 @@ extern "C" __global__ __launch_bounds__(kTailWg) void k_huff_merge_tail(const De
     // Workgroup (image, group): the image is the fast grid dimension, so that the groups that have items -- the first
     // few of every image -- are consecutive workgroup ids and spread over all XCDs and CUs; with the group as the fast
     // dimension they recur with the period of the grid and land on a fraction of the CUs.
-    const uint32_t img = blockIdx.x, group = blockIdx.y;
+    const uint32_t img = picture_of_slot(blockIdx.x, gridDim.x), group = blockIdx.y;
     const DevImage &im = images[img];
     if (!im.valid) return;
     const uint32_t count = g_item_count[img];
@@ -1525,7 +1538,7 @@ extern "C" __global__ __launch_bounds__(kPrefixWg) void k_huff_prefix(const DevI
 {
     extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, a window per lane
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
-    const uint32_t img = blockIdx.x, group = blockIdx.y;
+    const uint32_t img = picture_of_slot(blockIdx.x, gridDim.x), group = blockIdx.y;
     const DevImage &im = images[img];
     if (!im.valid || !im.emit || img_flags[im.status_idx]) return;
     const uint32_t count = g_item_count[img];
@@ -1672,7 +1685,7 @@ extern "C" __global__ __launch_bounds__(256) void k_block_gather(const DevImage 
     __shared__ uint32_t s_B[kGatherSubs], s_n[kGatherSubs], s_d0m[kGatherSubs];
     __shared__ int32_t s_lbl[kGatherSubs];
     __shared__ uint8_t s_fs[kGatherSubs + 1], s_exz[kGatherSubs];
-    const uint32_t img = blockIdx.x;
+    const uint32_t img = picture_of_slot(blockIdx.x, gridDim.x);
     const DevImage &im = images[img];
     const uint32_t s0 = blockIdx.y * kGatherSubs, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (!im.valid || !im.emit || s0 >= im.himg.nsub || img_flags[im.status_idx]) return;
@@ -2172,7 +2185,7 @@ __global__ __launch_bounds__(256) void k_dc_scan_t(const DevImage *images, const
     __shared__ int32_t s_carry[3];
     __shared__ uint32_t s_gave_up;
     if (threadIdx.x == 0) s_gave_up = 0;
-    const uint32_t img = blockIdx.x, seg = blockIdx.y;         // (the image is the fast dimension, see above)
+    const uint32_t img = picture_of_slot(blockIdx.x, gridDim.x), seg = blockIdx.y;         // (the image is the fast dimension, see above)
     const DevImage &im = images[img];
     const uint32_t seg0 = seg * kDcSegMcus;
     if (!im.valid || im.bpm != BPM || seg0 >= im.nmcu || img_flags[im.status_idx] || im.nseg > 1) return;
