@@ -125,6 +125,7 @@ extern "C" {
     pub fn mjx_batch_bytes(b: *const mjx_batch, scan_bytes: *mut u64, rgb_bytes: *mut u64, coef_bytes: *mut u64,
                            pixels: *mut u64) -> c_int;
     pub fn mjx_batch_geometry(b: *const mjx_batch, subsequences: *mut u64, blocks: *mut u64, chunks: *mut u64) -> c_int;
+    pub fn mjx_batch_unconverged_runs(b: *const mjx_batch, runs: *mut u64) -> c_int;
     pub fn mjx_batch_kernel_ms(b: *mut mjx_batch, ms: *mut c_double, launches: *mut u64, reset: c_int) -> c_int;
     pub fn mjx_decode_scans(ctx: *mut mjx_ctx, descs: *const mjx_scan_desc, n: usize, opts: *const mjx_opts,
                             rgb_dev: *mut *mut u8, status: *mut c_int, out: *mut *mut mjx_batch) -> c_int;

@@ -200,6 +200,12 @@ int mjx_batch_bytes(const mjx_batch *b, uint64_t *scan_bytes, uint64_t *rgb_byte
  * chosen per image), coefficient blocks, and the kernel chunks the batch is processed in (one launch per kernel class and chunk) */
 int mjx_batch_geometry(const mjx_batch *b, uint64_t *subsequences, uint64_t *blocks, uint64_t *chunks);
 
+/* Runs of a chunk, since the batch was created, whose synchronisation rounds had not converged when the rest of the entropy stage
+ * was enqueued behind them: the chunk's pictures were skipped in that run.  mjx_batch_wait examines and repairs the LAST decode
+ * only, so a caller that enqueues several mjx_batch_decode calls before one wait (a throughput measurement) reads here whether
+ * every one of them did the whole work.  Synchronises the batch's streams. */
+int mjx_batch_unconverged_runs(const mjx_batch *b, uint64_t *runs);
+
 /* accumulated kernel time (ms) and launch count per kernel class since the last reset (profiling enabled) */
 enum {
     MJX_K_GATHER = 0,     /* multi-scan pictures only: component streams -> the picture's stream (k_planar_*) */

@@ -104,6 +104,7 @@ SYMBOLS = {
     "mjx_batch_compare_rgb": (_int, [_vp, _P(_sz), _vp, _P(_sz), _sz, _P(ctypes.c_uint32), _P(ctypes.c_uint64)]),
     "mjx_batch_bytes": (_int, [_vp] + [_P(ctypes.c_uint64)] * 4),
     "mjx_batch_geometry": (_int, [_vp] + [_P(ctypes.c_uint64)] * 3),
+    "mjx_batch_unconverged_runs": (_int, [_vp, _P(ctypes.c_uint64)]),
     "mjx_batch_kernel_ms": (_int, [_vp, _P(ctypes.c_double), _P(ctypes.c_uint64), _int]),
     "mjx_decode_scans": (_int, [_vp, _P(ScanDesc), _sz, _P(Opts), _P(_P(ctypes.c_uint8)), _P(_int), _P(_vp)]),
     "mjx_pool_create": (_int, [_P(_int), _sz, _P(_vp)]),
@@ -303,6 +304,13 @@ class Batch:
         v = [ctypes.c_uint64() for _ in range(3)]
         _check(lib().mjx_batch_geometry(self.h, *[ctypes.byref(x) for x in v]))
         return dict(subsequences=v[0].value, blocks=v[1].value, chunks=v[2].value)
+
+    def unconverged_runs(self):
+        """Chunk runs since creation whose synchronisation had not converged in time (their pictures were skipped in that run; wait()
+        repairs the last decode only): a throughput loop that enqueues several decodes before one wait checks this stays put."""
+        v = ctypes.c_uint64()
+        _check(lib().mjx_batch_unconverged_runs(self.h, ctypes.byref(v)))
+        return v.value
 
     def kernel_ms(self, reset=False):
         ms = (ctypes.c_double * len(KERNEL_NAMES))()

@@ -93,6 +93,7 @@ struct mjx_ctx {
     // bits of the subsequence in front of their own and record a checkpoint every emit_cp_bits bits; MJX_SINGLE_DECODE=0: every
     // picture takes the two-pass kernels (k_huff_spec ... k_huff_write).
     bool single_decode = true;
+    bool planar_direct = true;     // multi-scan pictures: stage B reads the scans' streams (MJX_PLANAR_DIRECT=0: always through the gather kernels)
     bool emit_merge_listed = true;  // MJX_EMIT_MERGE_LISTED=0: the first merge round of such pictures runs its head slices in place, as for the others
     // (emit_min_sub_bits = the long subsequences of scans of 0.79 MB and more, mjx_huff.h: with the 4096 .. 5120-bit subsequences of
     // shorter scans the warm-up is half a subsequence -- 4096 x 1080p 15.3-16.4 ms per step at 2048 / 1024 / 512 bits of warm-up
@@ -134,6 +135,7 @@ struct ImageInfo {
     uint32_t chunk = 0;
     uint32_t role = 0;             // 0 ordinary picture; multi-scan files: 1 = one scan (internal), 2 = the picture
     uint32_t nparts = 0;           // role 2: scans in front of it
+    bool planar = false;           // role 2: read without the gather (no stream of its own: mjx_batch_copy_coefs has nothing to expand)
 };
 
 struct Chunk {
@@ -149,7 +151,9 @@ struct Chunk {
     uint32_t max_wg = 0, merge_wgs = 0, max_tiles = 0, lut_cap = 0, max_tile_blocks = 0, mode_mask = 0, layout_mask = 0, max_segs = 0, bpm_mask = 0, max_restart_segs = 0;
     uint64_t plane_words = 0;      // REF_COMPAT scratch of the chunk
     uint32_t max_pixel_wgs = 0;
+    uint32_t min_sub_bits = 0xffffffffu;   // shortest subsequence length among its scans (chunk_fix_passes)
     bool has_gather = false;       // holds multi-scan pictures (k_planar_gather runs)
+    bool has_copy = false;         // ... some of which are gathered into a stream of their own (the others are read from their scans' streams)
     bool has_emit = false, has_spec = false;   // holds pictures whose first decode emits (k_huff_emit ...) / pictures of the two-pass path
 };
 
@@ -255,6 +259,8 @@ struct mjx_batch {
     size_t rgb_pool_bytes = 0;
     int *d_status = nullptr;
     unsigned long long *d_planes = nullptr;   // REF_COMPAT: f32 planes with write-order keys (chunk scratch)
+    uint32_t *d_unconv = nullptr;       // [chunks]: runs of the chunk whose synchronisation rounds had not converged when the rest of the entropy stage ran
+                                        // (its pictures were skipped; mjx_batch_wait repairs the last run only) -- mjx_batch_unconverged_runs
     uint32_t *d_mismatch = nullptr;     // [chunks][kMisWords]: re-decodes of every synchronisation round; [kMaxFix]: set when the one-pass DC prediction gave up
     uint32_t *h_mismatch = nullptr;     // pinned mirror
     size_t huff_lds = 0, huff_lds2 = 0, idct_lds = 0;      // tables + HuffImage in LDS: the plain set (write pass), the set with pair parts (counting passes)
@@ -384,6 +390,49 @@ void release(mjx_batch *b)
     delete b;
 }
 
+void fill_dev_image(const ImagePlan &p, DevImage &d);
+
+// A multi-scan picture (role 2, plans[kp]; its scans are the nparts plans in front of it): can stage B read its tiles straight
+// from the scans' streams (DevImage::planar)?  Not with keep_coefs (mjx_batch_copy_coefs expands the gathered stream), not when a
+// tile touches more than two MCU rows or more segments than the kernel holds, not when an interleaved scan's MCU grid is not the
+// picture's -- those go through the gather kernels as before.
+bool planar_ok(const mjx_ctx *ctx, bool keep_coefs, const std::vector<ImagePlan> &plans, size_t kp, uint32_t *tile_mcus_out)
+{
+    const ImagePlan &pic = plans[kp];
+    if (!ctx->planar_direct || keep_coefs || pic.role != 2 || pic.status != MJX_OK || kp < pic.nparts || pic.ncomp != 3) return false;
+    DevImage pd;
+    fill_dev_image(pic, pd);
+    const uint32_t T = pd.tile_mcus;
+    uint32_t kinds = 0;
+    for (uint32_t j = 0; j < pic.nparts; j++) {
+        const ImagePlan &sp = plans[kp - pic.nparts + j];
+        if (sp.status != MJX_OK || sp.role != 1 || sp.part_idx != j) return false;
+        // (the kernel finds a block's place by shifts: a segment's blocks per MCU of the picture are a power of two and land in
+        // consecutive slots of the MCU)
+        auto pow2 = [](uint32_t x) { return x && !(x & (x - 1)); };
+        if (sp.ncomp == 1) {
+            for (uint32_t c = 0; c < 3; c++)
+                if (pic.src_part[c] == j) {
+                    if (!pow2(pic.h[c])) return false;
+                    kinds += pic.v[c];
+                }
+        } else {
+            if (sp.mcux != pic.mcux || sp.mcuy != pic.mcuy || !pow2(sp.bpm)) return false;
+            int prev = -1;
+            for (uint32_t q = 0; q < sp.ncomp; q++)
+                for (uint32_t c = 0; c < 3; c++)
+                    if (pic.src_part[c] == j && pic.src_comp[c] == q) {
+                        if (prev >= 0 && int(c) != prev + 1) return false;
+                        prev = int(c);
+                    }
+            kinds += 1;
+        }
+    }
+    const uint32_t pieces = (pic.mcux + T - 2) / pic.mcux + 1;          // MCU rows a tile of T consecutive MCUs can touch
+    if (tile_mcus_out) *tile_mcus_out = T;
+    return (T & (T - 1)) == 0 && kinds >= 1 && kinds <= kPlanarKinds && pieces <= 2 && pieces * kinds <= kPlanarSegs;
+}
+
 // Fills the DevImage of image i from its plan (offsets are assigned by the caller).
 void fill_dev_image(const ImagePlan &p, DevImage &d)
 {
@@ -413,6 +462,8 @@ void fill_dev_image(const ImagePlan &p, DevImage &d)
         d.log2_tile = 0;
         d.tile_mcus = 1;
         d.tile_blocks = 1;
+        d.nparts = p.nparts;
+        d.part_idx = p.part_idx;
     } else if (p.role == 2) {
         d.nparts = p.nparts;
         for (uint32_t c = 0; c < 3; c++) {
@@ -487,6 +538,7 @@ void plan_chunks(mjx_batch *b)
                 c.entries += inf.ent_cap;
                 c.tiles += inf.ntiles + 1;
                 c.nsub += d.himg.nsub;
+                if (d.himg.nsub > 1) c.min_sub_bits = std::min(c.min_sub_bits, d.himg.sub_bits);
                 c.scan_bytes += inf.scan_len;
                 c.blocks += (inf.nblocks + 7) & ~uint64_t(7);          // regions of DC differences start on 32-byte sectors
                 c.max_wg = std::max<uint32_t>(c.max_wg, (d.himg.nsub + kHuffWg - 1) / kHuffWg);
@@ -497,12 +549,12 @@ void plan_chunks(mjx_batch *b)
                     c.max_tiles = std::max<uint32_t>(c.max_tiles, (d.nmcu + T - 1) / T);
                     c.max_tile_blocks = std::max<uint32_t>(c.max_tile_blocks, T * d.bpm);
                 }
-                if (d.role == 2) c.has_gather = true;
+                if (d.role == 2) { c.has_gather = true; if (!d.planar) c.has_copy = true; }
                 if (d.emit) c.has_emit = true; else if (d.role != 2) c.has_spec = true;
                 c.lut_cap = std::max<uint32_t>(c.lut_cap, d.lut_n);
                 c.lut2_cap = std::max<uint32_t>(c.lut2_cap, d.lut2_n);
                 c.mode_mask |= 1u << d.mode;
-                if (d.role != 1) c.layout_mask |= d.ent_rows ? 2u : 1u;
+                if (d.role != 1) c.layout_mask |= d.planar ? 4u : d.ent_rows ? 2u : 1u;
                 c.bpm_mask |= 1u << d.bpm;
                 if (d.nseg > 1) c.max_restart_segs = std::max(c.max_restart_segs, d.nseg);
                 if (d.mode == 2) {
@@ -575,6 +627,7 @@ int allocate_work_buffers(mjx_batch *b, DevArena &ar)
     // (d_img_entries, d_img_flags, d_status: laid out by build_batch inside the block of small pools, whose upload clears them)
     const size_t mm = std::max<size_t>(b->chunks.size(), 1) * kMisWords * sizeof(uint32_t);
     ar.take(&b->d_mismatch, mm);
+    ar.take(&b->d_unconv, std::max<size_t>(b->chunks.size(), 1) * sizeof(uint32_t));
     if (!ar.measuring && !b->h_mismatch) {
         b->h_mismatch = pinned_get(b->ctx, mm, &b->h_mismatch_bytes);
         if (!b->h_mismatch) return MJX_ERR_NOMEM;
@@ -605,6 +658,7 @@ int allocate_work_buffers(mjx_batch *b, DevArena &ar)
         }
     }
     if (ar.measuring) return MJX_OK;
+    HIPOK(hipMemsetAsync(b->d_unconv, 0, std::max<size_t>(b->chunks.size(), 1) * sizeof(uint32_t), b->ctx->upload));
     if (const char *e = std::getenv("MJX_POISON")) {
         // debugging aid: scratch that the kernels must write before they read it is filled with a byte pattern, so that a
         // read of stale memory (fresh allocations are usually zero, recycled ones hold the previous batch) shows at once
@@ -664,6 +718,18 @@ void prof_end(mjx_batch *b, hipStream_t st)
 {
     if (!b->ctx->profiling) return;
     (void)hipEventRecord(b->events.back().b, st);
+}
+
+// Synchronisation rounds enqueued up front for a chunk: the context's number (MJX_FIX_PASSES, 6), and ten where the chunk holds
+// scans cut shorter than 2048 bits -- small pictures in a large batch, cut so that they fill a workgroup (replan_subsequences):
+// the chains of subsequences that do not synchronise are as long in bits, hence longer in subsequences (measured: 16384 x 512x512
+// needs nine rounds, 8192 x 1024x768 eight, 32768 x 256x256 seven; a round with nothing to do is two launches that leave at
+// once).  Fewer than a chunk needs is not an error -- mjx_batch_wait runs the rest -- but costs that wait a second pass.
+int chunk_fix_passes(const mjx_batch *b, size_t ci)
+{
+    const int base = std::min(b->ctx->fix_passes, kMaxFix);
+    // (large chunks only: a small batch pays for every launch, and its wait is behind one decode anyway)
+    return (b->chunks[ci].min_sub_bits < 2048u && b->chunks[ci].nsub >= 65536u) ? std::max(base, std::min(10, kMaxFix)) : base;
 }
 
 // Enqueue one chunk.  `fix_passes` inter-workgroup passes are launched; the mismatch count of the last one is copied
@@ -743,7 +809,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         }
         // (the merge rounds are over: their straggler lists and counts are free, the scan lists the prefix pass's subsequences there)
         launch_huff_scan(st, nimg, imgs, SCR(d_exit), SCR(d_blkbase), SCR(d_ebase), b->d_img_entries, b->d_img_flags, b->d_segs, verdict,
-                         SCR(d_esub), SCR(d_items), SCR(d_pull), b->d_mismatch + ci * kMisWords + kMaxFix + 1);
+                         SCR(d_esub), SCR(d_items), SCR(d_pull), b->d_mismatch + ci * kMisWords + kMaxFix + 1, b->d_unconv + ci);
         prof_end(b, st);
         if (c.has_spec) {
             prof_begin(b, MJX_K_HUFF_WRITE, st);
@@ -766,7 +832,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         prof_end(b, st);
         if (c.has_gather) {
             prof_begin(b, MJX_K_GATHER, st);
-            launch_planar_gather(st, c.max_tiles, nimg, imgs, SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_img_flags);
+            launch_planar_gather(st, c.max_tiles, nimg, imgs, SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_img_flags, c.has_copy);
             prof_end(b, st);
         }
     }
@@ -1029,6 +1095,50 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
             d.himg.cp_bits = p.himg.sub_bits >= 2 * ctx->emit_cp_bits ? ctx->emit_cp_bits : uint32_t(kCpBits);
             d.himg.warm_bits = std::min(ctx->emit_warm_bits, p.himg.sub_bits / 32u * 32u);
         }
+        if (p.role == 1 && k + (p.nparts - p.part_idx) < nu) {       // a scan of a multi-scan file: segments instead of an offset per block?
+            const size_t kp = k + (p.nparts - p.part_idx);
+            uint32_t T = 0;
+            if (planar_ok(ctx, b->opts.keep_coefs != 0, plans, kp, &T)) {
+                const ImagePlan &pic = plans[kp];
+                d.seg_T = T;
+                d.seg_mcux = pic.mcux;
+                d.seg_S = planar_row_slots(pic.mcux, T);
+                d.seg_hs = d.seg_vs = 1;
+                if (p.ncomp == 1)
+                    for (uint32_t c = 0; c < 3; c++)
+                        if (pic.src_part[c] == p.part_idx) { d.seg_hs = pic.h[c]; d.seg_vs = pic.v[c]; }
+                inf.ntiles = p.mcuy * d.seg_S;
+            }
+        }
+        if (p.role == 2 && planar_ok(ctx, b->opts.keep_coefs != 0, plans, k, nullptr)) {
+            d.planar = 1;
+            uint32_t nk = 0, first[3] = {0, 0, 0};
+            for (uint32_t c = 1; c < 3; c++) first[c] = first[c - 1] + p.h[c - 1] * p.v[c - 1];
+            for (uint32_t j = 0; j < p.nparts; j++) {
+                const ImagePlan &sp = plans[k - p.nparts + j];
+                if (sp.ncomp == 1) {
+                    for (uint32_t c = 0; c < 3; c++) {
+                        if (p.src_part[c] != j) continue;
+                        for (uint32_t v = 0; v < p.v[c]; v++, nk++) {
+                            d.pk_back[nk] = uint8_t(p.nparts - j);
+                            d.pk_v[nk] = uint8_t(v); d.pk_vs[nk] = uint8_t(p.v[c]); d.pk_hs[nk] = uint8_t(p.h[c]); d.pk_u[nk] = uint8_t(p.h[c]);
+                            for (uint32_t w = 0; w < p.h[c]; w++) d.pk_map[nk][w] = uint8_t(first[c] + v * p.h[c] + w);
+                        }
+                    }
+                } else {
+                    d.pk_back[nk] = uint8_t(p.nparts - j);
+                    d.pk_v[nk] = 0; d.pk_vs[nk] = 1; d.pk_hs[nk] = 1; d.pk_u[nk] = uint8_t(sp.bpm);
+                    uint32_t at = 0;
+                    for (uint32_t q = 0; q < sp.ncomp; q++)
+                        for (uint32_t c = 0; c < 3; c++)
+                            if (p.src_part[c] == j && p.src_comp[c] == q)
+                                for (uint32_t o = 0; o < p.h[c] * p.v[c]; o++) d.pk_map[nk][at++] = uint8_t(first[c] + o);
+                    nk++;
+                }
+            }
+            d.pk_n = uint8_t(nk);
+            inf.planar = true;
+        }
         inf.emit = d.emit != 0;
         inf.emit_head = d.emit_head;
         inf.ent_rows = d.ent_rows;
@@ -1038,7 +1148,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
             if (i < p.nparts) return MJX_ERR_INVALID_ARG;
             inf.nparts = p.nparts;
             inf.ent_cap = 8;
-            for (uint32_t k = 1; k <= p.nparts; k++) inf.ent_cap += b->info[i - k].ent_cap;
+            for (uint32_t k = 1; k <= p.nparts && !inf.planar; k++) inf.ent_cap += b->info[i - k].ent_cap;
         }
         inf.ent_cap = (inf.ent_cap + 31) / 32 * 32;        // regions start on whole 128-byte lines (rows of the quad-interleaved stream)
         d.ent_cap = uint32_t(std::min<uint64_t>(inf.ent_cap, 0xffffffffu));
@@ -1469,6 +1579,7 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     if (const char *e = std::getenv("MJX_HOST_INTERLEAVE")) c->host_interleave = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_DESTUFF_DIRECT")) c->destuff_direct = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_SINGLE_DECODE")) c->single_decode = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MJX_PLANAR_DIRECT")) c->planar_direct = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_EMIT_MERGE_LISTED")) c->emit_merge_listed = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_EMIT_CP_BITS")) c->emit_cp_bits = uint32_t(std::max(long(kCpBits), std::atol(e))) / uint32_t(kCpBits) * uint32_t(kCpBits);
     if (const char *e = std::getenv("MJX_EMIT_WARM_BITS")) c->emit_warm_bits = uint32_t(std::max(0L, std::atol(e))) / 32u * 32u;
@@ -1642,6 +1753,7 @@ extern "C" int mjx_batch_tile(mjx_ctx *ctx, const mjx_batch *src, size_t times, 
         p.restart_mcus = d.restart_mcus;
         p.role = d.role;
         p.nparts = d.nparts;
+        p.part_idx = d.part_idx;
         for (uint32_t c = 0; c < 3; c++) {
             p.cbw[c] = d.cbw[c];
             p.cbh[c] = d.cbh[c];
@@ -1687,7 +1799,7 @@ extern "C" int mjx_batch_decode(mjx_batch *b, unsigned stages)
         b->upload_pending = false;
     }
     for (size_t ci = 0; ci < b->chunks.size(); ci++) {
-        const int rc = run_chunk(b, ci, stages, b->ctx->fix_passes);
+        const int rc = run_chunk(b, ci, stages, chunk_fix_passes(b, ci));
         if (rc != MJX_OK) return rc;
     }
     b->last_stages = stages;
@@ -1728,7 +1840,7 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
                 b->dc_two_pass = true;
                 first_set_rewritten = true;
                 HIPOK(hipMemsetAsync(b->d_status + c.first, 0, c.count * sizeof(int), b->ctx->stream));
-                const int rcd = run_chunk(b, ci, b->last_stages | MJX_STAGE_ENTROPY, std::min(b->ctx->fix_passes, kMaxFix), PH_ENTROPY_ALL, true);
+                const int rcd = run_chunk(b, ci, b->last_stages | MJX_STAGE_ENTROPY, chunk_fix_passes(b, ci), PH_ENTROPY_ALL, true);
                 if (rcd != MJX_OK) return rcd;
                 HIPOK(hipStreamSynchronize(b->ctx->stream));
                 collect_events(b);
@@ -1765,7 +1877,7 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
                 launch_emit_off(b->ctx->stream, b->d_images + cc.first, uint32_t(cc.count), b->d_img_flags);
                 HIPOK(hipMemsetAsync(b->d_status + cc.first, 0, cc.count * sizeof(int), b->ctx->stream));
                 HIPOK(hipMemsetAsync(b->d_img_flags + cc.first, 0, cc.count * sizeof(uint32_t), b->ctx->stream));
-                const int rcf = run_chunk(b, ci, b->last_stages | MJX_STAGE_ENTROPY, std::min(b->ctx->fix_passes, kMaxFix), PH_ENTROPY_ALL, true);
+                const int rcf = run_chunk(b, ci, b->last_stages | MJX_STAGE_ENTROPY, chunk_fix_passes(b, ci), PH_ENTROPY_ALL, true);
                 if (rcf != MJX_OK) return rcf;
                 HIPOK(hipStreamSynchronize(b->ctx->stream));
                 collect_events(b);
@@ -1779,7 +1891,7 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
             // one picture off the single-decode path, so this ends)
             if (fell_back && ++attempts < 64) { ci--; continue; }
             if (c.merge_wgs == 0) continue;
-            const int passes = std::min(b->ctx->fix_passes, kMaxFix);
+            const int passes = chunk_fix_passes(b, ci);
             if (b->h_mismatch[ci * kMisWords + passes - 1] == 0) continue;
             if (std::getenv("MJX_TIMING")) std::fprintf(stderr, "[mjx] chunk %zu unconverged after %d rounds (%u re-decodes in the last): repairing\n", ci, passes, b->h_mismatch[ci * kMisWords + passes - 1]);
             // k_huff_merge_loop could not get its workgroups resident together and gave up (count = all ones): its control words
@@ -1934,6 +2046,7 @@ extern "C" int mjx_batch_copy_coefs(mjx_batch *b, size_t iu, int16_t *host_coefs
     if (cap_blocks < inf.nblocks) return MJX_ERR_INVALID_ARG;
     if (!b->decoded_entropy) return MJX_ERR_INVALID_ARG;
     if (!b->opts.keep_coefs && int(inf.chunk) != b->last_chunk_resident) return MJX_ERR_INVALID_ARG;
+    if (inf.planar) return MJX_ERR_INVALID_ARG;        // (a multi-scan picture of a batch without keep_coefs: its coefficients only exist scan by scan)
     HIPOK(hipSetDevice(b->ctx->device));
     { const int rcs = sync_streams(b); if (rcs != MJX_OK) return rcs; }
     // expand the compact stream (entries + tile offsets + predicted DCs) into dense zig-zag blocks on the host
@@ -2075,6 +2188,29 @@ extern "C" int mjx_batch_bytes(const mjx_batch *b, uint64_t *scan_bytes, uint64_
         }
         *coef_bytes = total;
     }
+    return MJX_OK;
+    });
+}
+
+extern "C" int mjx_batch_unconverged_runs(const mjx_batch *b, uint64_t *runs)
+{
+    if (!b || !runs) return MJX_ERR_INVALID_ARG;
+    *runs = 0;
+    if (!b->parts.empty()) {
+        for (const mjx_batch *part : b->parts) {
+            uint64_t v = 0;
+            const int rc = mjx_batch_unconverged_runs(part, &v);
+            if (rc != MJX_OK) return rc;
+            *runs += v;
+        }
+        return MJX_OK;
+    }
+    return guarded([&]() -> int {
+    HIPOK(hipSetDevice(b->ctx->device));
+    { const int rcs = sync_streams(b); if (rcs != MJX_OK) return rcs; }
+    std::vector<uint32_t> v(std::max<size_t>(b->chunks.size(), 1));
+    HIPOK(hipMemcpy(v.data(), b->d_unconv, v.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint32_t x : v) *runs += x;
     return MJX_OK;
     });
 }

@@ -8,6 +8,7 @@ namespace mjx {
 
 constexpr int kWgLanes = 256;                                   // lanes of the scan / prefix-sum workgroups
 constexpr int kDcSegMcus = 2048;                                // MCUs per DC-prediction segment (k_dc_sums / k_dc_apply)
+constexpr uint32_t kPlanarKinds = 4, kPlanarSegs = 8;           // multi-scan pictures read without the gather: segment kinds per piece, segments per tile
 
 // One image of a chunk, as the kernels see it (HBM, read-only during decode).
 struct DevImage {
@@ -57,13 +58,46 @@ struct DevImage {
     // src_back[c] places before it in the image array, as that image's src_comp[c]-th component)
     uint32_t role;
     uint32_t src_back[3], src_comp[3];
-    uint32_t nparts;
+    uint32_t nparts;            // (role 1 as well: the scans of its file, of which it is the part_idx-th)
+    uint32_t part_idx;
     uint32_t cbw[3], cbh[3];    // role 2: block grid of each component's own scan
+    // Multi-scan pictures WITHOUT the gather (round 5, `planar`): stage B reads a tile's entries straight out of the scans' streams.
+    // A tile of the picture is, in every scan, a few runs of consecutive blocks -- per MCU row the tile touches ("piece") and per
+    // block row of the component inside the MCU row: a SEGMENT.  The write pass of a scan (role 1, seg_S != 0) records where every
+    // segment's entries begin instead of an offset per block: a cut lies at every scan-MCU-row start and wherever a tile of the
+    // picture begins (planar_cut); the table has seg_S slots per scan-MCU row (slot k = the k-th tile boundary inside the row).
+    //   role 1: seg_S, seg_T (the picture's MCUs per tile), seg_mcux (the picture's MCUs per row), seg_hs / seg_vs (scan MCUs per
+    //           picture MCU: the component's sampling factors for a one-component scan, 1 for an interleaved subset)
+    //   role 2: planar = 1; pk_n kinds of segments per piece, per kind: the scan (pk_back images before the picture), its block
+    //           row inside the MCU row (pk_v of pk_vs), scan MCUs per picture MCU (pk_hs), blocks of the segment per picture MCU
+    //           (pk_u) and where these land in the picture's MCU (pk_map)
+    uint32_t planar;
+    uint32_t seg_S, seg_T, seg_mcux, seg_hs, seg_vs;
+    uint8_t pk_n, pk_back[kPlanarKinds], pk_v[kPlanarKinds], pk_vs[kPlanarKinds], pk_hs[kPlanarKinds], pk_u[kPlanarKinds];
+    uint8_t pk_map[kPlanarKinds][kMaxBlocksPerMcu];
     // single decode (round 5): 1 = the picture's first decode emits (k_huff_emit, then k_huff_prefix + k_block_gather instead of
     // k_huff_spec ... k_huff_write): pictures of one scan without restart intervals, quad-interleaved stream
     uint32_t emit;
     uint32_t emit_head;         // groups of head room in front of the first decode's entries (kEmitHeadGroups; tests shrink it)
 };
+
+// Where the segments of a scan begin (DevImage::seg_S): the first cut at or after scan MCU q0, as the scan MCU it lies at and its
+// slot in the scan's table.  A cut lies at the start of every scan-MCU row and wherever a tile of the picture (seg_T picture MCUs
+// in raster order) begins; a cut past the component's last real column is the next row's start (T.81 A.2.2: a one-component scan
+// has no MCU padding blocks).  q0 at or past the scan's last MCU gives the sentinel slot, mcuy * seg_S.
+struct PlanarCut { uint32_t mcu, slot; };
+MJX_HD PlanarCut planar_cut(uint32_t q0, uint32_t scan_mcux, uint32_t S, uint32_t T, uint32_t pic_mcux, uint32_t hs, uint32_t vs)
+{
+    const uint32_t Rs = q0 / scan_mcux, Cs = q0 - Rs * scan_mcux;
+    if (Cs == 0) return PlanarCut{q0, Rs * S};
+    const uint32_t base = (Rs / vs) * pic_mcux;                  // the picture's first MCU in this MCU row
+    const uint32_t t = (base + (Cs + hs - 1) / hs + T - 1) / T;  // the tile that begins at or after this column
+    const uint32_t Cs2 = (t * T - base) * hs;
+    if (Cs2 >= scan_mcux) return PlanarCut{(Rs + 1) * scan_mcux, (Rs + 1) * S};
+    return PlanarCut{Rs * scan_mcux + Cs2, Rs * S + (t - base / T)};
+}
+// slots per scan-MCU row: the row's start + the tile boundaries inside a row of the picture
+MJX_HD uint32_t planar_row_slots(uint32_t pic_mcux, uint32_t T) { return (pic_mcux + T - 1) / T + 1; }
 
 // ---- compact coefficient stream, quad-interleaved (round 4) -----------------------------------------------------------
 // A write-pass lane appends 32-byte groups (8 entries) to a stream of its own.  Packed one lane's run behind the other (the linear
@@ -318,7 +352,8 @@ void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, con
                       uint32_t *ebase, uint32_t *img_entries, uint32_t *img_flags, const uint32_t *segs,
                       const uint32_t *verdict /* device word: re-decodes of the last synchronisation round, or null */,
                       const EmitSub *esub, uint32_t *items /* [chunk subsequences][6]: per picture the (subsequence, checkpoint interval) pieces k_huff_prefix decodes again */,
-                      uint32_t *item_count /* [chunk images] */, uint32_t *fallback /* device word: a picture goes to the two-pass kernels */);
+                      uint32_t *item_count /* [chunk images] */, uint32_t *fallback /* device word: a picture goes to the two-pass kernels */,
+                      uint32_t *unconverged /* device word, counted up when `verdict` is not zero */);
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                        const uint8_t *scan_pool, const LutEntry *lut_pool, const SubseqState *entry,
                        const uint32_t *blkbase, const uint32_t *ebase, uint32_t *entries, uint32_t *tile_eoff,
@@ -336,7 +371,7 @@ void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t
                        uint32_t layout_mask /* bit 0: pictures with a linear stream, bit 1: with a quad-interleaved one */);
 // multi-scan pictures: component streams (raster order) -> the picture's stream in MCU order, tile offsets, DC values
 void launch_planar_gather(hipStream_t st, uint32_t max_tiles, uint32_t nimg, const DevImage *images, uint32_t *entries,
-                          uint32_t *tile_eoff, int32_t *dcbuf, uint32_t *img_flags);
+                          uint32_t *tile_eoff, int32_t *dcbuf, uint32_t *img_flags, bool copy);
 void launch_rgb_compare(hipStream_t st, uint32_t npairs, uint64_t max_bytes, const RgbPair *pairs, uint32_t *maxdiff,
                         unsigned long long *ndiff);
 void launch_ref_color(hipStream_t st, uint32_t max_pixel_wgs, uint32_t nimg, const DevImage *images,

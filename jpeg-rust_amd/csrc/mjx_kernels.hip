@@ -259,6 +259,14 @@ struct StreamSink {
     uint32_t blk_bits;      // the current block's index, placed as in coef_entry (bits above the field: don't care),
                             // + 63 << 16: minus the scaled r = position
     uint32_t next_tile_blk, tile_idx, tile_blocks, total_blocks, ntiles;
+    const DevImage *seg_im; // a scan of a multi-scan picture that is read without the gather: the "tiles" are its segments (planar_cut)
+    __device__ __forceinline__ void next_cut(uint32_t from_blk)          // the first cut at or after block from_blk
+    {
+        const DevImage &im = *seg_im;
+        const PlanarCut c = planar_cut((from_blk + im.bpm - 1) / im.bpm, im.mcux, im.seg_S, im.seg_T, im.seg_mcux, im.seg_hs, im.seg_vs);
+        tile_idx = c.slot;
+        next_tile_blk = c.mcu * im.bpm;
+    }
     static __device__ __forceinline__ uint32_t block_bits(uint32_t blk) { return ((blk & 0xffu) << 22) + (63u << kRShift); }
     __device__ __forceinline__ void dc(uint32_t b, int v)
     {
@@ -267,8 +275,12 @@ struct StreamSink {
 #endif
         if (b == next_tile_blk) {           // first block of a stage-B tile: remember where its entries start
             tile_eoff[tile_idx] = tile_virt + ac_ring.off;
-            tile_idx++;
-            next_tile_blk += tile_blocks;
+            if (seg_im) {
+                next_cut(b + 1);
+            } else {
+                tile_idx++;
+                next_tile_blk += tile_blocks;
+            }
         }
     }
     __device__ __forceinline__ void ac(uint32_t, uint32_t r_scaled, int v)
@@ -1169,10 +1181,11 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *im
                                                                uint32_t *img_entries, uint32_t *img_flags,
                                                                const uint32_t *segs, const uint32_t *verdict,
                                                                const EmitSub *g_esub, uint32_t *g_items, uint32_t *g_item_count,
-                                                               uint32_t *fallback)
+                                                               uint32_t *fallback, uint32_t *unconverged)
 {
     __shared__ uint32_t s_tmp[4];
     const DevImage &im = images[blockIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && verdict && *verdict != 0) atomicAdd(unconverged, 1u);      // (one count per run of the chunk)
     if (!im.valid || im.role == 2) return;          // (role 2: a multi-scan picture, flagged by k_planar_gather)
     // `verdict` = what the last enqueued synchronisation round of this chunk re-decoded.  Non-zero: the entries are not
     // yet the fixed point (the host finds out at mjx_batch_wait and runs more rounds), block and entry counts of
@@ -1315,7 +1328,11 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
     sink.tile_blocks = im.tile_blocks;
     sink.total_blocks = h->total_blocks;
     sink.ntiles = (h->total_blocks + im.tile_blocks - 1) / im.tile_blocks;
-    {
+    sink.seg_im = im.seg_S ? &im : nullptr;
+    if (im.seg_S) {
+        sink.ntiles = im.mcuy * im.seg_S;                                  // (the sentinel's slot)
+        sink.next_cut(first_start);
+    } else {
         sink.tile_idx = (first_start + im.tile_blocks - 1) / im.tile_blocks;
         sink.next_tile_blk = sink.tile_idx * im.tile_blocks;
     }
@@ -1827,7 +1844,7 @@ extern "C" __global__ __launch_bounds__(256) void k_planar_count(const DevImage 
     const DevImage &im = images[img];
     const uint32_t T = im.tile_mcus;
     uint32_t bad;
-    if (!im.valid || im.role != 2 || tile >= (im.nmcu + T - 1) / T || planar_flags(images, im, img, img_flags, bad)) return;
+    if (!im.valid || im.role != 2 || im.planar || tile >= (im.nmcu + T - 1) / T || planar_flags(images, im, img, img_flags, bad)) return;
     const PlanarSlot p = planar_slot(images, im, img, tile, tile_eoff);
     uint32_t total;
     (void)wg_exclusive_scan(p.cnt, s_tmp, &total);
@@ -1844,6 +1861,10 @@ extern "C" __global__ __launch_bounds__(256) void k_planar_offsets(const DevImag
     uint32_t bad;
     if (planar_flags(images, im, img, img_flags, bad)) {          // a scan is short (or its chunk unconverged): no picture
         if (tid == 0) img_flags[im.status_idx] = bad;
+        return;
+    }
+    if (im.planar) {                                              // read without the gather: stage B only needs the verdict
+        if (tid == 0) img_flags[im.status_idx] = 0;
         return;
     }
     const uint32_t T = im.tile_mcus, ntiles = (im.nmcu + T - 1) / T;
@@ -1874,7 +1895,7 @@ extern "C" __global__ __launch_bounds__(256) void k_planar_copy(const DevImage *
     const uint32_t img = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     const DevImage &im = images[img];
     const uint32_t T = im.tile_mcus;
-    if (!im.valid || im.role != 2 || tile >= (im.nmcu + T - 1) / T || img_flags[im.status_idx]) return;
+    if (!im.valid || im.role != 2 || im.planar || tile >= (im.nmcu + T - 1) / T || img_flags[im.status_idx]) return;
     const PlanarSlot p = planar_slot(images, im, img, tile, tile_eoff);
     uint32_t total;
     const uint32_t at = wg_exclusive_scan(p.cnt, s_tmp, &total);
@@ -2573,16 +2594,26 @@ __device__ __forceinline__ uint32_t comp_of_block(uint32_t b, const uint8_t *s_c
 }
 
 template <int MODE, int N>
+__device__ __forceinline__ void scatter_at(const uint32_t *ent, const uint32_t *b, uint32_t nblk, float *tile_f,
+                                           const float *s_qm, const uint8_t *s_nat, const uint8_t *s_comp);
+template <int MODE, int N>
 __device__ __forceinline__ void scatter_batch(const uint32_t *ent, uint32_t first_lo, uint32_t nblk, float *tile_f,
                                               const float *s_qm, const uint8_t *s_nat, const uint8_t *s_comp)
 {
-    uint32_t b[N], pos[N], comp[N], nat[N];
+    uint32_t b[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) b[k] = ((ent[k] >> 22) - first_lo) & 0xffu;
+    scatter_at<MODE, N>(ent, b, nblk, tile_f, s_qm, s_nat, s_comp);
+}
+// (b[k]: the block slot of entry k in the tile; anything >= nblk is dropped)
+template <int MODE, int N>
+__device__ __forceinline__ void scatter_at(const uint32_t *ent, const uint32_t *b, uint32_t nblk, float *tile_f,
+                                           const float *s_qm, const uint8_t *s_nat, const uint8_t *s_comp)
+{
+    uint32_t pos[N], comp[N], nat[N];
     float qm[N];
 #pragma unroll
-    for (int k = 0; k < N; k++) {
-        b[k] = ((ent[k] >> 22) - first_lo) & 0xffu;
-        pos[k] = (ent[k] >> 16) & 63u;
-    }
+    for (int k = 0; k < N; k++) pos[k] = (ent[k] >> 16) & 63u;
 #pragma unroll
     for (int k = 0; k < N; k++) comp[k] = comp_of_block<MODE>(MODE == 1 ? b[k] : (b[k] < nblk ? b[k] : 0u), s_comp);
 #pragma unroll
@@ -2602,6 +2633,154 @@ __device__ __forceinline__ void scatter_batch(const uint32_t *ent, uint32_t firs
         *reinterpret_cast<float *>(base + at) = float(int32_t(int16_t(ent[k] & 0xffffu))) * qm[k];
 #endif
     }
+}
+
+// ---- multi-scan pictures read without the gather (round 5; DevImage::planar, mjx_kernels.h) ---------------------------------------
+// A tile's entries lie in up to kPlanarSegs segments of the scans' linear streams (pieces x kinds).  A ROUND of the scatter is one
+// segment's next 256 entries, one per lane, so which segment a lane's entry belongs to -- hence how its block label maps into the
+// tile -- is uniform over the workgroup: one packed word per round.  The workgroup keeps three tiles' worth of records in LDS -- the
+// tile being scattered, the one whose entries are being fetched, the one being prepared --: eight lanes (one per segment) look a
+// tile's segments up in the scans' tables two tiles ahead (the two loads are issued at the top of a tile iteration and used at its
+// settle point, a whole inverse DCT later) and list its rounds.
+struct alignas(4) PlanarKindL {      // per kind of segment, prepared once per workgroup
+    uint32_t ent_rel;                // the scan's stream region, relative to the file's first scan's
+    uint32_t tbl_off;                // its segment table in tile_eoff
+    uint32_t mcux, mcuy;             // the scan's MCU grid
+    uint16_t S;
+    uint8_t bpm, hs, vs, v, log2u, mapbase;
+};
+struct alignas(4) PlanarRound {
+    uint32_t src;                    // first entry of the round, relative to the file's first scan's region
+    uint32_t how;                    // low byte of the scan's index of the segment's first block [7:0] | block slot in the tile of the piece's first
+                                     // MCU [15:8] | slot inside the MCU of the segment's first block per MCU [23:16] | log2(blocks per MCU) [31:24]
+    uint32_t cnt;                    // entries of the round (<= 256; 0: no such round)
+};
+struct alignas(4) PlanarTile {
+    uint32_t start[kPlanarSegs];     // per segment: entries into the scan's region,
+    uint16_t len[kPlanarSegs];       // ... how many,
+    uint32_t how[kPlanarSegs];       // ... PlanarRound::how
+    PlanarRound rnd[8];              // the prefetched rounds
+    uint8_t rest_seg, rest_rnd, pad_[2];     // where the rounds beyond them begin (rest_seg == kPlanarSegs: nowhere)
+};
+struct PlanarProbe { uint32_t ia, ie, how; bool any; };
+// Segment j of the tile whose first MCU is m0 = row r0, column a0 of the picture: where its two table words are, and how its blocks
+// map into the tile.  (LOG2T: the tile is a power of two MCUs.)
+__device__ __forceinline__ PlanarProbe planar_probe(const PlanarKindL *kinds, uint32_t nk, uint32_t j, uint32_t m0, uint32_t r0, uint32_t a0,
+                                                    uint32_t log2T, uint32_t nmcu, uint32_t mcux, uint32_t bpm)
+{
+    PlanarProbe p{0, 0, 0, false};
+    const uint32_t piece = j >= nk ? 1u : 0u, kind = piece ? j - nk : j;       // (two pieces at most: the host sends other pictures through the gather)
+    if (m0 >= nmcu || kind >= nk) return p;
+    const uint32_t T = 1u << log2T, nm = min(T, nmcu - m0);
+    const uint32_t r = r0 + piece, a = piece ? 0u : a0, ms = r * mcux + a;      // the piece's first MCU
+    if (ms >= m0 + nm) return p;
+    const uint32_t b = min(mcux, a + (m0 + nm - ms));
+    const PlanarKindL &K = kinds[kind];
+    const uint32_t Rs = r * K.vs + K.v, Ca = a * K.hs;
+    if (Rs >= K.mcuy || Ca >= K.mcux) return p;
+    const uint32_t ia = Rs * K.S + ((ms >> log2T) - ((r * mcux) >> log2T));
+    p.ia = K.tbl_off + ia;
+    p.ie = K.tbl_off + (b * K.hs >= K.mcux ? (Rs + 1) * K.S : ia + 1);
+    p.how = (((Rs * K.mcux + Ca) * K.bpm) & 0xffu) | (((ms - m0) * bpm) << 8) | (uint32_t(K.mapbase) << 16) | (uint32_t(K.log2u) << 24);
+    p.any = true;
+    return p;
+}
+// Lanes 0 .. kPlanarSegs-1 of one wave, lane j with segment j's probe and table words: the tile's segment records and its rounds.
+// (Lock step: what the lanes store to LDS here is read back by their neighbours further down without a barrier.)
+template <uint32_t LANES>
+__device__ __forceinline__ void planar_list(PlanarTile &t, const PlanarKindL *kinds, uint32_t nk, uint32_t j, const PlanarProbe &p,
+                                            uint32_t start, uint32_t end)
+{
+    const uint32_t len = p.any && end > start ? min(end - start, 0xffffu) : 0u;
+    t.start[j] = start;
+    t.len[j] = uint16_t(len);
+    t.how[j] = p.how;
+    t.rnd[j].cnt = 0;                                              // (kPlanarSegs == the prefetched rounds: a lane clears the record of its number)
+    if (j == 0) t.rest_seg = uint8_t(kPlanarSegs);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t before = 0;
+    for (uint32_t i = 0; i < kPlanarSegs; i++) before += i < j ? (uint32_t(t.len[i]) + LANES - 1) / LANES : 0u;
+    const uint32_t ent_rel = kinds[j >= nk ? j - nk : j].ent_rel;
+    for (uint32_t r = 0; r * LANES < len; r++) {
+        const uint32_t k = before + r;
+        if (k < 8) t.rnd[k] = PlanarRound{ent_rel + start + r * LANES, p.how, min(LANES, len - r * LANES)};
+        else if (k == 8) { t.rest_seg = uint8_t(j); t.rest_rnd = uint8_t(r); }
+    }
+}
+// what a lane needs to find its block's DC value in the scan that carries its component (the same for every tile: a tile is whole MCUs)
+struct PlanarDc {
+    uint64_t base;                   // the scan's first block in dcbuf
+    uint32_t ky, kx, k0;             // block index in the scan = my * ky + mx * kx + k0   (mx, my: the MCU's column and row in the picture)
+    uint32_t rx, r0x, lx, ry, r0y, ly;       // the block exists in the scan if mx * rx + r0x < lx and my * ry + r0y < ly
+    uint32_t mt;                     // the lane's MCU inside the tile
+    bool lane;                       // the lane has a block slot at all
+};
+__device__ __forceinline__ PlanarDc planar_dc_prepare(const DevImage *images, const DevImage &im, uint32_t img, uint32_t bpm, uint32_t tile_blocks)
+{
+    PlanarDc d{};
+    const uint32_t tid = threadIdx.x;
+    d.lane = tid < tile_blocks;
+    d.mt = tid / bpm;
+    const uint32_t k = tid - d.mt * bpm, c = im.blk_comp[k];
+    const DevImage &sim = images[img - im.src_back[c]];
+    d.base = sim.coef_off;
+    if (sim.ncomp == 1) {            // raster order over the component's own grid
+        d.ky = im.cv[c] * im.cbw[c]; d.kx = im.ch[c]; d.k0 = im.blk_by[k] * im.cbw[c] + im.blk_bx[k];
+        d.rx = im.ch[c]; d.r0x = im.blk_bx[k]; d.lx = im.cbw[c];
+        d.ry = im.cv[c]; d.r0y = im.blk_by[k]; d.ly = im.cbh[c];
+    } else {                         // interleaved subset: that scan's MCU order (its grid is the picture's: the host checks)
+        d.ky = sim.mcux * sim.bpm; d.kx = sim.bpm; d.k0 = sim.cfirst[im.src_comp[c]] + im.blk_by[k] * im.ch[c] + im.blk_bx[k];
+        d.rx = 1; d.r0x = 0; d.lx = sim.mcux;
+        d.ry = 1; d.r0y = 0; d.ly = sim.mcuy;
+    }
+    return d;
+}
+template <int PF>
+struct PlanarFetch {
+    uint32_t ent[PF];
+    int32_t dc;
+};
+// (src: the entry pool from the file's first scan's region on; mx, my: column and row in the picture of the tile's first MCU)
+template <uint32_t LANES, int PF>
+__device__ __forceinline__ void tile_fetch_planar(const uint32_t *__restrict__ src, const PlanarTile &t, const int32_t *__restrict__ dcbuf,
+                                                  const PlanarDc &d, uint32_t m0, uint32_t r0, uint32_t a0, uint32_t nmcu, uint32_t mcux,
+                                                  PlanarFetch<PF> &f)
+{
+    const uint32_t tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < PF; k++) {
+        const uint32_t at = __builtin_amdgcn_readfirstlane(t.rnd[k].src), cnt = __builtin_amdgcn_readfirstlane(t.rnd[k].cnt);
+        f.ent[k] = tid < cnt ? __builtin_nontemporal_load(src + at + tid) : 0u;
+    }
+    // the lane's MCU: d.mt MCUs behind the tile's first (a tile spans two MCU rows at most)
+    uint32_t mx = a0 + d.mt, my = r0;
+    if (mx >= mcux) { mx -= mcux; my++; }
+    const bool real = d.lane && m0 + d.mt < nmcu && mx * d.rx + d.r0x < d.lx && my * d.ry + d.r0y < d.ly;
+    f.dc = real ? __builtin_nontemporal_load(dcbuf + d.base + (my * d.ky + mx * d.kx + d.k0)) : 0;
+}
+template <int PF>
+__device__ __forceinline__ void settle(PlanarFetch<PF> &f)
+{
+#pragma unroll
+    for (int k = 0; k < PF; k++) asm volatile("" : "+v"(f.ent[k]));
+    asm volatile("" : "+v"(f.dc));
+}
+// block slot in the tile of an entry of a round (how: PlanarRound::how, uniform)
+__device__ __forceinline__ uint32_t planar_block(uint32_t e, uint32_t how, uint32_t bpm)
+{
+    const uint32_t jb = ((e >> 22) - how) & 0xffu;               // the block inside the segment
+    const uint32_t l = how >> 24, fm = jb >> l;                   // its MCU of the picture, counted from the piece's first
+    return min(((how >> 8) & 0xffu) + ((how >> 16) & 0xffu) + fm * bpm + (jb - (fm << l)), 255u);
+}
+template <int MODE, int N>
+__device__ __forceinline__ void scatter_planar(const uint32_t *ent, const PlanarTile &t, uint32_t bpm, uint32_t nblk, float *tile_f,
+                                               const float *s_qm, const uint8_t *s_nat, const uint8_t *s_comp)
+{
+    uint32_t bs[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) bs[k] = planar_block(ent[k], __builtin_amdgcn_readfirstlane(t.rnd[k].how), bpm);
+    scatter_at<MODE, N>(ent, bs, nblk, tile_f, s_qm, s_nat, s_comp);
 }
 
 // One lane = one 8x8 block: 16 x ds_read_b128 of its row, 8 row + 8 column transforms in registers, back to the row.
@@ -2900,7 +3079,9 @@ extern "C" __global__ __launch_bounds__(256) void k_ref_color(const DevImage *im
 //            then issue the loads of the next tile
 //   phase 2  one lane = one 8x8 block: float AAN inverse DCT in registers (transform.rs:55-87 up to rounding)
 //   phase 3  chroma replication + YCbCr->RGB + packed stores
-template <int MODE, int PF, bool QUAD>
+//   SRC  where the entries come from: 0 the picture's linear stream, 1 its quad-interleaved stream, 2 the linear streams of the scans of
+//        a multi-scan picture (planar, above)
+template <int MODE, int PF, int SRC>
 __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__ images,
                                                      const uint32_t *__restrict__ entries,
                                                      const uint32_t *__restrict__ tile_eoff,
@@ -2915,11 +3096,14 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
     __shared__ uint8_t s_comp[MODE == 1 ? 4 : 256];     // (4:2:0: the component comes from arithmetic on the block index)
     // per tile of the workgroup (+ sentinel).  Linear stream: s_eoff = the tile's first entry.  Quad-interleaved stream (QUAD):
     // s_eoff = the subsequence and s_at = the entry in its column where the tile starts; s_cum: see quad_prepare
-    __shared__ uint32_t s_eoff[kTilesPerWg + 1];
+    constexpr bool QUAD = SRC == 1, PLANAR = SRC == 2;
+    __shared__ uint32_t s_eoff[PLANAR ? 1 : kTilesPerWg + 1];
     __shared__ uint16_t s_at[QUAD ? kTilesPerWg + 1 : 1];
     __shared__ QuadCum s_cum[QUAD ? kTilesPerWg : 1];
+    __shared__ PlanarKindL s_kind[PLANAR ? kPlanarKinds : 1];
+    __shared__ PlanarTile s_ptile[PLANAR ? 3 : 1];
     const DevImage &im = images[blockIdx.y];
-    if (!im.valid || im.mode != uint32_t(MODE) || (im.ent_rows != 0) != QUAD || img_flags[im.status_idx]) return;
+    if (!im.valid || im.mode != uint32_t(MODE) || (im.planar ? 2 : im.ent_rows != 0 ? 1 : 0) != SRC || img_flags[im.status_idx]) return;
     // everything the tile loop needs from the descriptor, read once (uniform -> scalar registers)
     constexpr uint32_t LANES = MODE == 1 ? kLanes420 : 256u;
     const uint32_t T = MODE == 1 ? kTile420 : (1u << im.log2_tile);
@@ -2940,7 +3124,7 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
     // The stream offsets of all the workgroup's tiles are fetched once: a tile's entries can then be requested without
     // first waiting for its offsets (two dependent round trips per tile were what paced the tile loop).
     // (Quad-interleaved stream: an offset is subsequence * column capacity + entry index in the column; split here, once.)
-    if (tid <= tiles_per_wg) {
+    if (!PLANAR && tid <= tiles_per_wg) {
         uint32_t v = eoff[min(tile0 + tid, ntiles)];
         if constexpr (QUAD) {
             const uint32_t cap = im.ent_rows * 8u, sub = v / cap;
@@ -2948,6 +3132,39 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
             v = sub;
         }
         s_eoff[tid] = v;
+    }
+    const uint32_t nk = PLANAR ? im.pk_n : 0u, log2T = im.log2_tile;
+    PlanarDc pdc{};
+    const uint32_t *__restrict__ psrc = entries;             // planar: the entry pool from the file's first scan's region on
+    uint32_t pr0 = 0, pa0 = 0;                                // ... row and column in the picture of the current tile's first MCU
+    if constexpr (PLANAR) {
+        const uint64_t base_off = images[blockIdx.y - im.nparts].ent_off;
+        psrc = entries + base_off;
+        pr0 = (tile0 * T) / mcux;
+        pa0 = tile0 * T - pr0 * mcux;
+        // the kinds of segments (one lane each), then the first two tiles' segments (the tile loop prepares two tiles ahead)
+        if (tid < nk) {
+            const DevImage &sim = images[blockIdx.y - im.pk_back[tid]];
+            PlanarKindL K{};
+            K.ent_rel = uint32_t(sim.ent_off - base_off);
+            K.tbl_off = sim.tile_off;
+            K.mcux = sim.mcux; K.mcuy = sim.mcuy;
+            K.S = uint16_t(sim.seg_S);
+            K.bpm = uint8_t(sim.bpm); K.hs = im.pk_hs[tid]; K.vs = im.pk_vs[tid]; K.v = im.pk_v[tid];
+            K.log2u = uint8_t(31 - __builtin_clz(uint32_t(im.pk_u[tid]) | 1u)); K.mapbase = im.pk_map[tid][0];
+            s_kind[tid] = K;
+        }
+        pdc = planar_dc_prepare(images, im, blockIdx.y, bpm, tile_blocks);
+        __syncthreads();
+        for (uint32_t which = 0; which < 2; which++) {          // (wave 0: see planar_list)
+            if (tid < kPlanarSegs) {
+                uint32_t a1 = pa0 + which * T, r1 = pr0;
+                if (a1 >= mcux) { a1 -= mcux; r1++; }
+                const PlanarProbe pp = planar_probe(s_kind, nk, tid, (tile0 + which) * T, r1, a1, log2T, nmcu, mcux, bpm);
+                const uint32_t st0 = pp.any ? tile_eoff[pp.ia] : 0u, en0 = pp.any ? tile_eoff[pp.ie] : 0u;
+                planar_list<LANES>(s_ptile[(tile0 + which) % 3u], s_kind, nk, tid, pp, st0, en0);
+            }
+        }
     }
     __syncthreads();
     const QuadView qv{s_eoff, s_at, s_cum, entries + im.ent_off, im.ent_rows, im.himg.nsub};
@@ -2957,8 +3174,10 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
     }
     constexpr int QR = PF / 8;       // quad-interleaved stream: rounds that are prefetched
     static_assert(!QUAD || PF % 8 == 0, "whole groups per lane and round");
-    typename std::conditional<QUAD, QuadFetch<QR>, TileFetch<PF>>::type cur;
+    static_assert(!PLANAR || PF == 8, "the planar form prefetches eight rounds");
+    typename std::conditional<QUAD, QuadFetch<QR>, typename std::conditional<PLANAR, PlanarFetch<PF>, TileFetch<PF>>::type>::type cur;
     if constexpr (QUAD) tile_fetch_quad<LANES>(src, qv, 0, dcs, tile0, tile_blocks, total_blocks, cur);
+    else if constexpr (PLANAR) tile_fetch_planar<LANES, PF>(psrc, s_ptile[tile0 % 3u], dcbuf, pdc, tile0 * T, pr0, pa0, nmcu, mcux, cur);
     else tile_fetch<LANES, PF>(src, s_eoff, dcs, tile0, tile_blocks, total_blocks, cur);
     for (uint32_t i = tid; i < 192; i += LANES) s_qm[i] = qmult[im.qm_off + i];
     if (tid < 64) {
@@ -2995,10 +3214,42 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
             __syncthreads();
         }
         MJX_SB(0);
+        // (planar: the two table words of the segment this lane prepares, two tiles ahead -- used at the settle point below)
+        PlanarProbe ahead{0, 0, 0, false};
+        uint32_t ahead_st = 0, ahead_en = 0;
+        uint32_t pr1 = pr0, pa1 = pa0 + T;                        // the next tile's first MCU
+        if constexpr (PLANAR) {
+            if (pa1 >= mcux) { pa1 -= mcux; pr1++; }
+            if (tid < kPlanarSegs && tile + 2 < tile1) {
+                uint32_t a2 = pa1 + T, r2 = pr1;
+                if (a2 >= mcux) { a2 -= mcux; r2++; }
+                ahead = planar_probe(s_kind, nk, tid, (tile + 2) * T, r2, a2, log2T, nmcu, mcux, bpm);
+                if (ahead.any) {
+                    ahead_st = tile_eoff[ahead.ia];
+                    ahead_en = tile_eoff[ahead.ie];
+                }
+            }
+        }
         {   // phase 1
             const uint32_t first_lo = (tile * tile_blocks) & 0xffu;
             const uint32_t wave0 = tid & ~63u;
-            if constexpr (QUAD) {
+            if constexpr (PLANAR) {
+                // as many rounds as the tile has -- a uniform choice between a few batch sizes, as for the linear stream below
+                const PlanarTile &pt = s_ptile[tile % 3u];
+                if (__builtin_amdgcn_readfirstlane(pt.rnd[4].cnt) == 0) scatter_planar<MODE, 4>(cur.ent, pt, bpm, nblk, tile_f, s_qm, s_nat, s_comp);
+                else if (__builtin_amdgcn_readfirstlane(pt.rnd[6].cnt) == 0) scatter_planar<MODE, 6>(cur.ent, pt, bpm, nblk, tile_f, s_qm, s_nat, s_comp);
+                else scatter_planar<MODE, 8>(cur.ent, pt, bpm, nblk, tile_f, s_qm, s_nat, s_comp);
+                // what the tile has beyond the prefetched rounds (dense streams)
+                for (uint32_t j = pt.rest_seg, r0 = pt.rest_rnd; j < kPlanarSegs; j++, r0 = 0) {
+                    const uint32_t rel = s_kind[j >= nk ? j - nk : j].ent_rel + pt.start[j], len = pt.len[j], how = pt.how[j];
+                    for (uint32_t i0 = r0 * LANES; i0 < len; i0 += LANES) {
+                        uint32_t e1[1], b1[1];
+                        e1[0] = i0 + tid < len ? psrc[rel + i0 + tid] : 0u;
+                        b1[0] = planar_block(e1[0], how, bpm);
+                        scatter_at<MODE, 1>(e1, b1, nblk, tile_f, s_qm, s_nat, s_comp);
+                    }
+                }
+            } else if constexpr (QUAD) {
                 // the prefetched groups of the tile (see quad_load); what a tile has beyond them takes further rounds
 #pragma unroll
                 for (int r = 0; r < QR; r++) {
@@ -3044,6 +3295,7 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
         auto nxt = cur;
         if (tile + 1 < tile1) {
             if constexpr (QUAD) tile_fetch_quad<LANES>(src, qv, tile + 1 - tile0, dcs, tile + 1, tile_blocks, total_blocks, nxt);
+            else if constexpr (PLANAR) tile_fetch_planar<LANES, PF>(psrc, s_ptile[(tile + 1) % 3u], dcbuf, pdc, (tile + 1) * T, pr1, pa1, nmcu, mcux, nxt);
             else tile_fetch<LANES, PF>(src, s_eoff + (tile + 1 - tile0), dcs, tile + 1, tile_blocks, total_blocks, nxt);
         }
         MJX_SB(2);
@@ -3057,6 +3309,12 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
         // before this tile's pixel stores go out.  Left to the next iteration, the wait for them is a vmcnt(0) that
         // sits behind those stores -- a full store drain per tile.
         settle(nxt);
+        if constexpr (PLANAR) {
+            // the segments of the tile after the next one (its records were the previous tile's: nobody reads them any more)
+            if (tid < kPlanarSegs && tile + 2 < tile1) planar_list<LANES>(s_ptile[(tile + 2) % 3u], s_kind, nk, tid, ahead, ahead_st, ahead_en);
+            pr0 = pr1;
+            pa0 = pa1;
+        }
         MJX_SB(5);
         if (MODE == 1) {                                                  // phase 3
             // interior tile: all 32 MCUs in one MCU row, fully inside the image, rows 4-byte aligned
@@ -3154,10 +3412,11 @@ int configure_kernels(size_t huff_lds, size_t idct_lds)
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_prefix), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     }
     if (e == hipSuccess && idct_lds > 64 * 1024) {
-        const void *fns[] = {reinterpret_cast<const void *>(k_idct_color<0, kPrefetch, false>), reinterpret_cast<const void *>(k_idct_color<0, 8, true>),
-                             reinterpret_cast<const void *>(k_idct_color<1, kPrefetch, false>), reinterpret_cast<const void *>(k_idct_color<1, kPrefetchDense, false>),
-                             reinterpret_cast<const void *>(k_idct_color<1, 8, true>), reinterpret_cast<const void *>(k_idct_color<1, 16, true>),
-                             reinterpret_cast<const void *>(k_idct_color<2, kPrefetch, false>), reinterpret_cast<const void *>(k_idct_color<2, 8, true>)};
+        const void *fns[] = {reinterpret_cast<const void *>(k_idct_color<0, kPrefetch, 0>), reinterpret_cast<const void *>(k_idct_color<0, 8, 1>),
+                             reinterpret_cast<const void *>(k_idct_color<1, kPrefetch, 0>), reinterpret_cast<const void *>(k_idct_color<1, kPrefetchDense, 0>),
+                             reinterpret_cast<const void *>(k_idct_color<1, 8, 1>), reinterpret_cast<const void *>(k_idct_color<1, 16, 1>),
+                             reinterpret_cast<const void *>(k_idct_color<2, kPrefetch, 0>), reinterpret_cast<const void *>(k_idct_color<2, 8, 1>),
+                             reinterpret_cast<const void *>(k_idct_color<0, 8, 2>), reinterpret_cast<const void *>(k_idct_color<1, 8, 2>)};
         for (const void *f : fns)
             if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
     }
@@ -3250,9 +3509,9 @@ void launch_huff_prefix(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t t
 
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,
                       uint32_t *ebase, uint32_t *img_entries, uint32_t *img_flags, const uint32_t *segs, const uint32_t *verdict,
-                      const EmitSub *esub, uint32_t *items, uint32_t *item_count, uint32_t *fallback)
+                      const EmitSub *esub, uint32_t *items, uint32_t *item_count, uint32_t *fallback, uint32_t *unconverged)
 {
-    hipLaunchKernelGGL(k_huff_scan, dim3(nimg), dim3(kWgLanes), 0, st, images, exit_, blkbase, ebase, img_entries, img_flags, segs, verdict, esub, items, item_count, fallback);
+    hipLaunchKernelGGL(k_huff_scan, dim3(nimg), dim3(kWgLanes), 0, st, images, exit_, blkbase, ebase, img_entries, img_flags, segs, verdict, esub, items, item_count, fallback, unconverged);
 }
 
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
@@ -3301,40 +3560,43 @@ void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t
     const uint64_t total = uint64_t(max_tiles) * nimg;
     const uint32_t tpw = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(kTilesPerWg), total / 3072)));
     const uint32_t gx = (max_tiles + tpw - 1) / tpw;
-    // (layout_mask: bit 0 = the chunk has pictures with a linear stream, bit 1 = with a quad-interleaved one; a kernel form
-    // leaves the other kind's pictures alone)
+    // (layout_mask: bit 0 = the chunk has pictures with a linear stream, bit 1 = with a quad-interleaved one, bit 2 = multi-scan
+    // pictures read straight from their scans' streams; a kernel form leaves the other kinds' pictures alone)
 #define MJX_IDCT(M, P, Q) hipLaunchKernelGGL((k_idct_color<M, P, Q>), dim3(gx, nimg), dim3(M == 1 ? kLanes420 : 256u), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags, tpw)
     if (mode_mask & 1u) {
-        if (layout_mask & 1u) MJX_IDCT(0, kPrefetch, false);
-        if (layout_mask & 2u) MJX_IDCT(0, 8, true);
+        if (layout_mask & 1u) MJX_IDCT(0, kPrefetch, 0);
+        if (layout_mask & 2u) MJX_IDCT(0, 8, 1);
+        if (layout_mask & 4u) MJX_IDCT(0, 8, 2);
     }
     if (mode_mask & 2u) {
         // (linear streams that are dense -- more than ~2048 entries per tile: quality 90 and up -- take the form that prefetches
         // twelve words per lane instead of eight: 18.2 -> 17.2 ms per 2048 4K pictures at quality 90; at quality 75 the four
         // extra loads per lane and tile cost 0.15 ms)
         if (layout_mask & 1u) {
-            if (dense) MJX_IDCT(1, kPrefetchDense, false);
-            else MJX_IDCT(1, kPrefetch, false);
+            if (dense) MJX_IDCT(1, kPrefetchDense, 0);
+            else MJX_IDCT(1, kPrefetch, 0);
         }
         // (quad-interleaved streams: one round of 256 groups prefetched, two for dense streams -- 20.2 -> ... ms at quality 90)
         if (layout_mask & 2u) {
-            if (dense) MJX_IDCT(1, 16, true);
-            else MJX_IDCT(1, 8, true);
+            if (dense) MJX_IDCT(1, 16, 1);
+            else MJX_IDCT(1, 8, 1);
         }
+        if (layout_mask & 4u) MJX_IDCT(1, 8, 2);
     }
     if (mode_mask & 4u) {
-        if (layout_mask & 1u) MJX_IDCT(2, kPrefetch, false);
-        if (layout_mask & 2u) MJX_IDCT(2, 8, true);
+        if (layout_mask & 1u) MJX_IDCT(2, kPrefetch, 0);
+        if (layout_mask & 2u) MJX_IDCT(2, 8, 1);
     }
 #undef MJX_IDCT
 }
 
 void launch_planar_gather(hipStream_t st, uint32_t max_tiles, uint32_t nimg, const DevImage *images, uint32_t *entries,
-                          uint32_t *tile_eoff, int32_t *dcbuf, uint32_t *img_flags)
+                          uint32_t *tile_eoff, int32_t *dcbuf, uint32_t *img_flags, bool copy)
 {
-    hipLaunchKernelGGL(k_planar_count, dim3(max_tiles, nimg), dim3(256), 0, st, images, tile_eoff, img_flags);
+    // (copy == false: every multi-scan picture of the chunk is read without the gather -- k_planar_offsets only hands the scans' verdicts on)
+    if (copy) hipLaunchKernelGGL(k_planar_count, dim3(max_tiles, nimg), dim3(256), 0, st, images, tile_eoff, img_flags);
     hipLaunchKernelGGL(k_planar_offsets, dim3(nimg), dim3(256), 0, st, images, tile_eoff, img_flags);
-    hipLaunchKernelGGL(k_planar_copy, dim3(max_tiles, nimg), dim3(256), 0, st, images, entries, tile_eoff, dcbuf, img_flags);
+    if (copy) hipLaunchKernelGGL(k_planar_copy, dim3(max_tiles, nimg), dim3(256), 0, st, images, entries, tile_eoff, dcbuf, img_flags);
 }
 
 void launch_rgb_compare(hipStream_t st, uint32_t npairs, uint64_t max_bytes, const RgbPair *pairs, uint32_t *maxdiff,

@@ -98,6 +98,14 @@ void replan_subsequences(ImagePlan &p, uint32_t base_bits, bool allow_long)
         return;
     }
     base_bits = std::max<uint32_t>(uint32_t(kCpBits), std::min<uint32_t>(base_bits, uint32_t(kLongSubseqBits)) / uint32_t(kCpBits) * uint32_t(kCpBits));
+    // A scan that does not fill one workgroup at the default length is cut shorter, so that it does: the workgroup holds its LDS for
+    // as long as its longest lane decodes, whatever the number of lanes at work (the chroma scans of a three-scan 4K file: 272 and 219
+    // subsequences of 4096 bits -- half a workgroup idle for the whole pass; round 5).
+    static const bool fit_short = [] { const char *e = std::getenv("MJX_FIT_SHORT"); return !e || std::atoi(e) != 0; }();     // (MJX_FIT_SHORT=0: A/B)
+    if (fit_short && base_bits == uint32_t(kSubseqBits) && p.nseg == 1 && p.restart_mcus == 0 && p.himg.total_bits < uint32_t(kSubseqBits) * uint32_t(kHuffWg) / 4u * 3u) {       // (under three quarters of a workgroup)
+        const uint32_t fit = ((p.himg.total_bits + uint32_t(kHuffWg) - 1) / uint32_t(kHuffWg) + uint32_t(kCpBits) - 1) / uint32_t(kCpBits) * uint32_t(kCpBits);
+        base_bits = std::max<uint32_t>(4u * uint32_t(kCpBits), std::min(base_bits, fit));
+    }
     const uint32_t top = base_bits * 5 / 4;
     auto bit0 = [&](uint32_t g) { return p.seg[2 * size_t(g) + 1]; };
     p.himg.sub_bits = choose_subseq_bits(p.himg.total_bits, base_bits);
@@ -408,6 +416,8 @@ void plan_input(const mjx_scan_desc &d, const mjx_opts &opts, std::vector<ImageP
         ImagePlan &pp = out.back();
         plan_image(sub, opts, pp, true);
         pp.role = 1;
+        pp.part_idx = k;
+        pp.nparts = d.n_parts;
         if (pp.status != MJX_OK) bad = pp.status;
     }
     if (bad == MJX_OK && seen != 7u) bad = MJX_ERR_UNSUPPORTED_FORMAT;

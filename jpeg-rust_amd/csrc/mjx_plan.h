@@ -51,7 +51,8 @@ struct ImagePlan {
     // itself as role 2 (no scan: its coefficient stream is gathered from the role-1 streams, then stage B as usual).
     uint32_t role = 0;
     uint32_t cbw[3] = {0, 0, 0}, cbh[3] = {0, 0, 0};   // role 2: the components' own block grids (T.81 A.2.2)
-    uint32_t nparts = 0;                               // role 2: scans in front of the picture
+    uint32_t nparts = 0;                               // role 2: scans in front of the picture; role 1: scans of its file
+    uint32_t part_idx = 0;                             // role 1: which of them this is (the picture's plan lies nparts - part_idx plans behind)
     uint32_t src_part[3] = {0, 0, 0}, src_comp[3] = {0, 0, 0};   // ... which of them carries component c, as its n-th component
 };
 

@@ -30,13 +30,15 @@ for name, data in forms:
     if want is None: want = rgb[0]
     same = all(np.array_equal(r, want) for r in rgb)          # the twins must give the source's picture bit for bit
     batch.kernel_ms(reset=True)
+    unconv0 = batch.unconverged_runs()
     t0 = time.perf_counter()
     for _ in range(a.steps): batch.decode()
     batch.wait()
     el = time.perf_counter() - t0
     assert all(batch.status(i) == mjx.OK for i in range(len(batch)))
+    unconv = batch.unconverged_runs() - unconv0            # (steps whose pictures were skipped: see bench.py)
     by, kms = batch.bytes(), batch.kernel_ms()
-    print(json.dumps({"form": name, "file_bytes": len(data), "images": len(batch), "equal_to_interleaved": same,
+    print(json.dumps({"form": name, "file_bytes": len(data), "images": len(batch), "equal_to_interleaved": same, "unconverged_chunk_runs": unconv,
                       "Gpixels/s": round(by["pixels"] * a.steps / el / 1e9, 1), "ms_per_step": round(el / a.steps * 1e3, 3),
                       "geometry": base.geometry(),
                       "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in kms.items() if v[1]},
