@@ -508,3 +508,42 @@ extern "C" int emul_single_decode_cp(const uint8_t *jpeg, size_t len, int layout
     mjx_free_scan(&d);
     return nb <= cap_blocks ? (bad ? MJX_ERR_BAD_HUFFMAN : MJX_OK) : MJX_ERR_NOMEM;
 }
+
+// ---- round 5: multi-scan pictures read without the gather, and what the planner decides per scan ------------------------------------
+// The cuts of a scan's stream as k_huff_write records them (StreamSink::next_cut): the first cut at or after block 0, then always
+// the first one behind the last.  Returns the number of cuts (mcu_out / slot_out hold the first `cap`).
+extern "C" int emul_planar_cuts(unsigned scan_mcux, unsigned scan_mcuy, unsigned T, unsigned pic_mcux, unsigned hs, unsigned vs,
+                                unsigned *mcu_out, unsigned *slot_out, int cap)
+{
+    const uint32_t S = planar_row_slots(pic_mcux, T), nmcu = scan_mcux * scan_mcuy;
+    int n = 0;
+    for (uint32_t q = 0; q < nmcu;) {
+        const PlanarCut c = planar_cut(q, scan_mcux, S, T, pic_mcux, hs, vs);
+        if (c.mcu >= nmcu) break;
+        if (n < cap) { mcu_out[n] = c.mcu; slot_out[n] = c.slot; }
+        n++;
+        q = c.mcu + 1;
+    }
+    return n;
+}
+// plan_input on a file: per plan {role, part_idx, ncomp, bpm, himg.bpm (the decoder's block-in-MCU period), sub_bits, nsub, status}
+extern "C" int emul_plan_parts(const uint8_t *jpeg, size_t len, int *out /* [cap][8] */, int cap)
+{
+    mjx_opts opts{};
+    mjx_scan_desc d;
+    const int rc = mjx_parse(jpeg, len, &opts, &d);
+    if (rc) return -rc;
+    std::vector<ImagePlan> plans;
+    plan_input(d, opts, plans);
+    int n = 0;
+    for (const ImagePlan &p : plans) {
+        if (n < cap) {
+            int *o = out + 8 * n;
+            o[0] = int(p.role); o[1] = int(p.part_idx); o[2] = int(p.ncomp); o[3] = int(p.bpm); o[4] = int(p.himg.bpm);
+            o[5] = int(p.himg.sub_bits); o[6] = int(p.himg.nsub); o[7] = p.status;
+        }
+        n++;
+    }
+    mjx_free_scan(&d);
+    return n;
+}

@@ -658,3 +658,132 @@ def test_single_decode_beside_restart_pictures_and_device_destuffing(mjx, orc, t
         assert np.abs(b.rgb(i).astype(int) - ref.rgb.astype(int)).max() <= TOL, f
     b.close()
     ctx.close()
+
+
+def test_multi_scan_pictures_read_from_their_scans_streams_equal_the_gathered_ones(mjx, orc, tmp_path):
+    """Round 5 (DevImage::planar): without keep_coefs stage B reads a multi-scan picture's tiles straight from the scans' streams
+    -- the write pass records where a tile's segments begin instead of an offset per block -- where the geometry allows (two MCU
+    rows per tile at most, eight segments); other pictures, and every picture of a keep_coefs batch, go through the gather kernels.
+    Twins of synthetic pictures in both scan forms, with restart intervals, odd MCU rows, 4:4:4 / 4:2:2 / 4:2:0, one picture too
+    narrow for the direct path; tiled over several chunks.  The same bytes with MJX_PLANAR_DIRECT=0, the source's picture bit for
+    bit, and the oracle's within 1."""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_multiscan
+    cases = [((1936, 1088, "420", 75, 1), {}), ((1936, 1088, "420", 75, 1), {"chroma_together": True}), ((1000, 600, "420", 85, 2), {"restart": 50}),
+             ((520, 264, "444", 60, 3), {}), ((1333, 217, "422", 80, 4), {"chroma_together": True}), ((40, 300, "420", 75, 5), {}),
+             ((1024, 96, "420", 90, 6), {"restart": 64, "chroma_together": True})]
+    srcs, twins = [], []
+    for (w, h, sub, q, seed), kw in cases:
+        srcs.append(mjx.synth_jpeg(w, h, sub, q, seed=seed))
+        twins.append(make_multiscan.twin(srcs[-1], **kw))
+    for i, d in enumerate(srcs + twins):
+        (tmp_path / ("f%02d.jpg" % i)).write_bytes(d)
+    n = len(cases)
+    script = tmp_path / "planar.py"
+    script.write_text(
+        "import os, sys, hashlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge\n"
+        "mjx = ge.load_package()\n"
+        "ctx = mjx.Context(0)\n"
+        "files = [open(os.path.join(%r, 'f%%02d.jpg' %% i), 'rb').read() for i in range(%d)]\n"
+        "scans = [mjx.ParsedScan(d) for d in files]\n"
+        "for chunk in (0, 3):\n"
+        "    base = mjx.Batch(ctx, scans, chunk_images=chunk)\n"
+        "    b = base.tile(3)\n"
+        "    b.decode(); b.wait(); b.decode(); b.wait()\n"
+        "    st = [b.status(i) for i in range(len(b))]\n"
+        "    direct = []\n"
+        "    for i in range(%d, %d):\n"
+        "        try:\n"
+        "            b.coefs(len(b) - %d + i); direct.append(0)\n"
+        "        except Exception:\n"
+        "            direct.append(1)\n"
+        "    print(chunk, sum(st), ''.join(map(str, direct)), ' '.join(hashlib.sha256(b.rgb(i).tobytes()).hexdigest()[:16] for i in range(len(b))))\n"
+        "    b.close(); base.close()\n" % (ROOT, str(tmp_path), 2 * n, n, 2 * n, 2 * n))
+    outs = {}
+    for name, extra in (("direct", {}), ("gather", {"MJX_PLANAR_DIRECT": "0"})):
+        env = {k: v for k, v in os.environ.items() if k != "MJX_PLANAR_DIRECT"}
+        out = subprocess.run([sys.executable, str(script)], env=dict(env, **extra), capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, name + out.stdout[-2000:] + out.stderr[-3000:]
+        outs[name] = [l.split() for l in out.stdout.strip().splitlines()]
+    for name, lines in outs.items():
+        assert len(lines) == 2 and all(l[1] == "0" for l in lines), (name, lines)                  # every status OK
+        for l in lines:
+            h = l[3:]
+            assert len(h) == 6 * n
+            for rep in range(3):
+                for k in range(n):
+                    assert h[rep * 2 * n + n + k] == h[k] == h[rep * 2 * n + k], (name, l[0], rep, k)      # the twin's picture = its source's, every copy
+    # which pictures took the direct path (the last copy's chunk is resident: their coefficients cannot be expanded): all but the
+    # 40-pixel-wide one, whose tiles touch eleven MCU rows; none with MJX_PLANAR_DIRECT=0
+    # (first line: one chunk; in the second the last copies' chunk holds only some of them, and the rest cannot be expanded anyway)
+    assert outs["direct"][0][2] == "1111101", outs["direct"][0][:3]
+    assert outs["gather"][0][2] == "0000000", outs["gather"][0][:3]
+    assert [l[3:] for l in outs["direct"]] == [l[3:] for l in outs["gather"]]
+    ctx = mjx.Context(0)
+    scans = [mjx.ParsedScan(d) for d in twins]
+    for keep in (False, True):
+        b = mjx.Batch(ctx, scans, keep_coefs=keep)
+        b.decode(); b.wait()
+        for k, (src, tw) in enumerate(zip(srcs, twins)):
+            ref = orc.decode(src, layout=orc.LAYOUT_STD)
+            assert b.status(k) == mjx.OK and np.abs(b.rgb(k).astype(int) - ref.rgb.astype(int)).max() <= TOL, (keep, k)
+            if keep:
+                ref_ms = orc.decode(tw, layout=orc.LAYOUT_STD, ext_dri=True, ext_multiscan=True)
+                assert np.array_equal(b.coefs(k), orc.interleave(ref_ms)), k
+        b.close()
+    ctx.close()
+
+
+def test_runs_that_did_not_converge_in_time_are_counted(mjx, orc, tmp_path):
+    """mjx_batch_unconverged_runs (round 5): several decodes enqueued before one wait -- bench.py's timed region -- are only whole
+    work if every chunk's synchronisation rounds had converged when the kernels behind them ran; mjx_batch_wait repairs the last
+    decode only.  With one round enqueued up front (MJX_FIX_PASSES=1) a batch of noisy pictures does not converge: the count goes
+    up by one per decode and chunk, the picture after the wait is still right.  With the default rounds it stays 0."""
+    import subprocess
+    script = tmp_path / "unconv.py"
+    script.write_text(
+        "import os, sys, hashlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge\n"
+        "mjx = ge.load_package()\n"
+        "ctx = mjx.Context(0, throughput_plan=True)\n"
+        "datas = [mjx.synth_jpeg(1920, 1080, '420', 90, seed=s, noise_sigma=12.0) for s in range(4)]\n"
+        "base = mjx.Batch(ctx, [mjx.ParsedScan(d) for d in datas])\n"
+        "b = base.tile(64)\n"
+        "b.decode(); b.wait()\n"
+        "u0 = b.unconverged_runs()\n"
+        "for _ in range(3): b.decode()\n"
+        "b.wait()\n"
+        "print(u0, b.unconverged_runs(), b.geometry()['chunks'], sum(b.status(i) for i in range(len(b))), hashlib.sha256(b.rgb(len(b) - 1).tobytes()).hexdigest()[:16])\n" % ROOT)
+    res = {}
+    for name, extra in (("default", {}), ("one_round", {"MJX_FIX_PASSES": "1", "MJX_MERGE_LOOP": "0"})):
+        env = {k: v for k, v in os.environ.items() if k not in ("MJX_FIX_PASSES", "MJX_MERGE_LOOP")}
+        out = subprocess.run([sys.executable, str(script)], env=dict(env, **extra), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, name + out.stdout[-2000:] + out.stderr[-3000:]
+        res[name] = out.stdout.strip().split()
+    assert res["default"][:2] == ["0", "0"] and res["default"][3] == "0", res
+    u0, u1, chunks, bad, _ = res["one_round"]
+    assert int(u0) >= 1 and int(u1) - int(u0) == 3 * int(chunks) and bad == "0", res
+    assert res["one_round"][4] == res["default"][4]                      # the repaired picture = the picture
+
+
+def test_small_pictures_in_a_large_batch_are_cut_to_fill_their_workgroup(mjx, orc, gpu_ctx):
+    """replan_subsequences (round 5): a scan under three quarters of a workgroup's worth of 512-byte subsequences is cut shorter,
+    so that its one workgroup is full (16384 x 512x512: 208 -> 323 Gpixels/s).  Geometry, T0 and RGB of such a batch."""
+    datas = [mjx.synth_jpeg(512, 512, "420", 75, seed=s) for s in range(3)] + [mjx.synth_jpeg(256, 256, "444", 75, seed=7)]
+    scans = [mjx.ParsedScan(d) for d in datas]
+    ctx = mjx.Context(0, throughput_plan=True)
+    b = mjx.Batch(ctx, scans, keep_coefs=True)
+    geo = b.geometry()
+    per_picture = geo["subsequences"] / len(datas)
+    assert 150 <= per_picture <= 512, geo          # (at 512 bytes per subsequence: ~50 per 512x512 picture; the cut stops at 1024 bits)
+    b.decode(); b.wait()
+    for i, d in enumerate(datas):
+        ref = orc.decode(d, layout=orc.LAYOUT_STD)
+        assert b.status(i) == mjx.OK and np.array_equal(b.coefs(i), orc.interleave(ref)), i
+        assert np.abs(b.rgb(i).astype(int) - ref.rgb.astype(int)).max() <= TOL, i
+    b.close()
+    ctx.close()

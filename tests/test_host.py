@@ -4,6 +4,7 @@ import ctypes
 import io
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -591,3 +592,86 @@ def test_traffic_collection_sums_per_step_and_bench_refuses_per_launch_files(tmp
     assert abs(got[0]["idct_color"]["write_bytes"] / (3 * 3840 * 2160 * 256) - 1.0) < 0.01
     old = json.load(open(os.path.join(ROOT, "profiles", "r04h_traffic.json")))
     assert old.get("basis") != "per_step"                     # (what committed_traffic() would have scaled to half the real traffic)
+
+
+# ---- round 5: multi-scan pictures without the gather; what the planner decides per scan -----------------------------------------------
+@pytest.fixture(scope="module")
+def emul_lib(mjx):
+    lib = ctypes.CDLL(os.path.join(ROOT, "tests", "emul", "libhuff_emul.so"))
+    lib.emul_planar_cuts.argtypes = [ctypes.c_uint] * 6 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    lib.emul_plan_parts.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+    return lib
+
+
+@pytest.mark.parametrize("pic_mcux,pic_mcuy,T,hs,vs,clip_x,clip_y", [
+    (240, 135, 32, 2, 2, 0, 0), (240, 135, 32, 1, 1, 0, 0), (121, 68, 32, 2, 2, 1, 1), (121, 68, 32, 1, 1, 0, 0), (33, 9, 32, 2, 1, 1, 0),
+    (63, 14, 32, 1, 2, 0, 1), (84, 28, 64, 2, 1, 1, 0), (32, 5, 32, 2, 2, 0, 0), (31, 5, 32, 2, 2, 1, 1), (100, 3, 16, 4, 1, 3, 0)])
+def test_segment_cuts_of_a_scan_are_what_stage_b_looks_up(emul_lib, pic_mcux, pic_mcuy, T, hs, vs, clip_x, clip_y):
+    """DevImage::seg_S (mjx_kernels.h: planar_cut): the write pass of a one-component scan records a cut at every row start of the
+    component's own block grid and wherever a tile of the picture begins.  Stage B (planar_probe) finds a tile's segment from the
+    tile's first MCU alone -- table slot = row * S + (tile index - index of the row's first tile), its end = the next slot or the next
+    row's first -- and that must be the writer's numbering for every tile, piece and block row, also where the component's grid is
+    clipped short of the MCU grid (T.81 A.2.2)."""
+    scan_mcux, scan_mcuy = pic_mcux * hs - clip_x, pic_mcuy * vs - clip_y        # the component's own grid (blocks)
+    cap = scan_mcuy * (pic_mcux // T + 3) + 8
+    mcu, slot = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+    n = emul_lib.emul_planar_cuts(scan_mcux, scan_mcuy, T, pic_mcux, hs, vs, mcu.ctypes.data, slot.ctypes.data, cap)
+    assert 0 < n <= cap
+    mcu, slot = mcu[:n].astype(np.int64), slot[:n].astype(np.int64)
+    S = (pic_mcux + T - 1) // T + 1
+    assert mcu[0] == 0 and np.all(np.diff(mcu) > 0) and len(set(slot.tolist())) == n and slot.max() < scan_mcuy * S
+    where = dict(zip(slot.tolist(), mcu.tolist()))
+    nxt = dict(zip(mcu.tolist(), mcu.tolist()[1:] + [scan_mcux * scan_mcuy]))
+    nmcu, covered = pic_mcux * pic_mcuy, 0
+    for tile in range((nmcu + T - 1) // T):
+        m0 = tile * T
+        nm = min(T, nmcu - m0)
+        m = m0
+        while m < m0 + nm:                                  # the tile's pieces: one per MCU row it touches
+            r, a = divmod(m, pic_mcux)
+            b = min(pic_mcux, a + (m0 + nm - m))
+            for v in range(vs):
+                Rs, Ca = r * vs + v, a * hs
+                if Rs >= scan_mcuy or Ca >= scan_mcux:
+                    continue
+                ia = Rs * S + (m // T - (r * pic_mcux) // T)
+                ie = (Rs + 1) * S if b * hs >= scan_mcux else ia + 1
+                assert where[ia] == Rs * scan_mcux + Ca, (tile, r, a, v)
+                end = where.get(ie, scan_mcux * scan_mcuy)
+                assert end == nxt[where[ia]] == Rs * scan_mcux + min(b * hs, scan_mcux), (tile, r, a, v)
+                covered += end - where[ia]
+            m += b - a
+    assert covered == scan_mcux * scan_mcuy                 # every block of the scan belongs to exactly one segment
+
+
+def test_planner_shares_tables_and_fills_workgroups(mjx, emul_lib):
+    """mjx_plan.cpp, round 5.  (a) Slots that hold the same Huffman table share one decode table, and the decoder's block-in-MCU
+    state counts inside the period of the MCU's table sequence: Cb + Cr in a scan of their own (both on the chroma tables) have
+    period 1 -- two decodes that only disagree on which chroma block they are in coincide (1024 luma + chroma 4K files: 41.7 ms of
+    merge rounds before).  (b) A scan under three quarters of a workgroup of 4096-bit subsequences is cut shorter, down to 1024
+    bits, so that its workgroup is full."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_multiscan
+
+    def parts(data):
+        out = (ctypes.c_int * 64)()
+        n = emul_lib.emul_plan_parts(data, len(data), out, 8)
+        assert 0 < n <= 8
+        return [list(out[8 * i:8 * i + 8]) for i in range(n)]
+    src = mjx.synth_jpeg(640, 480, "420", 85, seed=3)
+    (p,) = parts(src)
+    assert p[0] == 0 and p[3] == 6 and p[4] == 6 and p[7] == 0               # Y Y Y Y Cb Cr on two table pairs: period 6
+    two = parts(make_multiscan.twin(src, chroma_together=True))
+    assert [q[0] for q in two] == [1, 1, 2] and [q[1] for q in two[:2]] == [0, 1]
+    assert two[1][2] == 2 and two[1][3] == 2 and two[1][4] == 1              # the chroma scan: two blocks per MCU, one state
+    three = parts(make_multiscan.twin(src))
+    assert [q[0] for q in three] == [1, 1, 1, 2] and all(q[4] == 1 for q in three[:3])
+    gray = parts(mjx.synth_jpeg(64, 64, "gray", 75, seed=1))
+    assert gray[0][3] == gray[0][4] == 1
+    # (b): sub_bits * nsub covers the scan; small scans are cut to fill ~512 lanes but not below 1024 bits
+    for (w, h, q), (lo, hi) in (((512, 512, 75), (1024, 1024)), ((1024, 768, 75), (1280, 2304)), ((1280, 720, 75), (1792, 3072)),
+                                ((1920, 1080, 75), (4096, 5120)), ((96, 64, 75), (1024, 1024))):
+        (p,) = parts(mjx.synth_jpeg(w, h, "420", q, seed=5))
+        assert lo <= p[5] <= hi and p[5] % 256 == 0, (w, h, p)
+        if p[5] > 1024:
+            assert 384 <= p[6] <= 640, (w, h, p)
