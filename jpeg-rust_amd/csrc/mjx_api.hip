@@ -152,6 +152,7 @@ struct Chunk {
     uint64_t plane_words = 0;      // REF_COMPAT scratch of the chunk
     uint32_t max_pixel_wgs = 0;
     uint32_t min_sub_bits = 0xffffffffu;   // shortest subsequence length among its scans (chunk_fix_passes)
+    int learned_passes = 0;        // rounds a repair in mjx_batch_wait found this chunk to need: later decodes of the batch enqueue them up front
     bool has_gather = false;       // holds multi-scan pictures (k_planar_gather runs)
     bool has_copy = false;         // ... some of which are gathered into a stream of their own (the others are read from their scans' streams)
     bool has_emit = false, has_spec = false;   // holds pictures whose first decode emits (k_huff_emit ...) / pictures of the two-pass path
@@ -729,7 +730,9 @@ int chunk_fix_passes(const mjx_batch *b, size_t ci)
 {
     const int base = std::min(b->ctx->fix_passes, kMaxFix);
     // (large chunks only: a small batch pays for every launch, and its wait is behind one decode anyway)
-    return (b->chunks[ci].min_sub_bits < 2048u && b->chunks[ci].nsub >= 65536u) ? std::max(base, std::min(10, kMaxFix)) : base;
+    // A chunk that a wait had to repair remembers what it needed: the same pictures need the same rounds the next time.
+    const int rule = (b->chunks[ci].min_sub_bits < 2048u && b->chunks[ci].nsub >= 65536u) ? std::max(base, std::min(10, kMaxFix)) : base;
+    return std::max(rule, std::min(b->chunks[ci].learned_passes, kMaxFix));
 }
 
 // Enqueue one chunk.  `fix_passes` inter-workgroup passes are launched; the mismatch count of the last one is copied
@@ -1917,12 +1920,20 @@ extern "C" int mjx_batch_wait(mjx_batch *b)
                 if (rc != MJX_OK) return rc;
             }
             const int more = intact ? passes : kMaxFix;
+            int rounds_run = intact ? passes : 0;
             for (;;) {
                 rc = run_chunk(b, ci, MJX_STAGE_ENTROPY, more, PH_FIX, true);
                 if (rc != MJX_OK) return rc;
                 HIPOK(hipStreamSynchronize(b->ctx->stream));
                 if (std::getenv("MJX_TIMING")) std::fprintf(stderr, "[mjx]   repair rounds: %u re-decodes left\n", b->h_mismatch[ci * kMisWords + more - 1]);
-                if (b->h_mismatch[ci * kMisWords + more - 1] == 0) break;
+                if (b->h_mismatch[ci * kMisWords + more - 1] == 0) {
+                    // what the chunk needed: the rounds before this set + the first of this set that found nothing (+ 1: that round must run)
+                    int first_zero = more - 1;
+                    while (first_zero > 0 && b->h_mismatch[ci * kMisWords + first_zero - 1] == 0) first_zero--;
+                    b->chunks[ci].learned_passes = std::min(kMaxFix, std::max(b->chunks[ci].learned_passes, rounds_run + first_zero + 1));
+                    break;
+                }
+                rounds_run += more;
                 { const int rcg = loop_gave_up(b->h_mismatch[ci * kMisWords + more - 1]); if (rcg != MJX_OK) return rcg; }
             }
             rc = run_chunk(b, ci, b->last_stages | MJX_STAGE_ENTROPY, 0, PH_TAIL, true);

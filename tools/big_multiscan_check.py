@@ -18,5 +18,11 @@ for kw in (dict(), dict(chroma_together=True), dict(restart=240)):
         assert b.status(i) == mjx.OK, (kw, i, b.status(i))
         assert np.array_equal(b.coefs(i), orc.interleave(ref)), (kw, i)
         assert np.abs(b.rgb(i).astype(int) - ref.rgb.astype(int)).max() <= 1, (kw, i)
+    # ... and without kept coefficients, where stage B reads the twin straight from its scans' streams (DevImage::planar): the same bytes
+    p = mjx.Batch(ctx, [mjx.ParsedScan(d) for d in datas])
+    p.decode(); p.wait()
+    for i in range(3):
+        assert p.status(i) == mjx.OK and np.array_equal(p.rgb(i), b.rgb(i)), (kw, i)
     print("ok", kw, "file bytes", len(tw), b.geometry())
+    p.close()
     b.close()

@@ -96,8 +96,18 @@ while done < total:
     batch = mjx.Batch(ctx, scans, keep_coefs=True, chunk_images=chunk,
                       layout=mjx.LAYOUT_REF_COMPAT if ref_layout else mjx.LAYOUT_STANDARD)
     batch.decode(); batch.wait()
+    # the same list without kept coefficients: multi-scan pictures are then read straight from their scans' streams (DevImage::planar,
+    # round 5) and every picture must come out byte for byte as above
+    plain = None
+    if not ref_layout and any(len(what) == 4 for _, what in items):
+        plain = mjx.Batch(ctx, scans, chunk_images=chunk)
+        plain.decode(); plain.wait()
     for i, (d, what) in enumerate(items):
         multiscan = len(what) == 4
+        if plain is not None:
+            assert plain.status(i) == batch.status(i), ("status without keep_coefs", what[:3], seed)
+            if batch.status(i) == mjx.OK:
+                assert np.array_equal(plain.rgb(i), batch.rgb(i)), ("RGB without keep_coefs", what[:3], seed)
         try:
             ref = orc.decode(d, layout=orc.LAYOUT_REF if ref_layout else orc.LAYOUT_STD, ext_dri=True, ext_1bit=True,
                              ext_multiscan=multiscan)
@@ -114,5 +124,7 @@ while done < total:
         assert diff.max() <= 1, ("T2", what, int(diff.max()), seed)
         differ += int((diff > 0).sum())
     batch.close()
+    if plain is not None:
+        plain.close()
     done += len(items)
 print("fuzz ok: seed %d, %d images, %d samples off by one%s" % (seed, done, differ, ", %d reference panics reported" % panics if ref_layout else ""))
