@@ -292,11 +292,16 @@ struct DestuffImg {
 // mjx_batch_compare_rgb: one pair of pictures (device pointers: the pictures may live in different pools)
 struct RgbPair { const uint8_t *a, *b; uint64_t bytes; };
 
-// MCUs per stage-B tile: a power of two so that lane -> (MCU, strip) is a shift, and at most 256 strips per row.
+// MCUs per stage-B tile: a power of two so that lane -> (MCU, strip) is a shift, and at most 256 strips per row.  At most
+// MJX_GENERIC_TILE_BLOCKS blocks: the 4:2:0 kernel's 192, so that three workgroups fit a CU (round 5: a tile of 256 blocks -- 4:2:2,
+// 64 MCUs -- held 69.6 KB of LDS, two workgroups per CU, and every picture of its batch was launched with that).
+#ifndef MJX_GENERIC_TILE_BLOCKS
+#define MJX_GENERIC_TILE_BLOCKS 192
+#endif
 inline uint32_t tile_mcus(uint32_t bpm, uint32_t hmax)
 {
     uint32_t t = 1;
-    while (t * 2 * bpm <= 256) t *= 2;
+    while (t * 2 * bpm <= MJX_GENERIC_TILE_BLOCKS) t *= 2;
     const uint32_t cap = 256 / (2 * hmax);
     return t < cap ? t : cap;
 }

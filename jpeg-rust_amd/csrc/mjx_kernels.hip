@@ -2829,14 +2829,35 @@ __device__ __forceinline__ void idct_row_inplace(float *rowf)
 // Reads 4 horizontally adjacent samples of one component for the pixel strip starting at MCU-local (x, y);
 // replicates when the component is subsampled (box replication: the reference never interpolates).
 // Sampling ratios are 1 or 2 (jpeg/mod.rs:275-277), so the divisions are shifts.
-__device__ __forceinline__ void load4(const float *tile, const DevImage &im, uint32_t mcu_blk0, uint32_t c,
+// What the generic pixel phase needs of the picture's sampling layout, read ONCE per workgroup into registers: read through the
+// descriptor inside the row loop, every field was fetched again after every store to the picture (a byte pointer may alias
+// anything) -- the pixel phase of a 4:2:2 tile took 30.7 k cycles per wave where the 4:2:0 form takes 9.1 k for twice the pixels
+// (round 5, tools/stamp_stage_b.py).
+struct GenShape {
+    uint32_t xsh[3], ysh[3];         // log2 of the replication of component c's samples
+    uint32_t first[3], ch[3];        // its first block inside the MCU, its blocks per MCU row
+    uint32_t ncomp, bpm, hmax, vmax, log2_tile, width, height, mcux;
+};
+__device__ __forceinline__ GenShape gen_shape(const DevImage &im)
+{
+    GenShape g;
+    for (uint32_t c = 0; c < 3; c++) {
+        g.xsh[c] = im.hmax > im.ch[c] ? 1 : 0;
+        g.ysh[c] = im.vmax > im.cv[c] ? 1 : 0;
+        g.first[c] = im.cfirst[c];
+        g.ch[c] = im.ch[c];
+    }
+    g.ncomp = im.ncomp; g.bpm = im.bpm; g.hmax = im.hmax; g.vmax = im.vmax; g.log2_tile = im.log2_tile;
+    g.width = im.width; g.height = im.height; g.mcux = im.mcux;
+    return g;
+}
+__device__ __forceinline__ void load4(const float *tile, const GenShape &g, uint32_t mcu_blk0, uint32_t c,
                                       uint32_t x, uint32_t y, float out[4])
 {
-    const uint32_t xsh = im.hmax > im.ch[c] ? 1 : 0, ysh = im.vmax > im.cv[c] ? 1 : 0;
-    const uint32_t xs = x >> xsh, ys = y >> ysh;
-    const uint32_t blk = mcu_blk0 + im.cfirst[c] + (ys >> 3) * im.ch[c] + (xs >> 3);
+    const uint32_t xs = x >> g.xsh[c], ys = y >> g.ysh[c];
+    const uint32_t blk = mcu_blk0 + g.first[c] + (ys >> 3) * g.ch[c] + (xs >> 3);
     const float *p = tile + blk * kPixStride + (ys & 7) * 8 + (xs & 7);
-    if (!xsh) {
+    if (!g.xsh[c]) {
         const float4 v = *reinterpret_cast<const float4 *>(p);
         out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
     } else {
@@ -2948,37 +2969,54 @@ __device__ __forceinline__ void pixels_420(uint32_t width, uint32_t height, uint
 }
 
 // Phase 3 for any sampling layout: 4-pixel strips; lane -> (MCU t, strip sx) is fixed, rows advance by 256/R per step.
-__device__ __forceinline__ void pixels_generic(const DevImage &im, const float *tile, uint32_t m0, uint32_t nm,
-                                               uint8_t *out_img, bool aligned)
+// INTERIOR: every MCU of the tile lies in one MCU row and fully inside the picture, rows are 4-byte aligned -- no bounds, plain 12-byte stores
+template <bool INTERIOR, bool COLOUR>
+__device__ __forceinline__ void pixels_generic_t(const GenShape &g, const float *tile, uint32_t m0, uint32_t nm,
+                                                 uint8_t *out_img, bool aligned)
 {
-    const uint32_t tid = threadIdx.x, bpm = im.bpm;
-    const uint32_t lstrips = im.hmax == 2 ? 2u : 1u;         // log2 of the 4-pixel strips per MCU row (2*hmax)
-    const uint32_t R = (1u << im.log2_tile) << lstrips;      // strips per pixel row of the tile (power of two <= 256)
+    const uint32_t tid = threadIdx.x, bpm = g.bpm;
+    const uint32_t lstrips = g.hmax == 2 ? 2u : 1u;          // log2 of the 4-pixel strips per MCU row (2*hmax)
+    const uint32_t R = (1u << g.log2_tile) << lstrips;       // strips per pixel row of the tile (power of two <= 256)
     const uint32_t q = tid & (R - 1);
     const uint32_t t = q >> lstrips, sx = q & ((1u << lstrips) - 1);
-    const uint32_t rows = 8 * im.vmax, lR = im.log2_tile + lstrips, rstep = 256u >> lR;
+    const uint32_t rows = 8 * g.vmax, lR = g.log2_tile + lstrips, rstep = 256u >> lR;
     if (t >= nm) return;
     const uint32_t m = m0 + t;
-    const uint32_t mx = m % im.mcux, my = m / im.mcux;
-    const uint32_t px = mx * 8 * im.hmax + sx * 4;
-    if (px >= im.width) return;
-    const uint32_t npix = min(4u, im.width - px);
-    for (uint32_t r = tid >> lR; r < rows; r += rstep) {
-        const uint32_t py = my * rows + r;
-        if (py >= im.height) break;
+    const uint32_t my = m / g.mcux, mx = m - my * g.mcux;
+    const uint32_t px = mx * 8 * g.hmax + sx * 4;
+    if (!INTERIOR && px >= g.width) return;
+    const uint32_t npix = INTERIOR ? 4u : min(4u, g.width - px);
+    uint8_t *dst = out_img + (size_t(my * rows + (tid >> lR)) * g.width + px) * 3;
+    const size_t dstep = size_t(rstep) * g.width * 3;
+    for (uint32_t r = tid >> lR; r < rows; r += rstep, dst += dstep) {
+        if (!INTERIOR && my * rows + r >= g.height) break;
         float yv[4], cbv[4], crv[4];
-        load4(tile, im, t * bpm, 0, sx * 4, r, yv);
+        load4(tile, g, t * bpm, 0, sx * 4, r, yv);
         Rgb p[4];
-        if (im.ncomp == 3) {
-            load4(tile, im, t * bpm, 1, sx * 4, r, cbv);
-            load4(tile, im, t * bpm, 2, sx * 4, r, crv);
+        if (COLOUR) {
+            load4(tile, g, t * bpm, 1, sx * 4, r, cbv);
+            load4(tile, g, t * bpm, 2, sx * 4, r, crv);
 #pragma unroll
             for (int k = 0; k < 4; k++) p[k] = ycc_to_rgb(yv[k], chroma_terms(cbv[k], crv[k]));
         } else {
 #pragma unroll
             for (int k = 0; k < 4; k++) p[k].r = p[k].g = p[k].b = yv[k];                          // decoder.rs:318-325 (+128 is in the samples)
         }
-        store4(out_img + (size_t(py) * im.width + px) * 3, pack4(p), aligned, npix);
+        if (INTERIOR) store_rgb4(dst, pack4(p));
+        else store4(dst, pack4(p), aligned, npix);
+    }
+}
+__device__ __forceinline__ void pixels_generic(const GenShape &g, const float *tile, uint32_t m0, uint32_t nm,
+                                               uint8_t *out_img, bool aligned)
+{
+    const uint32_t T = 1u << g.log2_tile, my0 = m0 / g.mcux, mx0 = m0 - my0 * g.mcux;
+    const bool interior = aligned && nm == T && mx0 + T <= g.mcux && (mx0 + T) * 8 * g.hmax <= g.width && (my0 + 1) * 8 * g.vmax <= g.height;
+    if (g.ncomp == 3) {
+        if (interior) pixels_generic_t<true, true>(g, tile, m0, nm, out_img, aligned);
+        else pixels_generic_t<false, true>(g, tile, m0, nm, out_img, aligned);
+    } else {
+        if (interior) pixels_generic_t<true, false>(g, tile, m0, nm, out_img, aligned);
+        else pixels_generic_t<false, false>(g, tile, m0, nm, out_img, aligned);
     }
 }
 
@@ -3192,6 +3230,8 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
     const float my_dc_qm = qmult[im.qm_off + my_comp * 64];
     const float my_dc_add = (MODE != 2 && my_comp == 0) ? 128.0f : 0.0f;
     float *tile_f = reinterpret_cast<float *>(smem_px);
+    GenShape gshape{};
+    if (MODE == 0) gshape = gen_shape(im);
     // (the first tile's words are settled before the loop, so that on no path into a tile iteration a load is pending
     // on them: see the settle point behind phase 2)
     settle(cur);
@@ -3326,7 +3366,7 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
         } else if (MODE == 2) {
             place_ref(im, tile_f, tile * tile_blocks, nblk, planes);
         } else {
-            pixels_generic(im, tile_f, m0, nm, out_img, aligned);
+            pixels_generic(gshape, tile_f, m0, nm, out_img, aligned);
         }
         MJX_SB(6);
         __syncthreads();
