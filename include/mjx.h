@@ -182,7 +182,9 @@ int mjx_batch_rgb_device(const mjx_batch *b, size_t i, void **dev_ptr, size_t *b
 /* copy image i's RGB to host memory (width*height*3 bytes) */
 int mjx_batch_copy_rgb(mjx_batch *b, size_t i, uint8_t *host_rgb);
 /* T0 stream of image i (needs keep_coefs, or i inside the last decoded chunk): blocks in decode (MCU-interleaved)
- * order, 64 x i16 zig-zag, DC prediction applied, before dequantisation.  `cap_blocks` = capacity of host buffer. */
+ * order, 64 x i16 zig-zag, DC prediction applied, before dequantisation.  `cap_blocks` = capacity of host buffer.
+ * A multi-scan picture needs keep_coefs: without it its coefficients only exist scan by scan (stage B reads them from the
+ * scans' streams) and the call returns MJX_ERR_INVALID_ARG. */
 int mjx_batch_copy_coefs(mjx_batch *b, size_t i, int16_t *host_coefs, size_t cap_blocks, size_t *nblocks);
 
 /* Verification helper (bench.py's parity gate, batch-scale tests): compares the decoded RGB of n pairs of pictures on the

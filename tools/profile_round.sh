@@ -27,6 +27,8 @@ timeout 400 python3 tools/e2e_from_files.py 2048 0 0 > $O/e2e_2048_host_destuff.
 timeout 400 python3 tools/e2e_from_files.py 512 0 1 > $O/e2e_512_device_destuff.txt 2>&1
 timeout 400 python3 tools/e2e_from_files.py 2048 0 1 > $O/e2e_2048_device_destuff.txt 2>&1
 timeout 400 python3 tools/batch_size_sweep.py > $O/batch_size_sweep.txt 2>&1
+timeout 900 bash tools/probes/small_parity.sh > $O/small_pictures_and_multiscan.txt 2>&1       # parity-gated lines: small pictures, 1080p, 4K, the multi-scan forms
+timeout 400 bash tools/probes/subsampling_sweep.sh > $O/subsampling_1080p_1stream.txt 2>&1    # 4:2:0 / 4:2:2 / 4:4:4 / grey, per-kernel times
 timeout 400 python3 tools/collect_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/traffic.json 256 3840 2160 > $O/traffic.log 2>&1
 timeout 400 python3 tools/pmc_summary.py $O/pmc_sqA/*counter_collection.csv $O/pmc_sqB/*counter_collection.csv > $O/pmc_sq_summary.txt 2>&1
 cp $O/stats2/*kernel_stats.csv $O/kernel_stats_2048x4K_default_streams.csv 2>/dev/null
