@@ -152,6 +152,7 @@ struct Chunk {
     uint64_t plane_words = 0;      // REF_COMPAT scratch of the chunk
     uint32_t max_pixel_wgs = 0;
     uint32_t min_sub_bits = 0xffffffffu;   // shortest subsequence length among its scans (chunk_fix_passes)
+    uint32_t max_nsub = 0;                 // subsequences of its longest scan
     int learned_passes = 0;        // rounds a repair in mjx_batch_wait found this chunk to need: later decodes of the batch enqueue them up front
     bool has_gather = false;       // holds multi-scan pictures (k_planar_gather runs)
     bool has_copy = false;         // ... some of which are gathered into a stream of their own (the others are read from their scans' streams)
@@ -540,6 +541,7 @@ void plan_chunks(mjx_batch *b)
                 c.tiles += inf.ntiles + 1;
                 c.nsub += d.himg.nsub;
                 if (d.himg.nsub > 1) c.min_sub_bits = std::min(c.min_sub_bits, d.himg.sub_bits);
+                c.max_nsub = std::max(c.max_nsub, d.himg.nsub);
                 c.scan_bytes += inf.scan_len;
                 c.blocks += (inf.nblocks + 7) & ~uint64_t(7);          // regions of DC differences start on 32-byte sectors
                 c.max_wg = std::max<uint32_t>(c.max_wg, (d.himg.nsub + kHuffWg - 1) / kHuffWg);
@@ -796,7 +798,8 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
                                   k > 0 ? b->d_mismatch + ci * kMisWords + k - 1 : nullptr,
                                   // (a chunk of pictures whose lanes warmed up: a fifth of the subsequences re-decode, not all of them --
                                   // the first round, too, only lists its items and the straggler kernel decodes them packed)
-                                  k == 0 && (phases & PH_SYNC) && !(c.has_emit && !c.has_spec && b->ctx->emit_merge_listed), SCR(d_esub));
+                                  k == 0 && (phases & PH_SYNC) && !(c.has_emit && !c.has_spec && b->ctx->emit_merge_listed), SCR(d_esub),
+                                  c.max_nsub ? c.max_nsub - 1 : 0u);
                 prof_end(b, st);
             }
         }

@@ -333,7 +333,8 @@ void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
                        uint32_t *cps, uint32_t *mismatches, uint32_t *items, uint32_t *item_count, const uint32_t *segs,
                        const uint32_t *prev_mismatches /* count of the round before, or null for the first */,
                        bool first_round /* most subsequences re-decode: the workgroups run their first slices in place */,
-                       EmitSub *esub /* pictures whose first decode emits: the merge depth is kept here */);
+                       EmitSub *esub /* pictures whose first decode emits: the merge depth is kept here */,
+                       uint32_t max_items /* subsequences of the chunk's longest scan - 1 (an upper bound will do) */);
 // The merge rounds of a small chunk in one launch (device-wide barrier between rounds); `participants` = the workgroups (x, image)
 // with x * merge_wg_lanes() + 1 < nsub(image): all of them must be resident at once (the caller checks against merge_loop_capacity()).
 void launch_huff_merge_loop(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,

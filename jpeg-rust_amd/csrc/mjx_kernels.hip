@@ -3499,14 +3499,17 @@ void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tab
 void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                        const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
                        uint32_t *cps, uint32_t *mismatches, uint32_t *items, uint32_t *item_count, const uint32_t *segs,
-                       const uint32_t *prev_mismatches, bool first_round, EmitSub *esub)
+                       const uint32_t *prev_mismatches, bool first_round, EmitSub *esub, uint32_t max_items)
 {
     // (item_count: this round's straggler counts, one per image, zeroed by the caller -- one memset for all the rounds of a chunk)
     const size_t lds = tables_lds + huff_merge_bytes() + pad_lds;
     hipLaunchKernelGGL(k_huff_merge, entropy_grid(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches, uint32_t(tables_lds), items, item_count, segs, prev_mismatches,
                        first_round ? uint32_t(kHeadSlices) : uint32_t(MJX_LATER_HEAD_SLICES), esub);
     const size_t tail_lds = tables_lds + size_t(kTailWg) * kMergeStride * 4;
-    hipLaunchKernelGGL(k_huff_merge_tail, dim3(nimg, max_wg * (kMergeWg / kTailWg)), dim3(kTailWg), tail_lds, st, images, scan_pool, lut_pool, exit_, cps, uint32_t(tables_lds), items, item_count, segs, esub);
+    // (max_items: the most items a picture of the chunk can list = its subsequences - 1.  A chunk of small pictures pays for these
+    // rounds in workgroup launches -- 32768 x 256x256: a million per step --: no second group of 256 for pictures that cannot fill one)
+    const uint32_t groups = std::max<uint32_t>(1u, std::min<uint32_t>(max_wg * (kMergeWg / kTailWg), (max_items + kTailWg - 1) / kTailWg));
+    hipLaunchKernelGGL(k_huff_merge_tail, dim3(nimg, groups), dim3(kTailWg), tail_lds, st, images, scan_pool, lut_pool, exit_, cps, uint32_t(tables_lds), items, item_count, segs, esub);
 }
 
 void launch_huff_merge_loop(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,

@@ -101,10 +101,12 @@ void replan_subsequences(ImagePlan &p, uint32_t base_bits, bool allow_long)
     // A scan that does not fill one workgroup at the default length is cut shorter, so that it does: the workgroup holds its LDS for
     // as long as its longest lane decodes, whatever the number of lanes at work (the chroma scans of a three-scan 4K file: 272 and 219
     // subsequences of 4096 bits -- half a workgroup idle for the whole pass; round 5).
-    static const bool fit_short = [] { const char *e = std::getenv("MJX_FIT_SHORT"); return !e || std::atoi(e) != 0; }();     // (MJX_FIT_SHORT=0: A/B)
+    // (MJX_FIT_SHORT=0: off, for the A/B; a value above 1: the shortest cut in bits instead of 1024)
+    static const uint32_t fit_floor = [] { const char *e = std::getenv("MJX_FIT_SHORT"); const long v = e ? std::atol(e) : 1; return uint32_t(v <= 1 ? v * 4 * kCpBits : std::max<long>(v, kCpBits)); }();
+    const bool fit_short = fit_floor != 0;
     if (fit_short && base_bits == uint32_t(kSubseqBits) && p.nseg == 1 && p.restart_mcus == 0 && p.himg.total_bits < uint32_t(kSubseqBits) * uint32_t(kHuffWg) / 4u * 3u) {       // (under three quarters of a workgroup)
         const uint32_t fit = ((p.himg.total_bits + uint32_t(kHuffWg) - 1) / uint32_t(kHuffWg) + uint32_t(kCpBits) - 1) / uint32_t(kCpBits) * uint32_t(kCpBits);
-        base_bits = std::max<uint32_t>(4u * uint32_t(kCpBits), std::min(base_bits, fit));
+        base_bits = std::max<uint32_t>(fit_floor / uint32_t(kCpBits) * uint32_t(kCpBits), std::min(base_bits, fit));
     }
     const uint32_t top = base_bits * 5 / 4;
     auto bit0 = [&](uint32_t g) { return p.seg[2 * size_t(g) + 1]; };
