@@ -316,6 +316,20 @@ def make_inputs(mjx, width, height, subsampling, quality, seeds):
         return list(ex.map(lambda s: mjx.synth_jpeg(width, height, subsampling, quality, s), seeds))
 
 
+def _any_rank(value):
+    """MAX of `value` over the ranks of a torch.distributed.run launch (the value itself at N = 1)."""
+    try:
+        import torch
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            t = torch.tensor([int(value)], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return int(t.item())
+    except ImportError:
+        pass
+    return int(value)
+
+
 def run_config(mjx, ctx, datas, per_gpu, stages, steps, warmup, chunk_images=0, device_destuff=False, sync_all=None,
                parity_images=0, host_side=None, latency_pass=False):
     """Builds the device-resident batch (unique pictures uploaded once, tiled on the device), times `steps` passes, and runs
@@ -364,21 +378,28 @@ def run_config(mjx, ctx, datas, per_gpu, stages, steps, warmup, chunk_images=0, 
     for _ in range(warmup):
         batch.decode(st)
         batch.wait()
-    batch.kernel_ms(reset=True)
-    unconv0 = batch.unconverged_runs()
-    if sync_all:
-        sync_all()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        batch.decode(st)
-    batch.wait()
-    if sync_all:
-        sync_all()
-    elapsed = time.perf_counter() - t0
     # The steps are enqueued back to back and waited for once, and mjx_batch_wait repairs the LAST decode only: a step whose
     # synchronisation rounds had not converged skipped its pictures (no stream, no stage B) and would count as a fast step.  The
-    # library counts such runs; a timed region that holds one is not a measurement.
-    unconv = batch.unconverged_runs() - unconv0
+    # library counts such runs; a timed region that holds one is not a measurement.  The wait that found it has repaired the batch
+    # and told its chunks how many rounds they need (Chunk::learned_passes), so the region is simply timed again -- at most twice.
+    retimed = 0
+    while True:
+        batch.kernel_ms(reset=True)
+        unconv0 = batch.unconverged_runs()
+        if sync_all:
+            sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            batch.decode(st)
+        batch.wait()
+        if sync_all:
+            sync_all()
+        elapsed = time.perf_counter() - t0
+        unconv = batch.unconverged_runs() - unconv0
+        # (every rank must take the same decision: the region is bracketed by barriers)
+        if not _any_rank(unconv) or retimed == 2 or os.environ.get("MJX_BENCH_IGNORE_STATUS"):
+            break
+        retimed += 1
     assert unconv == 0 or os.environ.get("MJX_BENCH_IGNORE_STATUS"), \
         "%d chunk runs of the timed region had not converged when their pictures were due: the steps did not do the whole work" % unconv
     # (round-4 review, weak #10: the figure above is the pipelined rate -- `steps` passes enqueued back to back, one wait;
@@ -395,7 +416,7 @@ def run_config(mjx, ctx, datas, per_gpu, stages, steps, warmup, chunk_images=0, 
     by = batch.bytes()
     kernels = {k: {"launches": v[1], "ms": round(v[0], 4)} for k, v in kms.items() if v[1]}
     kernels.pop("upload", None)                   # (upload-time kernels of a batch that was not tiled: not part of a step)
-    rec = {"elapsed": elapsed, "unconverged_chunk_runs": int(unconv), "one_pass_ms": round(one_pass * 1e3, 4), "per_gpu": per_gpu, "period": period, "by": by, "kernels": kernels, "nsub": nsub_total, "nblk": nblk,
+    rec = {"elapsed": elapsed, "unconverged_chunk_runs": int(unconv), "timed_again_after_a_repair": retimed, "one_pass_ms": round(one_pass * 1e3, 4), "per_gpu": per_gpu, "period": period, "by": by, "kernels": kernels, "nsub": nsub_total, "nblk": nblk,
            "chunks": geo["chunks"],
            "upload_side": {"kernels_ms_unique": round(up_ms, 4), "unique_pictures": period, "launches": int(up_n),
                            "ms_per_batch": round(up_ms * per_gpu / max(period, 1), 4), "pictures_per_batch": per_gpu,
@@ -635,6 +656,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "one_pass_latency_ms": rec["one_pass_ms"] or None,
         "unconverged_chunk_runs": rec["unconverged_chunk_runs"],       # (0, or the line is refused: every timed step did the whole work)
+        "timed_again_after_a_repair": rec["timed_again_after_a_repair"],   # (times the region was measured again because a step had not converged)
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%d x %dx%d %s baseline JPEG q%d per GPU (%d unique, tiled on device), de-stuffed scans "
