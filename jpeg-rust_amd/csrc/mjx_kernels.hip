@@ -3197,7 +3197,7 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
         for (uint32_t which = 0; which < 2; which++) {          // (wave 0: see planar_list)
             if (tid < kPlanarSegs) {
                 uint32_t a1 = pa0 + which * T, r1 = pr0;
-                if (a1 >= mcux) { a1 -= mcux; r1++; }
+                while (a1 >= mcux) { a1 -= mcux; r1++; }                     // (T = mcux + 1 from the row's last column: two rows on)
                 const PlanarProbe pp = planar_probe(s_kind, nk, tid, (tile0 + which) * T, r1, a1, log2T, nmcu, mcux, bpm);
                 const uint32_t st0 = pp.any ? tile_eoff[pp.ia] : 0u, en0 = pp.any ? tile_eoff[pp.ie] : 0u;
                 planar_list<LANES>(s_ptile[(tile0 + which) % 3u], s_kind, nk, tid, pp, st0, en0);
@@ -3259,10 +3259,10 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
         uint32_t ahead_st = 0, ahead_en = 0;
         uint32_t pr1 = pr0, pa1 = pa0 + T;                        // the next tile's first MCU
         if constexpr (PLANAR) {
-            if (pa1 >= mcux) { pa1 -= mcux; pr1++; }
+            while (pa1 >= mcux) { pa1 -= mcux; pr1++; }
             if (tid < kPlanarSegs && tile + 2 < tile1) {
                 uint32_t a2 = pa1 + T, r2 = pr1;
-                if (a2 >= mcux) { a2 -= mcux; r2++; }
+                while (a2 >= mcux) { a2 -= mcux; r2++; }
                 ahead = planar_probe(s_kind, nk, tid, (tile + 2) * T, r2, a2, log2T, nmcu, mcux, bpm);
                 if (ahead.any) {
                     ahead_st = tile_eoff[ahead.ia];

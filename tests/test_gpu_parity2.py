@@ -791,3 +791,23 @@ def test_small_pictures_in_a_large_batch_are_cut_to_fill_their_workgroup(mjx, or
         assert np.abs(b.rgb(i).astype(int) - ref.rgb.astype(int)).max() <= TOL, i
     b.close()
     ctx.close()
+
+
+def test_multi_scan_picture_whose_tiles_are_one_mcu_longer_than_its_rows(mjx, orc, gpu_ctx):
+    """Round-5 fuzz find (tests/golden/fuzz_r05b/ms_482x638.jpg, three scans, 31 MCUs per row, tiles of 32): walking from tile to
+    tile, the stage-B form that reads the scans' streams advanced the tile's first column by 32 and wrapped once -- from the row's
+    last column that is two rows on, and tile 31 read one MCU from the wrong row.  Only workgroups that walk several tiles do
+    that: 64 copies, against the gathered decode of the same batch and the oracle."""
+    d = open(os.path.join(ROOT, "tests", "golden", "fuzz_r05b", "ms_482x638.jpg"), "rb").read()
+    ref = orc.decode(d, layout=orc.LAYOUT_STD, ext_multiscan=True)
+    rgbs = []
+    for keep in (True, False):
+        base = mjx.Batch(gpu_ctx, [mjx.ParsedScan(d)], keep_coefs=keep)
+        b = base.tile(64)
+        b.decode(); b.wait()
+        assert all(b.status(i) == mjx.OK for i in range(len(b)))
+        rgbs.append([b.rgb(i) for i in (0, 31, 63)])
+        b.close(); base.close()
+    for x in rgbs[0] + rgbs[1]:
+        assert np.array_equal(x, rgbs[0][0])
+    assert np.abs(rgbs[0][0].astype(int) - ref.rgb.astype(int)).max() <= TOL
