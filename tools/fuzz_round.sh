@@ -18,5 +18,6 @@ echo "-- fuzz: MJX_STREAM_LINEAR=1 MJX_POISON=90";         MJX_STREAM_LINEAR=1 M
 echo "-- fuzz: REF_COMPAT, MJX_EMIT_MIN_SUB_BITS=256";     MJX_EMIT_MIN_SUB_BITS=256 timeout 1200 python3 tools/fuzz_parity.py 88 $N - ref 2>&1 | tail -2
 echo "-- hostile";                                          timeout 900 python3 tools/stress_hostile.py 2>&1 | tail -2
 echo "-- hostile, MJX_EMIT_MIN_SUB_BITS=256";              MJX_EMIT_MIN_SUB_BITS=256 timeout 900 python3 tools/stress_hostile.py 2>&1 | tail -2
+echo "-- fuzz_planar (multi-scan twins read from their scans' streams)"; timeout 1200 python3 tools/fuzz_planar.py 7 120 2>&1 | tail -2
 echo "-- big_multiscan";                                    timeout 900 python3 tools/big_multiscan_check.py 2>&1 | tail -3
 } > $OUT 2>&1
