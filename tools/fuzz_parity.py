@@ -26,7 +26,9 @@ total = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 dump = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else None   # directory that receives every batch before it runs
 ref_layout = len(sys.argv) > 4 and sys.argv[4] == "ref"
 rng = np.random.default_rng(seed)
-ctx = mjx.Context(0)
+# (FUZZ_THROUGHPUT_PLAN=1: the cut of a large batch -- 512-byte subsequences, scans below one workgroup cut shorter -- instead of the
+# short cuts a small batch gets)
+ctx = mjx.Context(0, throughput_plan=bool(int(os.environ.get("FUZZ_THROUGHPUT_PLAN", "0"))))
 
 
 def picture(w, h, kind):

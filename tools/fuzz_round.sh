@@ -13,6 +13,7 @@ echo "-- fuzz: MJX_EMIT_MIN_SUB_BITS=256 (single decode for every picture of one
 echo "-- fuzz: MJX_EMIT_MIN_SUB_BITS=256 MJX_EMIT_WARM_BITS=0 MJX_EMIT_CP_BITS=256"; MJX_EMIT_MIN_SUB_BITS=256 MJX_EMIT_WARM_BITS=0 MJX_EMIT_CP_BITS=256 timeout 1200 python3 tools/fuzz_parity.py 83 $N 2>&1 | tail -2
 echo "-- fuzz: MJX_EMIT_MIN_SUB_BITS=256 MJX_EMIT_HEAD=0 (no head room: fall-back path)"; MJX_EMIT_MIN_SUB_BITS=256 MJX_EMIT_WARM_BITS=0 MJX_EMIT_HEAD=0 timeout 1200 python3 tools/fuzz_parity.py 84 $N 2>&1 | tail -2
 echo "-- fuzz: MJX_EMIT_MIN_SUB_BITS=256 MJX_POISON=165 MJX_STREAMS=1"; MJX_EMIT_MIN_SUB_BITS=256 MJX_POISON=165 MJX_STREAMS=1 timeout 1200 python3 tools/fuzz_parity.py 85 $N 2>&1 | tail -2
+echo "-- fuzz: FUZZ_THROUGHPUT_PLAN=1 (the cut of a large batch: scans below one workgroup cut to fill it)"; FUZZ_THROUGHPUT_PLAN=1 timeout 1200 python3 tools/fuzz_parity.py 89 $N 2>&1 | tail -2
 echo "-- fuzz: MJX_SINGLE_DECODE=0";                       MJX_SINGLE_DECODE=0 timeout 1200 python3 tools/fuzz_parity.py 86 $N 2>&1 | tail -2
 echo "-- fuzz: MJX_STREAM_LINEAR=1 MJX_POISON=90";         MJX_STREAM_LINEAR=1 MJX_POISON=90 timeout 1200 python3 tools/fuzz_parity.py 87 $N 2>&1 | tail -2
 echo "-- fuzz: REF_COMPAT, MJX_EMIT_MIN_SUB_BITS=256";     MJX_EMIT_MIN_SUB_BITS=256 timeout 1200 python3 tools/fuzz_parity.py 88 $N - ref 2>&1 | tail -2
