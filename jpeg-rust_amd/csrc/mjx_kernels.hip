@@ -2874,18 +2874,26 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Phase 3 for 4:2:0 (Y 2x2, Cb 1x1, Cr 1x1): lane -> (MCU t, 4-pixel strip sx) fixed; each step handles a 4x2 pixel
 // patch that shares one pair of chroma samples per component (box replication).  INTERIOR: every pixel of the tile
 // lies inside the image and rows are 4-byte aligned, so all eight stores are unconditional 12-byte stores.
-template <bool INTERIOR>
+//   XCHG    the tile holds all its MCUs: every lane reads every sample it owns, as an exchange with zero, whether its pixels lie inside
+//           the picture or not -- the tile is clean for the next one (no zero-fill pass)
+//   BOUNDS  pixels may lie outside the picture (the last column of MCUs, the last row) or rows are not 4-byte aligned: stores are
+//           predicated per pixel; without it (an INTERIOR tile) all eight stores are unconditional 12-byte stores
+// (round 5: the exchange form used to need a tile inside one MCU row and fully inside the picture; a tile that wraps into the next
+// row -- one in 7.5 at 4K, one in 3.75 at 1080p -- or touches the picture's edge took plain reads, bounds everywhere, and cost
+// the tile behind it a zero-fill pass)
+template <bool XCHG, bool BOUNDS>
 __device__ __forceinline__ void pixels_420(uint32_t width, uint32_t height, uint32_t mcux, const float *tile, uint32_t m0,
                                            uint32_t nm, uint8_t *out_img, bool aligned)
 {
+    constexpr bool INTERIOR = XCHG && !BOUNDS;
     const uint32_t tid = threadIdx.x;
     const uint32_t q = tid % (kTile420 * 4), t = q >> 2, sx = q & 3;
-    if (!INTERIOR && t >= nm) return;
+    if (!XCHG && t >= nm) return;
     const uint32_t m = m0 + t;
     const uint32_t mx = m % mcux, my = m / mcux;
     const uint32_t px = mx * 16 + sx * 4;
-    if (!INTERIOR && px >= width) return;
-    const uint32_t npix = INTERIOR ? 4u : min(4u, width - px);
+    if (!XCHG && px >= width) return;
+    const uint32_t npix = INTERIOR ? 4u : (px < width ? min(4u, width - px) : 0u);
     const float *ybase = tile + (t * 6 + (sx >> 1)) * kPixStride + (sx & 1) * 4;
     const float *cbase = tile + (t * 6 + 4) * kPixStride + sx * 2;
     uint8_t *col = out_img + (size_t(my) * 16 * width + px) * 3;
@@ -2897,7 +2905,7 @@ __device__ __forceinline__ void pixels_420(uint32_t width, uint32_t height, uint
 #if defined(MJX_EXP_PLAIN_READS)       // (measurement build, garbage out: plain reads where the exchanges with zero are, no zero-fill pass either)
     if (false) {
 #else
-    if (INTERIOR && MJX_PIX_XCHG) {
+    if (XCHG && MJX_PIX_XCHG) {
 #endif
         // An interior tile: every sample of the tile is read exactly once in this phase, by exactly one lane -- so the read is an
         // exchange with zero (ds_wrxchg), and the tile is clean for the next one's coefficients without a zero-fill pass
@@ -2951,7 +2959,7 @@ __device__ __forceinline__ void pixels_420(uint32_t width, uint32_t height, uint
     for (uint32_t j = 0; j < 4; j++) {
         const uint32_t rp = tid / (kTile420 * 4) + 2 * j;
         const uint32_t py = my * 16 + rp * 2;
-        if (!INTERIOR && py >= height) break;
+        if (!INTERIOR && (py >= height || npix == 0)) break;
         const ChromaTerms c0 = chroma_terms(cb[j].x, cr[j].x), c1 = chroma_terms(cb[j].y, cr[j].y);
         Rgb p[4];
         p[0] = ycc_to_rgb(ya[j].x, c0); p[1] = ycc_to_rgb(ya[j].y, c0);
@@ -3358,11 +3366,15 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
         MJX_SB(5);
         if (MODE == 1) {                                                  // phase 3
             // interior tile: all 32 MCUs in one MCU row, fully inside the image, rows 4-byte aligned
-            const uint32_t mx0 = m0 % mcux, my0 = m0 / mcux;
-            const bool interior = aligned && nm == T && mx0 + T <= mcux && (mx0 + T) * 16 <= width && (my0 + 1) * 16 <= height;
-            if (interior) pixels_420<true>(width, height, mcux, tile_f, m0, nm, out_img, aligned);
-            else pixels_420<false>(width, height, mcux, tile_f, m0, nm, out_img, aligned);
-            clean = interior && MJX_PIX_XCHG;
+            // whole tile: all its 32 MCUs exist; interior: ... and every one of them lies fully inside the picture (the tile may wrap
+            // into the next MCU row), rows 4-byte aligned
+            const uint32_t mx0 = m0 % mcux, my1 = (m0 + T - 1) / mcux;
+            const bool whole = nm == T;
+            const bool interior = whole && aligned && (my1 + 1) * 16 <= height && (mcux * 16 <= width || mx0 + T < mcux);
+            if (interior) pixels_420<true, false>(width, height, mcux, tile_f, m0, nm, out_img, aligned);
+            else if (whole) pixels_420<true, true>(width, height, mcux, tile_f, m0, nm, out_img, aligned);
+            else pixels_420<false, true>(width, height, mcux, tile_f, m0, nm, out_img, aligned);
+            clean = whole && MJX_PIX_XCHG;
         } else if (MODE == 2) {
             place_ref(im, tile_f, tile * tile_blocks, nblk, planes);
         } else {
