@@ -212,7 +212,7 @@ class Context:
     def __del__(self):
         # not during interpreter shutdown: the HIP runtime may already be gone (its teardown aborts the process when a
         # device handle is released after it); the driver reclaims everything at exit anyway
-        if sys.is_finalizing():
+        if sys is None or sys.is_finalizing():          # (at interpreter shutdown module globals may be gone already)
             return
         try:
             self.close()
@@ -326,7 +326,7 @@ class Batch:
     def __del__(self):
         # not during interpreter shutdown: the HIP runtime may already be gone (its teardown aborts the process when a
         # device handle is released after it); the driver reclaims everything at exit anyway
-        if sys.is_finalizing():
+        if sys is None or sys.is_finalizing():          # (at interpreter shutdown module globals may be gone already)
             return
         try:
             self.close()
@@ -561,7 +561,7 @@ class Pool:
             self.h = _vp()
 
     def __del__(self):
-        if sys.is_finalizing():
+        if sys is None or sys.is_finalizing():          # (at interpreter shutdown module globals may be gone already)
             return
         try:
             self.close()
@@ -627,7 +627,7 @@ class PoolResult:
             self.h = _vp()
 
     def __del__(self):
-        if sys.is_finalizing():
+        if sys is None or sys.is_finalizing():          # (at interpreter shutdown module globals may be gone already)
             return
         try:
             self.close()
