@@ -459,7 +459,7 @@ void fill_dev_image(const ImagePlan &p, DevImage &d)
         d.nby = p.nby;
     }
     d.role = p.role;
-    if (p.role == 1) {                 // a scan of a multi-scan file: no stage B; one tile offset per block for the gather
+    if (p.role == 1) {                 // a scan of a multi-scan file: no stage B; one tile offset per block for the gather (build_batch: or segment cuts, seg_S)
         d.mode = 7;
         d.log2_tile = 0;
         d.tile_mcus = 1;

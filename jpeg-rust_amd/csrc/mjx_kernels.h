@@ -53,7 +53,8 @@ struct DevImage {
     uint32_t upload_short;  // ... and their diagnosis at upload (a scan of nothing but stuffing, fewer RSTn markers than intervals): the
                             // picture is truncated whatever the block counts of a later decode say (k_huff_scan ORs it in)
     // multi-scan files: role 1 = one scan as a picture of its own (one component in raster order, or two
-    // interleaved; entropy stage only; tile = one block, so tile_eoff holds an offset per block), role 2 = the picture
+    // interleaved; entropy stage only; tile = one block, so tile_eoff holds an offset per block -- or, seg_S != 0, where the picture's
+    // tile segments begin, see below), role 2 = the picture
     // (no scan; the k_planar_* kernels build its stream from the role-1 images: component c comes from the image
     // src_back[c] places before it in the image array, as that image's src_comp[c]-th component)
     uint32_t role;

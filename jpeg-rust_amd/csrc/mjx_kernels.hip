@@ -1793,7 +1793,8 @@ extern "C" __global__ __launch_bounds__(256) void k_block_gather(const DevImage 
 
 // Multi-scan pictures (beyond the reference, which stops after the first scan).  Every scan went through
 // the entropy stage as a one-component picture of its own: stream entries and DC values in the component's raster
-// order over its own block grid, one tile offset per block.  The picture's stream in MCU order is gathered from them:
+// order over its own block grid, one tile offset per block.  The picture's stream in MCU order is gathered from them (pictures of
+// keep_coefs batches and of geometries the direct form does not take; the others are read where they lie, DevImage::planar):
 //   k_planar_count    one workgroup per tile of the picture: a lane per block slot looks up its block's run in the
 //                     component stream (blocks that exist only as MCU padding have none); the tile's total
 //   k_planar_offsets  one workgroup per picture: exclusive scan of the totals -> tile offsets
