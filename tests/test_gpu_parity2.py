@@ -777,6 +777,8 @@ def test_runs_that_did_not_converge_in_time_are_counted(mjx, orc, tmp_path):
 def test_small_pictures_in_a_large_batch_are_cut_to_fill_their_workgroup(mjx, orc, gpu_ctx):
     """replan_subsequences (round 5): a scan under three quarters of a workgroup's worth of 512-byte subsequences is cut shorter,
     so that its one workgroup is full (16384 x 512x512: 208 -> 323 Gpixels/s).  Geometry, T0 and RGB of such a batch."""
+    if os.environ.get("MJX_FIT_SHORT") == "0":
+        pytest.skip("the rule is switched off (A/B run)")
     datas = [mjx.synth_jpeg(512, 512, "420", 75, seed=s) for s in range(3)] + [mjx.synth_jpeg(256, 256, "444", 75, seed=7)]
     scans = [mjx.ParsedScan(d) for d in datas]
     ctx = mjx.Context(0, throughput_plan=True)
