@@ -153,6 +153,7 @@ struct Chunk {
     uint32_t max_pixel_wgs = 0;
     uint32_t min_sub_bits = 0xffffffffu;   // shortest subsequence length among its scans (chunk_fix_passes)
     uint32_t max_nsub = 0;                 // subsequences of its longest scan
+    uint32_t wg = 128;                     // lanes of its k_huff_spec / k_huff_write workgroups: the largest its scans were cut for (ImagePlan::wg_lanes)
     int learned_passes = 0;        // rounds a repair in mjx_batch_wait found this chunk to need: later decodes of the batch enqueue them up front
     bool has_gather = false;       // holds multi-scan pictures (k_planar_gather runs)
     bool has_copy = false;         // ... some of which are gathered into a stream of their own (the others are read from their scans' streams)
@@ -459,6 +460,7 @@ void fill_dev_image(const ImagePlan &p, DevImage &d)
         d.nby = p.nby;
     }
     d.role = p.role;
+    d.wg_lanes = p.wg_lanes;
     if (p.role == 1) {                 // a scan of a multi-scan file: no stage B; one tile offset per block for the gather (build_batch: or segment cuts, seg_S)
         d.mode = 7;
         d.log2_tile = 0;
@@ -542,9 +544,10 @@ void plan_chunks(mjx_batch *b)
                 c.nsub += d.himg.nsub;
                 if (d.himg.nsub > 1) c.min_sub_bits = std::min(c.min_sub_bits, d.himg.sub_bits);
                 c.max_nsub = std::max(c.max_nsub, d.himg.nsub);
+                if (d.role != 2) c.wg = std::max<uint32_t>(c.wg, d.wg_lanes ? d.wg_lanes : uint32_t(kHuffWg));
                 c.scan_bytes += inf.scan_len;
                 c.blocks += (inf.nblocks + 7) & ~uint64_t(7);          // regions of DC differences start on 32-byte sectors
-                c.max_wg = std::max<uint32_t>(c.max_wg, (d.himg.nsub + kHuffWg - 1) / kHuffWg);
+                // (c.max_wg: set when the chunk is closed, from its longest scan and its workgroup size)
                 if (d.himg.nsub > 1) c.merge_wgs = std::max<uint32_t>(c.merge_wgs, (d.himg.nsub - 1 + kMergeWg - 1) / kMergeWg);
                 if (d.himg.nsub > 1) c.loop_participants += (d.himg.nsub - 1 + kMergeWg - 1) / kMergeWg;      // workgroups x with x * kMergeWg + 1 < nsub
                 const uint32_t T = d.tile_mcus;
@@ -574,6 +577,8 @@ void plan_chunks(mjx_batch *b)
         // one launch for all the merge rounds only when its workgroups are certain to be resident together (they wait for one
         // another): a twelfth of the device's 3 x 256 slots, so that a dozen such launches (other contexts, other processes) still
         // fit side by side; a launch that cannot get its workgroups together gives up by itself (kLoopGaveUp)
+        if (c.has_emit || b->has_stuffed) c.wg = uint32_t(kHuffWg);      // (k_huff_emit and its followers count in workgroups of kHuffWg; stuffed scans: lengths known on the device only)
+        c.max_wg = (c.max_nsub + c.wg - 1) / c.wg;
         if (c.loop_participants > b->ctx->merge_loop_max) c.loop_participants = 0;
         if (b->has_stuffed) c.loop_participants = 0;    // (its workgroups are counted from nsub, which only the device knows exactly for those scans)
         coef_running += c.blocks;
@@ -771,7 +776,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_SYNC)) {
         if (c.has_spec) {
             prof_begin(b, MJX_K_HUFF_SYNC, st);
-            launch_huff_spec(st, c.max_wg, nimg, b->huff_lds2, b->ctx->spec_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps), b->d_segs);
+            launch_huff_spec(st, c.max_wg, nimg, b->huff_lds2, b->ctx->spec_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps), b->d_segs, c.wg);
             prof_end(b, st);
         }
         if (c.has_emit) {       // single decode: these pictures' first decode emits (LDS as the write pass: plain tables, windows, rings)
@@ -820,7 +825,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         if (c.has_spec) {
             prof_begin(b, MJX_K_HUFF_WRITE, st);
             launch_huff_write(st, c.max_wg, nimg, b->huff_lds, b->ctx->write_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_blkbase), SCR(d_ebase),
-                                  SCR(d_entries), SCR(d_tile_eoff), SCR(d_dcd), b->d_status, b->d_img_flags, b->d_segs, SCR(d_exit), SCR(d_cps));
+                                  SCR(d_entries), SCR(d_tile_eoff), SCR(d_dcd), b->d_status, b->d_img_flags, b->d_segs, SCR(d_exit), SCR(d_cps), c.wg);
             prof_end(b, st);
         }
         if (c.has_emit) {       // the prefixes of the lanes whose entry was wrong; block words -> DC differences + tile offsets
@@ -1760,6 +1765,7 @@ extern "C" int mjx_batch_tile(mjx_ctx *ctx, const mjx_batch *src, size_t times, 
         p.role = d.role;
         p.nparts = d.nparts;
         p.part_idx = d.part_idx;
+        p.wg_lanes = d.wg_lanes ? d.wg_lanes : uint32_t(kHuffWg);
         for (uint32_t c = 0; c < 3; c++) {
             p.cbw[c] = d.cbw[c];
             p.cbh[c] = d.cbh[c];

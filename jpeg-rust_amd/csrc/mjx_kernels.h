@@ -59,6 +59,7 @@ struct DevImage {
     // src_back[c] places before it in the image array, as that image's src_comp[c]-th component)
     uint32_t role;
     uint32_t src_back[3], src_comp[3];
+    uint32_t wg_lanes;          // lanes of the entropy workgroups this scan was cut for (ImagePlan::wg_lanes; the chunk runs at its pictures' largest)
     uint32_t nparts;            // (role 1 as well: the scans of its file, of which it is the part_idx-th)
     uint32_t part_idx;
     uint32_t cbw[3], cbh[3];    // role 2: block grid of each component's own scan
@@ -328,7 +329,7 @@ void launch_scan_interleave(hipStream_t st, uint32_t max_pieces, uint32_t nimg, 
                             const uint8_t *linear, uint8_t *pool, const uint32_t *segs);
 void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                       const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
-                      uint32_t *cps, const uint32_t *segs);
+                      uint32_t *cps, const uint32_t *segs, uint32_t lanes /* per workgroup: kHuffWg, or 256 / 128 for a chunk of short scans */);
 void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                        const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
                        uint32_t *cps, uint32_t *mismatches, uint32_t *items, uint32_t *item_count, const uint32_t *segs,
@@ -365,7 +366,7 @@ void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
                        const uint8_t *scan_pool, const LutEntry *lut_pool, const SubseqState *entry,
                        const uint32_t *blkbase, const uint32_t *ebase, uint32_t *entries, uint32_t *tile_eoff,
                        int16_t *dcdiff, int *status, const uint32_t *img_flags, const uint32_t *segs, const SubseqState *exit_,
-                       uint32_t *cps /* measurement builds only */);
+                       uint32_t *cps /* measurement builds only */, uint32_t lanes /* as launch_huff_spec */);
 void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, const int16_t *dcdiff, int32_t *dcbuf,
                     int32_t *segsum, const uint32_t *img_flags, uint32_t bpm_mask, uint32_t max_restart_segs,
                     uint32_t *segflag = nullptr, uint32_t gen = 0,

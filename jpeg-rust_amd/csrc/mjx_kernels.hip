@@ -522,11 +522,13 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_spec(const DevImage
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
     const uint32_t img = entropy_grid_image(), wgi = entropy_grid_wg();
     const DevImage &im = images[img];
-    if (!im.valid || im.emit || wgi * kHuffWg >= im.himg.nsub) return;      // (emit: the picture's first decode is k_huff_emit's)
+    // (blockDim.x lanes: 512, or -- round 5 -- 256 / 128 for chunks whose scans are all that short: the LDS of these kernels is sized
+    // per lane, and a scan of a hundred subsequences in a workgroup of 512 holds four times the LDS it uses)
+    if (!im.valid || im.emit || wgi * blockDim.x >= im.himg.nsub) return;      // (emit: the picture's first decode is k_huff_emit's)
     const HuffImage *h;
     const LutEntry *lut;
     stage_tables<true>(im, lut_pool, smem, h, lut);
-    const uint32_t s = wgi * kHuffWg + threadIdx.x;
+    const uint32_t s = wgi * blockDim.x + threadIdx.x;
     const bool live = s < h->nsub;
     const LaneBits bits{scan_pool + im.scan_off, (live ? s : 0u) * 16u, im.scan_cols * 16u};
     const SubLoc loc = locate_sub(im, *h, segs, live ? s : 0u);
@@ -1272,11 +1274,11 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
     const uint32_t img = entropy_grid_image(), wgi = entropy_grid_wg();
     const DevImage &im = images[img];
-    if (!im.valid || im.emit || wgi * kHuffWg >= im.himg.nsub || img_flags[im.status_idx]) return;
+    if (!im.valid || im.emit || wgi * blockDim.x >= im.himg.nsub || img_flags[im.status_idx]) return;      // (blockDim.x: see k_huff_spec)
     const HuffImage *h;
     const LutEntry *lut;
     stage_tables(im, lut_pool, smem, h, lut);
-    const uint32_t s = wgi * kHuffWg + threadIdx.x;
+    const uint32_t s = wgi * blockDim.x + threadIdx.x;
     const bool live = s < h->nsub;
     const LaneBits gbits{scan_pool + im.scan_off, (live ? s : 0u) * 16u, im.scan_cols * 16u};
     SubseqState e = make_state(0, 0, 0);
@@ -1310,7 +1312,7 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
     sink.status = status + im.status_idx;
     const uint32_t first_start = blk + (e.z ? 1u : 0u);                    // first block whose DC this lane decodes
     {
-        uint32_t *rings = s_win + kHuffWg * kWinStride;
+        uint32_t *rings = s_win + blockDim.x * kWinStride;
         if (im.ent_rows) {          // quad-interleaved stream: the lane's column (stream_phys(s, 0)), groups four groups apart
             const uint32_t sl = live ? s : 0u;
             sink.ac_ring.begin(rings + threadIdx.x * kAcRingStride, entries + im.ent_off + im.ent_hdr + stream_phys(sl, 0, im.ent_rows), 0u);
@@ -1321,7 +1323,7 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_write(const DevImag
             sink.ac_ring.begin(rings + threadIdx.x * kAcRingStride, entries + im.ent_off, ebase);
             sink.tile_virt = 0;
         }
-        rings += kHuffWg * kAcRingStride;
+        rings += blockDim.x * kAcRingStride;
         sink.dc_ring.begin(rings + threadIdx.x * (DcRing16::kRing / 2), dcdiff + im.coef_off, first_start);
     }
     sink.blk_bits = StreamSink::block_bits(blk);
@@ -3444,9 +3446,11 @@ extern "C" __global__ __launch_bounds__(256) void k_rgb_compare(const RgbPair *p
 // host launchers (declared in mjx_kernels.h)
 // ------------------------------------------------------------------------------------------------
 size_t huff_lds_bytes(uint32_t lut_cap_entries) { return (sizeof(HuffImage) + size_t(lut_cap_entries) * sizeof(LutEntry) + 15) / 16 * 16; }
-size_t huff_window_bytes() { return size_t(kHuffWg) * kWinStride * 4; }
+size_t huff_window_bytes(uint32_t lanes) { return size_t(lanes) * kWinStride * 4; }
+size_t huff_window_bytes() { return huff_window_bytes(uint32_t(kHuffWg)); }
 size_t huff_merge_bytes() { return size_t(kMergeWg) * kMergeStride * 4 + (kMergeWg / 64 + 1) * 4; }
-size_t huff_stage_bytes() { return size_t(kHuffWg) * (kAcRingStride * 4 + DcRing16::kRing * 2); }    // the write pass's rings
+size_t huff_stage_bytes(uint32_t lanes) { return size_t(lanes) * (kAcRingStride * 4 + DcRing16::kRing * 2); }    // the write pass's rings
+size_t huff_stage_bytes() { return huff_stage_bytes(uint32_t(kHuffWg)); }
 
 uint32_t tile_mcus_420() { return kTile420; }
 uint32_t stream_group_entries() { return kAcGroup; }
@@ -3503,10 +3507,11 @@ void launch_scan_interleave(hipStream_t st, uint32_t max_pieces, uint32_t nimg, 
 
 void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                       const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
-                      uint32_t *cps, const uint32_t *segs)
+                      uint32_t *cps, const uint32_t *segs, uint32_t lanes)
 {
-    const size_t lds = tables_lds + huff_window_bytes() + pad_lds;
-    hipLaunchKernelGGL(k_huff_spec, entropy_grid(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, uint32_t(tables_lds), segs);
+    // (lanes: 512, or 256 / 128 for a chunk of short scans -- max_wg counts workgroups of that size; the occupancy pad belongs to the full size)
+    const size_t lds = tables_lds + huff_window_bytes(lanes) + (lanes == uint32_t(kHuffWg) ? pad_lds : 0);
+    hipLaunchKernelGGL(k_huff_spec, entropy_grid(max_wg, nimg), dim3(lanes), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, uint32_t(tables_lds), segs);
 }
 
 void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
@@ -3573,10 +3578,11 @@ void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, con
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                        const uint8_t *scan_pool, const LutEntry *lut_pool, const SubseqState *entry,
                        const uint32_t *blkbase, const uint32_t *ebase, uint32_t *entries, uint32_t *tile_eoff,
-                       int16_t *dcdiff, int *status, const uint32_t *img_flags, const uint32_t *segs, const SubseqState *exit_, uint32_t *cps)
+                       int16_t *dcdiff, int *status, const uint32_t *img_flags, const uint32_t *segs, const SubseqState *exit_, uint32_t *cps,
+                       uint32_t lanes)
 {
-    const size_t lds = tables_lds + huff_window_bytes() + huff_stage_bytes() + pad_lds;
-    hipLaunchKernelGGL(k_huff_write, entropy_grid(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, blkbase, ebase, entries, tile_eoff, dcdiff, status, img_flags, uint32_t(tables_lds), segs, exit_, cps);
+    const size_t lds = tables_lds + huff_window_bytes(lanes) + huff_stage_bytes(lanes) + (lanes == uint32_t(kHuffWg) ? pad_lds : 0);
+    hipLaunchKernelGGL(k_huff_write, entropy_grid(max_wg, nimg), dim3(lanes), lds, st, images, scan_pool, lut_pool, entry, blkbase, ebase, entries, tile_eoff, dcdiff, status, img_flags, uint32_t(tables_lds), segs, exit_, cps);
 }
 
 void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevImage *images, const int16_t *dcd, int32_t *dcbuf,

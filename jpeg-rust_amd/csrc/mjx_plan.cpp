@@ -84,6 +84,7 @@ static int plan_ref_layout(ImagePlan &p)
 // segment (one segment without restart intervals); sets himg.sub_bits, himg.nsub and the first subsequence of every segment.
 void replan_subsequences(ImagePlan &p, uint32_t base_bits, bool allow_long)
 {
+    p.wg_lanes = uint32_t(kHuffWg);
     if (p.role == 2 || p.seg.size() < 2 * (size_t(p.nseg) + 1)) return;        // (role 2: no scan of its own)
     // long scans without restart intervals: long subsequences (mjx_huff.h: kLongSubseqBits), unless the caller asks for short ones
     if (allow_long && base_bits == uint32_t(kSubseqBits) && p.nseg == 1 && p.restart_mcus == 0 && (long long)p.himg.total_bits >= kLongScanBits)
@@ -104,8 +105,15 @@ void replan_subsequences(ImagePlan &p, uint32_t base_bits, bool allow_long)
     // (MJX_FIT_SHORT=0: off, for the A/B; a value above 1: the shortest cut in bits instead of 1024)
     static const uint32_t fit_floor = [] { const char *e = std::getenv("MJX_FIT_SHORT"); const long v = e ? std::atol(e) : 1; return uint32_t(v <= 1 ? v * 4 * kCpBits : std::max<long>(v, kCpBits)); }();
     const bool fit_short = fit_floor != 0;
+    p.wg_lanes = uint32_t(kHuffWg);
     if (fit_short && base_bits == uint32_t(kSubseqBits) && p.nseg == 1 && p.restart_mcus == 0 && p.himg.total_bits < uint32_t(kSubseqBits) * uint32_t(kHuffWg) / 4u * 3u) {       // (under three quarters of a workgroup)
-        const uint32_t fit = ((p.himg.total_bits + uint32_t(kHuffWg) - 1) / uint32_t(kHuffWg) + uint32_t(kCpBits) - 1) / uint32_t(kCpBits) * uint32_t(kCpBits);
+        // ... of 512 lanes, or -- the LDS of the counting and the write pass is sized per lane -- of 256 / 128, the fewest that
+        // hold the scan at the default length: four times the workgroups per CU for the same scan (32768 x 256x256: 130 -> 176
+        // Gpixels/s, 16384 x 500x375: 235 -> 284; `-DMJX_HUFF_WG=128` had measured it for the whole library)
+        uint32_t lanes = uint32_t(kHuffWg);
+        while (lanes > 128u && uint64_t(p.himg.total_bits) <= uint64_t(lanes / 2u) * uint32_t(kSubseqBits)) lanes /= 2u;
+        p.wg_lanes = lanes;
+        const uint32_t fit = ((p.himg.total_bits + lanes - 1) / lanes + uint32_t(kCpBits) - 1) / uint32_t(kCpBits) * uint32_t(kCpBits);
         base_bits = std::max<uint32_t>(fit_floor / uint32_t(kCpBits) * uint32_t(kCpBits), std::min(base_bits, fit));
     }
     const uint32_t top = base_bits * 5 / 4;

@@ -35,6 +35,8 @@ struct ImagePlan {
     // the stuffed length -- an upper bound; himg.total_bits, himg.nsub and the segment table are bounds and placeholders here,
     // the device writes the exact values into the DevImage (k_destuff_prefix, k_restart_geometry).
     bool stuffed = false;
+    uint32_t wg_lanes = uint32_t(kHuffWg);         // lanes of the entropy workgroups the scan is cut for: 512, or 256 / 128 for a scan that fills no more
+                                                   // (replan_subsequences; k_huff_spec / k_huff_write run a chunk at its pictures' largest)
     uint32_t nsub_layout = 0;                      // subsequences the scan pool region is laid out for (0: himg.nsub; a batch tiled from
                                                    // one that was de-stuffed on the device keeps the region of the bound)
     // REF_COMPAT placement (decoder.rs:239-250): replication factors per component, block grid of the image

@@ -785,7 +785,7 @@ def test_small_pictures_in_a_large_batch_are_cut_to_fill_their_workgroup(mjx, or
     b = mjx.Batch(ctx, scans, keep_coefs=True)
     geo = b.geometry()
     per_picture = geo["subsequences"] / len(datas)
-    assert 150 <= per_picture <= 512, geo          # (at 512 bytes per subsequence: ~50 per 512x512 picture; the cut stops at 1024 bits)
+    assert 90 <= per_picture <= 256, geo           # (at 512 bytes per subsequence: ~50 per 512x512 picture; now ~110: 128 lanes' worth, 1024 bits at least)
     b.decode(); b.wait()
     for i, d in enumerate(datas):
         ref = orc.decode(d, layout=orc.LAYOUT_STD)

@@ -648,8 +648,8 @@ def test_planner_shares_tables_and_fills_workgroups(mjx, emul_lib):
     """mjx_plan.cpp, round 5.  (a) Slots that hold the same Huffman table share one decode table, and the decoder's block-in-MCU
     state counts inside the period of the MCU's table sequence: Cb + Cr in a scan of their own (both on the chroma tables) have
     period 1 -- two decodes that only disagree on which chroma block they are in coincide (1024 luma + chroma 4K files: 41.7 ms of
-    merge rounds before).  (b) A scan under three quarters of a workgroup of 4096-bit subsequences is cut shorter, down to 1024
-    bits, so that its workgroup is full."""
+    merge rounds before).  (b) A scan under three quarters of a workgroup of 4096-bit subsequences is cut so that it fills a
+    workgroup of 128, 256 or 512 lanes -- the fewest that hold it -- with subsequences of 1024 bits at least."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import make_multiscan
 
@@ -668,10 +668,10 @@ def test_planner_shares_tables_and_fills_workgroups(mjx, emul_lib):
     assert [q[0] for q in three] == [1, 1, 1, 2] and all(q[4] == 1 for q in three[:3])
     gray = parts(mjx.synth_jpeg(64, 64, "gray", 75, seed=1))
     assert gray[0][3] == gray[0][4] == 1
-    # (b): sub_bits * nsub covers the scan; small scans are cut to fill ~512 lanes but not below 1024 bits
-    for (w, h, q), (lo, hi) in (((512, 512, 75), (1024, 1024)), ((1024, 768, 75), (1280, 2304)), ((1280, 720, 75), (1792, 3072)),
-                                ((1920, 1080, 75), (4096, 5120)), ((96, 64, 75), (1024, 1024))):
+    # (b): a scan below three quarters of a workgroup is cut for the fewest lanes -- 128, 256 or 512 -- that hold it at up to 4096
+    # bits each, and fills them (not below 1024 bits per subsequence); from 1080p up nothing changes
+    for (w, h, q), (lo, hi), (nlo, nhi) in (((512, 512, 75), (2048, 2560), (100, 128)), ((1024, 768, 75), (3072, 4096), (200, 256)),
+                                            ((1280, 720, 75), (3584, 4096), (200, 256)), ((1920, 1080, 75), (4096, 5120), (400, 512)),
+                                            ((256, 256, 75), (1024, 1024), (40, 128)), ((96, 64, 75), (1024, 1024), (1, 16))):
         (p,) = parts(mjx.synth_jpeg(w, h, "420", q, seed=5))
-        assert lo <= p[5] <= hi and p[5] % 256 == 0, (w, h, p)
-        if p[5] > 1024:
-            assert 384 <= p[6] <= 640, (w, h, p)
+        assert lo <= p[5] <= hi and p[5] % 256 == 0 and nlo <= p[6] <= nhi, (w, h, p)
