@@ -92,6 +92,8 @@ struct mjx_ctx {
     // emit_min_sub_bits bits (the long ones), are decoded ONCE by an emitting pass (k_huff_emit) whose lanes warm up over the last emit_warm_bits
     // bits of the subsequence in front of their own and record a checkpoint every emit_cp_bits bits; MJX_SINGLE_DECODE=0: every
     // picture takes the two-pass kernels (k_huff_spec ... k_huff_write).
+    uint8_t *rgb_pin = nullptr;    // pinned block mjx_batch_copy_rgb copies through (8 MB, allocated on first use)
+    std::mutex rgb_pin_mu;
     bool single_decode = true;
     bool planar_direct = true;     // multi-scan pictures: stage B reads the scans' streams (MJX_PLANAR_DIRECT=0: always through the gather kernels)
     bool emit_merge_listed = true;  // MJX_EMIT_MERGE_LISTED=0: the first merge round of such pictures runs its head slices in place, as for the others
@@ -1641,6 +1643,7 @@ extern "C" void mjx_ctx_destroy(mjx_ctx *ctx)
     if (ctx->upload) { (void)hipStreamSynchronize(ctx->upload); (void)hipStreamDestroy(ctx->upload); }
     if (ctx->parse_arena) (void)hipHostFree(ctx->parse_arena);
     if (ctx->pin_small) (void)hipHostFree(ctx->pin_small);
+    if (ctx->rgb_pin) (void)hipHostFree(ctx->rgb_pin);
     for (int k = 0; k < 2; k++) {
         if (ctx->stage_pin[k]) (void)hipHostFree(ctx->stage_pin[k]);
         if (ctx->stage_done[k]) (void)hipEventDestroy(ctx->stage_done[k]);
@@ -2049,7 +2052,32 @@ extern "C" int mjx_batch_copy_rgb(mjx_batch *b, size_t iu, uint8_t *host_rgb)
     if (inf.status != MJX_OK) return inf.status;
     HIPOK(hipSetDevice(b->ctx->device));
     { const int rcs = sync_streams(b); if (rcs != MJX_OK) return rcs; }
-    HIPOK(hipMemcpy(host_rgb, b->d_rgb + inf.rgb_off, size_t(inf.rgb_bytes), hipMemcpyDeviceToHost));
+    // Through a pinned block of the context, in pieces: a copy straight into the caller's memory makes the runtime register those
+    // pages with the driver for the transfer, and when the caller frees them -- a picture of a megabyte and more is an mmap of
+    // its own -- the unmapping of a registered range evicts the process's queues for a moment: every later call then waited
+    // 20-30 ms (in steps of ten) on its first synchronisation.  Seen on 2x2-chroma.jpeg (1.3 MB of RGB) through mjx_decode, not on
+    // lena.jpeg (0.8 MB: under the runtime's own staging limit); round 5, tools/probes/oneshot_2x2.py.
+    {
+        mjx_ctx *ctx = b->ctx;
+        std::lock_guard<std::mutex> lk(ctx->rgb_pin_mu);
+        const size_t kPiece = size_t(8) << 20;
+        if (!ctx->rgb_pin) {
+            void *hp = nullptr;
+            if (hipHostMalloc(&hp, kPiece, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); hp = nullptr; }
+            ctx->rgb_pin = static_cast<uint8_t *>(hp);
+        }
+        const uint8_t *src = b->d_rgb + inf.rgb_off;
+        const size_t total = size_t(inf.rgb_bytes);
+        if (!ctx->rgb_pin) {
+            HIPOK(hipMemcpy(host_rgb, src, total, hipMemcpyDeviceToHost));
+        } else {
+            for (size_t at = 0; at < total; at += kPiece) {
+                const size_t n = std::min(kPiece, total - at);
+                HIPOK(hipMemcpy(ctx->rgb_pin, src + at, n, hipMemcpyDeviceToHost));
+                std::memcpy(host_rgb + at, ctx->rgb_pin, n);
+            }
+        }
+    }
     return MJX_OK;
     });
 }
