@@ -2042,6 +2042,36 @@ extern "C" int mjx_batch_rgb_device(const mjx_batch *b, size_t iu, void **dev_pt
     return MJX_OK;
 }
 
+// Device -> host memory the library does not own, through a pinned block of the context, in pieces: a copy straight into the
+// caller's memory makes the runtime register those pages with the driver for the transfer, and when the caller frees them -- a
+// picture of a megabyte and more is an mmap of its own -- the unmapping of a registered range evicts the process's queues for a
+// moment: every later call then waited 20-30 ms (in steps of ten) on its first synchronisation.  Seen on 2x2-chroma.jpeg (1.3 MB of
+// RGB) through mjx_decode, not on lena.jpeg (0.8 MB: under the runtime's own staging limit); round 5, tools/probes/oneshot_2x2.py.
+static int copy_from_device(mjx_ctx *ctx, void *host, const void *dev, size_t total)
+{
+    if (total < (size_t(512) << 10)) {                        // (small: the runtime stages these itself)
+        HIPOK(hipMemcpy(host, dev, total, hipMemcpyDeviceToHost));
+        return MJX_OK;
+    }
+    std::lock_guard<std::mutex> lk(ctx->rgb_pin_mu);
+    const size_t kPiece = size_t(8) << 20;
+    if (!ctx->rgb_pin) {
+        void *hp = nullptr;
+        if (hipHostMalloc(&hp, kPiece, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); hp = nullptr; }
+        ctx->rgb_pin = static_cast<uint8_t *>(hp);
+    }
+    if (!ctx->rgb_pin) {
+        HIPOK(hipMemcpy(host, dev, total, hipMemcpyDeviceToHost));
+        return MJX_OK;
+    }
+    for (size_t at = 0; at < total; at += kPiece) {
+        const size_t n = std::min(kPiece, total - at);
+        HIPOK(hipMemcpy(ctx->rgb_pin, static_cast<const uint8_t *>(dev) + at, n, hipMemcpyDeviceToHost));
+        std::memcpy(static_cast<uint8_t *>(host) + at, ctx->rgb_pin, n);
+    }
+    return MJX_OK;
+}
+
 extern "C" int mjx_batch_copy_rgb(mjx_batch *b, size_t iu, uint8_t *host_rgb)
 {
     if (b && !b->parts.empty()) { mjx_batch *pb; size_t pi; return route(b, iu, pb, pi) ? mjx_batch_copy_rgb(pb, pi, host_rgb) : MJX_ERR_INVALID_ARG; }
@@ -2052,33 +2082,7 @@ extern "C" int mjx_batch_copy_rgb(mjx_batch *b, size_t iu, uint8_t *host_rgb)
     if (inf.status != MJX_OK) return inf.status;
     HIPOK(hipSetDevice(b->ctx->device));
     { const int rcs = sync_streams(b); if (rcs != MJX_OK) return rcs; }
-    // Through a pinned block of the context, in pieces: a copy straight into the caller's memory makes the runtime register those
-    // pages with the driver for the transfer, and when the caller frees them -- a picture of a megabyte and more is an mmap of
-    // its own -- the unmapping of a registered range evicts the process's queues for a moment: every later call then waited
-    // 20-30 ms (in steps of ten) on its first synchronisation.  Seen on 2x2-chroma.jpeg (1.3 MB of RGB) through mjx_decode, not on
-    // lena.jpeg (0.8 MB: under the runtime's own staging limit); round 5, tools/probes/oneshot_2x2.py.
-    {
-        mjx_ctx *ctx = b->ctx;
-        std::lock_guard<std::mutex> lk(ctx->rgb_pin_mu);
-        const size_t kPiece = size_t(8) << 20;
-        if (!ctx->rgb_pin) {
-            void *hp = nullptr;
-            if (hipHostMalloc(&hp, kPiece, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); hp = nullptr; }
-            ctx->rgb_pin = static_cast<uint8_t *>(hp);
-        }
-        const uint8_t *src = b->d_rgb + inf.rgb_off;
-        const size_t total = size_t(inf.rgb_bytes);
-        if (!ctx->rgb_pin) {
-            HIPOK(hipMemcpy(host_rgb, src, total, hipMemcpyDeviceToHost));
-        } else {
-            for (size_t at = 0; at < total; at += kPiece) {
-                const size_t n = std::min(kPiece, total - at);
-                HIPOK(hipMemcpy(ctx->rgb_pin, src + at, n, hipMemcpyDeviceToHost));
-                std::memcpy(host_rgb + at, ctx->rgb_pin, n);
-            }
-        }
-    }
-    return MJX_OK;
+    return copy_from_device(b->ctx, host_rgb, b->d_rgb + inf.rgb_off, size_t(inf.rgb_bytes));
     });
 }
 
@@ -2102,9 +2106,9 @@ extern "C" int mjx_batch_copy_coefs(mjx_batch *b, size_t iu, int16_t *host_coefs
     const bool sec = b->resident_second && !b->opts.keep_coefs;
     const uint32_t *tile_eoff = sec ? b->alt.d_tile_eoff : b->d_tile_eoff, *entries = sec ? b->alt.d_entries : b->d_entries;
     const int32_t *dcs = sec ? b->alt.d_dc : b->d_dc;
-    HIPOK(hipMemcpy(eoff.data(), tile_eoff + inf.tile_off, eoff.size() * 4, hipMemcpyDeviceToHost));
+    { const int rcc = copy_from_device(b->ctx, eoff.data(), tile_eoff + inf.tile_off, eoff.size() * 4); if (rcc != MJX_OK) return rcc; }
     std::vector<int32_t> dc(size_t(inf.nblocks));
-    HIPOK(hipMemcpy(dc.data(), dcs + inf.coef_off, dc.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    { const int rcc = copy_from_device(b->ctx, dc.data(), dcs + inf.coef_off, dc.size() * sizeof(int32_t)); if (rcc != MJX_OK) return rcc; }
     std::memset(host_coefs, 0, size_t(inf.nblocks) * 128);
     auto place = [&](uint32_t first, uint32_t e) {
         const uint64_t blk = first + (((e >> 22) - first) & 0xffu);
@@ -2114,7 +2118,7 @@ extern "C" int mjx_batch_copy_coefs(mjx_batch *b, size_t iu, int16_t *host_coefs
         // quad-interleaved: a tile runs from (subsequence, entry) of its own offset to that of the next one, through the whole
         // runs (the 16-bit group counts at the head of the region) of the subsequences between
         std::vector<uint32_t> ent(size_t(inf.ent_cap));
-        HIPOK(hipMemcpy(ent.data(), entries + inf.ent_off, ent.size() * 4, hipMemcpyDeviceToHost));
+        { const int rcc = copy_from_device(b->ctx, ent.data(), entries + inf.ent_off, ent.size() * 4); if (rcc != MJX_OK) return rcc; }
         const uint32_t *runs = ent.data();                   // one run word per subsequence: first group, end group, label offset (mjx_kernels.h)
         const uint32_t *col = ent.data() + inf.ent_hdr;
         const uint32_t cap = inf.ent_rows * 8u;
@@ -2136,7 +2140,7 @@ extern "C" int mjx_batch_copy_coefs(mjx_batch *b, size_t iu, int16_t *host_coefs
         const uint32_t nent = eoff.back();
         if (nent > inf.ent_cap) return MJX_ERR_DEVICE;
         std::vector<uint32_t> ent(size_t(nent) + 1);
-        if (nent) HIPOK(hipMemcpy(ent.data(), entries + inf.ent_off, size_t(nent) * 4, hipMemcpyDeviceToHost));
+        if (nent) { const int rcc = copy_from_device(b->ctx, ent.data(), entries + inf.ent_off, size_t(nent) * 4); if (rcc != MJX_OK) return rcc; }
         for (uint32_t t = 0; t < inf.ntiles; t++) {
             const uint32_t first = t * inf.tile_blocks;
             for (uint32_t j = eoff[t]; j < eoff[t + 1] && j < nent; j++) place(first, ent[j]);
