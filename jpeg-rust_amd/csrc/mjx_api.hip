@@ -95,6 +95,7 @@ struct mjx_ctx {
     uint8_t *rgb_pin = nullptr;    // pinned block mjx_batch_copy_rgb copies through (8 MB, allocated on first use)
     std::mutex rgb_pin_mu;
     bool single_decode = true;
+    bool merge_memo = true;        // two generations per subsequence in the merge rounds (MJX_MERGE_MEMO=0: one, as before round 5)
     bool planar_direct = true;     // multi-scan pictures: stage B reads the scans' streams (MJX_PLANAR_DIRECT=0: always through the gather kernels)
     bool emit_merge_listed = true;  // MJX_EMIT_MERGE_LISTED=0: the first merge round of such pictures runs its head slices in place, as for the others
     // (emit_min_sub_bits = the long subsequences of scans of 0.79 MB and more, mjx_huff.h: with the 4096 .. 5120-bit subsequences of
@@ -246,6 +247,7 @@ struct mjx_batch {
     uint32_t *d_segs = nullptr;         // restart segments of the unique images: (first subsequence, first bit) pairs
     std::vector<uint32_t> h_segs;       // host copy (mjx_batch_tile rebuilds plans from it)
     SubseqState *d_entry = nullptr, *d_exit = nullptr;
+    uint8_t *d_gen = nullptr;           // [chunk subsequences]: which of the two sets of entry / exit / checkpoints is current (Gen2)
     uint32_t *d_blkbase = nullptr;
     uint32_t *d_cps = nullptr;          // [chunk subsequences / 256][kMaxCp][256] checkpoints (two words each)
     EmitSub *d_esub = nullptr;          // per subsequence of the chunk: what the emitting first decode left behind (single decode)
@@ -264,6 +266,7 @@ struct mjx_batch {
     size_t rgb_pool_bytes = 0;
     int *d_status = nullptr;
     unsigned long long *d_planes = nullptr;   // REF_COMPAT: f32 planes with write-order keys (chunk scratch)
+    uint32_t gen_stride = 0;            // subsequences between the two sets of entry / exit / checkpoints (0: one set, MJX_MERGE_MEMO=0)
     uint32_t *d_unconv = nullptr;       // [chunks]: runs of the chunk whose synchronisation rounds had not converged when the rest of the entropy stage ran
                                         // (its pictures were skipped; mjx_batch_wait repairs the last run only) -- mjx_batch_unconverged_runs
     uint32_t *d_mismatch = nullptr;     // [chunks][kMisWords]: re-decodes of every synchronisation round; [kMaxFix]: set when the one-pass DC prediction gave up
@@ -276,6 +279,7 @@ struct mjx_batch {
     // second set of per-chunk scratch for the chunks that run on ctx->stream2 (null = single stream)
     struct Alt {
         SubseqState *d_entry = nullptr, *d_exit = nullptr;
+        uint8_t *d_gen = nullptr;
         uint32_t *d_blkbase = nullptr, *d_ebase = nullptr, *d_cps = nullptr, *d_pull = nullptr, *d_items = nullptr;
         EmitSub *d_esub = nullptr;
         int32_t *d_segsum = nullptr, *d_dc = nullptr;
@@ -611,10 +615,14 @@ int allocate_work_buffers(mjx_batch *b, DevArena &ar)
         max_tile_blocks = std::max(max_tile_blocks, c.max_tile_blocks);
     }
     const uint64_t coef_blocks = b->opts.keep_coefs ? std::max<uint64_t>(total_blocks, 1) : max_blocks;
-    ar.take(&b->d_entry, size_t(max_nsub) * sizeof(SubseqState));
-    ar.take(&b->d_exit, size_t(max_nsub) * sizeof(SubseqState));
+    // (two sets of entry / exit / checkpoints per subsequence, the second gen_stride behind the first: Gen2, mjx_kernels.hip)
+    b->gen_stride = b->ctx->merge_memo ? uint32_t((size_t(max_nsub) + 255) / 256 * 256) : 0u;
+    const size_t sets_nsub = size_t(max_nsub) + 2 * size_t(b->gen_stride);       // (a third set: what a re-decode records while it runs)
+    ar.take(&b->d_entry, sets_nsub * sizeof(SubseqState));
+    ar.take(&b->d_exit, sets_nsub * sizeof(SubseqState));
+    ar.take(&b->d_gen, sets_nsub + 16);
     ar.take(&b->d_blkbase, size_t(max_nsub) * sizeof(uint32_t));
-    ar.take(&b->d_cps, (size_t(max_nsub) + 256) / 256 * 256 * kMaxCp * 2 * sizeof(uint32_t));
+    ar.take(&b->d_cps, (sets_nsub + 256) / 256 * 256 * kMaxCp * 2 * sizeof(uint32_t));
     ar.take(&b->d_esub, size_t(max_nsub) * sizeof(EmitSub));
     size_t max_imgs = 1;
     for (const Chunk &c : b->chunks) max_imgs = std::max(max_imgs, c.count);
@@ -646,11 +654,12 @@ int allocate_work_buffers(mjx_batch *b, DevArena &ar)
     if (b->ctx->nstreams == 2 && b->chunks.size() > 1) {          // second scratch set for the chunks on stream2
         mjx_batch::Alt &a = b->alt;
         b->dual = true;
-        ar.take(&a.d_entry, size_t(max_nsub) * sizeof(SubseqState));
-        ar.take(&a.d_exit, size_t(max_nsub) * sizeof(SubseqState));
+        ar.take(&a.d_entry, sets_nsub * sizeof(SubseqState));
+        ar.take(&a.d_exit, sets_nsub * sizeof(SubseqState));
+        ar.take(&a.d_gen, sets_nsub + 16);
         ar.take(&a.d_blkbase, size_t(max_nsub) * sizeof(uint32_t));
         ar.take(&a.d_ebase, size_t(max_nsub) * sizeof(uint32_t));
-        ar.take(&a.d_cps, (size_t(max_nsub) + 256) / 256 * 256 * kMaxCp * 2 * sizeof(uint32_t));
+        ar.take(&a.d_cps, (sets_nsub + 256) / 256 * 256 * kMaxCp * 2 * sizeof(uint32_t));
         ar.take(&a.d_esub, size_t(max_nsub) * sizeof(EmitSub));
         ar.take(&a.d_pull, max_imgs * kMaxFix * sizeof(uint32_t));
         ar.take(&a.d_items, size_t(max_nsub) * 6 * sizeof(uint32_t));
@@ -775,7 +784,12 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     const uint32_t nimg = uint32_t(c.count);
     int32_t *dcb = SCR(d_dc);              // image offsets already include the chunk base
     fix_passes = std::min(fix_passes, kMaxFix);
+    // (two generations per subsequence in the merge rounds -- Gen2, mjx_kernels.hip -- for the pictures of the two-pass path; a chunk
+    // of nothing but pictures whose first decode emits runs exactly as before)
+    const uint32_t gen_stride = c.has_spec ? b->gen_stride : 0u;
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_SYNC)) {
+        // (every subsequence starts with its first decode in the first set and nothing in the second)
+        if (gen_stride) HIPOK(hipMemsetAsync(SCR(d_gen), 0, size_t(c.nsub), st));
         if (c.has_spec) {
             prof_begin(b, MJX_K_HUFF_SYNC, st);
             launch_huff_spec(st, c.max_wg, nimg, b->huff_lds2, b->ctx->spec_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps), b->d_segs, c.wg);
@@ -794,7 +808,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
             prof_begin(b, MJX_K_HUFF_FIX, st);
             launch_huff_merge_loop(st, c.merge_wgs, nimg, b->huff_lds2, b->ctx->merge_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps),
                                    b->d_mismatch + ci * kMisWords + fix_passes - 1, b->d_segs, b->d_loopctl + ci * 8,
-                                   c.loop_participants + (b->ctx->loop_fault ? 1u : 0u), kLoopRounds, b->ctx->loop_fault ? 1u << 12 : 1u << 22, SCR(d_esub));
+                                   c.loop_participants + (b->ctx->loop_fault ? 1u : 0u), kLoopRounds, b->ctx->loop_fault ? 1u << 12 : 1u << 22, SCR(d_esub), SCR(d_gen), gen_stride);
             prof_end(b, st);
         } else if (c.merge_wgs > 0) {
             HIPOK(hipMemsetAsync(SCR(d_pull), 0, size_t(nimg) * std::max(fix_passes, 1) * sizeof(uint32_t), st));      // the straggler counts of every round
@@ -806,7 +820,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
                                   // (a chunk of pictures whose lanes warmed up: a fifth of the subsequences re-decode, not all of them --
                                   // the first round, too, only lists its items and the straggler kernel decodes them packed)
                                   k == 0 && (phases & PH_SYNC) && !(c.has_emit && !c.has_spec && b->ctx->emit_merge_listed), SCR(d_esub),
-                                  c.max_nsub ? c.max_nsub - 1 : 0u);
+                                  c.max_nsub ? c.max_nsub - 1 : 0u, SCR(d_gen), gen_stride);
                 prof_end(b, st);
             }
         }
@@ -822,7 +836,8 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         }
         // (the merge rounds are over: their straggler lists and counts are free, the scan lists the prefix pass's subsequences there)
         launch_huff_scan(st, nimg, imgs, SCR(d_exit), SCR(d_blkbase), SCR(d_ebase), b->d_img_entries, b->d_img_flags, b->d_segs, verdict,
-                         SCR(d_esub), SCR(d_items), SCR(d_pull), b->d_mismatch + ci * kMisWords + kMaxFix + 1, b->d_unconv + ci);
+                         SCR(d_esub), SCR(d_items), SCR(d_pull), b->d_mismatch + ci * kMisWords + kMaxFix + 1, b->d_unconv + ci,
+                         SCR(d_entry), SCR(d_gen), gen_stride);
         prof_end(b, st);
         if (c.has_spec) {
             prof_begin(b, MJX_K_HUFF_WRITE, st);
@@ -1593,6 +1608,7 @@ extern "C" int mjx_ctx_create(int device, mjx_ctx **out)
     if (const char *e = std::getenv("MJX_DESTUFF_DIRECT")) c->destuff_direct = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_SINGLE_DECODE")) c->single_decode = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_PLANAR_DIRECT")) c->planar_direct = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MJX_MERGE_MEMO")) c->merge_memo = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_EMIT_MERGE_LISTED")) c->emit_merge_listed = std::atoi(e) != 0;
     if (const char *e = std::getenv("MJX_EMIT_CP_BITS")) c->emit_cp_bits = uint32_t(std::max(long(kCpBits), std::atol(e))) / uint32_t(kCpBits) * uint32_t(kCpBits);
     if (const char *e = std::getenv("MJX_EMIT_WARM_BITS")) c->emit_warm_bits = uint32_t(std::max(0L, std::atol(e))) / 32u * 32u;

@@ -336,14 +336,17 @@ void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t ta
                        const uint32_t *prev_mismatches /* count of the round before, or null for the first */,
                        bool first_round /* most subsequences re-decode: the workgroups run their first slices in place */,
                        EmitSub *esub /* pictures whose first decode emits: the merge depth is kept here */,
-                       uint32_t max_items /* subsequences of the chunk's longest scan - 1 (an upper bound will do) */);
+                       uint32_t max_items /* subsequences of the chunk's longest scan - 1 (an upper bound will do) */,
+                       uint8_t *gen /* [chunk subsequences]: which of the two sets of entry / exit / checkpoints is current (Gen2, mjx_kernels.hip) */,
+                       uint32_t gen_stride /* subsequences between the two sets (a multiple of 256); 0: one set */);
 // The merge rounds of a small chunk in one launch (device-wide barrier between rounds); `participants` = the workgroups (x, image)
 // with x * merge_wg_lanes() + 1 < nsub(image): all of them must be resident at once (the caller checks against merge_loop_capacity()).
 void launch_huff_merge_loop(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                             const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
                             uint32_t *cps, uint32_t *verdict, const uint32_t *segs, uint32_t *ctl, uint32_t participants, uint32_t max_rounds,
                             uint32_t spin_limit,       // spin_limit: polls of a barrier (~1.5 us each) before a workgroup gives up
-                            EmitSub *esub);
+                            EmitSub *esub,
+                            uint8_t *gen, uint32_t gen_stride /* as launch_huff_merge */);
 // single decode (round 5): the first decode of a picture emits (k_huff_emit); after the merge rounds and the scan, k_huff_prefix
 // re-decodes what lay in front of the merge point for the lanes whose entry was wrong and k_block_gather makes dcdiff / tile offsets
 size_t huff_prefix_bytes();
@@ -356,12 +359,13 @@ void launch_huff_prefix(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t t
                         const uint32_t *cps, EmitSub *esub, const uint32_t *blkbase, uint32_t *entries, int *status, uint32_t *img_flags,
                         uint32_t *fallback /* device word: a picture had no head room for its prefix */, int16_t *dcdiff, uint32_t *tile_eoff,
                         const uint32_t *items, const uint32_t *item_count /* as written by k_huff_scan */);
-void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,
+void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, SubseqState *exit_, uint32_t *blkbase,
                       uint32_t *ebase, uint32_t *img_entries, uint32_t *img_flags, const uint32_t *segs,
                       const uint32_t *verdict /* device word: re-decodes of the last synchronisation round, or null */,
                       const EmitSub *esub, uint32_t *items /* [chunk subsequences][6]: per picture the (subsequence, checkpoint interval) pieces k_huff_prefix decodes again */,
                       uint32_t *item_count /* [chunk images] */, uint32_t *fallback /* device word: a picture goes to the two-pass kernels */,
-                      uint32_t *unconverged /* device word, counted up when `verdict` is not zero */);
+                      uint32_t *unconverged /* device word, counted up when `verdict` is not zero */,
+                      SubseqState *entry, uint8_t *gen, uint32_t gen_stride /* the rounds' second set is folded back into the first here */);
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                        const uint8_t *scan_pool, const LutEntry *lut_pool, const SubseqState *entry,
                        const uint32_t *blkbase, const uint32_t *ebase, uint32_t *entries, uint32_t *tile_eoff,

@@ -573,16 +573,35 @@ static_assert(kCpBits == 256, "a merge slice is one interval of kCpBits = 256 bi
 // Returns true when the item is finished (its exit and checkpoints are final), false when `it` holds the progress.
 // `depth` (when the item finishes): kEmitAll if the re-decode left the subsequence without meeting the previous decode's path,
 // else 1 + the index of the checkpoint where it met it.
+// Two generations (round 5, Gen2): every subsequence keeps the decode before the last as well -- entry, exit, checkpoints, in a second
+// set of the chunk's arrays `stride` subsequences behind the first; gen[idx] bit 0 = the set that is current, bit 1 = the other set
+// holds a decode.  A re-decode records its checkpoints in a scratch set (the third, 2 x stride behind the first) and compares with
+// BOTH recorded paths.  When it is done (merge_finish): it met the current path -- the usual case -- and its few checkpoints in
+// front of the meeting point replace that path's, in place; or it met the older path: the same there, and the sets change roles;
+// or it met neither and becomes the current decode in the older one's place.  Why: where content does not synchronise (runs of identical flat MCUs) a wrong state is handed
+// from lane to lane, each lane re-decodes from it without ever meeting its own -- true -- first decode and used to overwrite that
+// decode's checkpoints; the truth, one round behind, then had to decode every subsequence in full again.  With the older decode
+// kept it meets it at the first checkpoint, and a lane whose entry merely RETURNS to the one its older decode started from takes
+// that decode back without decoding (round_begin).  An item carries the set it writes and whether the other one is valid in zc
+// (bits 16, 17).  stride == 0: one generation, as before (pictures whose first decode emitted: k_huff_prefix needs that decode's
+// own checkpoints).
+struct Gen2 { uint8_t *gen; uint32_t stride; };
 __device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, const HuffImage &h, const LutEntry *lut,
                                             const unsigned char *region, uint32_t *my_win, const SubseqState *g_exit,
-                                            uint32_t *g_cps, SubseqState &x, const uint32_t *segs, uint32_t &depth)
+                                            uint32_t *g_cps, SubseqState &x, const uint32_t *segs, uint32_t &depth, Gen2 g2, uint32_t &met)
 {
     const SubLoc loc = locate_sub(im, h, segs, it.s);
     const uint32_t sub_start = loc.start, end_bit = loc.end - loc.start;       // (the lane works relative to its subsequence)
-    const GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + it.s), 0};
+    const uint32_t gs = im.emit ? 0u : g2.stride, oset = gs ? (it.zc >> 16) & 1u : 0u, cset = gs ? oset ^ 1u : 0u;
+    const bool other_valid = gs && ((it.zc >> 17) & 1u);
+    const uint32_t idx_c = im.sub_off + it.s + cset * gs, idx_o = im.sub_off + it.s + oset * gs;
+    const GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(idx_c), 0};          // the current decode's checkpoints
+    const GlobalCps cpo{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(idx_o), 0};          // the older decode's
+    const GlobalCps cpw{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + it.s + 2u * gs), 0};   // where this decode records (gs == 0: in place)
     bool fin = false;
     depth = kEmitAll;
-    x = make_state(it.p, it.zc & 0xffu, it.zc >> 8, it.n, it.m);
+    met = 0;
+    x = make_state(it.p, it.zc & 0xffu, (it.zc >> 8) & 0xffu, it.n, it.m);
     const uint32_t pl = it.p - sub_start;
     if (it.p >= sub_start && pl <= end_bit) {                      // (else nothing starts inside s)
         // it.k counts slices (intervals of kCpBits); a checkpoint lies at the end of slice it.k when that boundary is a multiple of the
@@ -591,6 +610,7 @@ __device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, c
         const bool at_cp = (it.k + 1u) % per == 0u;
         const uint32_t ck = (it.k + 1u) / per - 1u;                // index of that checkpoint
         const uint32_t old_word = (at_cp && ck < uint32_t(kMaxCp)) ? cps.get_w(ck) : 0u;   // requested early
+        const uint32_t old_word2 = (at_cp && ck < uint32_t(kMaxCp) && other_valid) ? cpo.get_w(ck) : 0u;
         const uint32_t wi1 = (pl + 31u) >> 5, wbase = (wi1 ? 4u * wi1 - 4u : 0u) & ~15u;
         const LaneBits bits{region, it.s * 16u, im.scan_cols * 16u};
 #pragma unroll
@@ -603,7 +623,7 @@ __device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, c
         }
         LdsWindow win{reinterpret_cast<const unsigned char *>(my_win), wbase, 0u};
         LaneState st;
-        lane_begin(st, win, h, make_state(pl, it.zc & 0xffu, it.zc >> 8));
+        lane_begin(st, win, h, make_state(pl, it.zc & 0xffu, (it.zc >> 8) & 0xffu));
         win.rp = uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)(my_win))) + (st.wn - 4u - wbase);
         st.n = it.n;
         lane_add_m(st, it.m);
@@ -619,18 +639,25 @@ __device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, c
         } else {
             const uint32_t state = cp_state_word(st);
             if (at_cp && (old_word & kCpStateMask) == state) {     // met the previous decode's path
-                const SubseqState old_exit = g_exit[im.sub_off + it.s];
+                const SubseqState old_exit = g_exit[idx_c];
                 fin = true;
                 depth = ck + 1u;
+                met = 1;
                 x = make_state(old_exit.p, old_exit.z, old_exit.c, st.n + ((old_word >> 16) & 0x7fffu), lane_m(st) + cps.get_m(ck));
+            } else if (at_cp && other_valid && (old_word2 & kCpStateMask) == state) {     // ... the path of the decode before it
+                const SubseqState old_exit = g_exit[idx_o];
+                fin = true;
+                depth = ck + 1u;
+                met = 2;
+                x = make_state(old_exit.p, old_exit.z, old_exit.c, st.n + ((old_word2 >> 16) & 0x7fffu), lane_m(st) + cpo.get_m(ck));
             } else {
-                if (at_cp) cps.set(ck, state | (st.n << 16), lane_m(st));
+                if (at_cp) cpw.set(ck, state | (st.n << 16), lane_m(st));
                 it.k++;
             }
         }
         if (!fin) {
             it.p = lane_pos(st) + sub_start;
-            it.zc = lane_z(st) | (lane_c(st, h) << 8);
+            it.zc = lane_z(st) | (lane_c(st, h) << 8) | (it.zc & 0x30000u);
             it.n = st.n;
             it.m = lane_m(st);
         }
@@ -643,15 +670,62 @@ __device__ __forceinline__ bool merge_slice(MergeItem &it, const DevImage &im, c
 // first decode emitted keep, per subsequence, the deepest point at which any of its re-decodes met the recorded path: from there on
 // the first decode's entries are the true ones (k_huff_prefix writes what lies in front of it).
 __device__ __forceinline__ void merge_finish(const MergeItem &it, const DevImage &im, const SubseqState &x,
-                                             SubseqState *g_exit, uint32_t *g_cps, EmitSub *g_esub, uint32_t depth)
+                                             SubseqState *g_entry, SubseqState *g_exit, uint32_t *g_cps, EmitSub *g_esub, uint32_t depth,
+                                             Gen2 g2, uint32_t met)
 {
-    const GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(im.sub_off + it.s), 0};
-    checkpoint_fixup(cps, it.k / (im.himg.cp_bits / uint32_t(kCpBits)), x.n, x.m);
-    g_exit[im.sub_off + it.s] = x;
+    const uint32_t gs = im.emit ? 0u : g2.stride, idx = im.sub_off + it.s;
+    const uint32_t per = im.himg.cp_bits / uint32_t(kCpBits), nrec = it.k / per;      // checkpoints this decode recorded
+    if (!gs) {
+        const GlobalCps cps{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(idx), 0};
+        checkpoint_fixup(cps, nrec, x.n, x.m);
+        g_exit[idx] = x;
+    } else {
+        // where the decode's path now lives: with the path it met (in front of the meeting point its own checkpoints replace that
+        // path's), or -- it met neither -- in the older decode's place
+        const uint32_t oset = (it.zc >> 16) & 1u, cset = oset ^ 1u, dset = met == 1 ? cset : oset;
+        const GlobalCps src{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(idx + 2u * gs), 0};
+        const GlobalCps dst{reinterpret_cast<unsigned char *>(g_cps), cps_byte_off(idx + dset * gs), 0};
+        for (uint32_t j = 0; j < nrec; j++) {                     // (counts so far -> counts to the exit, as checkpoint_fixup)
+            const CpPair v = src.get_pair(j);
+            dst.set(j, (v.w & kCpStateMask) | ((x.n - ((v.w >> 16) & 0x7fffu)) << 16), x.m - v.m);
+        }
+        g_entry[idx + dset * gs] = g_entry[idx + 2u * gs];         // (the state this decode started from: round_begin left it there)
+        g_exit[idx + dset * gs] = x;
+        if (met != 1) g2.gen[idx] = uint8_t(oset | 2u);            // the set that held the older decode is the current one now
+    }
     if (im.emit) {
         uint32_t &kf = g_esub[im.sub_off + it.s].kfix;             // (one lane per subsequence and round: no race)
         kf = kf > depth ? kf : depth;
     }
+}
+
+// What a lane does at the start of a round: subsequence it.s must start where it.s - 1 ended.  Returns true when it has to be decoded
+// again (the item is set up: its new entry is written, into the set this decode will write); `changed` also when the lane took its
+// older decode back instead (its entry returned to the one that decode started from: no decoding, but its exit has changed).
+__device__ __forceinline__ bool round_begin(MergeItem &it, const DevImage &im, SubseqState *g_entry, const SubseqState *g_exit,
+                                            const uint32_t *segs, Gen2 g2, bool &changed)
+{
+    const uint32_t idx = im.sub_off + it.s, gs = im.emit ? 0u : g2.stride;
+    const uint32_t g = gs ? g2.gen[idx] : 0u, cur = g & 1u, gp = gs ? g2.gen[idx - 1] & 1u : 0u;
+    const SubseqState prev = g_exit[idx - 1 + gp * gs];
+    bool active = !same_entry(prev, g_entry[idx + cur * gs]);
+    if (im.nseg > 1 && locate_sub(im, im.himg, segs, it.s).seg_sub0 == it.s) active = false;   // a segment's first: entry known
+    it.p = prev.p;
+    it.zc = prev.z | (uint32_t(prev.c) << 8);
+    changed = active;
+    if (active && gs) {
+        const uint32_t other = cur ^ 1u;
+        if ((g & 2u) && same_entry(prev, g_entry[idx + other * gs])) {
+            g2.gen[idx] = uint8_t(other | 2u);                     // the older decode started from exactly this state: it is the current one again
+            active = false;
+        } else {
+            it.zc |= (other << 16) | ((g & 2u) << 16);             // (bit 16: the set that is not current; bit 17: it holds a decode)
+            g_entry[idx + 2u * gs] = make_state(prev.p, prev.z, prev.c);      // (for merge_finish: the set it belongs to is known then)
+        }
+    } else if (active) {
+        g_entry[idx] = make_state(prev.p, prev.z, prev.c);
+    }
+    return active;
 }
 
 extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevImage *images, const uint8_t *scan_pool,
@@ -659,8 +733,9 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
                                                                 SubseqState *g_exit, uint32_t *g_cps, uint32_t *mismatches,
                                                                 uint32_t win_off, uint32_t *g_items, uint32_t *g_item_count,
                                                                 const uint32_t *segs, const uint32_t *prev_mismatches,
-                                                                uint32_t head_slices, EmitSub *g_esub)
+                                                                uint32_t head_slices, EmitSub *g_esub, uint8_t *g_gen, uint32_t gen_stride)
 {
+    const Gen2 g2{g_gen, gen_stride};
     // A round behind one that re-decoded nothing has nothing to do either (the fixed point is reached): it leaves at
     // once, its own count stays zero, and so does every later round's.  That makes spare rounds nearly free (a launch),
     // so enough of them are enqueued for streams that synchronise slowly (noisy pictures at quality >= 95 need 5..15).
@@ -673,24 +748,21 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
     if (!im.valid || wgi * kMergeWg + 1 >= im.himg.nsub) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     MergeItem it{wgi * kMergeWg + tid + 1, 0, 0, 0, 0, 0};
-    bool active = false;
-    if (it.s < im.himg.nsub) {
-        const SubseqState prev = g_exit[im.sub_off + it.s - 1];
-        active = !same_entry(prev, g_entry[im.sub_off + it.s]);
-        if (im.nseg > 1 && locate_sub(im, im.himg, segs, it.s).seg_sub0 == it.s) active = false;   // a segment's first: entry known
-        it.p = prev.p;
-        it.zc = prev.z | (uint32_t(prev.c) << 8);
-        if (active) g_entry[im.sub_off + it.s] = make_state(prev.p, prev.z, prev.c);
-    }
+    bool active = false, changed = false;
+    if (it.s < im.himg.nsub) active = round_begin(it, im, g_entry, g_exit, segs, g2, changed);
     {   // nothing to repair in this workgroup?  (not __syncthreads_or: its static LDS word would be padded to kLutAlign)
-        const unsigned long long mm = __builtin_amdgcn_ballot_w64(active);   // (all lanes vote: outside the branch)
-        if (lane == 0) s_cnt[wave] = uint32_t(__popcll(mm));
+        // (what is counted is what CHANGED -- lanes that decode again and lanes that took their older decode back: the fixed point
+        // is a round in which nothing changes)
+        const unsigned long long mm = __builtin_amdgcn_ballot_w64(changed);   // (all lanes vote: outside the branch)
+        const unsigned long long ma = __builtin_amdgcn_ballot_w64(active);
+        if (lane == 0) s_cnt[wave] = uint32_t(__popcll(mm)) | (uint32_t(__popcll(ma)) << 16);
         __syncthreads();
         uint32_t any = 0;
         for (uint32_t w = 0; w < kMergeWg / 64; w++) any += s_cnt[w];
         if (!any) return;
-        if (tid == 0) atomicAdd(mismatches, any);                          // one atomic per workgroup, not per wave: all of them hit one word
+        if (tid == 0) atomicAdd(mismatches, any & 0xffffu);                // one atomic per workgroup, not per wave: all of them hit one word
         __syncthreads();                                                   // (s_cnt is written again in the slice loop)
+        if (!(any >> 16)) return;                                          // nothing to decode here
     }
     auto hand_over = [&](unsigned long long mask, uint32_t rank) {      // the wave's unfinished items -> k_huff_merge_tail
         uint32_t base = 0;
@@ -718,9 +790,9 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
     for (uint32_t slice = 0;; slice++) {
         if (active) {
             SubseqState x;
-            uint32_t depth;
-            if (merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x, segs, depth)) {
-                merge_finish(it, im, x, g_exit, g_cps, g_esub, depth);
+            uint32_t depth, met;
+            if (merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x, segs, depth, g2, met)) {
+                merge_finish(it, im, x, g_entry, g_exit, g_cps, g_esub, depth, g2, met);
                 active = false;
             }
         }
@@ -761,11 +833,12 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
 static_assert(MJX_TAIL_WG <= MJX_MERGE_WG && MJX_MERGE_WG % MJX_TAIL_WG == 0, "the straggler kernel's grid is the merge grid times kMergeWg / kTailWg");
 constexpr uint32_t kTailWg = MJX_TAIL_WG;      // lanes per workgroup (measured 64 / 128 / 256: 2.50 / 2.30 / 2.20 ms of merge rounds per 2048 pictures)
 extern "C" __global__ __launch_bounds__(kTailWg) void k_huff_merge_tail(const DevImage *images, const uint8_t *scan_pool,
-                                                                    const LutEntry *lut_pool, SubseqState *g_exit,
+                                                                    const LutEntry *lut_pool, SubseqState *g_entry, SubseqState *g_exit,
                                                                     uint32_t *g_cps, uint32_t win_off,
                                                                     const uint32_t *g_items, const uint32_t *g_item_count,
-                                                                    const uint32_t *segs, EmitSub *g_esub)
+                                                                    const uint32_t *segs, EmitSub *g_esub, uint8_t *g_gen, uint32_t gen_stride)
 {
+    const Gen2 g2{g_gen, gen_stride};
     extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, a window per lane
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
     // Workgroup (image, group): the image is the fast grid dimension, so that the groups that have items -- the first
@@ -788,9 +861,9 @@ extern "C" __global__ __launch_bounds__(kTailWg) void k_huff_merge_tail(const De
     // every lane runs its item to the end first; the read-modify-write of the recorded checkpoints then happens once
     // for the whole wave instead of after every slice for the lanes that happen to finish there
     SubseqState x;
-    uint32_t depth;
-    while (!merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x, segs, depth)) {}
-    merge_finish(it, im, x, g_exit, g_cps, g_esub, depth);
+    uint32_t depth, met;
+    while (!merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x, segs, depth, g2, met)) {}
+    merge_finish(it, im, x, g_entry, g_exit, g_cps, g_esub, depth, g2, met);
 }
 
 // ---- the merge rounds of a small batch in one launch ------------------------------------------------------------------
@@ -835,8 +908,9 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge_loop(const D
                                                                      SubseqState *g_exit, uint32_t *g_cps, uint32_t *verdict,
                                                                      uint32_t win_off, const uint32_t *segs, uint32_t *ctl,
                                                                      uint32_t participants, uint32_t max_rounds, uint32_t spin_limit,
-                                                                     EmitSub *g_esub)
+                                                                     EmitSub *g_esub, uint8_t *g_gen, uint32_t gen_stride)
 {
+    const Gen2 g2{g_gen, gen_stride};
     extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, windows (= item exchange), wave counts
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
     uint32_t *s_cnt = s_win + kMergeWg * kMergeStride;
@@ -854,25 +928,18 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge_loop(const D
         uint32_t *count = ctl + 2 + round % 3;
         if (tid == 0) ctl[2 + (round + 1) % 3] = 0;                        // the next round's count (nobody reads or adds to it in this round)
         MergeItem it{blockIdx.x * kMergeWg + tid + 1, 0, 0, 0, 0, 0};
-        bool active = false;
-        if (it.s < im.himg.nsub) {
-            const SubseqState prev = g_exit[im.sub_off + it.s - 1];
-            active = !same_entry(prev, g_entry[im.sub_off + it.s]);
-            if (im.nseg > 1 && locate_sub(im, im.himg, segs, it.s).seg_sub0 == it.s) active = false;
-            it.p = prev.p;
-            it.zc = prev.z | (uint32_t(prev.c) << 8);
-            if (active) g_entry[im.sub_off + it.s] = make_state(prev.p, prev.z, prev.c);
-        }
+        bool active = false, changed = false;
+        if (it.s < im.himg.nsub) active = round_begin(it, im, g_entry, g_exit, segs, g2, changed);
         {
-            const unsigned long long mm = __ballot(active);
+            const unsigned long long mm = __ballot(changed);
             if (lane == 0 && mm) atomicAdd(count, uint32_t(__popcll(mm)));
         }
         for (;;) {
             if (active) {
                 SubseqState x;
-                uint32_t depth;
-                if (merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x, segs, depth)) {
-                    merge_finish(it, im, x, g_exit, g_cps, g_esub, depth);
+                uint32_t depth, met;
+                if (merge_slice(it, im, *h, lut, bytes, my_win, g_exit, g_cps, x, segs, depth, g2, met)) {
+                    merge_finish(it, im, x, g_entry, g_exit, g_cps, g_esub, depth, g2, met);
                     active = false;
                 }
             }
@@ -1178,12 +1245,13 @@ __device__ __forceinline__ uint32_t prefix_intervals(const DevImage &im, uint32_
     const uint32_t L = im.himg.sub_bits, start = s * L, len = min(start + L, im.himg.total_bits) - start;
     return max(1u, (len + im.himg.cp_bits - 1u) / im.himg.cp_bits);
 }
-extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *images, const SubseqState *g_exit,
+extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *images, SubseqState *g_exit,
                                                                uint32_t *g_blkbase, uint32_t *g_ebase,
                                                                uint32_t *img_entries, uint32_t *img_flags,
                                                                const uint32_t *segs, const uint32_t *verdict,
                                                                const EmitSub *g_esub, uint32_t *g_items, uint32_t *g_item_count,
-                                                               uint32_t *fallback, uint32_t *unconverged)
+                                                               uint32_t *fallback, uint32_t *unconverged, SubseqState *g_entry,
+                                                               uint8_t *g_gen, uint32_t gen_stride)
 {
     __shared__ uint32_t s_tmp[4];
     const DevImage &im = images[blockIdx.x];
@@ -1204,6 +1272,18 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *im
     const uint32_t nsub = im.himg.nsub, tid = threadIdx.x;
     const uint32_t per = (nsub + kWgLanes - 1) / kWgLanes;
     const uint32_t a = min(nsub, tid * per), b = min(nsub, a + per);
+    if (gen_stride && !im.emit) {
+        // the rounds are over: where a subsequence's current decode lies in the second set (Gen2), its entry and exit move to the
+        // first -- everything behind this kernel reads the first set only
+        for (uint32_t s = a; s < b; s++) {
+            const uint32_t idx = im.sub_off + s;
+            if (g_gen[idx] & 1u) {
+                g_entry[idx] = g_entry[idx + gen_stride];
+                g_exit[idx] = g_exit[idx + gen_stride];
+            }
+            g_gen[idx] = 0;
+        }
+    }
     uint32_t sum_n = 0, sum_m = 0;
     for (uint32_t s = a; s < b; s++) { sum_n += g_exit[im.sub_off + s].n; sum_m += stream_run(g_exit[im.sub_off + s].m); }
     uint32_t total_n, total_m;
@@ -3517,26 +3597,26 @@ void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tab
 void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                        const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
                        uint32_t *cps, uint32_t *mismatches, uint32_t *items, uint32_t *item_count, const uint32_t *segs,
-                       const uint32_t *prev_mismatches, bool first_round, EmitSub *esub, uint32_t max_items)
+                       const uint32_t *prev_mismatches, bool first_round, EmitSub *esub, uint32_t max_items, uint8_t *gen, uint32_t gen_stride)
 {
     // (item_count: this round's straggler counts, one per image, zeroed by the caller -- one memset for all the rounds of a chunk)
     const size_t lds = tables_lds + huff_merge_bytes() + pad_lds;
     hipLaunchKernelGGL(k_huff_merge, entropy_grid(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, mismatches, uint32_t(tables_lds), items, item_count, segs, prev_mismatches,
-                       first_round ? uint32_t(kHeadSlices) : uint32_t(MJX_LATER_HEAD_SLICES), esub);
+                       first_round ? uint32_t(kHeadSlices) : uint32_t(MJX_LATER_HEAD_SLICES), esub, gen, gen_stride);
     const size_t tail_lds = tables_lds + size_t(kTailWg) * kMergeStride * 4;
     // (max_items: the most items a picture of the chunk can list = its subsequences - 1.  A chunk of small pictures pays for these
     // rounds in workgroup launches -- 32768 x 256x256: a million per step --: no second group of 256 for pictures that cannot fill one)
     const uint32_t groups = std::max<uint32_t>(1u, std::min<uint32_t>(max_wg * (kMergeWg / kTailWg), (max_items + kTailWg - 1) / kTailWg));
-    hipLaunchKernelGGL(k_huff_merge_tail, dim3(nimg, groups), dim3(kTailWg), tail_lds, st, images, scan_pool, lut_pool, exit_, cps, uint32_t(tables_lds), items, item_count, segs, esub);
+    hipLaunchKernelGGL(k_huff_merge_tail, dim3(nimg, groups), dim3(kTailWg), tail_lds, st, images, scan_pool, lut_pool, entry, exit_, cps, uint32_t(tables_lds), items, item_count, segs, esub, gen, gen_stride);
 }
 
 void launch_huff_merge_loop(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                             const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
                             uint32_t *cps, uint32_t *verdict, const uint32_t *segs, uint32_t *ctl, uint32_t participants, uint32_t max_rounds,
-                            uint32_t spin_limit, EmitSub *esub)
+                            uint32_t spin_limit, EmitSub *esub, uint8_t *gen, uint32_t gen_stride)
 {
     const size_t lds = tables_lds + huff_merge_bytes() + pad_lds;
-    hipLaunchKernelGGL(k_huff_merge_loop, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, verdict, uint32_t(tables_lds), segs, ctl, participants, max_rounds, spin_limit, esub);
+    hipLaunchKernelGGL(k_huff_merge_loop, dim3(max_wg, nimg), dim3(kMergeWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, verdict, uint32_t(tables_lds), segs, ctl, participants, max_rounds, spin_limit, esub, gen, gen_stride);
 }
 
 void launch_emit_off(hipStream_t st, DevImage *images, uint32_t nimg, const uint32_t *img_flags)
@@ -3568,11 +3648,12 @@ void launch_huff_prefix(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t t
                        const_cast<uint32_t *>(entries), dcdiff, tile_eoff, img_flags, status);
 }
 
-void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, const SubseqState *exit_, uint32_t *blkbase,
+void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, SubseqState *exit_, uint32_t *blkbase,
                       uint32_t *ebase, uint32_t *img_entries, uint32_t *img_flags, const uint32_t *segs, const uint32_t *verdict,
-                      const EmitSub *esub, uint32_t *items, uint32_t *item_count, uint32_t *fallback, uint32_t *unconverged)
+                      const EmitSub *esub, uint32_t *items, uint32_t *item_count, uint32_t *fallback, uint32_t *unconverged,
+                      SubseqState *entry, uint8_t *gen, uint32_t gen_stride)
 {
-    hipLaunchKernelGGL(k_huff_scan, dim3(nimg), dim3(kWgLanes), 0, st, images, exit_, blkbase, ebase, img_entries, img_flags, segs, verdict, esub, items, item_count, fallback, unconverged);
+    hipLaunchKernelGGL(k_huff_scan, dim3(nimg), dim3(kWgLanes), 0, st, images, exit_, blkbase, ebase, img_entries, img_flags, segs, verdict, esub, items, item_count, fallback, unconverged, entry, gen, gen_stride);
 }
 
 void launch_huff_write(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
