@@ -702,29 +702,66 @@ __device__ __forceinline__ void merge_finish(const MergeItem &it, const DevImage
 // What a lane does at the start of a round: subsequence it.s must start where it.s - 1 ended.  Returns true when it has to be decoded
 // again (the item is set up: its new entry is written, into the set this decode will write); `changed` also when the lane took its
 // older decode back instead (its entry returned to the one that decode started from: no decoding, but its exit has changed).
-__device__ __forceinline__ bool round_begin(MergeItem &it, const DevImage &im, SubseqState *g_entry, const SubseqState *g_exit,
-                                            const uint32_t *segs, Gen2 g2, bool &changed)
+// (cooperative: every thread of the merge workgroup calls it, `live` = the thread has a subsequence.  Remembered decodes are taken
+// back in a SWEEP: when a lane takes its older decode back its exit changes, and the lane behind it -- in the same workgroup --
+// may find that very exit to be what ITS older decode started from, and so on; the lanes' current exits stand in LDS (`s_x`, in the
+// window area, unused at this point) and the workgroup iterates until no lane changes hands any more -- lane k is settled after k
+// iterations at the latest, a picture of photographs after one.  The predecessor of the workgroup's first lane is read once.)
+__device__ __forceinline__ bool round_begin(MergeItem &it, bool live, const DevImage &im, SubseqState *g_entry, const SubseqState *g_exit,
+                                            const uint32_t *segs, Gen2 g2, bool &changed, unsigned long long *s_x, uint32_t *s_any)
 {
-    const uint32_t idx = im.sub_off + it.s, gs = im.emit ? 0u : g2.stride;
-    const uint32_t g = gs ? g2.gen[idx] : 0u, cur = g & 1u, gp = gs ? g2.gen[idx - 1] & 1u : 0u;
-    const SubseqState prev = g_exit[idx - 1 + gp * gs];
-    bool active = !same_entry(prev, g_entry[idx + cur * gs]);
-    if (im.nseg > 1 && locate_sub(im, im.himg, segs, it.s).seg_sub0 == it.s) active = false;   // a segment's first: entry known
-    it.p = prev.p;
-    it.zc = prev.z | (uint32_t(prev.c) << 8);
-    changed = active;
-    if (active && gs) {
-        const uint32_t other = cur ^ 1u;
-        if ((g & 2u) && same_entry(prev, g_entry[idx + other * gs])) {
-            g2.gen[idx] = uint8_t(other | 2u);                     // the older decode started from exactly this state: it is the current one again
-            active = false;
-        } else {
-            it.zc |= (other << 16) | ((g & 2u) << 16);             // (bit 16: the set that is not current; bit 17: it holds a decode)
-            g_entry[idx + 2u * gs] = make_state(prev.p, prev.z, prev.c);      // (for merge_finish: the set it belongs to is known then)
-        }
-    } else if (active) {
-        g_entry[idx] = make_state(prev.p, prev.z, prev.c);
+    const uint32_t idx = im.sub_off + it.s, gs = im.emit ? 0u : g2.stride, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    changed = false;
+    if (!gs) {                                                      // one generation: every lane for itself (uniform: im.emit is the picture's)
+        if (!live) return false;
+        const SubseqState prev = g_exit[idx - 1];
+        bool active = !same_entry(prev, g_entry[idx]);
+        if (im.nseg > 1 && locate_sub(im, im.himg, segs, it.s).seg_sub0 == it.s) active = false;   // a segment's first: entry known
+        it.p = prev.p;
+        it.zc = prev.z | (uint32_t(prev.c) << 8);
+        if (active) g_entry[idx] = make_state(prev.p, prev.z, prev.c);
+        changed = active;
+        return active;
     }
+    auto head = [](const SubseqState &st) { return (unsigned long long)st.p | ((unsigned long long)st.z << 32) | ((unsigned long long)st.c << 40); };
+    const uint32_t g = live ? g2.gen[idx] : 0u;
+    uint32_t cur = g & 1u;
+    const bool valid2 = (g & 2u) != 0;
+    unsigned long long e[2] = {0, 0}, x[2] = {0, 0}, prev_glob = 0;
+    bool seg_first = false;
+    if (live) {
+        e[cur] = head(g_entry[idx + cur * gs]);
+        x[cur] = head(g_exit[idx + cur * gs]);
+        if (valid2) { e[cur ^ 1u] = head(g_entry[idx + (cur ^ 1u) * gs]); x[cur ^ 1u] = head(g_exit[idx + (cur ^ 1u) * gs]); }
+        seg_first = im.nseg > 1 && locate_sub(im, im.himg, segs, it.s).seg_sub0 == it.s;
+        if (tid == 0) prev_glob = head(g_exit[idx - 1 + (g2.gen[idx - 1] & 1u) * gs]);
+    }
+    s_x[tid] = x[cur];
+    __syncthreads();
+    bool flipped = false;
+    for (uint32_t iter = 0; iter < uint32_t(kMergeWg); iter++) {
+        const unsigned long long prev = tid ? s_x[tid - 1] : prev_glob;
+        const bool flip = live && !seg_first && valid2 && prev != e[cur] && prev == e[cur ^ 1u];
+        const unsigned long long mm = __builtin_amdgcn_ballot_w64(flip);
+        if (lane == 0) s_any[wave] = mm ? 1u : 0u;
+        __syncthreads();                                            // (also: every lane has read its neighbour's exit of this iteration)
+        uint32_t any = 0;
+        for (uint32_t w = 0; w < uint32_t(kMergeWg) / 64u; w++) any |= s_any[w];
+        if (!any) break;
+        if (flip) { cur ^= 1u; s_x[tid] = x[cur]; flipped = true; }
+        __syncthreads();
+    }
+    const unsigned long long prev = tid ? s_x[tid - 1] : prev_glob;
+    const bool active = live && !seg_first && prev != e[cur];
+    __syncthreads();                                                // (s_x lies in the window area: the slices may write there from here on)
+    if (flipped) g2.gen[idx] = uint8_t(cur | 2u);                  // the older decode started from exactly this state: it is the current one again
+    it.p = uint32_t(prev);
+    it.zc = uint32_t(prev >> 32) & 0xffffu;                         // z | c << 8
+    if (active) {
+        it.zc |= ((cur ^ 1u) << 16) | (valid2 ? 1u << 17 : 0u);     // (bit 16: the set that is not current; bit 17: it holds a decode)
+        g_entry[idx + 2u * gs] = make_state(uint32_t(prev), uint32_t(prev >> 32) & 0xffu, uint32_t(prev >> 40) & 0xffu);   // (for merge_finish)
+    }
+    changed = active || flipped;
     return active;
 }
 
@@ -749,7 +786,7 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge(const DevIma
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     MergeItem it{wgi * kMergeWg + tid + 1, 0, 0, 0, 0, 0};
     bool active = false, changed = false;
-    if (it.s < im.himg.nsub) active = round_begin(it, im, g_entry, g_exit, segs, g2, changed);
+    active = round_begin(it, it.s < im.himg.nsub, im, g_entry, g_exit, segs, g2, changed, reinterpret_cast<unsigned long long *>(s_win), s_cnt);
     {   // nothing to repair in this workgroup?  (not __syncthreads_or: its static LDS word would be padded to kLutAlign)
         // (what is counted is what CHANGED -- lanes that decode again and lanes that took their older decode back: the fixed point
         // is a round in which nothing changes)
@@ -929,7 +966,7 @@ extern "C" __global__ __launch_bounds__(kMergeWg) void k_huff_merge_loop(const D
         if (tid == 0) ctl[2 + (round + 1) % 3] = 0;                        // the next round's count (nobody reads or adds to it in this round)
         MergeItem it{blockIdx.x * kMergeWg + tid + 1, 0, 0, 0, 0, 0};
         bool active = false, changed = false;
-        if (it.s < im.himg.nsub) active = round_begin(it, im, g_entry, g_exit, segs, g2, changed);
+        active = round_begin(it, it.s < im.himg.nsub, im, g_entry, g_exit, segs, g2, changed, reinterpret_cast<unsigned long long *>(s_win), s_cnt);
         {
             const unsigned long long mm = __ballot(changed);
             if (lane == 0 && mm) atomicAdd(count, uint32_t(__popcll(mm)));

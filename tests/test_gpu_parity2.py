@@ -813,3 +813,73 @@ def test_multi_scan_picture_whose_tiles_are_one_mcu_longer_than_its_rows(mjx, or
     for x in rgbs[0] + rgbs[1]:
         assert np.array_equal(x, rgbs[0][0])
     assert np.abs(rgbs[0][0].astype(int) - ref.rgb.astype(int)).max() <= TOL
+
+
+def test_flat_content_is_exact_and_is_not_decoded_lane_by_lane(mjx, orc, tmp_path):
+    """Round 5 (Gen2, mjx_kernels.hip): runs of identical flat MCUs are periodic bit strings; a decode that enters one out of phase
+    stays on a self-consistent wrong parse, and the subsequences inside were put right one per synchronisation round, each decoded in
+    full again (a two-tone 4K page: 104 ms).  With two recorded decodes per subsequence the truth meets the first decode at its first
+    checkpoint and remembered exits cross a workgroup per round (1.5 ms).  Flat pictures of several kinds, alone and tiled: T0 equal to
+    the oracle, RGB within 1, the same bytes with MJX_MERGE_MEMO=0 -- and, loosely, not slower than that by more than a half."""
+    Image = pytest.importorskip("PIL.Image")
+    import io
+    import subprocess
+    rng = np.random.default_rng(3)
+
+    def jpeg(a, q=75, sub=2):
+        buf = io.BytesIO()
+        Image.fromarray(a).save(buf, "JPEG", quality=q, subsampling=sub)
+        return buf.getvalue()
+    pics = []
+    a = np.full((1080, 1920, 3), 255, np.uint8); a[:, :960] = 128
+    pics.append(jpeg(a))                                                   # two flat halves
+    a = np.full((1080, 1920, 3), 255, np.uint8)
+    for y in range(60, 1000, 60):
+        a[y:y + 20, 100:1800] = rng.integers(0, 255, (20, 1700, 1))
+    pics.append(jpeg(a))                                                   # a white page with noisy lines
+    a = np.zeros((768, 1024, 3), np.uint8)
+    for by in range(0, 768, 128):
+        for bx in range(0, 1024, 128):
+            a[by:by + 128, bx:bx + 128] = rng.integers(0, 256, 3)
+    pics.append(jpeg(a, q=90, sub=0))                                      # flat tiles, 4:4:4
+    a = np.full((600, 800), 200, np.uint8); a[200:400, 300:500] = 30
+    pics.append(jpeg(a))                                                   # grey, a dark square on a flat ground
+    for i, d in enumerate(pics):
+        (tmp_path / ("flat%d.jpg" % i)).write_bytes(d)
+    script = tmp_path / "flat.py"
+    script.write_text(
+        "import os, sys, time, hashlib\n"
+        "sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge\n"
+        "mjx = ge.load_package()\n"
+        "ctx = mjx.Context(0)\n"
+        "files = [open(os.path.join(%r, 'flat%%d.jpg' %% i), 'rb').read() for i in range(%d)]\n"
+        "out, el = [], 0.0\n"
+        "for d in files:\n"
+        "    for copies in (1, 24):\n"
+        "        base = mjx.Batch(ctx, [mjx.ParsedScan(d)], keep_coefs=copies == 1)\n"
+        "        b = base.tile(copies) if copies > 1 else base\n"
+        "        b.decode(); b.wait()\n"
+        "        t = time.perf_counter(); b.decode(); b.wait(); el += time.perf_counter() - t\n"
+        "        assert all(b.status(i) == 0 for i in range(len(b)))\n"
+        "        out.append(hashlib.sha256(b.rgb(len(b) - 1).tobytes() + (b.coefs(0).tobytes() if copies == 1 else b'')).hexdigest()[:16])\n"
+        "        b.close()\n"
+        "        if b is not base: base.close()\n"
+        "print(' '.join(out), '%%.3f' %% (el * 1e3))\n" % (ROOT, str(tmp_path), len(pics)))
+    res = {}
+    for name, extra in (("two", {}), ("one", {"MJX_MERGE_MEMO": "0"})):
+        env = {k: v for k, v in os.environ.items() if k != "MJX_MERGE_MEMO"}
+        o = subprocess.run([sys.executable, str(script)], env=dict(env, **extra), capture_output=True, text=True, timeout=900)
+        assert o.returncode == 0, name + o.stdout[-2000:] + o.stderr[-3000:]
+        res[name] = o.stdout.strip().split()
+    assert res["two"][:-1] == res["one"][:-1], res
+    assert float(res["two"][-1]) < 1.5 * float(res["one"][-1]) + 1.0, res          # (measured: 6 ms against 45)
+    ctx = mjx.Context(0)
+    for d in pics:
+        ref = orc.decode(d, layout=orc.LAYOUT_STD)
+        b = mjx.Batch(ctx, [mjx.ParsedScan(d)], keep_coefs=True)
+        b.decode(); b.wait()
+        assert b.status(0) == mjx.OK and np.array_equal(b.coefs(0), orc.interleave(ref))
+        assert np.abs(b.rgb(0).astype(int) - ref.rgb.astype(int)).max() <= TOL
+        b.close()
+    ctx.close()
