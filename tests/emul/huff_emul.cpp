@@ -150,7 +150,110 @@ extern "C" int emul_decode_coefs_sub(const uint8_t *jpeg, size_t len, int layout
         g_entry[s] = e;
         iter_ticks[0].push_back(ns.ticks - t0);
     }
-    for (;;) {                                                             // k_huff_merge rounds
+    // Two generations per subsequence (Gen2, mjx_kernels.hip; MJX_MERGE_MEMO=0 or mode 1: one, the loop below): the decode before the
+    // last is kept -- entry, exit, checkpoints -- in a second set, gen[s] bit 0 = the current set, bit 1 = the other one holds a
+    // decode.  A round: every workgroup's worth of lanes first takes remembered decodes back in a sweep (round_begin), then the lanes
+    // that still do not start where their predecessor ended decode again, recording in a scratch set and comparing with both
+    // recorded paths (merge_slice), and settle as merge_finish does.  Rounds see the previous round's exits (mode 0).
+    const char *memo_env = std::getenv("MJX_MERGE_MEMO");
+    const bool two = mode == 0 && !(memo_env && std::atoi(memo_env) == 0);
+    if (two) {
+        std::vector<SubseqState> ent[3], ext[2];
+        std::vector<uint32_t> cp[3];
+        std::vector<uint8_t> gen(nsub, 0);
+        ent[0] = g_entry; ent[1].assign(nsub, make_state(0, 0, 0)); ent[2] = ent[1];
+        ext[0] = g_exit; ext[1].assign(nsub, make_state(0, 0, 0));
+        cp[0] = g_cps; cp[1].assign(g_cps.size(), 0xdeadbeefu); cp[2] = cp[1];
+        auto cps_of = [&](int k, uint32_t s) { return HostCps{cp[k].data() + size_t(s) * kMaxCp * 2}; };
+        for (;;) {
+            long changed = 0;
+            iter_ticks.emplace_back();
+            std::vector<SubseqState> snap_exit(nsub);
+            for (uint32_t s = 0; s < nsub; s++) snap_exit[s] = ext[gen[s] & 1][s];
+            std::vector<char> active(nsub, 0);
+            std::vector<SubseqState> start(nsub);
+            for (uint32_t w0 = 1; w0 < nsub; w0 += uint32_t(kMergeWg)) {      // a merge workgroup: lanes w0 .. w0 + kMergeWg - 1
+                const uint32_t w1 = std::min<uint32_t>(nsub, w0 + uint32_t(kMergeWg));
+                std::vector<SubseqState> cur_exit(w1 - w0);
+                std::vector<char> flipped(w1 - w0, 0);
+                for (uint32_t s = w0; s < w1; s++) cur_exit[s - w0] = ext[gen[s] & 1][s];
+                for (uint32_t iter = 0; iter < uint32_t(kMergeWg); iter++) {
+                    std::vector<char> flip(w1 - w0, 0);
+                    bool any = false;
+                    for (uint32_t s = w0; s < w1; s++) {
+                        const SubseqState prev = s == w0 ? snap_exit[s - 1] : cur_exit[s - 1 - w0];
+                        const uint32_t c = gen[s] & 1;
+                        if ((gen[s] & 2) && !same_entry(prev, ent[c][s]) && same_entry(prev, ent[c ^ 1][s])) { flip[s - w0] = 1; any = true; }
+                    }
+                    if (!any) break;
+                    for (uint32_t s = w0; s < w1; s++)
+                        if (flip[s - w0]) { gen[s] = uint8_t((gen[s] & 1) ^ 1) | 2; cur_exit[s - w0] = ext[gen[s] & 1][s]; flipped[s - w0] = 1; }
+                }
+                for (uint32_t s = w0; s < w1; s++) {
+                    const SubseqState prev = s == w0 ? snap_exit[s - 1] : cur_exit[s - 1 - w0];
+                    active[s] = !same_entry(prev, ent[gen[s] & 1][s]);
+                    start[s] = make_state(prev.p, prev.z, prev.c);
+                    if (active[s] || flipped[s - w0]) changed++;
+                }
+            }
+            for (uint32_t s = 1; s < nsub; s++) {
+                if (!active[s]) continue;
+                const uint32_t cset = gen[s] & 1, oset = cset ^ 1;
+                const bool other_valid = (gen[s] & 2) != 0;
+                const SubseqState e = start[s];
+                ent[2][s] = e;
+                const HostCps cc = cps_of(int(cset), s), co = cps_of(int(oset), s), cw = cps_of(2, s);
+                uint32_t met = 0, nrec = 0;
+                SubseqState x = make_state(e.p, e.z, e.c);
+                const long t0 = ns.ticks;
+                if (e.p <= end_of(s)) {
+                    LaneState st; LaneEvents ev;
+                    lane_begin(st, bits, img2, e);
+                    events_begin<2>(ev, s * img.sub_bits, end_of(s), img2.cp_bits);
+                    uint32_t blk = 0;
+                    for (;;) {
+                        const bool crossed = symbol_step<false, true>(st, bits, lut2, img2, blk, ns);
+                        if (!crossed || st.wn < ev.next_wn) continue;
+                        if (st.wn >= ev.end_wn) break;
+                        const uint32_t state = cp_state_word(st);
+                        const uint32_t w_c = cc.get(ev.k), w_o = other_valid ? co.get(ev.k) : 0u;
+                        if ((w_c & kCpStateMask) == state) {
+                            met = 1;
+                            x = make_state(ext[cset][s].p, ext[cset][s].z, ext[cset][s].c, st.n + ((w_c >> 16) & 0x7fffu), lane_m(st) + cc.get_m(ev.k));
+                            break;
+                        }
+                        if (other_valid && (w_o & kCpStateMask) == state) {
+                            met = 2;
+                            x = make_state(ext[oset][s].p, ext[oset][s].z, ext[oset][s].c, st.n + ((w_o >> 16) & 0x7fffu), lane_m(st) + co.get_m(ev.k));
+                            break;
+                        }
+                        cw.set(ev.k, state | (st.n << 16), lane_m(st));
+                        ev.k++;
+                        ev.next_wn += ev.cp_bytes;
+                        if (ev.next_wn > ev.end_wn) ev.next_wn = ev.end_wn;
+                    }
+                    nrec = ev.k;
+                    if (!met) x = make_state(lane_pos(st), lane_z(st), lane_c(st, img2), st.n, lane_m(st));
+                }
+                iter_ticks.back().push_back(ns.ticks - t0);
+                const uint32_t dset = met == 1 ? cset : oset;
+                const HostCps dst = cps_of(int(dset), s);
+                for (uint32_t j = 0; j < nrec; j++) {
+                    const CpPair v = cw.get_pair(j);
+                    dst.set(j, (v.w & kCpStateMask) | ((x.n - ((v.w >> 16) & 0x7fffu)) << 16), x.m - v.m);
+                }
+                ent[dset][s] = ent[2][s];
+                ext[dset][s] = x;
+                if (met != 1) gen[s] = uint8_t(oset | 2);
+                redecodes++;
+            }
+            rounds++;
+            if (changed == 0) break;
+            if (rounds > 100000) return MJX_ERR_INVALID_ARG;
+        }
+        for (uint32_t s = 0; s < nsub; s++) { g_entry[s] = ent[gen[s] & 1][s]; g_exit[s] = ext[gen[s] & 1][s]; }      // (k_huff_scan folds the sets)
+    }
+    for (; !two;) {                                                        // k_huff_merge rounds, one recorded decode per subsequence
         long redone = 0;
         iter_ticks.emplace_back();
         std::vector<SubseqState> snap;

@@ -675,3 +675,28 @@ def test_planner_shares_tables_and_fills_workgroups(mjx, emul_lib):
                                             ((256, 256, 75), (1024, 1024), (40, 128)), ((96, 64, 75), (1024, 1024), (1, 16))):
         (p,) = parts(mjx.synth_jpeg(w, h, "420", q, seed=5))
         assert lo <= p[5] <= hi and p[5] % 256 == 0 and nlo <= p[6] <= nhi, (w, h, p)
+
+
+def test_emulated_rounds_keep_two_decodes_per_subsequence(mjx, orc, emul, monkeypatch):
+    """Gen2 (mjx_kernels.hip; the emulation mirrors it): where content does not synchronise -- a grey half beside a white half is a
+    periodic bit string per MCU row -- the subsequences inside used to be put right one per round and decoded in full again; with the
+    decode before the last kept, the truth meets the first decode at its first checkpoint and remembered exits cross a workgroup per
+    round.  Same coefficients either way; the rounds drop from hundreds to a dozen, a photograph's do not rise."""
+    Image = pytest.importorskip("PIL.Image")
+    a = np.full((1080, 1920, 3), 255, np.uint8)
+    a[:, :960] = 128
+    buf = io.BytesIO()
+    Image.fromarray(a).save(buf, "JPEG", quality=75, subsampling=2)
+    flat = buf.getvalue()
+    photo = _read("2x2-chroma.jpeg")
+    for data, sub_bits in ((flat, 512), (flat, 4096), (photo, 512), (_read("lena.jpeg"), 1024)):
+        ref = orc.interleave(orc.decode(data, layout=orc.LAYOUT_STD))
+        rounds = {}
+        for memo in ("1", "0"):
+            monkeypatch.setenv("MJX_MERGE_MEMO", memo)
+            rc, coefs, st = emul(data, 0, 0, sub_bits)
+            assert rc == 0 and np.array_equal(coefs, ref), (memo, sub_bits)
+            rounds[memo] = st[1]
+        assert rounds["1"] <= rounds["0"], rounds
+        if data is flat:
+            assert rounds["1"] * 5 < rounds["0"] and rounds["1"] <= 40, rounds
