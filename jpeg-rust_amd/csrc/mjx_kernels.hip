@@ -1312,13 +1312,21 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *im
     if (gen_stride && !im.emit) {
         // the rounds are over: where a subsequence's current decode lies in the second set (Gen2), its entry and exit move to the
         // first -- everything behind this kernel reads the first set only
-        for (uint32_t s = a; s < b; s++) {
-            const uint32_t idx = im.sub_off + s;
-            if (g_gen[idx] & 1u) {
-                g_entry[idx] = g_entry[idx + gen_stride];
-                g_exit[idx] = g_exit[idx + gen_stride];
+        // (the bytes stay as they are: the next decode of the chunk clears them all, and no round runs between this fold and then --
+        // the fold itself may run again; four bytes in flight at a time: the thread's subsequences are few and the loads dependent
+        // on nothing)
+        for (uint32_t s0 = a; s0 < b; s0 += 4) {
+            uint32_t gq[4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) gq[q] = s0 + q < b ? g_gen[im.sub_off + s0 + q] : 0u;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {
+                const uint32_t idx = im.sub_off + s0 + q;
+                if (gq[q] & 1u) {
+                    g_entry[idx] = g_entry[idx + gen_stride];
+                    g_exit[idx] = g_exit[idx + gen_stride];
+                }
             }
-            g_gen[idx] = 0;
         }
     }
     uint32_t sum_n = 0, sum_m = 0;
