@@ -788,11 +788,10 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
     // of nothing but pictures whose first decode emits runs exactly as before)
     const uint32_t gen_stride = c.has_spec ? b->gen_stride : 0u;
     if ((stages & MJX_STAGE_ENTROPY) && (phases & PH_SYNC)) {
-        // (every subsequence starts with its first decode in the first set and nothing in the second)
-        if (gen_stride) HIPOK(hipMemsetAsync(SCR(d_gen), 0, size_t(c.nsub), st));
+        // (every subsequence starts with its first decode in the first set and nothing in the second: k_huff_spec clears its byte)
         if (c.has_spec) {
             prof_begin(b, MJX_K_HUFF_SYNC, st);
-            launch_huff_spec(st, c.max_wg, nimg, b->huff_lds2, b->ctx->spec_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps), b->d_segs, c.wg);
+            launch_huff_spec(st, c.max_wg, nimg, b->huff_lds2, b->ctx->spec_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps), b->d_segs, c.wg, gen_stride ? SCR(d_gen) : nullptr);
             prof_end(b, st);
         }
         if (c.has_emit) {       // single decode: these pictures' first decode emits (LDS as the write pass: plain tables, windows, rings)

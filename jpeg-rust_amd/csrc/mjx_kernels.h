@@ -329,7 +329,8 @@ void launch_scan_interleave(hipStream_t st, uint32_t max_pieces, uint32_t nimg, 
                             const uint8_t *linear, uint8_t *pool, const uint32_t *segs);
 void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                       const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
-                      uint32_t *cps, const uint32_t *segs, uint32_t lanes /* per workgroup: kHuffWg, or 256 / 128 for a chunk of short scans */);
+                      uint32_t *cps, const uint32_t *segs, uint32_t lanes /* per workgroup: kHuffWg, or 256 / 128 for a chunk of short scans */,
+                      uint8_t *gen /* [chunk subsequences] cleared per subsequence (Gen2), or null */);
 void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                        const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
                        uint32_t *cps, uint32_t *mismatches, uint32_t *items, uint32_t *item_count, const uint32_t *segs,

@@ -516,7 +516,7 @@ __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry,
 extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_spec(const DevImage *images, const uint8_t *scan_pool,
                                                                    const LutEntry *lut_pool, SubseqState *g_entry,
                                                                    SubseqState *g_exit, uint32_t *g_cps, uint32_t win_off,
-                                                                   const uint32_t *segs)
+                                                                   const uint32_t *segs, uint8_t *g_gen)
 {
     extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, windows
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
@@ -540,6 +540,7 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_spec(const DevImage
     x.p += loc.start;
     g_entry[im.sub_off + s] = make_state(loc.start, 0, 0);
     g_exit[im.sub_off + s] = x;
+    if (g_gen) g_gen[im.sub_off + s] = 0;                                   // (Gen2: this decode lies in the first set, the second holds nothing)
 }
 
 // k_huff_merge: one synchronisation round.  Subsequence s must start where s-1 ended: if entry[s] differs from
@@ -3632,11 +3633,11 @@ void launch_scan_interleave(hipStream_t st, uint32_t max_pieces, uint32_t nimg, 
 
 void launch_huff_spec(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                       const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_,
-                      uint32_t *cps, const uint32_t *segs, uint32_t lanes)
+                      uint32_t *cps, const uint32_t *segs, uint32_t lanes, uint8_t *gen)
 {
     // (lanes: 512, or 256 / 128 for a chunk of short scans -- max_wg counts workgroups of that size; the occupancy pad belongs to the full size)
     const size_t lds = tables_lds + huff_window_bytes(lanes) + (lanes == uint32_t(kHuffWg) ? pad_lds : 0);
-    hipLaunchKernelGGL(k_huff_spec, entropy_grid(max_wg, nimg), dim3(lanes), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, uint32_t(tables_lds), segs);
+    hipLaunchKernelGGL(k_huff_spec, entropy_grid(max_wg, nimg), dim3(lanes), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, uint32_t(tables_lds), segs, gen);
 }
 
 void launch_huff_merge(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
