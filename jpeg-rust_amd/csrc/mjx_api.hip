@@ -876,7 +876,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         if (c.plane_words) HIPOK(hipMemsetAsync(SCR(d_planes), 0, size_t(c.plane_words) * 8, sp));
         // (dense: over ~1400 bytes of scan per stage-B tile -- more than the 2048 stream entries the kernel's default form prefetches)
         launch_idct_color(sp, c.max_tiles, nimg, b->idct_lds + b->ctx->idct_lds_pad, imgs, SCR(d_entries), SCR(d_tile_eoff), dcb, b->d_qm, b->d_rgb, c.mode_mask, SCR(d_planes), b->d_img_flags,
-                          c.scan_bytes > uint64_t(c.tiles) * 1400u, c.layout_mask);
+                          c.scan_bytes > uint64_t(c.tiles) * (1400u * tile_mcus_420() / 32u), c.layout_mask, b->ctx->idct_lds_pad);
         if (c.plane_words) launch_ref_color(sp, c.max_pixel_wgs, nimg, imgs, SCR(d_planes), b->d_rgb, b->d_img_flags);
         prof_end(b, sp);
         if (sp != st) {

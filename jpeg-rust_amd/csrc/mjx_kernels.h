@@ -381,7 +381,8 @@ void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t
                        const uint32_t *entries, const uint32_t *tile_eoff, const int32_t *dcbuf, const float *qmult,
                        uint8_t *rgb, uint32_t mode_mask, unsigned long long *planes, const uint32_t *img_flags,
                        bool dense /* the chunk's linear streams are dense (many entries per tile): deeper prefetch in the 4:2:0 kernel */,
-                       uint32_t layout_mask /* bit 0: pictures with a linear stream, bit 1: with a quad-interleaved one */);
+                       uint32_t layout_mask /* bit 0: pictures with a linear stream, bit 1: with a quad-interleaved one */,
+                       size_t lds_pad = 0 /* part of `lds` that is occupancy padding (a test knob): the 4:2:0 form sizes its own tile and adds it */);
 // multi-scan pictures: component streams (raster order) -> the picture's stream in MCU order, tile offsets, DC values
 void launch_planar_gather(hipStream_t st, uint32_t max_tiles, uint32_t nimg, const DevImage *images, uint32_t *entries,
                           uint32_t *tile_eoff, int32_t *dcbuf, uint32_t *img_flags, bool copy);

@@ -2596,11 +2596,30 @@ constexpr int kPrefetch = MJX_PREFETCH;         // stream entries per lane held 
 constexpr int kPrefetchDense = MJX_PREFETCH_DENSE;   // ... in the 4:2:0 kernel's form for dense streams (3072 per tile: quality 90 and up), chosen per chunk by the host
 static_assert(MJX_PREFETCH == 8 && MJX_PREFETCH_DENSE > 8, "scatter batches of 4, 6, 8 and the full depth");
 constexpr int kTilesPerWg = MJX_TILES_PER_WG;
-#ifndef MJX_TILE420
-#define MJX_TILE420 32
+// The 4:2:0 kernel has two forms.  MJX_WIDE420 = 1 (round 6, MODE 3 below): 16 lanes per MCU, tiles of 16 MCUs = 25 KB of LDS, the
+// inverse DCT split into a column pass (two lanes per block) and a row pass fused with the colour step (a lane per 8 x 2 pixels) --
+// twice the waves per LDS byte of the other form.  MJX_WIDE420 = 0: 8 lanes per MCU, tiles of 32 MCUs = 52 KB, a lane per block
+// for the whole transform (rounds 1-5, MODE 1).
+#ifndef MJX_WIDE420
+#define MJX_WIDE420 0
 #endif
-constexpr uint32_t kTile420 = MJX_TILE420;        // MCUs per tile of the 4:2:0 kernel; its workgroup has 8 lanes per MCU
-constexpr uint32_t kLanes420 = kTile420 * 8;
+#ifndef MJX_TILE420
+#define MJX_TILE420 (MJX_WIDE420 ? 16 : 32)
+#endif
+constexpr uint32_t kTile420 = MJX_TILE420;        // MCUs per tile of the 4:2:0 kernel
+constexpr uint32_t kLanes420 = kTile420 * (MJX_WIDE420 ? 16 : 8);
+constexpr int kMode420 = MJX_WIDE420 ? 3 : 1;     // the kernel form (template MODE) that takes the pictures of DevImage::mode 1
+static_assert(!MJX_WIDE420 || kTile420 == 16, "the wide form's lane maps are written for 256 lanes = 16 MCUs");
+// MODE 3: an MCU's six blocks lie in three SUPER-ROWS of kWRow floats -- (Y00, Y01), (Y10, Y11), (Cb, Cr) --, 128 values + 4 of padding
+// (an odd number of 16-byte slots: the 16 lanes of a ds_read_b128 group, one MCU apart, fall into 16 different slots).  Inside a
+// super-row, lane q (0..3) of the column pass owns the eight floats  m * 32 + 8 q .. + 7  of every row pair m (0..3):
+//   coefficients   Y, block side sd = q >> 1, columns c = 4 (q & 1) .. + 3:   (r >> 1) * 32 + 8 q + (r & 1) * 4 + (c & 3)
+//                  chroma, columns c = 2 q, 2 q + 1, both components:          (r >> 1) * 32 + 8 q + (r & 1) * 4 + (c & 1) * 2 + comp
+//   after the column pass (written back in place)
+//                  Y:       (r >> 1) * 32 + sd * 16 + c * 2 + (r & 1)      -- (row 2m, row 2m+1) of a column side by side: the row pass's pairs
+//                  chroma:  unchanged                                       -- (Cb, Cr) of a column side by side
+constexpr uint32_t kWRow = 132, kWMcu = 3 * kWRow;
+constexpr uint32_t wide_tile_bytes() { return kTile420 * kWMcu * 4; }
 
 template <int PF>
 struct TileFetch {
@@ -2710,12 +2729,26 @@ __device__ __forceinline__ void quad_mask(uint32_t *ent, uint32_t k_lo, uint32_t
 // granule that is the third workgroup per CU -- measured: 17.6 instead of 15.5 ms per 2048 pictures.)
 // where a lane sends the entries that must not land: a padding word (floats 64..67 of a block row are never read) of a row of
 // its own -- rows 0..127 exist in every tile allocation (tile_mcus), and the 32 lanes of an LDS store group hit 32 banks
-__device__ __forceinline__ uint32_t dump_bytes() { return (threadIdx.x & 127u) * uint32_t(kPixStride * 4) + (64u + ((threadIdx.x >> 3) & 3u)) * 4u; }
+template <int MODE>
+__device__ __forceinline__ uint32_t dump_bytes()
+{
+    // (MODE 3: the four padding words of super-rows 0..7 -- 32 lanes, 32 banks)
+    if (MODE == 3) return (threadIdx.x & 7u) * (kWRow * 4u) + (128u + ((threadIdx.x >> 3) & 3u)) * 4u;
+    return (threadIdx.x & 127u) * uint32_t(kPixStride * 4) + (64u + ((threadIdx.x >> 3) & 3u)) * 4u;
+}
+// MODE 3: where block b of the tile (MCU order, Y Y Y Y Cb Cr) keeps its coefficients -- bytes into the tile, to which the position's
+// table entry is added (s_nat: 64 entries for luminance, 64 for chrominance)
+__device__ __forceinline__ uint32_t wide_block_bytes(uint32_t b)
+{
+    const uint32_t t = (b * 171u) >> 10, j = b - 6u * t;
+    const uint32_t in_mcu = j < 4u ? (j >> 1) * (kWRow * 4u) + (j & 1u) * 64u : 2u * kWRow * 4u + (j & 1u) * 4u;
+    return t * (kWMcu * 4u) + in_mcu;
+}
 
 template <int MODE>
 __device__ __forceinline__ uint32_t comp_of_block(uint32_t b, const uint8_t *s_comp)
 {
-    if (MODE == 1) {                                        // Y Y Y Y Cb Cr: block b of the tile, b < 256
+    if (MODE == 1 || MODE == 3) {                           // Y Y Y Y Cb Cr: block b of the tile, b < 256
         const uint32_t j = b - 6u * ((b * 171u) >> 10);     // (171 / 1024: exact quotient by 6 below 512)
         return j < 4u ? 0u : j - 3u;
     }
@@ -2744,18 +2777,18 @@ __device__ __forceinline__ void scatter_at(const uint32_t *ent, const uint32_t *
 #pragma unroll
     for (int k = 0; k < N; k++) pos[k] = (ent[k] >> 16) & 63u;
 #pragma unroll
-    for (int k = 0; k < N; k++) comp[k] = comp_of_block<MODE>(MODE == 1 ? b[k] : (b[k] < nblk ? b[k] : 0u), s_comp);
+    for (int k = 0; k < N; k++) comp[k] = comp_of_block<MODE>((MODE == 1 || MODE == 3) ? b[k] : (b[k] < nblk ? b[k] : 0u), s_comp);
 #pragma unroll
     for (int k = 0; k < N; k++) {
         qm[k] = s_qm[comp[k] * 64u + pos[k]];
-        nat[k] = s_nat[pos[k]];
+        nat[k] = s_nat[MODE == 3 ? pos[k] + (comp[k] ? 64u : 0u) : pos[k]];
     }
     unsigned char *base = reinterpret_cast<unsigned char *>(tile_f);
-    const uint32_t dump = dump_bytes();
+    const uint32_t dump = dump_bytes<MODE>();
 #pragma unroll
     for (int k = 0; k < N; k++) {
         const bool ok = b[k] < nblk && pos[k] != 0;           // pos == 0 marks a null entry (the write pass fills up its runs with them)
-        const uint32_t at = ok ? b[k] * uint32_t(kPixStride * 4) + nat[k] * 4u : dump;
+        const uint32_t at = ok ? (MODE == 3 ? wide_block_bytes(b[k]) : b[k] * uint32_t(kPixStride * 4)) + nat[k] * 4u : dump;
 #if defined(MJX_EXP_NO_SCATTER_STORE)  // (measurement build, garbage out: the scatter phase without its LDS stores)
         asm volatile("" :: "v"(at), "v"(float(int32_t(int16_t(ent[k] & 0xffffu))) * qm[k]));
 #else
@@ -3246,7 +3279,140 @@ extern "C" __global__ __launch_bounds__(256) void k_ref_color(const DevImage *im
     dst[0] = uint8_t(word); dst[1] = uint8_t(word >> 8); dst[2] = uint8_t(word >> 16);
 }
 
+// ---- MODE 3: the wide 4:2:0 form (round 6; layout: kWRow above) ----------------------------------------------------------------
+// Phase 2, the column pass: a lane owns four columns of a luminance block, or two columns of both chrominance blocks of an MCU --
+// eight rows x four floats, one ds_read_b128 per row, two packed 8-point transforms down the columns (the two columns of a pair, or
+// the Cb and the Cr column, side by side in packed fp32 instructions), eight ds_write_b128 back to where the rows came from.
+// Lanes 0 .. 8T-1 are luminance (MCU t = lane % T, then super-row and q), lanes 8T .. 12T-1 chrominance: the kind is uniform over a
+// wave, and the 16 lanes of a ds_read_b128 group are 16 MCUs of one q -- 16 different 16-byte slots (kWMcu / 4 = 99 is odd).
+__device__ __forceinline__ void wide_column_pass(float *tile_f, uint32_t nm)
+{
+    constexpr uint32_t T = kTile420;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t t = tid % T, g = tid / T;                 // g: 0..7 luminance (super-row g >> 2, q = g & 3), 8..11 chrominance (q = g - 8)
+    if (g >= 12u || t >= nm) return;
+    const bool chroma = g >= 8u;
+    float4 *p = reinterpret_cast<float4 *>(tile_f + t * kWMcu + (chroma ? 2u : g >> 2) * kWRow + 8u * (g & 3u));
+    float_pair a[8], b[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const float4 v = p[(r >> 1) * 8 + (r & 1)];
+        a[r] = float_pair{v.x, v.y};
+        b[r] = float_pair{v.z, v.w};
+    }
+    idct8(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
+    idct8(b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7]);
+    if (chroma) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) p[(r >> 1) * 8 + (r & 1)] = make_float4(a[r].x, a[r].y, b[r].x, b[r].y);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            p[m * 8] = make_float4(a[2 * m].x, a[2 * m + 1].x, a[2 * m].y, a[2 * m + 1].y);
+            p[m * 8 + 1] = make_float4(b[2 * m].x, b[2 * m + 1].x, b[2 * m].y, b[2 * m + 1].y);
+        }
+    }
+}
+
+__device__ __forceinline__ void store_rgb4_plain(uint8_t *dst, const Rgb4 &v)
+{
+#if defined(MJX_EXP_NO_RGB_STORE)
+    asm volatile("" :: "v"(v.a), "v"(v.b), "v"(v.c), "v"(dst));
+    return;
+#endif
+    *reinterpret_cast<Rgb4 *>(dst) = v;
+}
+
+// Phase 3, row pass + colour: lane -> (row pair k of the MCU, side sd, MCU t) = 8 x 2 pixels.  It takes the two luminance rows as
+// eight (row 2m, row 2m+1) pairs -- 64 contiguous bytes -- and row k of both chrominance blocks as eight (Cb, Cr) pairs, runs one
+// packed 8-point transform along each, keeps the four chrominance samples over its pixels (columns 4 sd .. 4 sd + 3; the other side's
+// lane computes the same transform for the other four) and converts: 2 x 24 bytes, two 12-byte stores per row.  A wave's 64 lanes
+// write the 8-pixel halves of 16 MCUs of two row pairs: 768 contiguous bytes per row from each pair of store instructions (plain
+// stores: L2 merges the two halves of a line; as streaming stores the same shape took 19.8 instead of 9.1 ms per 51 GB,
+// tools/probes/rgb_store_probe.hip).
+//   XCHG   the tile holds all its MCUs: the luminance rows are read as an exchange with zero and the chrominance rows -- read by both
+//          sides' lanes -- are cleared by them, two pieces each, behind the reads: the tile is clean for the next one
+//   BOUNDS pixels may lie outside the picture, or rows are not 4-byte aligned: stores predicated per pixel
+template <bool XCHG, bool BOUNDS>
+__device__ __forceinline__ void pixels_wide(uint32_t width, uint32_t height, uint32_t mcux, float *tile, uint32_t m0, uint32_t nm,
+                                            uint8_t *out_img, bool aligned)
+{
+    constexpr uint32_t T = kTile420;
+    constexpr bool INTERIOR = XCHG && !BOUNDS;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t t = tid % T, sd = (tid / T) & 1u, k = tid / (2u * T);
+    if (!XCHG && t >= nm) return;
+    const uint32_t m = m0 + t;
+    const uint32_t mx = m % mcux, my = m / mcux;
+    float *yb = tile + t * kWMcu + (k >> 2) * kWRow + (k & 3u) * 32u + sd * 16u;
+    float *cb = tile + t * kWMcu + 2u * kWRow + (k >> 1) * 32u + (k & 1u) * 4u;
+    float_pair y[8], c[8];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float4 v = *reinterpret_cast<const float4 *>(cb + 8 * q);
+        c[2 * q] = float_pair{v.x, v.y};
+        c[2 * q + 1] = float_pair{v.z, v.w};
+    }
+    if (XCHG && MJX_PIX_XCHG) {
+        // (one statement with its wait: the compiler does not track LDS operations inside asm, see pixels_420)
+        const f32x2 zero = {0.0f, 0.0f};
+        const uint32_t ay = uint32_t(uintptr_t((const __attribute__((address_space(3))) float *)(yb)));
+        f32x4 y0, y1, y2, y3;
+        asm volatile(
+            "ds_wrxchg2_rtn_b64 %0, %4, %5, %5 offset1:1\n\t"
+            "ds_wrxchg2_rtn_b64 %1, %4, %5, %5 offset0:2 offset1:3\n\t"
+            "ds_wrxchg2_rtn_b64 %2, %4, %5, %5 offset0:4 offset1:5\n\t"
+            "ds_wrxchg2_rtn_b64 %3, %4, %5, %5 offset0:6 offset1:7\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3)
+            : "v"(ay), "v"(zero)
+            : "memory");
+        y[0] = float_pair{y0.x, y0.y}; y[1] = float_pair{y0.z, y0.w};
+        y[2] = float_pair{y1.x, y1.y}; y[3] = float_pair{y1.z, y1.w};
+        y[4] = float_pair{y2.x, y2.y}; y[5] = float_pair{y2.z, y2.w};
+        y[6] = float_pair{y3.x, y3.y}; y[7] = float_pair{y3.z, y3.w};
+        // the chrominance row: this side's lane clears pieces 2 sd and 2 sd + 1 (every lane of the wave has read by now: the reads
+        // above are earlier instructions of the same wave, and a wave's LDS instructions execute in order)
+        *reinterpret_cast<float4 *>(cb + 16u * sd) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(cb + 16u * sd + 8u) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 v = *reinterpret_cast<const float4 *>(yb + 4 * q);
+            y[2 * q] = float_pair{v.x, v.y};
+            y[2 * q + 1] = float_pair{v.z, v.w};
+        }
+    }
+    idct8(y[0], y[1], y[2], y[3], y[4], y[5], y[6], y[7]);          // y[x] = (pixel x of row 2k, of row 2k + 1)
+    idct8(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);          // c[x] = (Cb, Cr) sample x of chrominance row k
+    const uint32_t px = mx * 16u + sd * 8u, py = my * 16u + k * 2u;
+    uint8_t *dst = out_img + (size_t(py) * width + px) * 3;
+    const uint32_t npix = INTERIOR ? 8u : (px < width ? min(8u, width - px) : 0u);
+    if (!INTERIOR && (py >= height || npix == 0)) return;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {                                    // four pixels x two rows at a time
+        Rgb r0[4], r1[4];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const float_pair cc = sd ? c[4 + 2 * h + i] : c[2 * h + i];
+            const ChromaTerms ct = chroma_terms(cc.x, cc.y);
+            const float_pair ya = y[4 * h + 2 * i], yb2 = y[4 * h + 2 * i + 1];
+            r0[2 * i] = ycc_to_rgb(ya.x, ct); r0[2 * i + 1] = ycc_to_rgb(yb2.x, ct);
+            r1[2 * i] = ycc_to_rgb(ya.y, ct); r1[2 * i + 1] = ycc_to_rgb(yb2.y, ct);
+        }
+        const uint32_t left = npix > 4u * h ? npix - 4u * h : 0u;
+        if (INTERIOR) {
+            store_rgb4_plain(dst + 12 * h, pack4(r0));
+            store_rgb4_plain(dst + size_t(width) * 3 + 12 * h, pack4(r1));
+        } else if (left) {
+            store4(dst + 12 * h, pack4(r0), aligned, left);
+            if (py + 1 < height) store4(dst + size_t(width) * 3 + 12 * h, pack4(r1), aligned, left);
+        }
+    }
+}
+
 // MODE 0: any sampling layout.  MODE 1: Y 2x2 + Cb 1x1 + Cr 1x1 (4:2:0, 6 blocks per MCU, tile = 32 MCUs).
+// MODE 3: the same pictures (DevImage::mode 1) in the wide form (above): 16 lanes per MCU, tile = 16 MCUs.
 // MODE 2: any sampling layout, REF_COMPAT placement into the f32 plane scratch (k_ref_color finishes the image).
 //   phase 0  zero the tile's sample rows in LDS
 //   phase 1  scatter the tile's slice of the compact coefficient stream into them, entry-parallel (lane i holds
@@ -3267,8 +3433,8 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
     // (its own symbol: dynamic LDS arrays of one name share their alignment, and the entropy kernels ask for 2 KiB)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_px[];
     __shared__ float s_qm[3 * 64];
-    __shared__ uint8_t s_nat[64];
-    __shared__ uint8_t s_comp[MODE == 1 ? 4 : 256];     // (4:2:0: the component comes from arithmetic on the block index)
+    __shared__ uint8_t s_nat[MODE == 3 ? 128 : 64];     // (MODE 3: the luminance table, then the chrominance one)
+    __shared__ uint8_t s_comp[(MODE == 1 || MODE == 3) ? 4 : 256];     // (4:2:0: the component comes from arithmetic on the block index)
     // per tile of the workgroup (+ sentinel).  Linear stream: s_eoff = the tile's first entry.  Quad-interleaved stream (QUAD):
     // s_eoff = the subsequence and s_at = the entry in its column where the tile starts; s_cum: see quad_prepare
     constexpr bool QUAD = SRC == 1, PLANAR = SRC == 2;
@@ -3278,11 +3444,12 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
     __shared__ PlanarKindL s_kind[PLANAR ? kPlanarKinds : 1];
     __shared__ PlanarTile s_ptile[PLANAR ? 3 : 1];
     const DevImage &im = images[blockIdx.y];
-    if (!im.valid || im.mode != uint32_t(MODE) || (im.planar ? 2 : im.ent_rows != 0 ? 1 : 0) != SRC || img_flags[im.status_idx]) return;
+    if (!im.valid || im.mode != uint32_t(MODE == 3 ? 1 : MODE) || (im.planar ? 2 : im.ent_rows != 0 ? 1 : 0) != SRC || img_flags[im.status_idx]) return;
     // everything the tile loop needs from the descriptor, read once (uniform -> scalar registers)
-    constexpr uint32_t LANES = MODE == 1 ? kLanes420 : 256u;
-    const uint32_t T = MODE == 1 ? kTile420 : (1u << im.log2_tile);
-    const uint32_t bpm = MODE == 1 ? 6u : im.bpm;
+    constexpr bool M420 = MODE == 1 || MODE == 3;
+    constexpr uint32_t LANES = M420 ? kLanes420 : 256u;
+    const uint32_t T = M420 ? kTile420 : (1u << im.log2_tile);
+    const uint32_t bpm = M420 ? 6u : im.bpm;
     const uint32_t nmcu = im.nmcu, width = im.width, height = im.height, mcux = im.mcux;
     const uint32_t total_blocks = im.himg.total_blocks;
     const uint32_t tile_blocks = T * bpm;
@@ -3359,19 +3526,29 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
         constexpr uint8_t ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                                     41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                     30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+        if (MODE == 3) {    // ... -> the float inside the block's quarter of its super-row (kWRow above), luminance and chrominance
+            const uint32_t r = ZZ[tid] >> 3, c = ZZ[tid] & 7u;
+            s_nat[tid] = uint8_t((r >> 1) * 32u + (c >> 2) * 8u + (r & 1u) * 4u + (c & 3u));
+            s_nat[64 + tid] = uint8_t((r >> 1) * 32u + (c >> 1) * 8u + (r & 1u) * 4u + (c & 1u) * 2u);
+        } else
         s_nat[tid] = uint8_t(idct_slot(ZZ[tid]));      // zig-zag position -> where the inverse DCT expects the coefficient
     }
-    if (MODE != 1 && tid < tile_blocks) s_comp[tid] = im.blk_comp[tid % bpm];
+    if (!M420 && tid < tile_blocks) s_comp[tid] = im.blk_comp[tid % bpm];
     // the lane's own block slot (tid) has the same component in every tile (a tile is whole MCUs): its DC multiplier and level shift
     const uint32_t my_comp = im.blk_comp[tid % bpm];
-    const float my_dc_qm = qmult[im.qm_off + my_comp * 64];
-    const float my_dc_add = (MODE != 2 && my_comp == 0) ? 128.0f : 0.0f;
+    float my_dc_qm = qmult[im.qm_off + my_comp * 64];
+    float my_dc_add = (MODE != 2 && my_comp == 0) ? 128.0f : 0.0f;
     float *tile_f = reinterpret_cast<float *>(smem_px);
     GenShape gshape{};
     if (MODE == 0) gshape = gen_shape(im);
     // (the first tile's words are settled before the loop, so that on no path into a tile iteration a load is pending
     // on them: see the settle point behind phase 2)
     settle(cur);
+    // (... and the lane's DC multiplier: first used inside the loop, its load would be waited for there -- in every iteration, with
+    // a vmcnt(0) that also drains the pixel stores of the tile before: the wait-count pass merges the loop's entry state into its
+    // back edge.  Round 6: found in the ISA; it was a store drain per tile and wave right behind the pixel phase.)
+    asm volatile("" : "+v"(my_dc_qm), "+v"(my_dc_add));
+    if (!M420) asm volatile("" :: "v"(gshape.width));
 
 #ifdef MJX_STAMP_B
     WaveStamp sp;
@@ -3386,7 +3563,7 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
         const uint32_t nm = min(T, nmcu - m0), nblk = nm * bpm;
         if (!clean) {   // phase 0
             float4 *z = reinterpret_cast<float4 *>(smem_px);
-            const uint32_t nq = nblk * (kPixStride / 4);
+            const uint32_t nq = MODE == 3 ? nm * (kWMcu / 4) : nblk * (kPixStride / 4);
             for (uint32_t i = tid; i < nq; i += LANES) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             __syncthreads();
         }
@@ -3467,6 +3644,9 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
             // prescaled transform is the same constant on all 64 samples); REF_COMPAT adds it per pixel in k_ref_color,
             // where samples no block covers must come out as 0 + 128
             MJX_SB(1);
+            if (MODE == 3) {
+                if (tid < nblk) *reinterpret_cast<float *>(smem_px + wide_block_bytes(tid)) = float(cur.dc) * my_dc_qm + my_dc_add;
+            } else
             if (tid < nblk) tile_f[tid * kPixStride] = float(cur.dc) * my_dc_qm + my_dc_add;
         }
         auto nxt = cur;
@@ -3478,7 +3658,9 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
         MJX_SB(2);
         __syncthreads();
         MJX_SB(3);
-        if (tid < nblk) idct_row_inplace(tile_f + tid * kPixStride);      // phase 2
+        if (MODE == 3) wide_column_pass(tile_f, nm);                      // phase 2
+        else
+        if (tid < nblk) idct_row_inplace(tile_f + tid * kPixStride);
         MJX_SB(4);
         __syncthreads();
         MJX_SB(3);
@@ -3493,7 +3675,15 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
             pa0 = pa1;
         }
         MJX_SB(5);
-        if (MODE == 1) {                                                  // phase 3
+        if (MODE == 3) {                                                  // phase 3
+            const uint32_t mx0 = m0 % mcux, my1 = (m0 + T - 1) / mcux;
+            const bool whole = nm == T;
+            const bool interior = whole && aligned && (my1 + 1) * 16 <= height && (mcux * 16 <= width || mx0 + T < mcux);
+            if (interior) pixels_wide<true, false>(width, height, mcux, tile_f, m0, nm, out_img, aligned);
+            else if (whole) pixels_wide<true, true>(width, height, mcux, tile_f, m0, nm, out_img, aligned);
+            else pixels_wide<false, true>(width, height, mcux, tile_f, m0, nm, out_img, aligned);
+            clean = whole && MJX_PIX_XCHG;
+        } else if (MODE == 1) {
             // interior tile: all 32 MCUs in one MCU row, fully inside the image, rows 4-byte aligned
             // whole tile: all its 32 MCUs exist; interior: ... and every one of them lies fully inside the picture (the tile may wrap
             // into the next MCU row), rows 4-byte aligned
@@ -3596,10 +3786,10 @@ int configure_kernels(size_t huff_lds, size_t idct_lds)
     }
     if (e == hipSuccess && idct_lds > 64 * 1024) {
         const void *fns[] = {reinterpret_cast<const void *>(k_idct_color<0, kPrefetch, 0>), reinterpret_cast<const void *>(k_idct_color<0, 8, 1>),
-                             reinterpret_cast<const void *>(k_idct_color<1, kPrefetch, 0>), reinterpret_cast<const void *>(k_idct_color<1, kPrefetchDense, 0>),
-                             reinterpret_cast<const void *>(k_idct_color<1, 8, 1>), reinterpret_cast<const void *>(k_idct_color<1, 16, 1>),
+                             reinterpret_cast<const void *>(k_idct_color<kMode420, kPrefetch, 0>), reinterpret_cast<const void *>(k_idct_color<kMode420, kPrefetchDense, 0>),
+                             reinterpret_cast<const void *>(k_idct_color<kMode420, 8, 1>), reinterpret_cast<const void *>(k_idct_color<kMode420, 16, 1>),
                              reinterpret_cast<const void *>(k_idct_color<2, kPrefetch, 0>), reinterpret_cast<const void *>(k_idct_color<2, 8, 1>),
-                             reinterpret_cast<const void *>(k_idct_color<0, 8, 2>), reinterpret_cast<const void *>(k_idct_color<1, 8, 2>)};
+                             reinterpret_cast<const void *>(k_idct_color<0, 8, 2>), reinterpret_cast<const void *>(k_idct_color<kMode420, 8, 2>)};
         for (const void *f : fns)
             if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(idct_lds));
     }
@@ -3740,7 +3930,7 @@ void launch_dc_scan(hipStream_t st, uint32_t max_segs, uint32_t nimg, const DevI
 void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t lds, const DevImage *images,
                        const uint32_t *entries, const uint32_t *tile_eoff, const int32_t *dcbuf, const float *qmult,
                        uint8_t *rgb, uint32_t mode_mask, unsigned long long *planes, const uint32_t *img_flags, bool dense,
-                       uint32_t layout_mask)
+                       uint32_t layout_mask, size_t lds_pad)
 {
     // A workgroup walks up to kTilesPerWg consecutive tiles of its image (offsets fetched once, the next tile's loads in
     // flight during this tile's arithmetic) -- when the launch has tiles to spare: with fewer than a few rounds of 3
@@ -3751,7 +3941,9 @@ void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t
     const uint32_t gx = (max_tiles + tpw - 1) / tpw;
     // (layout_mask: bit 0 = the chunk has pictures with a linear stream, bit 1 = with a quad-interleaved one, bit 2 = multi-scan
     // pictures read straight from their scans' streams; a kernel form leaves the other kinds' pictures alone)
-#define MJX_IDCT(M, P, Q) hipLaunchKernelGGL((k_idct_color<M, P, Q>), dim3(gx, nimg), dim3(M == 1 ? kLanes420 : 256u), lds, st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags, tpw)
+    // (the 4:2:0 form's tile has its own size: the wide form's 25 KB must not be rounded up to the other pictures' tiles)
+    const size_t lds420 = MJX_WIDE420 ? wide_tile_bytes() + lds_pad : lds;
+#define MJX_IDCT(M, P, Q) hipLaunchKernelGGL((k_idct_color<M, P, Q>), dim3(gx, nimg), dim3((M == 1 || M == 3) ? kLanes420 : 256u), (M == 3 ? lds420 : lds), st, images, entries, tile_eoff, dcbuf, qmult, rgb, planes, img_flags, tpw)
     if (mode_mask & 1u) {
         if (layout_mask & 1u) MJX_IDCT(0, kPrefetch, 0);
         if (layout_mask & 2u) MJX_IDCT(0, 8, 1);
@@ -3762,15 +3954,15 @@ void launch_idct_color(hipStream_t st, uint32_t max_tiles, uint32_t nimg, size_t
         // twelve words per lane instead of eight: 18.2 -> 17.2 ms per 2048 4K pictures at quality 90; at quality 75 the four
         // extra loads per lane and tile cost 0.15 ms)
         if (layout_mask & 1u) {
-            if (dense) MJX_IDCT(1, kPrefetchDense, 0);
-            else MJX_IDCT(1, kPrefetch, 0);
+            if (dense) MJX_IDCT(kMode420, kPrefetchDense, 0);
+            else MJX_IDCT(kMode420, kPrefetch, 0);
         }
         // (quad-interleaved streams: one round of 256 groups prefetched, two for dense streams -- 20.2 -> ... ms at quality 90)
         if (layout_mask & 2u) {
-            if (dense) MJX_IDCT(1, 16, 1);
-            else MJX_IDCT(1, 8, 1);
+            if (dense) MJX_IDCT(kMode420, 16, 1);
+            else MJX_IDCT(kMode420, 8, 1);
         }
-        if (layout_mask & 4u) MJX_IDCT(1, 8, 2);
+        if (layout_mask & 4u) MJX_IDCT(kMode420, 8, 2);
     }
     if (mode_mask & 4u) {
         if (layout_mask & 1u) MJX_IDCT(2, kPrefetch, 0);

@@ -22,7 +22,7 @@ f(out, 0)
 v = list(out)
 names = ["zero fill (+ its barrier)", "scatter (+ mask, further rounds)", "DC term + next tile's fetch issued", "barriers around the IDCT", "IDCT", "settle: wait for the next tile's words", "pixels", "last barrier"]
 tot = sum(v[:8])
-tile_mcus = {"420": 32, "422": 32, "444": 64, "gray": 128, "440": 32}.get(sub, 32)
+tile_mcus = {"420": int(os.environ.get("MJX_TILE420", "16")), "422": 32, "444": 64, "gray": 128, "440": 32}.get(sub, 32)
 mw, mh = {"420": (16, 16), "422": (16, 8), "440": (8, 16), "444": (8, 8), "gray": (8, 8)}.get(sub, (16, 16))
 mcus = ((W + mw - 1) // mw) * ((H + mh - 1) // mh)
 tiles = (mcus + tile_mcus - 1) // tile_mcus * copies // 16
