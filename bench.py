@@ -116,6 +116,51 @@ KERNEL_ALIAS = {"k_huff_spec": "huff_sync", "k_huff_merge": "huff_fix", "k_huff_
                 "k_planar_copy": "gather", "k_huff_emit": "huff_emit", "k_huff_prefix": "huff_prefix", "k_block_gather": "huff_prefix"}
 
 
+def pmc_sum_by_class(directory, counters):
+    """Sums of rocprofv3 --pmc counters over the dispatches of each decode kernel class: {class: {counter: value}}."""
+    import collections, csv, glob
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] not in counters:
+                continue
+            k = r["Kernel_Name"].split("(")[0].replace("void mjx::", "").split("<")[0].strip()
+            if k in KERNEL_ALIAS:
+                acc[KERNEL_ALIAS[k]][r["Counter_Name"]] += float(r["Counter_Value"])
+    return {k: dict(v) for k, v in acc.items()}
+
+
+# Units of a CU next to HBM (round-5 review, next #5): which one is busiest per kernel class.  Prices from tools/probes/op_cost_probe.hip
+# (profiles/r06_op_costs.txt): a SIMD of gfx950 issues a wave64 v_add/mul/fma_f32, v_mov, v_and, v_add_u32 ... in 2 cycles when two or
+# more of its waves have one ready (4 for a lone wave), and v_pk_*_f32, v_cvt_*, v_mad_*24, v_bfe, v_lshl_*, v_perm, v_cmp ... in 4
+# cycles whatever the occupancy -- these kernels are made of the second kind, so the share is quoted at 4 cycles, with the 2-cycle
+# figure beside it as the lower bound.  The chip's cycles during a dispatch = GRBM_GUI_ACTIVE / 8 (summed over the 8 XCDs, guide s.DVFS).
+SQ_COUNTERS = ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAVES", "GRBM_GUI_ACTIVE")
+N_SIMD, N_CU, HBM_ACHIEVABLE_GBS = 1024, 256, 6300.0
+
+
+def unit_shares(sq, hbm_bytes):
+    """{class: shares of the chip's time its dispatches kept each unit busy} from the SQ pass (+ the traffic of the TCC passes)."""
+    out = {}
+    for k, c in sq.items():
+        cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        if cyc <= 0 or "SQ_INSTS_VALU" not in c:
+            continue
+        o = {"chip_cycles": int(cyc), "valu_insts": int(c["SQ_INSTS_VALU"]),
+             "valu_issue_share_at_4_cycles": round(c["SQ_INSTS_VALU"] * 4.0 / (N_SIMD * cyc), 3),
+             "valu_issue_share_at_2_cycles": round(c["SQ_INSTS_VALU"] * 2.0 / (N_SIMD * cyc), 3),
+             "lds_active_share": round(c.get("SQ_LDS_IDX_ACTIVE", 0.0) / (N_CU * cyc), 3),
+             "lds_bank_conflict_share_of_active": round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(c.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0), 3)}
+        if k in hbm_bytes and c.get("ms"):
+            o["ms_in_pmc_pass"] = round(c["ms"], 4)
+            o["clock_GHz_in_pmc_pass"] = round(cyc / (c["ms"] * 1e6), 3)
+            o["hbm_share_of_achievable"] = round(hbm_bytes[k] / (c["ms"] / 1e3) / 1e9 / HBM_ACHIEVABLE_GBS, 3)
+        cand = {"valu_issue": o["valu_issue_share_at_4_cycles"], "lds": o["lds_active_share"], "hbm": o.get("hbm_share_of_achievable", 0.0)}
+        o["busiest_unit"] = max(cand, key=cand.get)
+        out[k] = o
+    return out
+
+
 def pmc_bytes_by_class(directory, counter):
     """Sum of a rocprofv3 --pmc counter (KB) over the dispatches of each decode kernel class, in bytes."""
     import collections, csv, glob
@@ -151,24 +196,41 @@ def observe_traffic(args):
     if not exe:
         return None
     out = {}
+    sq = None
     with tempfile.TemporaryDirectory(prefix="mjx_pmc_", dir="/tmp") as tmp:
         env = dict(os.environ, MJX_STREAMS="1", TMPDIR="/tmp")
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        # (a third pass, SQ + GRBM counters: which unit of the CUs each kernel class keeps busiest -- unit_shares(); its failure
+        # costs the line that object only)
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
             d = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "-d", d, "-o", "out", "--output-format", "csv", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+            pmc = list(SQ_COUNTERS) if counter == "SQ" else [counter]
+            cmd = [exe, "--pmc"] + pmc + ["-d", d, "-o", "out", "--output-format", "csv", "--", sys.executable, os.path.join(ROOT, "bench.py"),
                    "--no-cpu-baseline", "--no-extra", "--no-parity", "--steps", "1", "--warmup", "0", "--images-per-gpu", str(args.traffic_images),
                    "--width", str(args.width), "--height", str(args.height), "--subsampling", args.subsampling, "--quality", str(args.quality),
                    "--unique", str(min(args.unique, args.traffic_images))]
+            child_out = os.path.join(tmp, counter + ".stdout")
             try:
-                p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
-                try:
-                    rc = p.wait(timeout=180)
-                except subprocess.TimeoutExpired:
-                    os.killpg(p.pid, signal.SIGKILL)          # (the group this call started, nothing else)
-                    p.wait()
-                    return None
+                with open(child_out, "w") as fo:
+                    p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=fo, stderr=subprocess.DEVNULL, start_new_session=True)
+                    try:
+                        rc = p.wait(timeout=180)
+                    except subprocess.TimeoutExpired:
+                        os.killpg(p.pid, signal.SIGKILL)          # (the group this call started, nothing else)
+                        p.wait()
+                        rc = -1
             except OSError:
-                return None
+                rc = -1
+            if counter == "SQ":
+                if rc == 0:
+                    try:
+                        sq = pmc_sum_by_class(d, set(SQ_COUNTERS))
+                        line = [l for l in open(child_out) if l.startswith("{")][-1]
+                        for k, v in json.loads(line)["kernels"].items():        # the pass's own HIP-event times: the clock it ran at
+                            if k in sq:
+                                sq[k]["ms"] = v["ms"]
+                    except Exception:
+                        sq = None
+                continue
             if rc != 0:
                 return None
             out[counter] = pmc_bytes_by_class(d, counter)
@@ -177,10 +239,11 @@ def observe_traffic(args):
     # (the classes are SUMMED over the child's dispatches -- a batch of two chunks launches every kernel twice -- so the figure
     # is per step of `traffic_images` pictures whatever the chunking)
     classes = sorted(set(out["FETCH_SIZE"]) | set(out["WRITE_SIZE"]))
-    return ({k: {"fetch_bytes": int(2 * out["FETCH_SIZE"].get(k, 0)), "write_bytes": int(out["WRITE_SIZE"].get(k, 0)),
-                 "hbm_bytes": int(2 * out["FETCH_SIZE"].get(k, 0) + out["WRITE_SIZE"].get(k, 0))} for k in classes},
-            args.traffic_images, "observed in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH x 2), "
-            "%d pictures, one stream, one step" % args.traffic_images)
+    per = {k: {"fetch_bytes": int(2 * out["FETCH_SIZE"].get(k, 0)), "write_bytes": int(out["WRITE_SIZE"].get(k, 0)),
+               "hbm_bytes": int(2 * out["FETCH_SIZE"].get(k, 0) + out["WRITE_SIZE"].get(k, 0))} for k in classes}
+    units = unit_shares(sq, {k: v["hbm_bytes"] for k, v in per.items()}) if sq else None
+    return (per, args.traffic_images, "observed in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH x 2), "
+            "%d pictures, one stream, one step" % args.traffic_images, units)
 
 
 def committed_traffic():
@@ -198,7 +261,7 @@ def committed_traffic():
     if "huff_fix_tail" in k:                                   # (older collections list the straggler kernel on its own, per launch)
         k["huff_fix"] = {f: 6 * (k["huff_fix"][f] + k["huff_fix_tail"][f]) for f in ("fetch_bytes", "write_bytes", "hbm_bytes")}
     k = {c: v for c, v in k.items() if c in set(KERNEL_ALIAS.values())}
-    return k, t["images_per_step"], "committed collection profiles/%s (not observed in this run)" % os.path.basename(files[-1])
+    return k, t["images_per_step"], "committed collection profiles/%s (not observed in this run)" % os.path.basename(files[-1]), t.get("units")
 
 
 def shard_seeds(rank, world, unique):
@@ -479,8 +542,16 @@ def rooflines(rec, steps, stages, traffic=None):
         e2e_bytes = by["scan"] + by["rgb"]
         e2e = e2e_bytes * steps / rec["elapsed"] / 1e9
         tot_traffic = sum(tr_step(k) or 0 for k in kernels) if traffic else None
+        # what this design could reach at the bytes it really moves: its traffic at the ~6.3 TB/s the guide measures as achievable
+        # (round-5 review, next #5) -- frac is what it reaches, ceiling_frac what it could, 0.60 what the north star asks
+        ceiling_ms = tot_traffic / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3 if tot_traffic else None
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(e2e, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(e2e / HBM_PEAK_GBS, 5), "traffic": tot_traffic,
+                           "ceiling_ms_per_step": round(ceiling_ms, 3) if ceiling_ms else None,
+                           "ceiling_frac": round(e2e_bytes / (ceiling_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if ceiling_ms else None,
+                           "ceiling_definition": "traffic / 6.3 TB/s (HBM rate a copy reaches on MI355X): the step time, and the fraction of "
+                                                 "the 8 TB/s roofline, this design would reach if every byte it moves moved at that rate",
+                           "busiest_unit_per_kernel": (traffic[3] if traffic and len(traffic) > 3 else None),
                            "traffic_source": traffic[2] if traffic else None,
                            "bytes_per_step": int(e2e_bytes), "wall_ms_per_step": round(wall_ms, 4),
                            "kernel_ms_per_step_summed": round(tot_ms / steps, 4),
@@ -598,8 +669,20 @@ def e2e_pool(mjx, datas, files_per_device, width, height):
                 best, slots = dt, info
     finally:
         pool.close()
+    # the host bound made visible (round-5 review, weak #8 / next #8): one thread's marker walk + de-stuffing rate on these files,
+    # and what the slots' parse threads together could feed -- an 8-GPU node is host-bound when that is below 8 x the resident rate
+    t = time.perf_counter()
+    probe = [mjx.ParsedScan(d) for d in files[:64]]
+    parse_s = (time.perf_counter() - t) / len(probe)
+    for sc in probe:
+        sc.close()
+    threads_total = sum(s["parse_threads"] for s in slots)
+    for s in slots:
+        s["files_per_s_per_parse_thread"] = round(s["files"] / (s["ms"] / 1e3) / max(s["parse_threads"], 1), 1) if s["ms"] > 0 else None
     return {"devices": ndev, "files": n_files, "ms": round(best * 1e3, 2), "Mpixels/s": round(n_files * width * height / best / 1e6, 1),
             "files/s": round(n_files / best, 1), "slots": slots,
+            "parse_ms_per_file_one_thread": round(parse_s * 1e3, 4), "parse_files_per_s_per_thread": round(1.0 / parse_s, 1),
+            "parse_threads_total": threads_total, "host_parse_bound_files_per_s": round(threads_total / parse_s, 1),
             "note": "one process, mjx_pool_decode_batch over all visible devices (host bytes -> RGB resident on the device that decoded "
                     "it), best of 3 calls; PCIe-inclusive, never part of `value`; slots[].ms = wall clock of the slot's own mjx_decode_batch"}
 

@@ -203,7 +203,8 @@ int mjx_batch_bytes(const mjx_batch *b, uint64_t *scan_bytes, uint64_t *rgb_byte
 int mjx_batch_geometry(const mjx_batch *b, uint64_t *subsequences, uint64_t *blocks, uint64_t *chunks);
 
 /* Runs of a chunk, since the batch was created, whose synchronisation rounds had not converged when the rest of the entropy stage
- * was enqueued behind them: the chunk's pictures were skipped in that run.  mjx_batch_wait examines and repairs the LAST decode
+ * was enqueued behind them: the chunk's pictures were skipped in that run -- and runs in which a picture left the single-decode
+ * path on the device (it is skipped by the rest of that run too).  mjx_batch_wait examines and repairs the LAST decode
  * only, so a caller that enqueues several mjx_batch_decode calls before one wait (a throughput measurement) reads here whether
  * every one of them did the whole work.  Synchronises the batch's streams. */
 int mjx_batch_unconverged_runs(const mjx_batch *b, uint64_t *runs);

@@ -847,7 +847,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         if (c.has_emit) {       // the prefixes of the lanes whose entry was wrong; block words -> DC differences + tile offsets
             prof_begin(b, MJX_K_HUFF_PREFIX, st);
             launch_huff_prefix(st, c.max_wg, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps), SCR(d_esub), SCR(d_blkbase),
-                               SCR(d_entries), b->d_status, b->d_img_flags, b->d_mismatch + ci * kMisWords + kMaxFix + 1, SCR(d_dcd), SCR(d_tile_eoff), SCR(d_items), SCR(d_pull));
+                               SCR(d_entries), b->d_status, b->d_img_flags, b->d_mismatch + ci * kMisWords + kMaxFix + 1, SCR(d_dcd), SCR(d_tile_eoff), SCR(d_items), SCR(d_pull), b->d_unconv + ci);
             prof_end(b, st);
         }
         prof_begin(b, MJX_K_DC_SCAN, st);
@@ -1105,8 +1105,9 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
         if (p.restart_mcus) inf.ent_cap = (uint64_t(p.scan_len) * 4 + 64 + group_pad) / stream_group_entries() * stream_group_entries();
         // A picture of one scan gets the quad-interleaved stream: one column of fixed capacity per subsequence (mjx_kernels.h,
         // stream_phys); tile offsets are 32-bit virtual indices into the columns.
+        const bool will_emit = ctx->single_decode && p.role == 0 && !ctx->linear_stream && p.nseg <= 1 && p.restart_mcus == 0 && p.himg.sub_bits >= ctx->emit_min_sub_bits;
         if (p.role == 0 && !ctx->linear_stream) {
-            const uint32_t rows = stream_rows_for(p.himg.sub_bits);
+            const uint32_t rows = stream_rows_for(p.himg.sub_bits, will_emit);
             const uint64_t cap = stream_quad_entries(layout_nsub(p), rows);
             if (rows < 65536u && cap < 0xffffffffull) {
                 d.ent_rows = rows;
@@ -1116,7 +1117,7 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
         }
         // single decode: the picture's first decode emits (one scan, no restart intervals, quad-interleaved stream, subsequences long
         // enough that the warm-up is a small share of them -- the short cuts of small batches keep the two-pass kernels)
-        if (ctx->single_decode && d.ent_rows && p.role == 0 && p.nseg <= 1 && p.restart_mcus == 0 && p.himg.sub_bits >= ctx->emit_min_sub_bits) {
+        if (will_emit && d.ent_rows) {
             d.emit = 1;
             d.emit_head = ctx->emit_head;
             d.himg.cp_bits = p.himg.sub_bits >= 2 * ctx->emit_cp_bits ? ctx->emit_cp_bits : uint32_t(kCpBits);
@@ -1439,6 +1440,10 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
                     size_t span_lo = 0, span_hi = 0;
                     for (; k1 < nu; k1++) {
                         const ImagePlan &p = plans[k1];
+                        // (a scan that is de-stuffed on the device has its pool region between its neighbours': a span that went on
+                        // across it would overwrite that region -- 0xAA from the fill above, which k_destuff_scatter relies on past the
+                        // scan's end -- with whatever the staging block holds there.  The span ends in front of it.  Round-5 advisor.)
+                        if (p.status == MJX_OK && p.stuffed && p.himg.nsub != 0 && first != nu) break;
                         if (p.status != MJX_OK || p.stuffed || p.himg.nsub == 0) continue;
                         const size_t lo = scan_off[k1], hi = lo + size_t(scan_region_bytes(layout_nsub(p), p.himg.sub_bits));
                         if (first != nu && hi - span_lo > kStage) break;

@@ -127,7 +127,11 @@ constexpr uint32_t kStreamQuad = MJX_STREAM_QUAD;      // columns interleaved pe
 constexpr uint32_t kEmitHeadGroups = 64;                       // entries: 512 of head room
 constexpr uint32_t kEmitHeadWords = kEmitHeadGroups * 4u;      // block words of head room: 256 (DevImage::emit_head scales both)
 constexpr uint32_t kEmitExtraRows = kEmitHeadGroups + kEmitHeadWords / 8u + 2u;
-MJX_HD uint32_t stream_rows_for(uint32_t sub_bits) { return (sub_bits / 2u + 1u + 7u) / 8u + 1u + kEmitExtraRows; }
+// (rows of a column: what the entries of a subsequence can need, and -- only for pictures whose first decode emits -- the head room and
+// the block words on top; a picture that cannot take the single-decode path does not pay for them: at 1024-bit subsequences the
+// column would be 164 rows instead of 66.  Round-5 advisor.)
+MJX_HD uint32_t stream_rows_base(uint32_t sub_bits) { return (sub_bits / 2u + 1u + 7u) / 8u + 1u; }
+MJX_HD uint32_t stream_rows_for(uint32_t sub_bits, bool emit = true) { return stream_rows_base(sub_bits) + (emit ? kEmitExtraRows : 0u); }
 MJX_HD uint64_t stream_quad_entries(uint32_t nsub, uint32_t rows) { return uint64_t((nsub + kStreamQuad - 1) / kStreamQuad) * rows * 8u * kStreamQuad; }
 // Head of a picture's stream region: one 32-bit word per subsequence -- the run of its entries in the column, in store groups,
 // and what is added to its entries' block labels:   first group [11:0] | end group [23:12] | label offset [31:24]
@@ -359,7 +363,8 @@ void launch_huff_prefix(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t t
                         const uint8_t *scan_pool, const LutEntry *lut_pool, const SubseqState *entry, const SubseqState *exit_,
                         const uint32_t *cps, EmitSub *esub, const uint32_t *blkbase, uint32_t *entries, int *status, uint32_t *img_flags,
                         uint32_t *fallback /* device word: a picture had no head room for its prefix */, int16_t *dcdiff, uint32_t *tile_eoff,
-                        const uint32_t *items, const uint32_t *item_count /* as written by k_huff_scan */);
+                        const uint32_t *items, const uint32_t *item_count /* as written by k_huff_scan */,
+                        uint32_t *unconverged /* device word, counted up by the first picture of the run that falls back */);
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, SubseqState *exit_, uint32_t *blkbase,
                       uint32_t *ebase, uint32_t *img_entries, uint32_t *img_flags, const uint32_t *segs,
                       const uint32_t *verdict /* device word: re-decodes of the last synchronisation round, or null */,

@@ -1192,7 +1192,11 @@ extern "C" __global__ __launch_bounds__(256) void k_destuff_scatter(const Destuf
             const uint32_t g = base.x + i, s = g / sub_bytes, r = g - s * sub_bytes;
             const uint8_t v = s_out[i];
             region[(size_t(r >> 4) * cols + s) * 16u + (r & 15u)] = v;
-            if (s > 0 && r < kLookPieces * 16u) region[(size_t(own_rows + (r >> 4)) * cols + (s - 1u)) * 16u + (r & 15u)] = v;
+            // ... and into the look-ahead rows of the columns in front: byte r of subsequence s is byte (j - 1) * sub_bytes + r behind the
+            // end of subsequence s - j.  (Subsequences of 64 bytes and more: j = 1 only.  Shorter ones -- MJX_FIT_SHORT below 512 bits --
+            // need their look-ahead from two or more followers; the single copy left those bytes 0xAA.  Round-5 advisor.)
+            for (uint32_t j = 1u, at = r; j <= s && at < kLookPieces * 16u; j++, at += sub_bytes)
+                region[(size_t(own_rows + (at >> 4)) * cols + (s - j)) * 16u + (at & 15u)] = v;
         }
         return;
     }
@@ -1375,7 +1379,9 @@ extern "C" __global__ __launch_bounds__(256) void k_huff_scan(const DevImage *im
         // the list has room for kItemDwords items per subsequence (the merge rounds' straggler list); a picture that needs more -- most
         // of its lanes decode most of their subsequence again: noise at quality 99 -- is better off with the two-pass kernels anyway
         if (total > nsub * uint32_t(kItemDwords) || nsub >= (1u << kItemShift)) {
-            if (tid == 0) { img_flags[im.status_idx] = 2u; atomicOr(fallback, 64u); g_item_count[blockIdx.x] = 0; }
+            // (the first picture of this run that falls back also counts the run: its pictures are skipped by everything behind, and a
+            // caller who enqueues several decodes before one wait learns of it from mjx_batch_unconverged_runs -- round-5 advisor)
+            if (tid == 0) { img_flags[im.status_idx] = 2u; if (atomicOr(fallback, 64u) == 0u) atomicAdd(unconverged, 1u); g_item_count[blockIdx.x] = 0; }
             return;
         }
         uint32_t *items = g_items + size_t(im.sub_off) * kItemDwords;
@@ -1679,7 +1685,7 @@ extern "C" __global__ __launch_bounds__(kPrefixWg) void k_huff_prefix(const DevI
                                                                     const SubseqState *g_exit, const uint32_t *g_cps, EmitSub *g_esub,
                                                                     const uint32_t *g_blkbase, uint32_t *entries, int *status,
                                                                     uint32_t *img_flags, uint32_t *fallback, uint32_t win_off,
-                                                                    const uint32_t *g_items, const uint32_t *g_item_count)
+                                                                    const uint32_t *g_items, const uint32_t *g_item_count, uint32_t *unconverged)
 {
     extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, a window per lane
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
@@ -1804,7 +1810,7 @@ extern "C" __global__ __launch_bounds__(kPrefixWg) void k_huff_prefix(const DevI
     if (failed) {
         // no room in front of the first decode's entries (or an inconsistency): the picture is decoded by the two-pass kernels instead
         img_flags[im.status_idx] = 2u;
-        atomicOr(fallback, why ? why : 128u);
+        if (atomicOr(fallback, why ? why : 128u) == 0u) atomicAdd(unconverged, 1u);      // (see k_huff_scan)
         return;
     }
     if (k != 0) return;
@@ -3873,13 +3879,13 @@ void launch_huff_emit(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tab
 void launch_huff_prefix(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, const DevImage *images,
                         const uint8_t *scan_pool, const LutEntry *lut_pool, const SubseqState *entry, const SubseqState *exit_,
                         const uint32_t *cps, EmitSub *esub, const uint32_t *blkbase, uint32_t *entries, int *status, uint32_t *img_flags,
-                        uint32_t *fallback, int16_t *dcdiff, uint32_t *tile_eoff, const uint32_t *items, const uint32_t *item_count)
+                        uint32_t *fallback, int16_t *dcdiff, uint32_t *tile_eoff, const uint32_t *items, const uint32_t *item_count, uint32_t *unconverged)
 {
     // (the picture is the fast grid dimension, as in the other entropy kernels; a wave per 64 listed items -- the grid is sized for
     // the list's capacity, the waves beyond a picture's count leave at once)
     const uint32_t groups = max_wg * (kHuffWg / kPrefixWg) * kItemDwords;     // (the list's capacity; a picture of the bench has ~270 items: five waves)
     hipLaunchKernelGGL(k_huff_prefix, dim3(nimg, groups), dim3(kPrefixWg), tables_lds + huff_prefix_bytes(), st, images, scan_pool, lut_pool, entry, exit_, cps, esub,
-                       blkbase, entries, status, img_flags, fallback, uint32_t(tables_lds), items, item_count);
+                       blkbase, entries, status, img_flags, fallback, uint32_t(tables_lds), items, item_count, unconverged);
     hipLaunchKernelGGL(k_block_gather, dim3(nimg, (max_wg * kHuffWg + kGatherSubs - 1) / kGatherSubs), dim3(256), 0, st, images, entry, exit_, esub, blkbase,
                        const_cast<uint32_t *>(entries), dcdiff, tile_eoff, img_flags, status);
 }

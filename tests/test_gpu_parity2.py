@@ -355,6 +355,58 @@ def test_pool_with_eight_slots_decodes_a_scaled_down_config_5(mjx, orc):
     pool.close()
 
 
+def test_pool_over_distinct_devices(mjx, orc):
+    """BASELINE config 5's sharding on real devices (round-5 review, next #8): one slot per visible GPU, all of them different
+    devices -- skipped on the 1-GPU boxes, runs the first time a multi-GPU node sees the suite.  File i of a round-robin deal must
+    land on device i mod N; every slot reports the parse threads it ran with (the slots share the host's processors: at most
+    max(2, P / 2N) each) and the NUMA node its host thread is bound to (the node of ITS device, or -1 where the platform names
+    none); every picture equals the first copy of its original bit for bit -- compared on the devices, which only works between
+    pictures of one device: the originals are decoded once per device for that -- and four pictures per device match the oracle."""
+    import torch
+    ndev = torch.cuda.device_count()                       # (counting devices does not initialise the GPU runtime in this process)
+    if ndev < 2:
+        pytest.skip("one visible device: the pool's multi-device path needs two")
+    P = int(mjx.lib().mjx_host_processors())
+    uniq = [mjx.synth_jpeg(640 + 16 * (s % 4), 480, ("420", "422", "444")[s % 3], 75, seed=s) for s in range(16)]
+    refs = [orc.decode(d, layout=orc.LAYOUT_STD) for d in uniq]
+    n = 64 * ndev
+    datas = [uniq[(i // ndev) % 16] for i in range(n)]     # (file i and file i + 16 N hold the same picture and land on the same device)
+    pool = mjx.Pool(list(range(ndev)))
+    assert len(pool) == ndev and sorted(pool.device(s) for s in range(ndev)) == list(range(ndev))
+    for rr in (True, False):
+        pool.set_deal(round_robin=rr)
+        res = pool.decode_batch(datas)
+        assert res.rc == mjx.OK and all(s == mjx.OK for s in res.status)
+        if rr:
+            assert res.slot_of == [i % ndev for i in range(n)]
+        per_slot = [sum(1 for s in res.slot_of if s == k) for k in range(ndev)]
+        assert min(per_slot) > 0, per_slot
+        nodes = []
+        for k in range(ndev):
+            threads, node = res.host(k)
+            assert 1 <= threads <= max(2, P // (2 * ndev)), (k, threads, P)
+            ctx = mjx.Context(pool.device(k))
+            want = int(mjx.lib().mjx_ctx_numa_node(ctx.h))
+            ctx.close()
+            assert node in (-1, want), (k, node, want)
+            nodes.append(node)
+            assert res.slot_ms(k) > 0.0
+        seen = {}
+        for i in range(n):
+            k = res.slot_of[i]
+            assert res.locate(i)[0] == k
+            if seen.get(k, 0) < 4:
+                seen[k] = seen.get(k, 0) + 1
+                assert np.abs(res.rgb(i).astype(int) - refs[(i // ndev) % 16].rgb.astype(int)).max() <= TOL, i
+        assert len(seen) == ndev
+        if rr:      # same picture, same device, 16 N files apart: equal bit for bit
+            idx = [i for i in range(16 * ndev, n)]
+            mx, cnt = res.compare_rgb(idx, [i - 16 * ndev for i in idx])
+            assert int(mx.max()) == 0 and int(cnt.sum()) == 0
+        res.close()
+    pool.close()
+
+
 def test_pool_slot_that_fails_keeps_the_other_slots_results(mjx, orc):
     """A device that errors must not poison the others: MJX_POOL_FAULT_SLOT=3 makes slot 3 of an eight-slot pool fail its call.
     Its files report the device error and have no picture, the call returns the error, and every file of the seven other
@@ -821,29 +873,10 @@ def test_flat_content_is_exact_and_is_not_decoded_lane_by_lane(mjx, orc, tmp_pat
     full again (a two-tone 4K page: 104 ms).  With two recorded decodes per subsequence the truth meets the first decode at its first
     checkpoint and remembered exits cross a workgroup per round (1.5 ms).  Flat pictures of several kinds, alone and tiled: T0 equal to
     the oracle, RGB within 1, the same bytes with MJX_MERGE_MEMO=0 -- and, loosely, not slower than that by more than a half."""
-    Image = pytest.importorskip("PIL.Image")
-    import io
     import subprocess
-    rng = np.random.default_rng(3)
-
-    def jpeg(a, q=75, sub=2):
-        buf = io.BytesIO()
-        Image.fromarray(a).save(buf, "JPEG", quality=q, subsampling=sub)
-        return buf.getvalue()
-    pics = []
-    a = np.full((1080, 1920, 3), 255, np.uint8); a[:, :960] = 128
-    pics.append(jpeg(a))                                                   # two flat halves
-    a = np.full((1080, 1920, 3), 255, np.uint8)
-    for y in range(60, 1000, 60):
-        a[y:y + 20, 100:1800] = rng.integers(0, 255, (20, 1700, 1))
-    pics.append(jpeg(a))                                                   # a white page with noisy lines
-    a = np.zeros((768, 1024, 3), np.uint8)
-    for by in range(0, 768, 128):
-        for bx in range(0, 1024, 128):
-            a[by:by + 128, bx:bx + 128] = rng.integers(0, 256, 3)
-    pics.append(jpeg(a, q=90, sub=0))                                      # flat tiles, 4:4:4
-    a = np.full((600, 800), 200, np.uint8); a[200:400, 300:500] = 30
-    pics.append(jpeg(a))                                                   # grey, a dark square on a flat ground
+    # (the pictures are fixtures since round 6 -- tests/golden/flat_r06/, written by make_flat.py there with Pillow: two flat halves, a
+    # white page with noisy lines, flat 4:4:4 tiles, a grey page with a dark square -- so the test never skips for want of Pillow)
+    pics = [open(os.path.join(ROOT, "tests", "golden", "flat_r06", "flat%d.jpg" % i), "rb").read() for i in range(4)]
     for i, d in enumerate(pics):
         (tmp_path / ("flat%d.jpg" % i)).write_bytes(d)
     script = tmp_path / "flat.py"
