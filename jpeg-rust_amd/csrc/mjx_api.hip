@@ -583,7 +583,7 @@ void plan_chunks(mjx_batch *b)
         // one launch for all the merge rounds only when its workgroups are certain to be resident together (they wait for one
         // another): a twelfth of the device's 3 x 256 slots, so that a dozen such launches (other contexts, other processes) still
         // fit side by side; a launch that cannot get its workgroups together gives up by itself (kLoopGaveUp)
-        if (c.has_emit || b->has_stuffed) c.wg = uint32_t(kHuffWg);      // (k_huff_emit and its followers count in workgroups of kHuffWg; stuffed scans: lengths known on the device only)
+        if (b->has_stuffed) c.wg = uint32_t(kHuffWg);      // (stuffed scans: lengths known on the device only.  k_huff_emit and its followers take the chunk's size since round 6)
         c.max_wg = (c.max_nsub + c.wg - 1) / c.wg;
         if (c.loop_participants > b->ctx->merge_loop_max) c.loop_participants = 0;
         if (b->has_stuffed) c.loop_participants = 0;    // (its workgroups are counted from nsub, which only the device knows exactly for those scans)
@@ -796,7 +796,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         }
         if (c.has_emit) {       // single decode: these pictures' first decode emits (LDS as the write pass: plain tables, windows, rings)
             prof_begin(b, MJX_K_HUFF_EMIT, st);
-            launch_huff_emit(st, c.max_wg, nimg, b->huff_lds, b->ctx->write_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps), SCR(d_esub), SCR(d_entries));
+            launch_huff_emit(st, c.max_wg, nimg, b->huff_lds, b->ctx->write_lds_pad, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps), SCR(d_esub), SCR(d_entries), c.wg);
             prof_end(b, st);
         }
     }
@@ -847,7 +847,7 @@ int run_chunk(mjx_batch *b, size_t ci, unsigned stages, int fix_passes, unsigned
         if (c.has_emit) {       // the prefixes of the lanes whose entry was wrong; block words -> DC differences + tile offsets
             prof_begin(b, MJX_K_HUFF_PREFIX, st);
             launch_huff_prefix(st, c.max_wg, nimg, b->huff_lds, imgs, b->d_scan, b->d_lut, SCR(d_entry), SCR(d_exit), SCR(d_cps), SCR(d_esub), SCR(d_blkbase),
-                               SCR(d_entries), b->d_status, b->d_img_flags, b->d_mismatch + ci * kMisWords + kMaxFix + 1, SCR(d_dcd), SCR(d_tile_eoff), SCR(d_items), SCR(d_pull), b->d_unconv + ci);
+                               SCR(d_entries), b->d_status, b->d_img_flags, b->d_mismatch + ci * kMisWords + kMaxFix + 1, SCR(d_dcd), SCR(d_tile_eoff), SCR(d_items), SCR(d_pull), b->d_unconv + ci, c.wg);
             prof_end(b, st);
         }
         prof_begin(b, MJX_K_DC_SCAN, st);

@@ -358,13 +358,14 @@ size_t huff_prefix_bytes();
 void launch_emit_off(hipStream_t st, DevImage *images, uint32_t nimg, const uint32_t *img_flags);     // fall-back: the flagged pictures leave the single-decode path (device copies patched in place)
 void launch_huff_emit(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                       const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_, uint32_t *cps,
-                      EmitSub *esub, uint32_t *entries);
+                      EmitSub *esub, uint32_t *entries, uint32_t lanes /* as launch_huff_spec */);
 void launch_huff_prefix(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, const DevImage *images,
                         const uint8_t *scan_pool, const LutEntry *lut_pool, const SubseqState *entry, const SubseqState *exit_,
                         const uint32_t *cps, EmitSub *esub, const uint32_t *blkbase, uint32_t *entries, int *status, uint32_t *img_flags,
                         uint32_t *fallback /* device word: a picture had no head room for its prefix */, int16_t *dcdiff, uint32_t *tile_eoff,
                         const uint32_t *items, const uint32_t *item_count /* as written by k_huff_scan */,
-                        uint32_t *unconverged /* device word, counted up by the first picture of the run that falls back */);
+                        uint32_t *unconverged /* device word, counted up by the first picture of the run that falls back */,
+                        uint32_t lanes /* of the chunk's entropy workgroups (max_wg counts those) */);
 void launch_huff_scan(hipStream_t st, uint32_t nimg, const DevImage *images, SubseqState *exit_, uint32_t *blkbase,
                       uint32_t *ebase, uint32_t *img_entries, uint32_t *img_flags, const uint32_t *segs,
                       const uint32_t *verdict /* device word: re-decodes of the last synchronisation round, or null */,

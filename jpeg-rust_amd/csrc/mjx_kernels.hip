@@ -1586,11 +1586,12 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_emit(const DevImage
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
     const uint32_t img = entropy_grid_image(), wgi = entropy_grid_wg();
     const DevImage &im = images[img];
-    if (!im.valid || !im.emit || wgi * kHuffWg >= im.himg.nsub) return;
+    // (blockDim.x lanes: 512, or -- round 6 -- 256 / 128 for a chunk whose scans are all that short: see k_huff_spec)
+    if (!im.valid || !im.emit || wgi * blockDim.x >= im.himg.nsub) return;
     const HuffImage *h;
     const LutEntry *lut;
     stage_tables(im, lut_pool, smem, h, lut);
-    const uint32_t s = wgi * kHuffWg + threadIdx.x;
+    const uint32_t s = wgi * blockDim.x + threadIdx.x;
     const bool live = s < h->nsub;
     const uint32_t sl = live ? s : 0u, L = h->sub_bits;
     const uint32_t start = sl * L, end = min(start + L, h->total_bits);
@@ -1613,10 +1614,10 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_emit(const DevImage
     uint32_t *column = entries + im.ent_off + im.ent_hdr + stream_phys(sl, 0, im.ent_rows);
     EmitSink sink;
     {
-        uint32_t *rings = s_win + kHuffWg * kWinStride;
+        uint32_t *rings = s_win + blockDim.x * kWinStride;
         sink.ac_ring.begin(rings + threadIdx.x * kAcRingStride, column, H);
         sink.ac_ring.gstride = kAcGroup * kStreamQuad;
-        rings += kHuffWg * kAcRingStride;
+        rings += blockDim.x * kAcRingStride;
         sink.blk_ring.begin(rings + threadIdx.x * BlkRing::kRing, column, im.ent_rows, Hb + (e0.z ? 1u : 0u));
     }
     sink.blk_bits = StreamSink::block_bits(0);
@@ -3870,23 +3871,24 @@ size_t huff_prefix_bytes() { return size_t(kPrefixWg) * kMergeStride * 4; }     
 
 void launch_huff_emit(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, size_t pad_lds, const DevImage *images,
                       const uint8_t *scan_pool, const LutEntry *lut_pool, SubseqState *entry, SubseqState *exit_, uint32_t *cps,
-                      EmitSub *esub, uint32_t *entries)
+                      EmitSub *esub, uint32_t *entries, uint32_t lanes)
 {
-    const size_t lds = tables_lds + huff_window_bytes() + huff_stage_bytes() + pad_lds;
-    hipLaunchKernelGGL(k_huff_emit, entropy_grid(max_wg, nimg), dim3(kHuffWg), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, esub, entries, uint32_t(tables_lds));
+    const size_t lds = tables_lds + huff_window_bytes(lanes) + huff_stage_bytes(lanes) + (lanes == uint32_t(kHuffWg) ? pad_lds : 0);
+    hipLaunchKernelGGL(k_huff_emit, entropy_grid(max_wg, nimg), dim3(lanes), lds, st, images, scan_pool, lut_pool, entry, exit_, cps, esub, entries, uint32_t(tables_lds));
 }
 
 void launch_huff_prefix(hipStream_t st, uint32_t max_wg, uint32_t nimg, size_t tables_lds, const DevImage *images,
                         const uint8_t *scan_pool, const LutEntry *lut_pool, const SubseqState *entry, const SubseqState *exit_,
                         const uint32_t *cps, EmitSub *esub, const uint32_t *blkbase, uint32_t *entries, int *status, uint32_t *img_flags,
-                        uint32_t *fallback, int16_t *dcdiff, uint32_t *tile_eoff, const uint32_t *items, const uint32_t *item_count, uint32_t *unconverged)
+                        uint32_t *fallback, int16_t *dcdiff, uint32_t *tile_eoff, const uint32_t *items, const uint32_t *item_count, uint32_t *unconverged,
+                        uint32_t lanes)
 {
     // (the picture is the fast grid dimension, as in the other entropy kernels; a wave per 64 listed items -- the grid is sized for
     // the list's capacity, the waves beyond a picture's count leave at once)
-    const uint32_t groups = max_wg * (kHuffWg / kPrefixWg) * kItemDwords;     // (the list's capacity; a picture of the bench has ~270 items: five waves)
+    const uint32_t groups = max_wg * (lanes / kPrefixWg) * kItemDwords;     // (the list's capacity; a picture of the bench has ~270 items: five waves)
     hipLaunchKernelGGL(k_huff_prefix, dim3(nimg, groups), dim3(kPrefixWg), tables_lds + huff_prefix_bytes(), st, images, scan_pool, lut_pool, entry, exit_, cps, esub,
                        blkbase, entries, status, img_flags, fallback, uint32_t(tables_lds), items, item_count, unconverged);
-    hipLaunchKernelGGL(k_block_gather, dim3(nimg, (max_wg * kHuffWg + kGatherSubs - 1) / kGatherSubs), dim3(256), 0, st, images, entry, exit_, esub, blkbase,
+    hipLaunchKernelGGL(k_block_gather, dim3(nimg, (max_wg * lanes + kGatherSubs - 1) / kGatherSubs), dim3(256), 0, st, images, entry, exit_, esub, blkbase,
                        const_cast<uint32_t *>(entries), dcdiff, tile_eoff, img_flags, status);
 }
 

@@ -82,13 +82,36 @@ static int plan_ref_layout(ImagePlan &p)
 
 // Cuts the scan of a planned picture into subsequences of about `base_bits` bits: p.seg holds the first bit of every
 // segment (one segment without restart intervals); sets himg.sub_bits, himg.nsub and the first subsequence of every segment.
+// (MJX_LONG_FIT=0: scans below kLongScanBits never take the long subsequences, as before round 6 -- for the A/B)
+static bool long_fit_enabled()
+{
+    static const bool on = [] { const char *e = std::getenv("MJX_LONG_FIT"); return !e || std::atoi(e) != 0; }();
+    return on;
+}
+
 void replan_subsequences(ImagePlan &p, uint32_t base_bits, bool allow_long)
 {
     p.wg_lanes = uint32_t(kHuffWg);
     if (p.role == 2 || p.seg.size() < 2 * (size_t(p.nseg) + 1)) return;        // (role 2: no scan of its own)
     // long scans without restart intervals: long subsequences (mjx_huff.h: kLongSubseqBits), unless the caller asks for short ones
+    uint32_t long_lanes = 0, long_bits = 0;
     if (allow_long && base_bits == uint32_t(kSubseqBits) && p.nseg == 1 && p.restart_mcus == 0 && (long long)p.himg.total_bits >= kLongScanBits)
         base_bits = uint32_t(kLongSubseqBits);
+    else if (allow_long && base_bits == uint32_t(kSubseqBits) && p.nseg == 1 && p.restart_mcus == 0 && !p.stuffed && long_fit_enabled()) {
+        // Round 6 (BASELINE config 4): a shorter scan whose long subsequences fill ONE workgroup of 256 lanes to seven
+        // eighths takes them as well -- a 1080p scan of 0.24 MB is 238 of them in a 256-lane workgroup -- and with them the single decode (k_huff_emit runs at the chunk's workgroup size since this round; at
+        // 512 lanes a 1080p picture held half an idle workgroup's LDS, which is why the long cut used to lose 13 % there).
+        // (the length may stretch to 5/4 of the long one, as choose_subseq_bits stretches it to save a workgroup)
+        // (256 lanes and up: what smaller scans do was settled on batches of small pictures in round 5 and is left alone)
+        // ... and 256 lanes only: measured (tools/ab_cfg.sh, MJX_LONG_FIT=0 / 1, same box) 4096 x 1080p 14.36 / 14.32 -> 13.84 / 14.08 ms per
+        // step (592 -> 608 Gpixels/s); a 4K scan at quality 50 in ONE 512-lane workgroup of 500 long subsequences loses to its two passes
+        // over 1000 short ones (21.5 -> 23.5 ms per 2048 pictures: k_huff_emit 10.5 ms against 2.0 + 5.6), so 512 lanes keep the old rule
+        for (uint32_t lanes = 256u; lanes <= 256u && !long_lanes; lanes *= 2u) {
+            const uint32_t fit = std::max<uint32_t>(uint32_t(kLongSubseqBits), ((p.himg.total_bits + lanes - 1) / lanes + uint32_t(kCpBits) - 1) / uint32_t(kCpBits) * uint32_t(kCpBits));
+            if (fit <= uint32_t(kMaxSubseqBits) && uint64_t(p.himg.total_bits) * 8u >= uint64_t(lanes) * uint32_t(kLongSubseqBits) * 7u) { long_lanes = lanes; long_bits = fit; }
+        }
+        if (long_lanes) base_bits = uint32_t(kLongSubseqBits);
+    }
     if (p.stuffed) {
         // the exact length and the restart offsets are only known on the device: an upper bound of the subsequence count
         // (every segment adds less than one to total / sub_bits) for the host's sizing, the subsequence length itself is final
@@ -105,7 +128,7 @@ void replan_subsequences(ImagePlan &p, uint32_t base_bits, bool allow_long)
     // (MJX_FIT_SHORT=0: off, for the A/B; a value above 1: the shortest cut in bits instead of 1024)
     static const uint32_t fit_floor = [] { const char *e = std::getenv("MJX_FIT_SHORT"); const long v = e ? std::atol(e) : 1; return uint32_t(v <= 1 ? v * 4 * kCpBits : std::max<long>(v, kCpBits)); }();
     const bool fit_short = fit_floor != 0;
-    p.wg_lanes = uint32_t(kHuffWg);
+    p.wg_lanes = long_lanes ? long_lanes : uint32_t(kHuffWg);
     if (fit_short && base_bits == uint32_t(kSubseqBits) && p.nseg == 1 && p.restart_mcus == 0 && p.himg.total_bits < uint32_t(kSubseqBits) * uint32_t(kHuffWg) / 4u * 3u) {       // (under three quarters of a workgroup)
         // ... of 512 lanes, or -- the LDS of the counting and the write pass is sized per lane -- of 256 / 128, the fewest that
         // hold the scan at the default length: four times the workgroups per CU for the same scan (32768 x 256x256: 130 -> 176
@@ -118,7 +141,7 @@ void replan_subsequences(ImagePlan &p, uint32_t base_bits, bool allow_long)
     }
     const uint32_t top = base_bits * 5 / 4;
     auto bit0 = [&](uint32_t g) { return p.seg[2 * size_t(g) + 1]; };
-    p.himg.sub_bits = choose_subseq_bits(p.himg.total_bits, base_bits);
+    p.himg.sub_bits = long_bits ? long_bits : choose_subseq_bits(p.himg.total_bits, base_bits);
     if (p.nseg == 1 && p.restart_mcus == 0) {
         p.himg.nsub = (p.himg.total_bits + p.himg.sub_bits - 1) / p.himg.sub_bits;
         p.seg[0] = 0;
