@@ -2973,6 +2973,9 @@ __device__ __forceinline__ void idct_row_inplace(float *rowf)
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) idct8(p[i][0], p[i][1], p[i][2], p[i][3], p[i][4], p[i][5], p[i][6], p[i][7]);
+    // (round 6: the second pass in plain instructions on the halves of the first pass's pairs -- no transposition, 272 plain operations
+    // instead of 136 packed ones + 64 moves -- measured 7.79 / 7.80 against 7.67 / 7.68 ms per 4096 x 1080p: not kept.  A packed fp32
+    // instruction takes 4 cycles of the SIMD, a plain one 2 with two or more waves ready and 4 for a lone wave: tools/probes/op_cost_probe.hip.)
     float_pair c[8][4];                 // c[r][j] = (column 2j, column 2j+1) of row r
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -3038,6 +3041,22 @@ __device__ __forceinline__ void load4(const float *tile, const GenShape &g, uint
 #ifndef MJX_PIX_XCHG
 #define MJX_PIX_XCHG 1
 #endif
+#ifndef MJX_PIX_PKADD
+#define MJX_PIX_PKADD 1
+#endif
+// (y.x + t.x, y.y + t.x) and (y.x + t.y, y.y + t.y): one v_pk_add_f32 each, the second operand's half chosen by op_sel / op_sel_hi
+__device__ __forceinline__ float_pair pk_add_lo(float_pair y, float_pair t)
+{
+    float_pair d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(y), "v"(t));
+    return d;
+}
+__device__ __forceinline__ float_pair pk_add_hi(float_pair y, float_pair t)
+{
+    float_pair d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(y), "v"(t));
+    return d;
+}
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Phase 3 for 4:2:0 (Y 2x2, Cb 1x1, Cr 1x1): lane -> (MCU t, 4-pixel strip sx) fixed; each step handles a 4x2 pixel
@@ -3131,14 +3150,34 @@ __device__ __forceinline__ void pixels_420(uint32_t width, uint32_t height, uint
         if (!INTERIOR && (py >= height || npix == 0)) break;
         const ChromaTerms c0 = chroma_terms(cb[j].x, cr[j].x), c1 = chroma_terms(cb[j].y, cr[j].y);
         Rgb p[4];
+#if MJX_PIX_PKADD
+        // two pixels per addition (v_pk_add_f32, the chroma term broadcast to both halves by op_sel): 12 packed instead of 24 plain
+        // additions per lane and step.  A packed instruction takes 4 cycles of the SIMD whatever the occupancy, a plain one 2 -- when
+        // two or more of the SIMD's waves have one ready, 4 for a lone wave (tools/probes/op_cost_probe.hip): never slower, and
+        // twice as fast whenever the other workgroups of the CU wait for memory.
+        const float_pair t0rg = {c0.r, c0.g}, t0b = {c0.b, c0.b}, t1rg = {c1.r, c1.g}, t1b = {c1.b, c1.b};
+        auto rows = [&](const f32x4 &y, Rgb *q) {
+            const float_pair y01 = __builtin_shufflevector(y, y, 0, 1), y23 = __builtin_shufflevector(y, y, 2, 3);
+            const float_pair r01 = pk_add_lo(y01, t0rg), g01 = pk_add_hi(y01, t0rg), b01 = pk_add_lo(y01, t0b);
+            const float_pair r23 = pk_add_lo(y23, t1rg), g23 = pk_add_hi(y23, t1rg), b23 = pk_add_lo(y23, t1b);
+            q[0] = Rgb{r01.x, g01.x, b01.x}; q[1] = Rgb{r01.y, g01.y, b01.y};
+            q[2] = Rgb{r23.x, g23.x, b23.x}; q[3] = Rgb{r23.y, g23.y, b23.y};
+        };
+        rows(ya[j], p);
+#else
         p[0] = ycc_to_rgb(ya[j].x, c0); p[1] = ycc_to_rgb(ya[j].y, c0);
         p[2] = ycc_to_rgb(ya[j].z, c1); p[3] = ycc_to_rgb(ya[j].w, c1);
+#endif
         uint8_t *dst = col + size_t(rp) * 2 * width * 3;
         if (INTERIOR) store_rgb4(dst, pack4(p));
         else store4(dst, pack4(p), aligned, npix);
         if (INTERIOR || py + 1 < height) {
+#if MJX_PIX_PKADD
+            rows(yb[j], p);
+#else
             p[0] = ycc_to_rgb(yb[j].x, c0); p[1] = ycc_to_rgb(yb[j].y, c0);
             p[2] = ycc_to_rgb(yb[j].z, c1); p[3] = ycc_to_rgb(yb[j].w, c1);
+#endif
             if (INTERIOR) store_rgb4(dst + size_t(width) * 3, pack4(p));
             else store4(dst + size_t(width) * 3, pack4(p), aligned, npix);
         }
