@@ -1006,6 +1006,24 @@ int build_batch(mjx_ctx *ctx, const std::vector<ImagePlan> &plans_in, const mjx_
             }
         }
     }
+    // Scans that took the long subsequences because they fill ONE 256-lane workgroup with them (replan_subsequences, round 6) keep
+    // them only in a batch of nothing else: a chunk runs its entropy kernels at its pictures' largest workgroup size, and next to
+    // 512-lane pictures such a scan would sit in half an idle workgroup (and the chunk would launch both kernel families: 2048 x
+    // 1080p 4:2:2, where two thirds of the pictures fit and a third does not, 390 -> 306 Gpixels/s).
+    {
+        bool any_fit = false, any_other = false;
+        for (const ImagePlan &p : *use) {
+            if (p.status != MJX_OK || p.role == 2) continue;
+            const bool fit = p.wg_lanes == 256u && p.himg.sub_bits >= uint32_t(kLongSubseqBits);
+            any_fit = any_fit || fit;
+            any_other = any_other || !fit;
+        }
+        if (any_fit && any_other) {
+            if (use == &plans_in) { replanned = plans_in; use = &replanned; }
+            for (ImagePlan &p : replanned)
+                if (p.status == MJX_OK && p.role != 2 && p.wg_lanes == 256u && p.himg.sub_bits >= uint32_t(kLongSubseqBits)) replan_subsequences(p, uint32_t(kSubseqBits), false);
+        }
+    }
     const std::vector<ImagePlan> &plans = *use;
     mjx_batch *b = new (std::nothrow) mjx_batch;
     if (!b) return MJX_ERR_NOMEM;

@@ -3044,6 +3044,9 @@ __device__ __forceinline__ void load4(const float *tile, const GenShape &g, uint
 #ifndef MJX_PIX_PKADD
 #define MJX_PIX_PKADD 1
 #endif
+#ifndef MJX_FETCH_EARLY
+#define MJX_FETCH_EARLY 1
+#endif
 // (y.x + t.x, y.y + t.x) and (y.x + t.y, y.y + t.y): one v_pk_add_f32 each, the second operand's half chosen by op_sel / op_sel_hi
 __device__ __forceinline__ float_pair pk_add_lo(float_pair y, float_pair t)
 {
@@ -3630,6 +3633,15 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
                 }
             }
         }
+        // The next tile's loads go out BEFORE this tile's entries are scattered (round 6; MJX_FETCH_EARLY=0: behind the scatter, as in
+        // rounds 2-5): what finds a lane's group -- quad_cell's reads of the workgroup's tables in LDS -- is then not queued behind the
+        // scatter's LDS stores, and the loads have the scatter phase on top of the inverse DCT to land in (13 more registers: cur and
+        // nxt are live together; still three waves per SIMD).
+        auto nxt = cur;
+        if (MJX_FETCH_EARLY && !PLANAR && tile + 1 < tile1) {
+            if constexpr (QUAD) tile_fetch_quad<LANES>(src, qv, tile + 1 - tile0, dcs, tile + 1, tile_blocks, total_blocks, nxt);
+            else if constexpr (!PLANAR) tile_fetch<LANES, PF>(src, s_eoff + (tile + 1 - tile0), dcs, tile + 1, tile_blocks, total_blocks, nxt);
+        }
         {   // phase 1
             const uint32_t first_lo = (tile * tile_blocks) & 0xffu;
             const uint32_t wave0 = tid & ~63u;
@@ -3695,8 +3707,7 @@ __global__ __launch_bounds__(256) void k_idct_color(const DevImage *__restrict__
             } else
             if (tid < nblk) tile_f[tid * kPixStride] = float(cur.dc) * my_dc_qm + my_dc_add;
         }
-        auto nxt = cur;
-        if (tile + 1 < tile1) {
+        if (!(MJX_FETCH_EARLY && !PLANAR) && tile + 1 < tile1) {
             if constexpr (QUAD) tile_fetch_quad<LANES>(src, qv, tile + 1 - tile0, dcs, tile + 1, tile_blocks, total_blocks, nxt);
             else if constexpr (PLANAR) tile_fetch_planar<LANES, PF>(psrc, s_ptile[(tile + 1) % 3u], dcbuf, pdc, (tile + 1) * T, pr1, pa1, nmcu, mcux, nxt);
             else tile_fetch<LANES, PF>(src, s_eoff + (tile + 1 - tile0), dcs, tile + 1, tile_blocks, total_blocks, nxt);

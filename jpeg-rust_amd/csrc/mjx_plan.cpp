@@ -97,7 +97,7 @@ void replan_subsequences(ImagePlan &p, uint32_t base_bits, bool allow_long)
     uint32_t long_lanes = 0, long_bits = 0;
     if (allow_long && base_bits == uint32_t(kSubseqBits) && p.nseg == 1 && p.restart_mcus == 0 && (long long)p.himg.total_bits >= kLongScanBits)
         base_bits = uint32_t(kLongSubseqBits);
-    else if (allow_long && base_bits == uint32_t(kSubseqBits) && p.nseg == 1 && p.restart_mcus == 0 && !p.stuffed && long_fit_enabled()) {
+    else if (allow_long && base_bits == uint32_t(kSubseqBits) && p.role == 0 && p.nseg == 1 && p.restart_mcus == 0 && !p.stuffed && long_fit_enabled()) {
         // Round 6 (BASELINE config 4): a shorter scan whose long subsequences fill ONE workgroup of 256 lanes to seven
         // eighths takes them as well -- a 1080p scan of 0.24 MB is 238 of them in a 256-lane workgroup -- and with them the single decode (k_huff_emit runs at the chunk's workgroup size since this round; at
         // 512 lanes a 1080p picture held half an idle workgroup's LDS, which is why the long cut used to lose 13 % there).
