@@ -103,7 +103,7 @@ void replan_subsequences(ImagePlan &p, uint32_t base_bits, bool allow_long)
         // 512 lanes a 1080p picture held half an idle workgroup's LDS, which is why the long cut used to lose 13 % there).
         // (the length may stretch to 5/4 of the long one, as choose_subseq_bits stretches it to save a workgroup)
         // (256 lanes and up: what smaller scans do was settled on batches of small pictures in round 5 and is left alone)
-        // ... and 256 lanes only: measured (tools/ab_cfg.sh, MJX_LONG_FIT=0 / 1, same box) 4096 x 1080p 14.36 / 14.32 -> 13.84 / 14.08 ms per
+        // ... and 256 lanes only: measured (tools/ab.sh -e MJX_LONG_FIT=0 -e MJX_LONG_FIT=1, same box) 4096 x 1080p 14.36 / 14.32 -> 13.84 / 14.08 ms per
         // step (592 -> 608 Gpixels/s); a 4K scan at quality 50 in ONE 512-lane workgroup of 500 long subsequences loses to its two passes
         // over 1000 short ones (21.5 -> 23.5 ms per 2048 pictures: k_huff_emit 10.5 ms against 2.0 + 5.6), so 512 lanes keep the old rule
         for (uint32_t lanes = 256u; lanes <= 256u && !long_lanes; lanes *= 2u) {

@@ -17,9 +17,13 @@ for k, c in rows.items():
         print("   lane utilisation (THREAD_CYCLES_VALU / ACTIVE_INST_VALU / 64): %.3f" % (d["SQ_THREAD_CYCLES_VALU"] / d["SQ_ACTIVE_INST_VALU"] / 64))
         print("   VALU busy share of wave cycles: %.3f ; wait_any %.3f ; wait_inst_any %.3f ; valu insts/wave %.0f" % (
             d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"], d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"], d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"], d["SQ_INSTS_VALU"] / d["SQ_WAVES"]))
-        # SQ_BUSY_CYCLES is summed over the chip's 32 shader engines; a SIMD-32 issues a wave64 VALU instruction in 2 cycles
+        # SQ_BUSY_CYCLES is summed over the chip's 32 shader engines.  One price for a wave64 vector instruction since round 6
+        # (tools/probes/op_cost_probe.hip): 4 cycles of its SIMD -- what the packed fp32, conversion, shift-left, bit-field,
+        # 24-bit multiply and compare instructions these kernels are made of take whatever the occupancy; the 2-cycle figure (plain
+        # f32 add / mul / fma, mov, and, add with two or more waves ready) is printed beside it as the lower bound.
         cyc = d["SQ_BUSY_CYCLES"] / 32.0
-        print("   VALU issue share of SIMD time (INSTS_VALU * 2 / (1024 SIMDs * BUSY_CYCLES / 32)): %.3f" % (d["SQ_INSTS_VALU"] * 2.0 / (1024.0 * cyc)))
+        print("   vector issue share of SIMD time at 4 cycles per instruction: %.3f   (at 2 cycles: %.3f)" % (
+            d["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cyc), d["SQ_INSTS_VALU"] * 2.0 / (1024.0 * cyc)))
     if d.get("SQ_INSTS_SALU") and d.get("SQ_INSTS_VALU"):
         print("   scalar instructions per vector instruction: %.2f" % (d["SQ_INSTS_SALU"] / d["SQ_INSTS_VALU"]))
     if "SQ_INSTS_LDS" in d and d.get("SQ_INSTS_LDS"):

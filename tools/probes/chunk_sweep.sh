@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel chunks per step (run through gpurun): by picture count (--chunk-images) and by scan bytes (MJX_CHUNK_SCAN_MB), default streams.
-#   tools/chunk_sweep.sh ["bench args" ...]      e.g.  tools/chunk_sweep.sh "" "--quality 90" "--width 1920 --height 1080 --images-per-gpu 4096"
+#   tools/probes/chunk_sweep.sh ["bench args" ...]      e.g.  tools/probes/chunk_sweep.sh "" "--quality 90" "--width 1920 --height 1080 --images-per-gpu 4096"
 show() { grep '^{' | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], round(d['value']), d['ms_per_step'], 'chunks', d['config'].get('chunks_per_step'))" "$1"; }
 Q="--no-cpu-baseline --no-extra --no-parity --no-traffic"
 [ $# -eq 0 ] && set -- ""

@@ -1,5 +1,5 @@
 #!/bin/bash
-# FETCH_SIZE of two builds on one box: tools/fetch_ab.sh outdir lib1 lib2
+# FETCH_SIZE of two builds on one box: tools/probes/fetch_ab.sh outdir lib1 lib2
 O=$1; shift
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for L in "$@"; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Default streams: LDS padding of the entropy kernels so that a CU that holds their workgroups has room left for stage B's
-# (run through gpurun).  Round 4: no gain -- and a write pass with one workgroup per CU is half again as slow (tools/occupancy_probe.sh).
+# (run through gpurun).  Round 4: no gain -- and a write pass with one workgroup per CU is half again as slow (tools/probes/occupancy_probe.sh).
 show() { grep '^{' | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], round(d['value']), d['ms_per_step'], {k:round(v['ms']/d['steps'],2) for k,v in d['kernels'].items()})" "$1"; }
 Q="--no-cpu-baseline --no-extra --no-parity --no-traffic"
 for r in 1 2; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Stream configurations of the context on one box (run through gpurun): tools/stream_sweep.sh
+# Stream configurations of the context on one box (run through gpurun): tools/probes/stream_sweep.sh
 show() { grep '^{' | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], round(d['value']), d['ms_per_step'])" "$1"; }
 Q="--no-cpu-baseline --no-extra --no-parity --no-traffic"
 for r in 1 2; do
