@@ -663,6 +663,67 @@ def test_dc_prediction_that_never_hears_from_its_predecessor_gives_up_and_two_pa
             assert "one-pass DC prediction gave up" in out.stderr, out.stderr[-2000:]
 
 
+def test_single_decode_in_256_lane_workgroups_for_1080p_class_scans(mjx, orc):
+    """Round 6 (BASELINE config 4; mjx_plan.cpp::replan_subsequences): a scan of one picture that fills ONE 256-lane workgroup with
+    long subsequences takes them, and the single-decode kernels (k_huff_emit, k_huff_prefix, k_block_gather) run at the chunk's
+    workgroup size -- when every picture of the batch is such a scan.  Pictures of different content and size inside the rule's
+    range, alone and tiled over two chunks: the emitting kernel must have run, T0 equal to the oracle, RGB within 1, the tiled copies
+    equal to their originals bit for bit.  The same list with a picture outside the range (a 720p one) must keep the two-pass kernels
+    for all of them, and MJX_LONG_FIT=0 (checked in a child process) gives the old cut -- same coefficients, same pictures."""
+    import subprocess
+    # (throughput_plan: the cut of a batch that fills the device, which a handful of pictures otherwise never gets -- bench.py's base batch)
+    ctx = mjx.Context(0, profiling=True, throughput_plan=True)
+    specs = [(1920, 1080, "420", 75, 6.0, 1), (1600, 1200, "420", 78, 8.0, 3), (2048, 1152, "420", 70, 6.0, 5), (1280, 960, "444", 72, 8.0, 10),
+             (1440, 1080, "420", 85, 6.0, 12), (1920, 1080, "422", 70, 4.0, 14)]
+    datas = []
+    for (w, h, sub, q, noise, seed) in specs:
+        d = mjx.synth_jpeg(w, h, sub, q, seed=seed, noise_sigma=noise)
+        sc = mjx.ParsedScan(d)
+        bits = sc.desc.scan_len * 8
+        sc.close()
+        if 256 * 8192 * 7 // 8 <= bits <= 256 * 10240:               # (inside the rule's range: 1.835 .. 2.62 Mbit)
+            datas.append(d)
+    assert len(datas) == 6, len(datas)
+    refs = [orc.decode(d, layout=orc.LAYOUT_STD) for d in datas]
+
+    def check(batch, n, want_emit):
+        batch.kernel_ms(reset=True)
+        for rep in range(2):
+            batch.decode(); batch.wait()
+        k = batch.kernel_ms()
+        assert (k["huff_emit"][1] > 0) == want_emit, k
+        assert (k["huff_write"][1] > 0) == (not want_emit), k
+        for i in range(n):
+            assert batch.status(i) == mjx.OK, (i, batch.status(i))
+            assert np.array_equal(batch.coefs(i), orc.interleave(refs[i])), i
+            assert np.abs(batch.rgb(i).astype(int) - refs[i].rgb.astype(int)).max() <= TOL, i
+    b = mjx.Batch(ctx, [mjx.ParsedScan(d) for d in datas], keep_coefs=True)
+    check(b, len(datas), True)
+    t = b.tile(40)
+    t.decode(); t.wait()
+    n = len(datas)
+    mx, cnt = t.compare_rgb(list(range(n, len(t))), t, [i % n for i in range(n, len(t))])
+    assert int(mx.max()) == 0 and int(cnt.sum()) == 0 and all(t.status(i) == mjx.OK for i in range(len(t)))
+    t.close()
+    b.close()
+    small = mjx.synth_jpeg(1280, 720, "420", 75, seed=9)
+    refs.append(orc.decode(small, layout=orc.LAYOUT_STD))
+    b = mjx.Batch(ctx, [mjx.ParsedScan(d) for d in datas + [small]], keep_coefs=True)
+    check(b, len(datas) + 1, False)                                   # (a mixed batch: the short cut and the two passes for everyone)
+    b.close()
+    ctx.close()
+    code = ("import os, sys, hashlib\nsys.path.insert(0, %r)\nimport __graft_entry__ as ge\nmjx = ge.load_package()\nctx = mjx.Context(0, throughput_plan=True)\n"
+            "d = mjx.synth_jpeg(1920, 1080, '420', 75, seed=1, noise_sigma=6.0)\nb = mjx.Batch(ctx, [mjx.ParsedScan(d)] * 3, keep_coefs=True)\n"
+            "b.decode(); b.wait()\nprint(b.geometry()['subsequences'], hashlib.sha256(b.coefs(2).tobytes() + b.rgb(2).tobytes()).hexdigest())\n" % ROOT)
+    outs = []
+    for env_extra in ({}, {"MJX_LONG_FIT": "0"}):
+        env = {k: v for k, v in os.environ.items() if k != "MJX_LONG_FIT"}
+        o = subprocess.run([sys.executable, "-c", code], env=dict(env, **env_extra), capture_output=True, text=True, timeout=600)
+        assert o.returncode == 0, o.stdout[-1000:] + o.stderr[-2000:]
+        outs.append(o.stdout.split())
+    assert outs[0][1] == outs[1][1] and int(outs[1][0]) > 1.8 * int(outs[0][0]), outs      # same result; half the subsequences with the long cut
+
+
 def test_single_decode_beside_restart_pictures_and_device_destuffing(mjx, orc, tmp_path):
     """Round-5 fuzz find (tests/golden/fuzz_r05): seven small files -- three with restart intervals, which keep the two-pass kernels,
     beside pictures whose first decode emits -- de-stuffed on the device.  Flat pictures' prefixes out-grew the head room, and the
