@@ -724,6 +724,42 @@ def test_single_decode_in_256_lane_workgroups_for_1080p_class_scans(mjx, orc):
     assert outs[0][1] == outs[1][1] and int(outs[1][0]) > 1.8 * int(outs[0][0]), outs      # same result; half the subsequences with the long cut
 
 
+def test_device_destuffing_fills_the_look_ahead_of_very_short_subsequences(mjx, orc, tmp_path):
+    """Round-5 advisor finding: k_destuff_scatter copied a subsequence's first 64 bytes into the look-ahead rows of the column in
+    front only -- complete while a subsequence is at least 64 bytes long.  With MJX_FIT_SHORT=256 (32-byte subsequences) the look-ahead
+    of column s would also need bytes of s + 2, which stayed 0xAA.  The scatter now writes every column in front that covers the
+    byte.  (Today's planner gives device-de-stuffed scans 512-byte subsequences whatever the knob says, so the loop is defensive; what
+    this test holds is the neighbourhood: small pictures under MJX_FIT_SHORT=256 -- 32-byte subsequences where the host de-stuffs --,
+    de-stuffed on the device directly, through the linear copy, and on the host, in the cut of a large batch: every coefficient the
+    oracle's, RGB within 1.)"""
+    import subprocess
+    script = tmp_path / "short.py"
+    script.write_text(
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "import __graft_entry__ as ge, oracle_binding as orc\n"
+        "mjx = ge.load_package()\n"
+        "ctx = mjx.Context(0, throughput_plan=True)\n"
+        "datas = [mjx.synth_jpeg(w, h, sub, q, seed=i) for i, (w, h, sub, q) in enumerate([(64, 64, '420', 90), (120, 80, '444', 95), (200, 150, '420', 85),\n"
+        "         (96, 96, '422', 98), (33, 47, 'gray', 99), (160, 120, '420', 97)])]\n"
+        "refs = [orc.decode(d, layout=orc.LAYOUT_STD) for d in datas]\n"
+        "subs = []\n"
+        "for dd in (True, False):\n"
+        "    b = mjx.Batch(ctx, [mjx.ParsedScan(d, device_destuff=dd) for d in datas], keep_coefs=True)\n"
+        "    b.decode(); b.wait()\n"
+        "    subs.append(b.geometry()['subsequences'])\n"
+        "    for i, ref in enumerate(refs):\n"
+        "        assert b.status(i) == 0, (dd, i, b.status(i))\n"
+        "        assert np.array_equal(b.coefs(i), orc.interleave(ref)), (dd, i)\n"
+        "        assert np.abs(b.rgb(i).astype(int) - ref.rgb.astype(int)).max() <= 1, (dd, i)\n"
+        "    b.close()\n"
+        "print('short ok', subs)\n" % (ROOT, ROOT))
+    for extra in ({"MJX_FIT_SHORT": "256"}, {"MJX_FIT_SHORT": "256", "MJX_DESTUFF_DIRECT": "0"}, {}):
+        env = {k: v for k, v in os.environ.items() if k not in ("MJX_FIT_SHORT", "MJX_DESTUFF_DIRECT")}
+        out = subprocess.run([sys.executable, str(script)], env=dict(env, **extra), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "short ok" in out.stdout, str(extra) + out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_single_decode_beside_restart_pictures_and_device_destuffing(mjx, orc, tmp_path):
     """Round-5 fuzz find (tests/golden/fuzz_r05): seven small files -- three with restart intervals, which keep the two-pass kernels,
     beside pictures whose first decode emits -- de-stuffed on the device.  Flat pictures' prefixes out-grew the head room, and the
