@@ -1584,6 +1584,8 @@ extern "C" __global__ __launch_bounds__(kHuffWg) void k_huff_emit(const DevImage
 {
     extern __shared__ __attribute__((aligned(kLutAlign))) unsigned char smem[];   // tables, HuffImage, windows, rings
     uint32_t *s_win = reinterpret_cast<uint32_t *>(smem + win_off);
+    // (round 6: a raised wave priority for this latency-bound pass beside stage B -- s_setprio 1 / 3 -- measured 25.57 / 25.43 against
+    // 25.63 ms per step, five passes of 20 steps each on one box, spread 0.25: nothing)
     const uint32_t img = entropy_grid_image(), wgi = entropy_grid_wg();
     const DevImage &im = images[img];
     // (blockDim.x lanes: 512, or -- round 6 -- 256 / 128 for a chunk whose scans are all that short: see k_huff_spec)
