@@ -392,6 +392,14 @@ constexpr int kWinDwords = MJX_WIN_DWORDS;
 #define MJX_WIN_PAD 1
 #endif
 constexpr int kWinStride = kWinDwords + MJX_WIN_PAD;      // odd stride: lanes spread over all banks
+#ifndef MJX_WIN_PREFETCH
+#define MJX_WIN_PREFETCH 1
+#endif
+#ifndef MJX_WIN_LEAD
+#define MJX_WIN_LEAD 20
+#endif
+constexpr uint32_t kWinLead = MJX_WIN_LEAD;                // bytes of window left to the fastest lane when the next pieces are requested (wave_decode)
+static_assert(MJX_WIN_DWORDS == 8 || !MJX_WIN_PREFETCH, "the prefetching restage moves windows of two 16-byte pieces");
 struct LdsWindow {
     const unsigned char *lds;    // lane's window
     uint32_t wbase;              // stream byte offset of the window's first dword (as of the last fill the caller noted)
@@ -472,11 +480,42 @@ __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry,
     WaveStamp sp;
     if (WRITE) sp.begin();
 #endif
+#if MJX_WIN_PREFETCH
+    // Round 6: the restage's loads are issued kWinLead bytes BEFORE the first lane runs out of window, into registers, and written to
+    // the windows when it does -- a restage used to be load, wait for L2 / HBM, write, with the whole wave parked (a fifth of an emitting
+    // wave's cycles in the stamps).  Between the two points a lane moves on by less than a window, so what it will need is two of the
+    // three pieces behind its window's first one: (wb + 1, wb + 2) or (wb + 2, wb + 3); a lane still inside its first piece keeps its window.
+    uint32_t wb = win.wbase >> 4;                                              // first piece of the lane's window
+    const uint32_t last_piece = (h.sub_bits >> 7) + kLookPieces - 1u;          // (the column's last row: scan_region_rows)
+    bool pf = false;                                                           // (uniform) the pieces are on their way
+    uint4 pa = make_uint4(0, 0, 0, 0), pb = pa, pc = pa;
+#endif
     while (running) {                                                          // per-lane loop: finished lanes are masked off
+#if MJX_WIN_PREFETCH
+        if (!pf && __builtin_amdgcn_ballot_w64(win.rp + kWinLead >= win_end)) {
+            pa = g.piece(min(wb + 1u, last_piece));
+            pb = g.piece(min(wb + 2u, last_piece));
+            pc = g.piece(min(wb + 3u, last_piece));
+            pf = true;
+        }
+        if (__builtin_amdgcn_ballot_w64(win.rp >= win_end)) {                  // uniform over the active lanes: restage
+            const uint32_t q1 = (st.wn - 4u) >> 4;                             // (w0, w1 are in registers; wn - 4 is read next)
+            if (q1 != wb) {
+                const bool two = q1 != wb + 1u;
+                const uint4 lo = two ? pb : pa, hi = two ? pc : pb;
+                my_win[0] = __builtin_bswap32(lo.x); my_win[1] = __builtin_bswap32(lo.y); my_win[2] = __builtin_bswap32(lo.z); my_win[3] = __builtin_bswap32(lo.w);
+                my_win[4] = __builtin_bswap32(hi.x); my_win[5] = __builtin_bswap32(hi.y); my_win[6] = __builtin_bswap32(hi.z); my_win[7] = __builtin_bswap32(hi.w);
+                win.rp = win_addr + ((st.wn - 4u) & 15u);
+                wb = q1;
+            }
+            pf = false;
+        }
+#else
         if (__builtin_amdgcn_ballot_w64(win.rp >= win_end)) {                  // uniform over the active lanes: restage
             window_fill(my_win, g, (st.wn - 4u) & ~15u);                       // (w0, w1 are in registers; wn - 4 is read next)
             win.rp = win_addr + ((st.wn - 4u) & 15u);
         }
+#endif
 #ifdef MJX_STAMP
         if (WRITE) { sp.at(0); (void)symbol_step<WRITE, PAIRSTEP>(st, win, lut, h, blk, sink, sp); sp.at(5); }
         else
