@@ -41,7 +41,10 @@ def draw():
         kw = dict(quality=int(rng.integers(40, 96)), optimize=bool(rng.random() < 0.5), subsampling=int(rng.integers(0, 3)))
         for _ in range(6):                                     # steer the quality until the scan lands in the range
             buf = io.BytesIO()
-            Image.fromarray(arr).save(buf, "JPEG", **kw)
+            try:
+                Image.fromarray(arr).save(buf, "JPEG", **kw)
+            except OSError:                                    # (Pillow gives up on some option combinations: another picture)
+                break
             d = buf.getvalue()
             sc = mjx.ParsedScan(d)
             bits = sc.desc.scan_len * 8
