@@ -12,7 +12,7 @@ for f in sys.argv[1:]:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), k))
 rows.sort()
 # the timed steps: the last dense cluster of k_idct_color launches; take the last 60 % of the span of all k_huff_spec launches
-spec = [r for r in rows if r[2] == "k_huff_spec"]
+spec = [r for r in rows if r[2] in ("k_huff_spec", "k_huff_emit")]      # (the first kernel of a chunk's entropy stage: two passes / single decode)
 t0 = spec[len(spec) // 2][0]
 t1 = max(r[1] for r in rows if r[2] == "k_idct_color")
 sel = [r for r in rows if r[0] >= t0 and r[1] <= t1]
@@ -45,3 +45,9 @@ for g, v in sorted(pair.items()):
     print("  %-16s %5.1f %%" % (g, 100.0 * v / span))
 for c, v in sorted(busy.items(), key=lambda x: -x[1]):
     print("  %-20s running %5.1f %% of the span" % (c, 100.0 * v / span))
+
+# the last step's launches of the long kernels, on the span's clock: where the stages really lie beside each other
+longk = [r for r in sel if r[1] - r[0] > 200000]
+print("launches longer than 0.2 ms (start .. end in ms from the span's start):")
+for a, b, k in longk[-12:]:
+    print("  %-16s %8.2f .. %8.2f  (%.2f ms)" % (k, (a - t0) / 1e6, (b - t0) / 1e6, (b - a) / 1e6))
