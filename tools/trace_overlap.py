@@ -4,7 +4,7 @@ by at least one kernel, by two or more kernel classes at once, and the time ever
     python tools/trace_overlap.py DIR/*kernel_trace.csv"""
 import csv, sys, collections
 rows = []
-for f in sys.argv[1:]:
+for f in [a for a in sys.argv[1:] if not a.isdigit()]:
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void mjx::", "").split("<")[0]
         if not k.startswith("k_"):
@@ -46,8 +46,10 @@ for g, v in sorted(pair.items()):
 for c, v in sorted(busy.items(), key=lambda x: -x[1]):
     print("  %-20s running %5.1f %% of the span" % (c, 100.0 * v / span))
 
-# the last step's launches of the long kernels, on the span's clock: where the stages really lie beside each other
-longk = [r for r in sel if r[1] - r[0] > 200000]
-print("launches longer than 0.2 ms (start .. end in ms from the span's start):")
-for a, b, k in longk[-12:]:
-    print("  %-16s %8.2f .. %8.2f  (%.2f ms)" % (k, (a - t0) / 1e6, (b - t0) / 1e6, (b - a) / 1e6))
+# the long launches at the end of the span, on the span's clock: where the stages really lie beside each other
+# (a trailing number on the command line = how many to print)
+count = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 14
+longk = [r for r in sel if r[1] - r[0] > 500000]
+print("launches longer than 0.5 ms (start .. end in ms from the span's start):")
+for a, b, k in longk[-count:]:
+    print("  %-18s %8.2f .. %8.2f  (%.2f ms)" % (k, (a - t0) / 1e6, (b - t0) / 1e6, (b - a) / 1e6))
