@@ -395,10 +395,6 @@ constexpr int kWinStride = kWinDwords + MJX_WIN_PAD;      // odd stride: lanes s
 #ifndef MJX_WIN_PREFETCH
 #define MJX_WIN_PREFETCH 1
 #endif
-#ifndef MJX_WIN_LEAD
-#define MJX_WIN_LEAD 20
-#endif
-constexpr uint32_t kWinLead = MJX_WIN_LEAD;                // bytes of window left to the fastest lane when the next pieces are requested (wave_decode)
 static_assert(MJX_WIN_DWORDS == 8 || !MJX_WIN_PREFETCH, "the prefetching restage moves windows of two 16-byte pieces");
 struct LdsWindow {
     const unsigned char *lds;    // lane's window
@@ -481,23 +477,21 @@ __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry,
     if (WRITE) sp.begin();
 #endif
 #if MJX_WIN_PREFETCH
-    // Round 6: the restage's loads are issued kWinLead bytes BEFORE the first lane runs out of window, into registers, and written to
-    // the windows when it does -- a restage used to be load, wait for L2 / HBM, write, with the whole wave parked (a fifth of an emitting
-    // wave's cycles in the stamps).  Between the two points a lane moves on by less than a window, so what it will need is two of the
-    // three pieces behind its window's first one: (wb + 1, wb + 2) or (wb + 2, wb + 3); a lane still inside its first piece keeps its window.
+    // Round 6: the pieces a restage will write are requested right behind the restage before it, into registers -- a restage used to be
+    // load, wait for L2 / HBM, write, with the whole wave parked (a fifth of an emitting wave's cycles in the stamps).  Between two
+    // restages a lane moves on by less than a window, so what it will need is two of the three pieces behind its window's first one:
+    // (wb + 1, wb + 2) or (wb + 2, wb + 3); a lane still inside its first piece keeps its window.
     uint32_t wb = win.wbase >> 4;                                              // first piece of the lane's window
     const uint32_t last_piece = (h.sub_bits >> 7) + kLookPieces - 1u;          // (the column's last row: scan_region_rows)
-    bool pf = false;                                                           // (uniform) the pieces are on their way
     uint4 pa = make_uint4(0, 0, 0, 0), pb = pa, pc = pa;
+    if (running) {
+        pa = g.piece(min(wb + 1u, last_piece));
+        pb = g.piece(min(wb + 2u, last_piece));
+        pc = g.piece(min(wb + 3u, last_piece));
+    }
 #endif
     while (running) {                                                          // per-lane loop: finished lanes are masked off
 #if MJX_WIN_PREFETCH
-        if (!pf && __builtin_amdgcn_ballot_w64(win.rp + kWinLead >= win_end)) {
-            pa = g.piece(min(wb + 1u, last_piece));
-            pb = g.piece(min(wb + 2u, last_piece));
-            pc = g.piece(min(wb + 3u, last_piece));
-            pf = true;
-        }
         if (__builtin_amdgcn_ballot_w64(win.rp >= win_end)) {                  // uniform over the active lanes: restage
             const uint32_t q1 = (st.wn - 4u) >> 4;                             // (w0, w1 are in registers; wn - 4 is read next)
             if (q1 != wb) {
@@ -508,7 +502,9 @@ __device__ __forceinline__ SubseqState wave_decode(bool live, SubseqState entry,
                 win.rp = win_addr + ((st.wn - 4u) & 15u);
                 wb = q1;
             }
-            pf = false;
+            pa = g.piece(min(wb + 1u, last_piece));                           // ... and the next restage's pieces
+            pb = g.piece(min(wb + 2u, last_piece));
+            pc = g.piece(min(wb + 3u, last_piece));
         }
 #else
         if (__builtin_amdgcn_ballot_w64(win.rp >= win_end)) {                  // uniform over the active lanes: restage
